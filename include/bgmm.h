@@ -1,0 +1,138 @@
+/*
+ * libbgmm_hip.so -- C-ABI of the MI355X (gfx950) collapsed-Gibbs reassignment path for the
+ * CRP / pCRP Gaussian mixture model with a normal-inverse-Wishart prior.
+ *
+ * The reference (junlulocky/PyBGMM) is pure Python and has no FFI layer; the interface this
+ * library replaces is the Python class surface of the hot path.  Each entry point below cites
+ * the reference code it stands in for (file:line relative to the reference checkout).  A host
+ * binds it with ctypes; pybgmm_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 on success or a negative BGMM_E* code,
+ *     with a human-readable message available from bgmm_last_error().
+ *   - all floating point is IEEE float64; labels / counts cross the boundary as int64
+ *     (the reference's platform int), data indices as int64.
+ *   - host pointers are borrowed only for the duration of the call.
+ *   - one context = one chain on one GPU; a context is not thread safe, distinct contexts
+ *     are independent (one per GPU for the multi-chain mode).
+ *   - `v_0` must be integer valued: the reference indexes its log / lgamma tables with it
+ *     (pybgmm/gaussian/gaussian_components.py:120-122, 238, 248).
+ */
+#ifndef BGMM_H
+#define BGMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bgmm_ctx bgmm_ctx;
+
+enum {
+    BGMM_OK = 0,
+    BGMM_EINVAL = -1,    /* bad argument (shape, label vector, v_0 < D, ...)            */
+    BGMM_EDEVICE = -2,   /* HIP runtime error (message holds hipGetErrorString)          */
+    BGMM_EKMAX = -3,     /* a new component would exceed K_max (the reference raises
+                            IndexError at the same point, gaussian_components.py:161-164) */
+    BGMM_ENOTPD = -4,    /* a component scatter matrix lost positive definiteness         */
+    BGMM_EUNSUPPORTED = -5
+};
+
+enum { BGMM_COV_FULL = 0 };   /* covariance_type="full" (igmm.py:104-105); diag/fixed: next rows */
+
+/* Library / build identification, e.g. "bgmm-hip 0.1 gfx950". */
+const char *bgmm_version(void);
+
+/* Message of the last failing call on this context (or of a failed bgmm_create when ctx==NULL). */
+const char *bgmm_last_error(const bgmm_ctx *ctx);
+
+/*
+ * GaussianComponents.__init__ + _cache (gaussian_components.py:75-127) without the
+ * assignments: uploads X[N,D] (row major), the NIW prior (prior/niw.py:10-23) and alpha,
+ * allocates K_max component slots, and evaluates the prior predictive of every point
+ * (`cached_log_prior`, :125-127 via :207-214) on the device.
+ *   lgamma_tab / log_tab: optional host tables of length v_0+N+2 holding lgamma(n/2) and
+ *   log(n) for n = [1, 1, 2, ..., v_0+N+1] (exactly the reference's `_cached_gammaln_by_2`
+ *   and `_cached_log_v`); pass NULL to have the library fill them with libm.
+ */
+int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
+                const double *X, const double *m_0, double k_0, int64_t v_0, const double *S_0,
+                double alpha, const double *lgamma_tab, const double *log_tab);
+
+void bgmm_destroy(bgmm_ctx *ctx);
+
+/*
+ * Initial component assignment (gaussian_components.py:96-111): labels must be -1 or cover
+ * 0..max consecutively (the reference asserts this, :103-105).  Sufficient statistics are
+ * accumulated in the reference's order (k ascending, i ascending, starting from
+ * S_0 + k_0 m_0 m_0^T) so that counts / m_N_numerators / S_N_partials are bit-identical.
+ */
+int bgmm_set_assignments(bgmm_ctx *ctx, const int64_t *z);
+
+/*
+ * One full Gibbs sweep = the body of `for i_iter` in CRPMM.collapsed_gibbs_sampler
+ * (igmm/crpmm.py:57-88) / PCRPMM.collapsed_gibbs_sampler (igmm/pcrpmm.py:93-131).
+ *   order : visiting order (np.random.permutation, pcrpmm.py:86-91) or NULL for 0..N-1
+ *   u     : one uniform per visit, in visiting order (random.random() of utils/utils.py:15)
+ *   power : pCRP exponent r; seating weight log(pow(n_k, r)) (pcrpmm.py:105-108).  Pass
+ *           use_power=0 for the plain CRP weight log(n_k) (crpmm.py:70, pcrpmm.py:109-112).
+ * Result: identical assignment trajectory to the reference for identical (order, u).
+ */
+int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, int32_t use_power, double power);
+
+/* Same sweep split in two so that the H2D copy of (order, u) can sit outside a timed region. */
+int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
+int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
+
+/* IGMM.log_marg (igmm/igmm.py:199-215) = CRP log P(z) + sum_k log_marg_k
+ * (gaussian_components.py:253-289). */
+int bgmm_log_marg(bgmm_ctx *ctx, double *out);
+/* GaussianComponents.log_marg_k(k) (gaussian_components.py:253-276). */
+int bgmm_log_marg_k(bgmm_ctx *ctx, int32_t k, double *out);
+
+/* components.K / .assignments / .counts[:K] (labels in the reference's numbering, i.e.
+ * after its swap-with-last deletes, gaussian_components.py:188-205). */
+int bgmm_get_K(bgmm_ctx *ctx, int32_t *K);
+int bgmm_get_assignments(bgmm_ctx *ctx, int64_t *z_out);
+int bgmm_get_counts(bgmm_ctx *ctx, int64_t *counts_out /* K entries */);
+
+/* components.m_N_numerators[:K], S_N_partials[:K], logdet_covars[:K], inv_covars[:K]
+ * (gaussian_components.py:86-89) in label order; any pointer may be NULL. */
+int bgmm_get_stats(bgmm_ctx *ctx, double *m_out, double *S_out, double *logdet_out, double *inv_out);
+
+/* components.cached_log_prior (gaussian_components.py:125-127), N entries. */
+int bgmm_get_log_prior(bgmm_ctx *ctx, double *out);
+
+/* GaussianComponents.log_post_pred(i) (gaussian_components.py:228-251): K entries. */
+int bgmm_log_post_pred(bgmm_ctx *ctx, int64_t i, double *out);
+
+/* GaussianComponents.add_item(i, k) / del_item(i) (gaussian_components.py:154-186). */
+int bgmm_add_item(bgmm_ctx *ctx, int64_t i, int32_t k);
+int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
+
+/*
+ * Measurement hooks.
+ *   sweep_stats: counters of the last sweep --
+ *     [0] lik_evals = sum over visits of K at that visit, [1] visits that changed component,
+ *     [2] speculative windows evaluated, [3] kernel steps issued, [4] likelihood-kernel launches
+ *     that did work, [5] rows x components scored (incl. re-scores after moves).
+ *   kernel timing: when enabled, every likelihood-kernel launch is bracketed by HIP events on
+ *     the context's own stream; get returns the number of timed launches that did work and the
+ *     sum of their durations in milliseconds since the last reset.
+ */
+int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out6);
+int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
+int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
+
+/* Tuning knobs (0 keeps the default): cap on the speculative window, forced likelihood
+ * kernel (0 auto, 1 VALU, 2 MFMA). */
+int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind);
+
+/* Blocks until all work queued on the context's stream has finished. */
+int bgmm_synchronize(bgmm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGMM_H */

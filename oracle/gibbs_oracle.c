@@ -1,0 +1,391 @@
+/*
+ * ORACLE (test infrastructure, not product code) -- plain-C restatement of the
+ * reference's collapsed-Gibbs reassignment path (CRP / pCRP Gaussian mixture,
+ * NIW prior, full covariance).  Scalar, single threaded, one visit at a time,
+ * with the reference's algorithmic structure: component statistics cached and
+ * restored around every visit, covariance log-determinant and inverse rebuilt
+ * FROM SCRATCH (LU with partial pivoting) on every removal and every move, a
+ * K * D^2 contraction for the Student-t predictive, one uniform per visit.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this file's shared object.  The product (pybgmm_amd + libbgmm_hip.so) never
+ * links, loads or calls it.
+ *
+ * Parity status: PINNED (tests/test_oracle_c.py): integer trajectories equal to
+ * the reference's own 2014 known-answer vectors and to the trajectories captured
+ * from the reference in tests/golden/; log marginals within 1e-9 relative.  Its
+ * floats are NOT bit-identical to numpy's (unblocked LU, different summation
+ * order); the numpy oracle (gibbs_numpy.py) is the bit-identical one.
+ *
+ * Reference file:line each function follows
+ *   go_create / tables / log_prior ... pybgmm/gaussian/gaussian_components.py:75-127, 207-214
+ *   go_set_assignments ............... :96-111   (k ascending, i ascending)
+ *   seat / unseat / drop_component ... :154-205
+ *   refresh_cov ...................... :319-331
+ *   predictive_all ................... :228-251
+ *   go_sweep ......................... pybgmm/igmm/crpmm.py:57-88, pybgmm/igmm/pcrpmm.py:93-131
+ *   draw (inside go_sweep) ........... pybgmm/utils/utils.py:15-20
+ *   go_log_marg ...................... pybgmm/igmm/igmm.py:199-215, gaussian_components.py:253-289
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int64_t N, D, K_max, K;
+    const double *X;            /* borrowed, N x D row major */
+    double *m0, *S0;
+    double k0, alpha;
+    int64_t v0;
+    double *tab_lgam, *tab_log; /* index n -> lgamma(n/2), log(n); slot 0 dud (n=1) */
+    int64_t tab_len;
+    double *prior_m, *prior_S;  /* k0*m0 and S0 + k0*m0 m0^T */
+    double *m, *S, *logdet, *inv;
+    int64_t *n, *z;
+    double *log_prior;
+    /* scratch */
+    double *lu, *col, *lp, *save_m, *save_S, *save_inv, *delta, *tmp;
+    int64_t *piv;
+} go_t;
+
+#define LOG_PI 1.1447298858494001741434273513530587116472948129153
+
+/* LU with partial pivoting in place; returns sign, fills piv. */
+static int lu_factor(double *a, int64_t n, int64_t *piv) {
+    int sign = 1;
+    for (int64_t j = 0; j < n; ++j) {
+        int64_t p = j;
+        double best = fabs(a[j * n + j]);
+        for (int64_t i = j + 1; i < n; ++i) {
+            double v = fabs(a[i * n + j]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[j] = p;
+        if (p != j) {
+            for (int64_t c = 0; c < n; ++c) {
+                double t = a[j * n + c]; a[j * n + c] = a[p * n + c]; a[p * n + c] = t;
+            }
+            sign = -sign;
+        }
+        double d = a[j * n + j];
+        if (d == 0.0) continue;
+        for (int64_t i = j + 1; i < n; ++i) {
+            double l = a[i * n + j] / d;
+            a[i * n + j] = l;
+            if (l != 0.0)
+                for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
+        }
+    }
+    return sign;
+}
+
+static double lu_logabsdet(const double *lu, int64_t n) {
+    double s = 0.0;
+    for (int64_t j = 0; j < n; ++j) s += log(fabs(lu[j * n + j]));
+    return s;
+}
+
+/* inverse from the factorisation: solve A x = e_c for every column c */
+static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col) {
+    for (int64_t c = 0; c < n; ++c) {
+        for (int64_t i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            int64_t p = piv[j];
+            if (p != j) { double t = col[j]; col[j] = col[p]; col[p] = t; }
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            double s = col[i];
+            for (int64_t t = 0; t < i; ++t) s -= lu[i * n + t] * col[t];
+            col[i] = s;
+        }
+        for (int64_t i = n - 1; i >= 0; --i) {
+            double s = col[i];
+            for (int64_t t = i + 1; t < n; ++t) s -= lu[i * n + t] * col[t];
+            col[i] = s / lu[i * n + i];
+        }
+        for (int64_t i = 0; i < n; ++i) out[i * n + c] = col[i];
+    }
+}
+
+static double slogdet_of(go_t *g, const double *a) {
+    int64_t D = g->D;
+    memcpy(g->lu, a, sizeof(double) * D * D);
+    lu_factor(g->lu, D, g->piv);
+    return lu_logabsdet(g->lu, D);
+}
+
+static void refresh_cov(go_t *g, int64_t k) {
+    int64_t D = g->D;
+    double k_N = g->k0 + (double)g->n[k];
+    double v_N = (double)(g->v0 + g->n[k]);
+    double scale = (k_N + 1.) / (k_N * (v_N - (double)D + 1.));
+    const double *m = g->m + k * D, *S = g->S + k * D * D;
+    for (int64_t a = 0; a < D; ++a) g->tmp[a] = m[a] / k_N;
+    for (int64_t a = 0; a < D; ++a)
+        for (int64_t b = 0; b < D; ++b)
+            g->lu[a * D + b] = scale * (S[a * D + b] - k_N * (g->tmp[a] * g->tmp[b]));
+    lu_factor(g->lu, D, g->piv);
+    g->logdet[k] = lu_logabsdet(g->lu, D);
+    lu_inverse(g->lu, g->piv, D, g->inv + k * D * D, g->col);
+}
+
+static void seat(go_t *g, int64_t i, int64_t k) {
+    int64_t D = g->D;
+    const double *x = g->X + i * D;
+    double *m = g->m + k * D, *S = g->S + k * D * D;
+    if (k == g->K) {
+        g->K += 1;
+        memcpy(m, g->prior_m, sizeof(double) * D);
+        memcpy(S, g->prior_S, sizeof(double) * D * D);
+    }
+    for (int64_t a = 0; a < D; ++a) m[a] += x[a];
+    for (int64_t a = 0; a < D; ++a)
+        for (int64_t b = 0; b < D; ++b) {
+            double o = x[a] * x[b];
+            S[a * D + b] += o;
+        }
+    g->n[k] += 1;
+    refresh_cov(g, k);
+    g->z[i] = k;
+}
+
+static void drop_component(go_t *g, int64_t k) {
+    int64_t D = g->D;
+    g->K -= 1;
+    int64_t last = g->K;
+    if (k != last) {
+        memcpy(g->m + k * D, g->m + last * D, sizeof(double) * D);
+        memcpy(g->S + k * D * D, g->S + last * D * D, sizeof(double) * D * D);
+        g->logdet[k] = g->logdet[last];
+        memcpy(g->inv + k * D * D, g->inv + last * D * D, sizeof(double) * D * D);
+        g->n[k] = g->n[last];
+        for (int64_t i = 0; i < g->N; ++i) if (g->z[i] == last) g->z[i] = k;
+    }
+    memset(g->m + last * D, 0, sizeof(double) * D);
+    memset(g->S + last * D * D, 0, sizeof(double) * D * D);
+    g->logdet[last] = 0.;
+    memset(g->inv + last * D * D, 0, sizeof(double) * D * D);
+    g->n[last] = 0;
+}
+
+static void unseat(go_t *g, int64_t i) {
+    int64_t D = g->D;
+    int64_t k = g->z[i];
+    if (k == -1) return;
+    g->n[k] -= 1;
+    g->z[i] = -1;
+    if (g->n[k] == 0) { drop_component(g, k); return; }
+    const double *x = g->X + i * D;
+    double *m = g->m + k * D, *S = g->S + k * D * D;
+    for (int64_t a = 0; a < D; ++a) m[a] -= x[a];
+    for (int64_t a = 0; a < D; ++a)
+        for (int64_t b = 0; b < D; ++b) {
+            double o = x[a] * x[b];
+            S[a * D + b] -= o;
+        }
+    refresh_cov(g, k);
+}
+
+static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
+                        double logdet, const double *inv, int64_t nu, double *delta) {
+    int64_t D = g->D;
+    for (int64_t a = 0; a < D; ++a) delta[a] = mu_num[a] / k_N - x[a];
+    double q = 0.0;
+    for (int64_t a = 0; a < D; ++a) {
+        double r = 0.0;
+        for (int64_t b = 0; b < D; ++b) r += delta[b] * inv[b * D + a];
+        q += r * delta[a];
+    }
+    double hd = (double)D / 2.;
+    return g->tab_lgam[nu + D] - g->tab_lgam[nu] - hd * g->tab_log[nu] - hd * LOG_PI
+           - 0.5 * logdet - (double)(nu + D) / 2. * log(1 + 1. / (double)nu * q);
+}
+
+/* ------------------------------------------------------------------------- */
+void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const double *m0,
+                double k0, int64_t v0, const double *S0, double alpha,
+                const double *tab_lgam, const double *tab_log) {
+    go_t *g = (go_t *)calloc(1, sizeof(go_t));
+    g->N = N; g->D = D; g->K_max = K_max; g->X = X; g->k0 = k0; g->v0 = v0; g->alpha = alpha;
+    g->m0 = (double *)malloc(sizeof(double) * D); memcpy(g->m0, m0, sizeof(double) * D);
+    g->S0 = (double *)malloc(sizeof(double) * D * D); memcpy(g->S0, S0, sizeof(double) * D * D);
+    g->tab_len = v0 + N + 2;
+    g->tab_lgam = (double *)malloc(sizeof(double) * g->tab_len);
+    g->tab_log = (double *)malloc(sizeof(double) * g->tab_len);
+    for (int64_t t = 0; t < g->tab_len; ++t) {
+        double n = (t == 0) ? 1.0 : (double)t;
+        g->tab_lgam[t] = tab_lgam ? tab_lgam[t] : lgamma(n / 2.);
+        g->tab_log[t] = tab_log ? tab_log[t] : log(n);
+    }
+    g->prior_m = (double *)malloc(sizeof(double) * D);
+    g->prior_S = (double *)malloc(sizeof(double) * D * D);
+    for (int64_t a = 0; a < D; ++a) g->prior_m[a] = k0 * m0[a];
+    for (int64_t a = 0; a < D; ++a)
+        for (int64_t b = 0; b < D; ++b) {
+            double o = m0[a] * m0[b];
+            double ko = k0 * o;
+            g->prior_S[a * D + b] = S0[a * D + b] + ko;
+        }
+    g->m = (double *)calloc(K_max * D, sizeof(double));
+    g->S = (double *)calloc(K_max * D * D, sizeof(double));
+    g->inv = (double *)calloc(K_max * D * D, sizeof(double));
+    g->logdet = (double *)calloc(K_max, sizeof(double));
+    g->n = (int64_t *)calloc(K_max, sizeof(int64_t));
+    g->z = (int64_t *)malloc(sizeof(int64_t) * N);
+    for (int64_t i = 0; i < N; ++i) g->z[i] = -1;
+    g->log_prior = (double *)malloc(sizeof(double) * N);
+    g->lu = (double *)malloc(sizeof(double) * D * D);
+    g->col = (double *)malloc(sizeof(double) * D);
+    g->piv = (int64_t *)malloc(sizeof(int64_t) * D);
+    g->lp = (double *)malloc(sizeof(double) * (K_max + 1));
+    g->save_m = (double *)malloc(sizeof(double) * D);
+    g->save_S = (double *)malloc(sizeof(double) * D * D);
+    g->save_inv = (double *)malloc(sizeof(double) * D * D);
+    g->delta = (double *)malloc(sizeof(double) * D);
+    g->tmp = (double *)malloc(sizeof(double) * D);
+
+    /* prior predictive of every point */
+    int64_t nu0 = v0 - D + 1;
+    double scale = (k0 + 1) / (k0 * (double)nu0);
+    double *cov = g->save_S, *iv = g->save_inv;
+    for (int64_t t = 0; t < D * D; ++t) cov[t] = scale * S0[t];
+    memcpy(g->lu, cov, sizeof(double) * D * D);
+    lu_factor(g->lu, D, g->piv);
+    double ld0 = lu_logabsdet(g->lu, D);
+    lu_inverse(g->lu, g->piv, D, iv, g->col);
+    for (int64_t i = 0; i < N; ++i)
+        g->log_prior[i] = student_t(g, X + i * D, m0, 1.0, ld0, iv, nu0, g->delta);
+    return g;
+}
+
+void go_destroy(void *h) {
+    go_t *g = (go_t *)h;
+    if (!g) return;
+    free(g->m0); free(g->S0); free(g->tab_lgam); free(g->tab_log); free(g->prior_m);
+    free(g->prior_S); free(g->m); free(g->S); free(g->inv); free(g->logdet); free(g->n);
+    free(g->z); free(g->log_prior); free(g->lu); free(g->col); free(g->piv); free(g->lp);
+    free(g->save_m); free(g->save_S); free(g->save_inv); free(g->delta); free(g->tmp);
+    free(g);
+}
+
+/* z: labels 0..Kinit-1 (consecutive) or -1; returns 0, or -1 on an invalid vector */
+int go_set_assignments(void *h, const int64_t *z) {
+    go_t *g = (go_t *)h;
+    int64_t zmax = -1;
+    for (int64_t i = 0; i < g->N; ++i) { if (z[i] < -1) return -1; if (z[i] > zmax) zmax = z[i]; }
+    if (zmax >= g->K_max) return -1;
+    for (int64_t k = 0; k <= zmax; ++k) {
+        int found = 0;
+        for (int64_t i = 0; i < g->N; ++i) if (z[i] == k) { found = 1; break; }
+        if (!found) return -1;
+    }
+    for (int64_t k = 0; k <= zmax; ++k)
+        for (int64_t i = 0; i < g->N; ++i)
+            if (z[i] == k) seat(g, i, k);
+    return 0;
+}
+
+/* One sweep.  order==NULL: visit 0..N-1.  use_power: weights log(pow(n, power)).
+ * n_visits <= N visits are performed (u[t] consumed at visit t).
+ * lik_evals (may be NULL) accumulates sum over visits of K_at_visit.
+ * Returns 0, or -2 if a new component would exceed K_max. */
+int go_sweep(void *h, const int64_t *order, const double *u, int use_power, double power,
+             int64_t n_visits, int64_t *lik_evals) {
+    go_t *g = (go_t *)h;
+    int64_t D = g->D;
+    double log_alpha = log(g->alpha);
+    for (int64_t t = 0; t < n_visits; ++t) {
+        int64_t i = order ? order[t] : t;
+        int64_t k_old = g->z[i], K_old = g->K;
+        double save_logdet = 0.; int64_t save_n = 0;
+        if (k_old >= 0) {
+            memcpy(g->save_m, g->m + k_old * D, sizeof(double) * D);
+            memcpy(g->save_S, g->S + k_old * D * D, sizeof(double) * D * D);
+            memcpy(g->save_inv, g->inv + k_old * D * D, sizeof(double) * D * D);
+            save_logdet = g->logdet[k_old]; save_n = g->n[k_old];
+        }
+        unseat(g, i);
+        int64_t K = g->K;
+        if (lik_evals) *lik_evals += K;
+        const double *x = g->X + i * D;
+        double top = -INFINITY;
+        for (int64_t k = 0; k < K; ++k) {
+            double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
+            int64_t nu = g->v0 + g->n[k] - D + 1;
+            g->lp[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
+                                     g->inv + k * D * D, nu, g->delta);
+            if (g->lp[k] > top) top = g->lp[k];
+        }
+        g->lp[K] = log_alpha + g->log_prior[i];
+        if (g->lp[K] > top) top = g->lp[K];
+        double s = 0.0;
+        for (int64_t k = 0; k <= K; ++k) s += exp(g->lp[k] - top);
+        double lse = log(s) + top;
+        double r = u[t];
+        int64_t k_new = K;
+        for (int64_t k = 0; k <= K; ++k) {
+            r = r - exp(g->lp[k] - lse);
+            if (r < 0) { k_new = k; break; }
+        }
+        if (k_new == k_old && g->K == K_old) {
+            memcpy(g->m + k_old * D, g->save_m, sizeof(double) * D);
+            memcpy(g->S + k_old * D * D, g->save_S, sizeof(double) * D * D);
+            memcpy(g->inv + k_old * D * D, g->save_inv, sizeof(double) * D * D);
+            g->logdet[k_old] = save_logdet; g->n[k_old] = save_n;
+            g->z[i] = k_old;
+        } else {
+            if (k_new >= g->K_max) return -2;
+            seat(g, i, k_new);
+        }
+    }
+    return 0;
+}
+
+double go_log_marg(void *h) {
+    go_t *g = (go_t *)h;
+    int64_t D = g->D, K = g->K;
+    double sum_n = 0., sum_lf = 0.;
+    for (int64_t k = 0; k < K; ++k) {
+        sum_n += (double)g->n[k];
+        if (g->n[k] > 0) sum_lf += lgamma((double)g->n[k]);
+    }
+    double log_pz = (double)(K - 1) * log(g->alpha) + lgamma(g->alpha) - lgamma(sum_n + g->alpha) + sum_lf;
+    double ld_S0 = slogdet_of(g, g->S0);
+    double hd = (double)D / 2.;
+    double log_px = 0.;
+    for (int64_t k = 0; k < K; ++k) {
+        double k_N = g->k0 + (double)g->n[k];
+        int64_t v_N = g->v0 + g->n[k];
+        const double *m = g->m + k * D, *S = g->S + k * D * D;
+        for (int64_t a = 0; a < D; ++a) g->tmp[a] = m[a] / k_N;
+        for (int64_t a = 0; a < D; ++a)
+            for (int64_t b = 0; b < D; ++b)
+                g->save_S[a * D + b] = S[a * D + b] - k_N * (g->tmp[a] * g->tmp[b]);
+        double ld = slogdet_of(g, g->save_S);
+        double gs = 0.;
+        for (int64_t j = 1; j <= D; ++j) gs += g->tab_lgam[v_N + 1 - j] - g->tab_lgam[g->v0 + 1 - j];
+        log_px += -(double)g->n[k] * hd * LOG_PI + hd * log(g->k0) - hd * log(k_N)
+                  + (double)g->v0 / 2. * ld_S0 - (double)v_N / 2. * ld + gs;
+    }
+    return log_pz + log_px;
+}
+
+int64_t go_K(void *h) { return ((go_t *)h)->K; }
+void go_get_assignments(void *h, int64_t *out) { go_t *g = (go_t *)h; memcpy(out, g->z, sizeof(int64_t) * g->N); }
+void go_get_counts(void *h, int64_t *out) { go_t *g = (go_t *)h; memcpy(out, g->n, sizeof(int64_t) * g->K); }
+void go_get_log_prior(void *h, double *out) { go_t *g = (go_t *)h; memcpy(out, g->log_prior, sizeof(double) * g->N); }
+void go_get_stats(void *h, double *m, double *S, double *logdet, double *inv) {
+    go_t *g = (go_t *)h; int64_t D = g->D, K = g->K;
+    if (m) memcpy(m, g->m, sizeof(double) * K * D);
+    if (S) memcpy(S, g->S, sizeof(double) * K * D * D);
+    if (logdet) memcpy(logdet, g->logdet, sizeof(double) * K);
+    if (inv) memcpy(inv, g->inv, sizeof(double) * K * D * D);
+}
+/* Student-t predictive of X[i] under every current component (no removal). */
+void go_log_post_pred(void *h, int64_t i, double *out) {
+    go_t *g = (go_t *)h; int64_t D = g->D;
+    for (int64_t k = 0; k < g->K; ++k)
+        out[k] = student_t(g, g->X + i * D, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
+                           g->inv + k * D * D, g->v0 + g->n[k] - D + 1, g->delta);
+}

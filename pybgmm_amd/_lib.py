@@ -1,0 +1,224 @@
+"""
+ctypes binding of libbgmm_hip.so (the C-ABI of include/bgmm.h).
+
+There is NO CPU fallback: if the shared object is missing, cannot be built, or
+no HIP device is visible, the calls raise.  ``oracle/`` is never imported here.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+_f64 = ctypes.POINTER(ctypes.c_double)
+_i64 = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+_lib = None
+
+ERRORS = {-1: "BGMM_EINVAL", -2: "BGMM_EDEVICE", -3: "BGMM_EKMAX", -4: "BGMM_ENOTPD",
+          -5: "BGMM_EUNSUPPORTED"}
+
+# every symbol include/bgmm.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "bgmm_version": (ctypes.c_char_p, []),
+    "bgmm_last_error": (ctypes.c_char_p, [_vp]),
+    "bgmm_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int64, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int32, _vp, _vp, ctypes.c_double,
+                                   ctypes.c_int64, _vp, ctypes.c_double, _vp, _vp]),
+    "bgmm_destroy": (None, [_vp]),
+    "bgmm_set_assignments": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_sweep": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_double]),
+    "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
+    "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
+    "bgmm_log_marg": (ctypes.c_int, [_vp, _f64]),
+    "bgmm_log_marg_k": (ctypes.c_int, [_vp, ctypes.c_int32, _f64]),
+    "bgmm_get_K": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "bgmm_get_assignments": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_counts": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bgmm_get_log_prior": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_log_post_pred": (ctypes.c_int, [_vp, ctypes.c_int64, _vp]),
+    "bgmm_add_item": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32]),
+    "bgmm_del_item": (ctypes.c_int, [_vp, ctypes.c_int64]),
+    "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
+    "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32]),
+    "bgmm_synchronize": (ctypes.c_int, [_vp]),
+}
+
+
+class BGMMError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "%s (%d): %s" % (ERRORS.get(code, "BGMM_E?"), code, message))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise OSError("libbgmm_hip.so not built: run `python __graft_entry__.py` "
+                          "(there is no CPU fallback)")
+        _build.build()
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context(object):
+    """One chain on one GPU.  Thin, argument-checked wrapper over the C-ABI."""
+
+    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, device=0, tables=None):
+        L = load()
+        self.L = L
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.N, self.D = self.X.shape
+        self.K_max = int(K_max)
+        m_0 = np.ascontiguousarray(m_0, dtype=np.float64)
+        S_0 = np.ascontiguousarray(S_0, dtype=np.float64)
+        if int(v_0) != v_0:
+            raise ValueError("v_0 must be integer valued (the reference indexes its "
+                             "log/gammaln tables with it)")
+        tl = tg = None
+        if tables is not None:
+            tl = np.ascontiguousarray(tables[0], dtype=np.float64)
+            tg = np.ascontiguousarray(tables[1], dtype=np.float64)
+            assert tl.shape == (int(v_0) + self.N + 2,) and tg.shape == tl.shape
+        h = _vp()
+        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max, 0,
+                           _ptr(self.X), _ptr(m_0), float(k_0), int(v_0), _ptr(S_0), float(alpha),
+                           _ptr(tl), _ptr(tg))
+        if rc != 0:
+            raise BGMMError(rc, (L.bgmm_last_error(None) or b"").decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bgmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise BGMMError(rc, (self.L.bgmm_last_error(self.h) or b"").decode())
+
+    # -- state ---------------------------------------------------------------
+    def set_assignments(self, z):
+        z = np.ascontiguousarray(z, dtype=np.int64)
+        assert z.shape == (self.N,)
+        self._ck(self.L.bgmm_set_assignments(self.h, _ptr(z)))
+
+    def sweep(self, u, order=None, power=None):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape == (self.N,)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int64)
+            assert order.shape == (self.N,)
+        self._ck(self.L.bgmm_sweep(self.h, _ptr(order), _ptr(u), 0 if power is None else 1,
+                                   1.0 if power is None else float(power)))
+
+    def stage(self, u, order=None):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int64)
+        self._ck(self.L.bgmm_stage_sweep_inputs(self.h, _ptr(order), _ptr(u)))
+
+    def sweep_staged(self, power=None):
+        self._ck(self.L.bgmm_sweep_staged(self.h, 0 if power is None else 1,
+                                          1.0 if power is None else float(power)))
+
+    @property
+    def K(self):
+        k = ctypes.c_int32(0)
+        self._ck(self.L.bgmm_get_K(self.h, ctypes.byref(k)))
+        return int(k.value)
+
+    def assignments(self):
+        z = np.empty(self.N, dtype=np.int64)
+        self._ck(self.L.bgmm_get_assignments(self.h, _ptr(z)))
+        return z
+
+    def counts(self):
+        c = np.empty(max(self.K, 1), dtype=np.int64)
+        self._ck(self.L.bgmm_get_counts(self.h, _ptr(c)))
+        return c[:self.K]
+
+    def stats(self, want_inv=True):
+        K, D = self.K, self.D
+        m, S = np.empty((K, D)), np.empty((K, D, D))
+        ld = np.empty(K)
+        iv = np.empty((K, D, D)) if want_inv else None
+        self._ck(self.L.bgmm_get_stats(self.h, _ptr(m), _ptr(S), _ptr(ld), _ptr(iv)))
+        return m, S, ld, iv
+
+    def log_prior(self):
+        out = np.empty(self.N, dtype=np.float64)
+        self._ck(self.L.bgmm_get_log_prior(self.h, _ptr(out)))
+        return out
+
+    def log_marg(self):
+        v = ctypes.c_double(0.0)
+        self._ck(self.L.bgmm_log_marg(self.h, ctypes.byref(v)))
+        return float(v.value)
+
+    def log_marg_k(self, k):
+        v = ctypes.c_double(0.0)
+        self._ck(self.L.bgmm_log_marg_k(self.h, int(k), ctypes.byref(v)))
+        return float(v.value)
+
+    def log_post_pred(self, i):
+        out = np.empty(max(self.K, 1), dtype=np.float64)
+        self._ck(self.L.bgmm_log_post_pred(self.h, int(i), _ptr(out)))
+        return out[:self.K]
+
+    def add_item(self, i, k):
+        self._ck(self.L.bgmm_add_item(self.h, int(i), int(k)))
+
+    def del_item(self, i):
+        self._ck(self.L.bgmm_del_item(self.h, int(i)))
+
+    # -- measurement ---------------------------------------------------------
+    def sweep_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._ck(self.L.bgmm_get_sweep_stats(self.h, _ptr(out)))
+        keys = ("lik_evals", "moves", "windows", "steps", "score_launches", "scored")
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def set_kernel_timing(self, on):
+        self._ck(self.L.bgmm_set_kernel_timing(self.h, 1 if on else 0))
+
+    def kernel_timing(self):
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0.0)
+        self._ck(self.L.bgmm_get_kernel_timing(self.h, ctypes.byref(n), ctypes.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def set_tuning(self, max_window=0, kernel_kind=0):
+        self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind)))
+
+    def synchronize(self):
+        self._ck(self.L.bgmm_synchronize(self.h))

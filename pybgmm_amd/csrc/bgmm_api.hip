@@ -1,0 +1,589 @@
+// Host side of libbgmm_hip.so: context, memory, the per-sweep launch schedule, and the
+// extern "C" entry points declared in include/bgmm.h.
+//
+// Sweep schedule (device driven, no host round trip per visit):
+//   sweep_begin                      reset window at visit 0, seating weights for this sweep
+//   repeat "steps" (queued blindly in chunks of T; a step is a no-op once the sweep is DONE):
+//     score   likelihood kernel over the window x {all labels | the <=2 slots a move touched}
+//     choice  one categorical draw per visit against the frozen state; atomicMin(first mover)
+//     apply   no mover: commit the window, open the next;   mover: commit the stays before
+//             it, apply the move (rank-1 statistics change), continue after it
+//     refresh Cholesky / inverse / constants of the <=2 touched slots
+//   after each chunk the host reads the control block (one small D2H + stream sync).
+#include "../../include/bgmm.h"
+#include "bgmm_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st);
+void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
+                         double *inv_out, hipStream_t st);
+
+static thread_local std::string g_create_error;
+
+struct bgmm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev d{};
+    std::string err;
+    std::vector<void *> allocs;
+    Ctrl *ctrl_host = nullptr;       // pinned mirror
+    Job *util_job = nullptr;         // device
+    double *util_q = nullptr;        // device [ldq]
+    double *util_out = nullptr;      // device [nslots + 8]
+    double *d_u = nullptr;
+    long long *d_order = nullptr;
+    bool have_order = false;
+    bool assigned = false;
+    int kernel_kind = KERNEL_AUTO;
+    int kind = KERNEL_VALU;          // resolved
+    int win_rows = 0;                // allocated q / choice rows
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev0, ev1;
+    long long timed_launches = 0;
+    double timed_ms = 0.0;
+    long long stats[6] = {0, 0, 0, 0, 0, 0};
+};
+
+#define CK(ctx, call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return BGMM_EDEVICE;                                                            \
+        }                                                                                   \
+    } while (0)
+
+template <typename T>
+static int dalloc(bgmm_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return BGMM_EDEVICE;
+    }
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+#define DALLOC(ctx, ptr, count)                         \
+    do {                                                \
+        int rc_ = dalloc((ctx), &(ptr), (count));       \
+        if (rc_) return rc_;                            \
+    } while (0)
+
+static int fail(bgmm_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+static const char *err_text(int code) {
+    switch (code) {
+        case -3: return "K_max exceeded: a new component was drawn while all K_max slots are in use";
+        case -4: return "a component scatter matrix is not positive definite";
+        case -1: return "invalid label";
+        default: return "device-side error";
+    }
+}
+
+static int check_device_error(bgmm_ctx *c) {
+    // ctrl_host must be current
+    if (c->ctrl_host->error != 0) {
+        const int e = c->ctrl_host->error;
+        return fail(c, e == -3 ? BGMM_EKMAX : e == -4 ? BGMM_ENOTPD : BGMM_EINVAL, err_text(e));
+    }
+    return 0;
+}
+
+static int fetch_ctrl(bgmm_ctx *c) {
+    CK(c, hipMemcpyAsync(c->ctrl_host, c->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static void resolve_kind(bgmm_ctx *c) {
+    int k = c->kernel_kind;
+    if (k == KERNEL_AUTO) k = (c->d.D >= 24) ? KERNEL_MFMA : KERNEL_VALU;
+    if (k == KERNEL_MFMA && c->d.Dp / 16 > 8) k = KERNEL_VALU;
+    c->kind = k;
+    c->d.rows_per_block = (k == KERNEL_MFMA) ? kMfmaRows : kValuRows;
+}
+
+extern "C" const char *bgmm_version(void) { return "bgmm-hip 0.1 gfx950"; }
+
+extern "C" const char *bgmm_last_error(const bgmm_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" void bgmm_destroy(bgmm_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev0) (void)hipEventDestroy(e);
+    for (auto e : c->ev1) (void)hipEventDestroy(e);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_max,
+                       const double *X, const double *m_0, double k_0, int64_t v_0,
+                       const double *S_0, double alpha, const double *lgamma_tab,
+                       const double *log_tab) {
+    c->device = device;
+    CK(c, hipSetDevice(device));
+    CK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    Dev &d = c->d;
+    d.N = N; d.D = D; d.Dp = (D + 15) / 16 * 16; d.K_max = K_max; d.nslots = K_max + 1;
+    d.nfrag = bgmm_nfrag(d.Dp); d.ldq = d.nslots;
+    d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
+    d.tab_len = v_0 + N + 2;
+    d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr;
+    resolve_kind(c);
+
+    const size_t DD = (size_t)D * D, ns = (size_t)d.nslots;
+    double *dX, *dtl, *dtg, *dpm, *dpS;
+    DALLOC(c, dX, (size_t)N * D);
+    DALLOC(c, d.log_prior, (size_t)N);
+    DALLOC(c, d.z, (size_t)N);
+    DALLOC(c, dtl, (size_t)d.tab_len);
+    DALLOC(c, dtg, (size_t)d.tab_len);
+    DALLOC(c, dpm, (size_t)D);
+    DALLOC(c, dpS, DD);
+    DALLOC(c, d.m, ns * D);
+    DALLOC(c, d.S, ns * DD);
+    DALLOC(c, d.mu, ns * D);
+    DALLOC(c, d.Wrm, ns * DD);
+    DALLOC(c, d.Wfrag, ns * d.nfrag * 64);
+    DALLOC(c, d.cvec, ns * d.Dp);
+    DALLOC(c, d.n, ns);
+    DALLOC(c, d.sc, ns);
+    DALLOC(c, d.perm, ns);
+    DALLOC(c, d.label_of_slot, ns);
+    DALLOC(c, d.ctrl, 1);
+    DALLOC(c, c->util_job, 1);
+    DALLOC(c, c->util_q, (size_t)d.ldq);
+    DALLOC(c, c->util_out, ns + 8);
+    DALLOC(c, c->d_u, (size_t)N);
+    DALLOC(c, c->d_order, (size_t)N);
+    // speculative window buffers: q rows bounded by ~1 GiB and by N
+    long long rows = 32768;
+    while (rows > 1024 && (size_t)rows * d.ldq * sizeof(double) > ((size_t)1 << 30)) rows >>= 1;
+    long long n_up = (N + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
+    if (rows > n_up) rows = n_up;
+    c->win_rows = (int)rows;
+    DALLOC(c, d.q, (size_t)rows * d.ldq);
+    DALLOC(c, d.choice, (size_t)rows);
+    CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
+
+    d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
+    CK(c, hipMemcpyAsync(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
+
+    // tables: the reference's n = [1, 1, 2, ..., v_0+N+1] (gaussian_components.py:120-122)
+    std::vector<double> tl(d.tab_len), tg(d.tab_len);
+    for (long long t = 0; t < d.tab_len; ++t) {
+        const double n = t == 0 ? 1.0 : (double)t;
+        tl[t] = lgamma_tab ? lgamma_tab[t] : std::lgamma(n / 2.0);
+        tg[t] = log_tab ? log_tab[t] : std::log(n);
+    }
+    CK(c, hipMemcpyAsync(dtl, tl.data(), sizeof(double) * d.tab_len, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(dtg, tg.data(), sizeof(double) * d.tab_len, hipMemcpyHostToDevice, c->stream));
+
+    // prior start of a fresh component (gaussian_components.py:161-164), rounded like numpy:
+    // k_0*m_0  and  S_0 + k_0*outer(m_0, m_0)
+    std::vector<double> pm(D), pS(DD);
+    for (int a = 0; a < D; ++a) pm[a] = k_0 * m_0[a];
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b < D; ++b) {
+            volatile double o = m_0[a] * m_0[b];
+            volatile double ko = k_0 * o;
+            pS[(size_t)a * D + b] = S_0[(size_t)a * D + b] + ko;
+        }
+    CK(c, hipMemcpyAsync(dpm, pm.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(dpS, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
+    // pseudo slot K_max = the bare prior (n = 0): its refresh yields C = S_0, mu = m_0
+    CK(c, hipMemsetAsync(d.n, 0, sizeof(int) * ns, c->stream));
+    CK(c, hipMemcpyAsync(d.m + (size_t)K_max * D, pm.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(d.S + (size_t)K_max * DD, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemsetAsync(d.z, 0xff, sizeof(int) * N, c->stream));
+    CK(c, hipMemsetAsync(d.ctrl, 0, sizeof(Ctrl), c->stream));
+    CK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope below
+
+    Ctrl init;
+    std::memset(&init, 0, sizeof(init));
+    init.job.mode = MODE_DONE;
+    init.first_mover = kNoMover;
+    init.win_cap = c->win_rows;
+    init.win_size = c->win_rows;
+    init.ema_run = (double)c->win_rows * 4.0;
+    init.last_mover = -1;
+    CK(c, hipMemcpy(d.ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice));
+    std::vector<int> ident(ns);
+    for (size_t i = 0; i < ns; ++i) ident[i] = (int)i;
+    CK(c, hipMemcpy(d.perm, ident.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+    CK(c, hipMemcpy(d.label_of_slot, ident.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+
+    // cached_log_prior: score every row against the pseudo slot, then the Student-t tail
+    const int pslot = K_max;
+    int *dslot;
+    DALLOC(c, dslot, 1);
+    CK(c, hipMemcpy(dslot, &pslot, sizeof(int), hipMemcpyHostToDevice));
+    launch_refresh_list(d, dslot, 1, c->stream);
+    Job job;
+    std::memset(&job, 0, sizeof(job));
+    job.pos = 0; job.win_base = 0; job.win_hi = N; job.mode = MODE_PARTIAL; job.K = 0;
+    job.n_dirty = 1; job.dirty[0] = pslot; job.chunks = 1;
+    CK(c, hipMemcpy(c->util_job, &job, sizeof(Job), hipMemcpyHostToDevice));
+    double *qcol;
+    DALLOC(c, qcol, (size_t)N);
+    launch_score(d, c->kind, c->util_job, qcol, 1, 0, N, c->stream);
+    launch_prior_lp(d, qcol, c->stream);
+    CK(c, hipGetLastError());
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (c->ctrl_host->error) return fail(c, BGMM_ENOTPD, "S_0 is not positive definite");
+    return 0;
+}
+
+extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int32_t K_max,
+                           int32_t cov_type, const double *X, const double *m_0, double k_0,
+                           int64_t v_0, const double *S_0, double alpha, const double *lgamma_tab,
+                           const double *log_tab) {
+    if (!out) return BGMM_EINVAL;
+    *out = nullptr;
+    if (cov_type != BGMM_COV_FULL) return fail(nullptr, BGMM_EUNSUPPORTED, "only covariance_type=\"full\" is implemented");
+    if (!X || !m_0 || !S_0 || N < 1 || D < 1 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
+    if (D > BGMM_MAX_D) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 128 is not supported yet");
+    if (N >= (1ll << 31) - 256) return fail(nullptr, BGMM_EUNSUPPORTED, "N must fit int32");
+    if (v_0 < D) return fail(nullptr, BGMM_EINVAL, "v_0 must be larger or equal to dimension of data");
+    if (!(k_0 > 0) || !(alpha > 0)) return fail(nullptr, BGMM_EINVAL, "k_0 and alpha must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, BGMM_EDEVICE, "no HIP device visible: libbgmm_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, BGMM_EINVAL, "device index out of range");
+    bgmm_ctx *c = new bgmm_ctx();
+    const int rc = create_impl(c, device, N, D, K_max, X, m_0, k_0, v_0, S_0, alpha, lgamma_tab, log_tab);
+    if (rc != 0) {
+        g_create_error = c->err;
+        bgmm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return BGMM_OK;
+}
+
+extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
+    if (!c || !z) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    const Dev &d = c->d;
+    const long long N = d.N;
+    long long zmax = -1;
+    for (long long i = 0; i < N; ++i) {
+        if (z[i] < -1) return fail(c, BGMM_EINVAL, "assignments must be -1 or >= 0");
+        if (z[i] > zmax) zmax = z[i];
+    }
+    const int K = (int)(zmax + 1);
+    if (K > d.K_max) return fail(c, BGMM_EINVAL, "initial assignments use more than K_max components");
+    std::vector<long long> offsets(K + 1, 0);
+    for (long long i = 0; i < N; ++i) if (z[i] >= 0) offsets[z[i] + 1] += 1;
+    for (int k = 0; k < K; ++k) {
+        if (offsets[k + 1] == 0) return fail(c, BGMM_EINVAL, "component labels must be consecutive from 0");
+        offsets[k + 1] += offsets[k];
+    }
+    std::vector<int> members((size_t)(offsets[K] > 0 ? offsets[K] : 1));
+    {
+        std::vector<long long> cur(offsets.begin(), offsets.end() - 1);
+        for (long long i = 0; i < N; ++i) if (z[i] >= 0) members[(size_t)cur[z[i]]++] = (int)i;
+    }
+    long long *dz, *doff;
+    int *dmem;
+    hipError_t e1 = hipMalloc((void **)&dz, sizeof(long long) * N);
+    hipError_t e2 = hipMalloc((void **)&doff, sizeof(long long) * (K + 1));
+    hipError_t e3 = hipMalloc((void **)&dmem, sizeof(int) * members.size());
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, BGMM_EDEVICE, "hipMalloc failed");
+    int rc = 0;
+    do {
+        if (hipMemcpy(dz, z, sizeof(long long) * N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(doff, offsets.data(), sizeof(long long) * (K + 1), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dmem, members.data(), sizeof(int) * members.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(c, BGMM_EDEVICE, "hipMemcpy failed");
+            break;
+        }
+        launch_init_labels(d, dz, K, c->stream);
+        launch_init_stats(d, dmem, doff, K, c->stream);
+        launch_refresh_list(d, nullptr, K, c->stream);
+        if (hipGetLastError() != hipSuccess) { rc = fail(c, BGMM_EDEVICE, "kernel launch failed"); break; }
+        rc = fetch_ctrl(c);
+        if (rc) break;
+        rc = check_device_error(c);
+    } while (0);
+    (void)hipFree(dz); (void)hipFree(doff); (void)hipFree(dmem);
+    if (rc == 0) c->assigned = true;
+    return rc;
+}
+
+extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const double *u) {
+    if (!c || !u) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpyAsync(c->d_u, u, sizeof(double) * c->d.N, hipMemcpyHostToDevice, c->stream));
+    c->have_order = order != nullptr;
+    if (order)
+        CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int ensure_events(bgmm_ctx *c, size_t n) {
+    while (c->ev0.size() < n) {
+        hipEvent_t a, b;
+        CK(c, hipEventCreate(&a));
+        CK(c, hipEventCreate(&b));
+        c->ev0.push_back(a);
+        c->ev1.push_back(b);
+    }
+    return 0;
+}
+
+extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
+    if (!c) return BGMM_EINVAL;
+    if (!c->assigned) return fail(c, BGMM_EINVAL, "bgmm_set_assignments has not been called");
+    CK(c, hipSetDevice(c->device));
+    Dev &d = c->d;
+    d.use_power = use_power ? 1 : 0;
+    d.power = use_power ? power : 1.0;
+    d.u = c->d_u;
+    d.order = c->have_order ? c->d_order : nullptr;
+    resolve_kind(c);
+    hipStream_t st = c->stream;
+    launch_sweep_begin(d, st);
+    long long steps_done = 0;
+    int T = 8;
+    for (;;) {
+        if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
+        for (int t = 0; t < T; ++t) {
+            if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
+            launch_score(d, c->kind, &d.ctrl->job, d.q, d.ldq, -1, c->win_rows, st);
+            if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
+            launch_choice(d, c->win_rows, st);
+            launch_apply(d, st);
+            launch_refresh_ctrl(d, st);
+        }
+        CK(c, hipGetLastError());
+        int rc = fetch_ctrl(c);
+        if (rc) return rc;
+        const Ctrl &h = *c->ctrl_host;
+        if (c->timing) {
+            const long long worked = h.n_steps - steps_done;   // the first `worked` steps did work
+            for (long long t = 0; t < worked && t < T; ++t) {
+                float ms = 0.f;
+                CK(c, hipEventElapsedTime(&ms, c->ev0[(size_t)t], c->ev1[(size_t)t]));
+                c->timed_ms += (double)ms;
+                c->timed_launches += 1;
+            }
+        }
+        steps_done = h.n_steps;
+        if (h.error != 0 || h.job.mode == MODE_DONE) break;
+        if (T < 256) T *= 2;
+    }
+    const Ctrl &h = *c->ctrl_host;
+    c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
+    c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
+    return check_device_error(c);
+}
+
+extern "C" int bgmm_sweep(bgmm_ctx *c, const int64_t *order, const double *u, int32_t use_power, double power) {
+    int rc = bgmm_stage_sweep_inputs(c, order, u);
+    if (rc) return rc;
+    return bgmm_sweep_staged(c, use_power, power);
+}
+
+extern "C" int bgmm_get_K(bgmm_ctx *c, int32_t *K) {
+    if (!c || !K) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    *K = c->ctrl_host->job.K;
+    return 0;
+}
+
+extern "C" int bgmm_get_assignments(bgmm_ctx *c, int64_t *z_out) {
+    if (!c || !z_out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    long long *dz;
+    CK(c, hipMalloc((void **)&dz, sizeof(long long) * c->d.N));
+    launch_labels(c->d, dz, nullptr, c->stream);
+    hipError_t e = hipMemcpyAsync(z_out, dz, sizeof(long long) * c->d.N, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dz);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_get_counts(bgmm_ctx *c, int64_t *counts_out) {
+    if (!c || !counts_out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const int K = c->ctrl_host->job.K;
+    long long *dc;
+    CK(c, hipMalloc((void **)&dc, sizeof(long long) * (c->d.K_max + 1)));
+    launch_labels(c->d, nullptr, dc, c->stream);
+    hipError_t e = hipMemcpyAsync(counts_out, dc, sizeof(long long) * K, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dc);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_get_stats(bgmm_ctx *c, double *m_out, double *S_out, double *logdet_out, double *inv_out) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const int K = c->ctrl_host->job.K, D = c->d.D;
+    if (K == 0) return 0;
+    const size_t DD = (size_t)D * D;
+    double *dm = nullptr, *dS = nullptr, *dl = nullptr, *di = nullptr;
+    hipError_t e = hipSuccess;
+    if (m_out && e == hipSuccess) e = hipMalloc((void **)&dm, sizeof(double) * K * D);
+    if (S_out && e == hipSuccess) e = hipMalloc((void **)&dS, sizeof(double) * K * DD);
+    if (logdet_out && e == hipSuccess) e = hipMalloc((void **)&dl, sizeof(double) * K);
+    if (inv_out && e == hipSuccess) e = hipMalloc((void **)&di, sizeof(double) * K * DD);
+    if (e == hipSuccess) {
+        launch_export_stats(c->d, K, dm, dS, dl, di, c->stream);
+        if (dm) e = hipMemcpyAsync(m_out, dm, sizeof(double) * K * D, hipMemcpyDeviceToHost, c->stream);
+        if (dS && e == hipSuccess) e = hipMemcpyAsync(S_out, dS, sizeof(double) * K * DD, hipMemcpyDeviceToHost, c->stream);
+        if (dl && e == hipSuccess) e = hipMemcpyAsync(logdet_out, dl, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream);
+        if (di && e == hipSuccess) e = hipMemcpyAsync(inv_out, di, sizeof(double) * K * DD, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(dm); (void)hipFree(dS); (void)hipFree(dl); (void)hipFree(di);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_get_log_prior(bgmm_ctx *c, double *out) {
+    if (!c || !out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpyAsync(out, c->d.log_prior, sizeof(double) * c->d.N, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bgmm_log_marg(bgmm_ctx *c, double *out) {
+    if (!c || !out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    launch_log_marg(c->d, c->util_out, c->util_out + 8, c->stream);
+    CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bgmm_log_marg_k(bgmm_ctx *c, int32_t k, double *out) {
+    if (!c || !out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
+    launch_log_marg(c->d, c->util_out, c->util_out + 8, c->stream);
+    CK(c, hipMemcpyAsync(out, c->util_out + 8 + k, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bgmm_log_post_pred(bgmm_ctx *c, int64_t i, double *out) {
+    if (!c || !out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const int K = c->ctrl_host->job.K;
+    if (K == 0) return 0;
+    Job job;
+    std::memset(&job, 0, sizeof(job));
+    job.pos = i; job.win_base = i; job.win_hi = i + 1; job.mode = MODE_FRESH; job.K = K;
+    job.chunks = K < kMaxChunks ? K : kMaxChunks;
+    CK(c, hipMemcpyAsync(c->util_job, &job, sizeof(Job), hipMemcpyHostToDevice, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    Dev d = c->d;
+    d.order = nullptr;
+    launch_score(d, c->kind, c->util_job, c->util_q, d.ldq, -1, 1, c->stream);
+    launch_post_pred(d, c->util_q, c->util_out, c->stream);
+    CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
+    launch_item_op(c->d, op, i, k, c->stream);
+    launch_refresh_ctrl(c->d, c->stream);
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    rc = check_device_error(c);
+    if (rc) {   // clear the sticky flag: the state was left untouched by a rejected op
+        c->ctrl_host->error = 0;
+        (void)hipMemcpy(&c->d.ctrl->error, &c->ctrl_host->error, sizeof(int), hipMemcpyHostToDevice);
+    }
+    c->assigned = true;
+    return rc;
+}
+
+extern "C" int bgmm_add_item(bgmm_ctx *c, int64_t i, int32_t k) { return item_op(c, 1, i, k); }
+extern "C" int bgmm_del_item(bgmm_ctx *c, int64_t i) { return item_op(c, 0, i, 0); }
+
+extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out6) {
+    if (!c || !out6) return BGMM_EINVAL;
+    for (int t = 0; t < 6; ++t) out6[t] = c->stats[t];
+    return 0;
+}
+
+extern "C" int bgmm_set_kernel_timing(bgmm_ctx *c, int32_t enabled) {
+    if (!c) return BGMM_EINVAL;
+    c->timing = enabled != 0;
+    c->timed_launches = 0;
+    c->timed_ms = 0.0;
+    return 0;
+}
+
+extern "C" int bgmm_get_kernel_timing(bgmm_ctx *c, int64_t *n_launches, double *total_ms) {
+    if (!c) return BGMM_EINVAL;
+    if (n_launches) *n_launches = c->timed_launches;
+    if (total_ms) *total_ms = c->timed_ms;
+    return 0;
+}
+
+extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
+    c->kernel_kind = kernel_kind;
+    resolve_kind(c);
+    if (max_window > 0) {
+        int rc = fetch_ctrl(c);
+        if (rc) return rc;
+        int cap = max_window < 256 ? 256 : max_window;
+        if (cap > c->win_rows) cap = c->win_rows;
+        c->ctrl_host->win_cap = cap;
+        if (c->ctrl_host->win_size > cap) c->ctrl_host->win_size = cap;
+        CK(c, hipMemcpy(&c->d.ctrl->win_cap, &c->ctrl_host->win_cap, sizeof(int), hipMemcpyHostToDevice));
+        CK(c, hipMemcpy(&c->d.ctrl->win_size, &c->ctrl_host->win_size, sizeof(int), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int bgmm_synchronize(bgmm_ctx *c) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}

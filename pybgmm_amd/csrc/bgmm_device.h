@@ -1,0 +1,121 @@
+// Shared device/host definitions of libbgmm_hip.so (gfx950 only).
+//
+// Data layout in HBM (all float64 unless noted), one chain per context:
+//   X[N][D]            row major data matrix, read-only after upload
+//   log_prior[N]       prior predictive of every point ("open a new table" likelihood)
+//   z[N]      int32    SLOT id of every point (-1 = unassigned).  Slots are stable storage
+//                      locations; the reference's LABELS (which change on swap-with-last
+//                      deletes) are the positions of `perm`: label j  <->  slot perm[j].
+//   per slot s (K_max component slots + 1 pseudo slot K_max that holds the bare prior):
+//     n[s]     int32   count
+//     m[s][D]          k_0 m_0 + sum x           (reference m_N_numerators)
+//     S[s][D][D]       S_0 + k_0 m_0 m_0^T + sum x x^T   (reference S_N_partials)
+//     mu[s][D]         m / (k_0 + n)
+//     Wrm[s][D][D]     inverse Cholesky factor of C = S - k_N mu mu^T (lower, row major)
+//     Wfrag[s][nfrag][64]  the same matrix NEGATED, pre-swizzled into v_mfma_f64_16x16x4
+//                      B-operand fragments (block-lower-triangular, zero padded to Dp)
+//     cvec[s][Dp]      Winv * mu  (so that  Winv (mu - x) = cvec - Winv x)
+//     sc[s]            scalar constants of the Student-t predictive (SlotConst)
+//   q[Wmax][ldq]       quadratic forms (mu_s - x)^T C_s^{-1} (mu_s - x) of the current window
+//   choice[Wmax] int32 drawn label of every visit of the current window
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BGMM_MAX_D 128
+#define BGMM_LOG_PI 1.1447298858494001741434273513530587116472948129153
+
+enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
+enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
+
+static constexpr unsigned long long kNoMover = ~0ull;
+static constexpr int kMaxChunks = 32;      // grid.y of the likelihood kernels
+static constexpr int kValuRows = 64;       // rows (visits) per block, VALU likelihood kernel
+static constexpr int kMfmaRows = 128;      // rows per block, MFMA likelihood kernel (4 waves x 2 x 16)
+static constexpr int kChoiceRows = 4;      // rows per block of the draw kernel (one wave per row)
+
+// Per-slot scalar constants.  As-is predictive of a point under slot s:
+//   lp = A - half_vd * log(1 + q * inv_cv)
+// "Home" predictive (the visited point removed from its own component; Sherman-Morrison
+// on the frozen factor, with s = q the as-is quadratic form):
+//   lp = A1 - 0.5*log(1 - a1*s) - half_vd1 * log(1 + coef1 * s / (1 - a1*s))
+struct SlotConst {
+    double A, half_vd, inv_cv;
+    double A1, half_vd1, coef1, a1;
+    double logdetC;
+    double logseat, logseat1;   // log(n^r), log((n-1)^r)   (r = 1 for the plain CRP)
+    double pad0, pad1;
+};
+
+// What a likelihood / draw kernel works on.  First member of Ctrl so that (const Job*)ctrl
+// is the live sweep job; utility calls (log_prior, log_post_pred) use a private Job.
+struct Job {
+    long long pos;        // first visit (or row) to process
+    long long win_base;   // q/choice row r holds visit win_base + r
+    long long win_hi;     // end (exclusive)
+    int mode;             // MODE_FRESH: all K active labels; MODE_PARTIAL: dirty[] only
+    int K;                // active labels
+    int n_dirty;
+    int dirty[2];
+    int chunks;           // label chunks per row block (<= kMaxChunks)
+    int pad;
+};
+
+struct Ctrl {
+    Job job;
+    long long n_visits;
+    unsigned long long first_mover;
+    int n_refresh;
+    int refresh[2];
+    int win_size;         // current adaptive window size
+    int win_cap;          // upper bound (host tuning; <= allocated rows of q)
+    int error;
+    double ema_run;       // running mean distance between movers
+    long long last_mover;
+    // counters of the current sweep
+    long long lik_evals, n_moves, n_windows, n_steps, n_score_launches, n_scored;
+};
+
+struct Dev {
+    long long N;
+    int D, Dp, K_max, nslots, nfrag, ldq;
+    int rows_per_block;          // of the active likelihood kernel (chunk policy)
+    long long tab_len, v0;
+    double k0, alpha, log_alpha;
+    const double *X;
+    double *log_prior;
+    int *z;
+    const double *tab_lgam, *tab_log;
+    const double *prior_m, *prior_S;
+    double *m, *S, *mu, *Wrm, *Wfrag, *cvec;
+    int *n;
+    SlotConst *sc;
+    int *perm, *label_of_slot;
+    Ctrl *ctrl;
+    double *q;
+    int *choice;
+    const double *u;
+    const long long *order;      // may be null (identity)
+    int use_power;
+    double power;
+};
+
+__host__ __device__ inline int bgmm_nfrag(int Dp) { int nJ = Dp / 16; return 2 * nJ * (nJ + 1); }
+
+// ---- host-side launchers (each defined next to its kernels) -------------------------------
+void launch_init_stats(const Dev &d, const int *members, const long long *offsets, int K_init,
+                       hipStream_t st);
+void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st);  // explicit slots
+void launch_refresh_ctrl(const Dev &d, hipStream_t st);                          // ctrl->refresh[]
+void launch_sweep_begin(const Dev &d, hipStream_t st);
+void launch_apply(const Dev &d, hipStream_t st);
+void launch_item_op(const Dev &d, int op, long long i, int label, hipStream_t st); // add/del item
+void launch_log_marg(const Dev &d, double *out_total, double *out_per_label, hipStream_t st);
+void launch_labels(const Dev &d, long long *z_out, long long *counts_out, hipStream_t st);
+void launch_prior_lp(const Dev &d, const double *qcol, hipStream_t st);
+void launch_post_pred(const Dev &d, const double *qrow, double *out, hipStream_t st);
+
+void launch_score(const Dev &d, int kind, const Job *job, double *q, int ldq, int col_override,
+                  long long max_rows, hipStream_t st);
+void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
+int refresh_lds_bytes(int D);

@@ -1,0 +1,117 @@
+// Draw kernel: for every visit of the window turn the quadratic forms into the reference's
+// categorical draw.  One wavefront per visit.
+//
+// Reference steps restated (file:line in the reference checkout):
+//   seating prior  log n_k  / log(n_k ** r) ........ igmm/crpmm.py:70, igmm/pcrpmm.py:105-112
+//   + Student-t posterior predictive ............... gaussian/gaussian_components.py:228-251
+//   new table: log(alpha) + cached_log_prior[i] .... igmm/crpmm.py:74
+//   prob = exp(lp - logsumexp(lp)) .................. igmm/crpmm.py:75
+//   u -= prob[j] in label order, first u < 0 wins ... utils/utils.py:15-20
+// The visited point's own component is scored with the point REMOVED (del_item, :171-186);
+// here that is the closed-form rank-1 downdate of the frozen factor (SlotConst::A1 ...).
+// A visit whose drawn label is its current one ("stay") leaves the reference's state
+// bit-identical (crpmm.py:82-85), which is what makes evaluating a whole window against
+// frozen state exact; the first visit that does not stay is published with atomicMin.
+#include "bgmm_device.h"
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wave_scan(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64 * kChoiceRows) void choice_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double lpbuf_all[];   // [kChoiceRows][ldq + 1]
+    Ctrl *c = d.ctrl;
+    const Job job = c->job;
+    if (job.mode == MODE_DONE) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p = job.pos + (long long)blockIdx.x * kChoiceRows + w;
+    if (p >= job.win_hi) return;
+    double *lp = lpbuf_all + (long long)w * (d.ldq + 1);
+
+    const long long i = d.order ? d.order[p] : p;
+    const int h = d.z[i];
+    const int K = job.K;
+    const int nh = h >= 0 ? d.n[h] : 0;
+    const bool home_live = h >= 0 && nh >= 2;          // removal keeps the component
+    const bool singleton = h >= 0 && nh == 1;          // removal deletes it (swap with last)
+    const int lab_h = singleton ? d.label_of_slot[h] : -1;
+    const int L = singleton ? K - 1 : K;               // labels after the removal
+    const double *__restrict__ qrow = d.q + (p - job.win_base) * (long long)d.ldq;
+
+    // pass 1: log scores into LDS, running max
+    double mx = -INFINITY;
+    for (int j = lane; j <= L; j += 64) {
+        double v;
+        if (j == L) {
+            v = d.log_alpha + d.log_prior[i];
+        } else {
+            const int s = (singleton && j == lab_h) ? d.perm[K - 1] : d.perm[j];
+            const double qv = qrow[s];
+            const SlotConst sc = d.sc[s];
+            if (home_live && s == h) {
+                const double den = 1.0 - sc.a1 * qv;
+                v = sc.logseat1 + sc.A1 - 0.5 * log(den) - sc.half_vd1 * log(1.0 + sc.coef1 * qv / den);
+            } else {
+                v = sc.logseat + sc.A - sc.half_vd * log(1.0 + qv * sc.inv_cv);
+            }
+        }
+        lp[j] = v;
+        mx = fmax(mx, v);
+    }
+    mx = wave_max(mx);
+    // pass 2: exp and total
+    double tot = 0.0;
+    for (int j = lane; j <= L; j += 64) {
+        const double e = exp(lp[j] - mx);
+        lp[j] = e;
+        tot += e;
+    }
+    tot = wave_sum(tot);
+    // pass 3: sequential-subtract scan in label order, 64 labels at a time
+    const double u = d.u[p];
+    double carry = 0.0;
+    int pick = L;                                        // fallback: last entry (utils.py:20)
+    for (int j0 = 0; j0 <= L; j0 += 64) {
+        const int j = j0 + lane;
+        const double pj = j <= L ? lp[j] / tot : 0.0;
+        const double cum = carry + wave_scan(pj, lane);
+        const bool hit = j <= L && (u - cum) < 0.0;
+        const unsigned long long m = __ballot(hit);
+        if (m) { pick = j0 + __ffsll((long long)m) - 1; break; }
+        carry = __shfl(cum, 63);
+    }
+    if (lane == 0) {
+        d.choice[p - job.win_base] = pick;
+        const bool stay = home_live && pick < L && d.perm[pick] == h;
+        if (!stay) atomicMin(&c->first_mover, (unsigned long long)p);
+    }
+}
+
+void launch_choice(const Dev &d, long long max_rows, hipStream_t st) {
+    if (max_rows <= 0) return;
+    const unsigned gx = (unsigned)((max_rows + kChoiceRows - 1) / kChoiceRows);
+    const int lds = kChoiceRows * (d.ldq + 1) * (int)sizeof(double);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)choice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(choice_kernel, dim3(gx), dim3(64 * kChoiceRows), lds, st, d);
+}

@@ -1,0 +1,198 @@
+// Likelihood kernels: the batched quadratic form
+//      q[r][s] = (mu_s - x_r)^T C_s^{-1} (mu_s - x_r) = || cvec_s - Winv_s x_r ||^2
+// of every visit r of the current speculative window against every listed component slot s.
+// This is the K*D^2 contraction of GaussianComponents.log_post_pred
+// (reference gaussian_components.py:240-244, the two einsums) evaluated for a whole tile of
+// visits at once against frozen component state.
+//
+//   score_valu_kernel : any D.  One lane per visit, x tile transposed in LDS, Winv rows
+//                       fetched through the scalar cache (wave-uniform), FP64 VALU FMAs.
+//   score_mfma_kernel : D padded to a multiple of 16.  v_mfma_f64_16x16x4_f64 with the x
+//                       tile resident in registers as A fragments for the whole slot loop,
+//                       the negated block-lower-triangular Winv streamed as pre-swizzled
+//                       B fragments (one coalesced 512-B load per MFMA), the accumulator
+//                       initialised with cvec so the MFMA chain directly yields
+//                       y = cvec - Winv x; q = sum y^2 by a 16-lane DPP/shuffle reduction.
+#include "bgmm_device.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct RowSpan {
+    long long p0;      // first visit of this block
+    long long hi;      // end of window
+    long long base;    // q row of visit p is p - base
+};
+
+// label t of the job's list -> slot
+__device__ __forceinline__ int job_slot(const Dev &d, const Job &job, int t) {
+    return job.mode == MODE_FRESH ? d.perm[t] : job.dirty[t];
+}
+
+// ------------------------------------------------------------------------------------------
+// VALU kernel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__restrict__ jobp,
+                                                         double *__restrict__ q, int ldq,
+                                                         int col_override) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
+    const Job job = *jobp;
+    if (job.mode == MODE_DONE) return;
+    const int chunk = blockIdx.y;
+    if (chunk >= job.chunks) return;
+    const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
+    if (p0 >= job.win_hi) return;
+    const int nlist = job.mode == MODE_FRESH ? job.K : job.n_dirty;
+    const int D = d.D;
+
+    // stage the x tile transposed: xs[l][r]
+    for (int e = threadIdx.x; e < kValuRows * D; e += 256) {
+        const int r = e / D, l = e % D;
+        const long long p = p0 + r;
+        double v = 0.0;
+        if (p < job.win_hi) {
+            const long long i = d.order ? d.order[p] : p;
+            v = d.X[i * D + l];
+        }
+        xs[l * kValuRows + r] = v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p = p0 + lane;
+    // labels of this chunk: chunk, chunk + chunks, ...; the 4 waves take them round robin
+    for (int t = chunk + job.chunks * w; t < nlist; t += job.chunks * 4) {
+        const int s = job_slot(d, job, t);
+        const double *__restrict__ W = d.Wrm + (long long)s * D * D;
+        const double *__restrict__ cv = d.cvec + (long long)s * d.Dp;
+        double qv = 0.0;
+        for (int j = 0; j < D; ++j) {
+            double acc = cv[j];
+            const double *__restrict__ Wj = W + j * D;
+            for (int l = 0; l <= j; ++l) acc = fma(-Wj[l], xs[l * kValuRows + lane], acc);
+            qv = fma(acc, acc, qv);
+        }
+        if (p < job.win_hi) q[(p - job.win_base) * ldq + (col_override >= 0 ? col_override : s)] = qv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA kernel.  NJ = Dp/16 column blocks; each wave owns RB x 16 rows.
+// Fragment conventions (v_mfma_f64_16x16x4_f64):
+//   A: lane holds A[i = lane&15][k = lane>>4]   -> x[row lane&15][4*kk + (lane>>4)]
+//   B: lane holds B[k = lane>>4][j = lane&15]   -> -Winv[16J + (lane&15)][4*kk + (lane>>4)]
+//   C/D: lane holds rows (lane>>4) + 4*r, r = 0..3, column lane&15
+// ------------------------------------------------------------------------------------------
+template <int NJ, int RB>
+__global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
+                                                         double *__restrict__ q, int ldq,
+                                                         int col_override) {
+    const Job job = *jobp;
+    if (job.mode == MODE_DONE) return;
+    const int chunk = blockIdx.y;
+    if (chunk >= job.chunks) return;
+    constexpr int ROWS_W = 16 * RB;              // rows per wave
+    const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
+    if (pb >= job.win_hi) return;
+    const int nlist = job.mode == MODE_FRESH ? job.K : job.n_dirty;
+    const int D = d.D;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long pw = pb + w * ROWS_W;
+    if (pw >= job.win_hi) return;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    // A fragments of this wave's rows, resident for the whole slot loop
+    double xf[RB][NJ * 4];
+#pragma unroll
+    for (int R = 0; R < RB; ++R) {
+        const long long p = pw + R * 16 + lr;
+        const bool live = p < job.win_hi;
+        const long long i = live ? (d.order ? d.order[p] : p) : 0;
+        const double *__restrict__ xrow = d.X + i * D;
+#pragma unroll
+        for (int kk = 0; kk < NJ * 4; ++kk) {
+            const int l = 4 * kk + lk;
+            xf[R][kk] = (live && l < D) ? xrow[l] : 0.0;
+        }
+    }
+
+    const int nfrag64 = d.nfrag * 64;
+    for (int t = chunk; t < nlist; t += job.chunks) {
+        const int s = job_slot(d, job, t);
+        const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
+        const double *__restrict__ cv = d.cvec + (long long)s * d.Dp + lr;
+        double qp[RB][4];
+#pragma unroll
+        for (int R = 0; R < RB; ++R)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+            const double cj = cv[16 * J];
+            v4d acc[RB];
+#pragma unroll
+            for (int R = 0; R < RB; ++R) acc[R] = (v4d){cj, cj, cj, cj};
+#pragma unroll
+            for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                const double b = wf[(2 * J * (J + 1) + kk) * 64];
+#pragma unroll
+                for (int R = 0; R < RB; ++R)
+                    acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], b, acc[R], 0, 0, 0);
+            }
+#pragma unroll
+            for (int R = 0; R < RB; ++R)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qp[R][r] = fma(acc[R][r], acc[R][r], qp[R][r]);
+        }
+        // sum over the 16 columns held by the 16 lanes of each (lane>>4) group
+        const int col = col_override >= 0 ? col_override : s;
+#pragma unroll
+        for (int R = 0; R < RB; ++R) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = qp[R][r];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                qp[R][r] = v;
+            }
+            // lane with lr == r writes row lk + 4*r
+            const double mine = lr == 0 ? qp[R][0] : lr == 1 ? qp[R][1] : lr == 2 ? qp[R][2] : qp[R][3];
+            const long long p = pw + R * 16 + lk + 4 * lr;
+            if (lr < 4 && p < job.win_hi) q[(p - job.win_base) * ldq + col] = mine;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int NJ>
+static void launch_mfma(const Dev &d, const Job *job, double *q, int ldq, int col_override,
+                        long long max_rows, hipStream_t st) {
+    const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
+    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
+                       ldq, col_override);
+}
+
+void launch_score(const Dev &d, int kind, const Job *job, double *q, int ldq, int col_override,
+                  long long max_rows, hipStream_t st) {
+    if (max_rows <= 0) return;
+    if (kind == KERNEL_MFMA) {
+        switch (d.Dp / 16) {
+            case 1: launch_mfma<1>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 2: launch_mfma<2>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 3: launch_mfma<3>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 4: launch_mfma<4>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 5: launch_mfma<5>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 6: launch_mfma<6>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 7: launch_mfma<7>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 8: launch_mfma<8>(d, job, q, ldq, col_override, max_rows, st); return;
+            default: break;
+        }
+    }
+    const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
+    const int lds = d.D * kValuRows * (int)sizeof(double);
+    hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, ldq,
+                       col_override);
+}

@@ -1,0 +1,564 @@
+// Component-state kernels: sufficient-statistics build, covariance refresh (Cholesky +
+// triangular inverse + Student-t constants), the move applier that advances the speculative
+// window, and the small read-out kernels (labels, log marginal, stats export).
+//
+// Reference behaviour restated here (file:line in the reference checkout):
+//   init_stats_kernel ........ gaussian_components.py:96-111, 154-169 (k ascending, i ascending)
+//   refresh_kernel ........... gaussian_components.py:319-331 (what it feeds: :228-251)
+//   apply_kernel / item ops .. gaussian_components.py:154-205, igmm/crpmm.py:82-88
+//   log_marg_kernel .......... igmm/igmm.py:199-215, gaussian_components.py:253-289
+// Compiled with -ffp-contract=off: `m += x`, `S += x*x'` must round the product and the sum
+// separately so that the statistics stay bit-identical to numpy's.
+#include "bgmm_device.h"
+
+#define TPB 256
+
+// ------------------------------------------------------------------------------------------
+// Initial statistics: one block per initial label, members visited in ascending i.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void init_stats_kernel(Dev d, const int *__restrict__ members,
+                                                         const long long *__restrict__ offsets) {
+    const int k = blockIdx.x;                 // initial label == slot
+    const int D = d.D;
+    const long long lo = offsets[k], hi = offsets[k + 1];
+    for (int e = threadIdx.x; e < D * D; e += TPB) {
+        const int a = e / D, b = e % D;
+        double acc = d.prior_S[e];
+        for (long long t = lo; t < hi; ++t) {
+            const double *x = d.X + (long long)members[t] * D;
+            acc = __dadd_rn(acc, __dmul_rn(x[a], x[b]));
+        }
+        d.S[(long long)k * D * D + e] = acc;
+    }
+    for (int a = threadIdx.x; a < D; a += TPB) {
+        double acc = d.prior_m[a];
+        for (long long t = lo; t < hi; ++t) acc = __dadd_rn(acc, d.X[(long long)members[t] * D + a]);
+        d.m[(long long)k * D + a] = acc;
+    }
+    if (threadIdx.x == 0) d.n[k] = (int)(hi - lo);
+}
+
+__global__ void init_labels_kernel(Dev d, const long long *__restrict__ z_in, int K_init) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.N) d.z[i] = (int)z_in[i];
+    if (i < d.K_max) { d.perm[i] = (int)i; d.label_of_slot[i] = (int)i; }
+    if (i == 0) {
+        Ctrl *c = d.ctrl;
+        c->job.K = K_init;
+        c->job.mode = MODE_DONE;
+        c->error = 0;
+        c->first_mover = kNoMover;
+        c->n_refresh = 0;
+    }
+    // slots that are not part of the initial labelling start empty
+    if (i >= K_init && i < d.K_max) d.n[i] = 0;
+}
+
+void launch_init_stats(const Dev &d, const int *members, const long long *offsets, int K_init,
+                       hipStream_t st) {
+    // (labels first: it zeroes the counts of unused slots)
+    (void)members; (void)offsets;
+    if (K_init > 0) hipLaunchKernelGGL(init_stats_kernel, dim3(K_init), dim3(TPB), 0, st, d, members, offsets);
+}
+
+// ------------------------------------------------------------------------------------------
+// Refresh: everything derived from (n, m, S) of one slot.
+//   C = S - k_N mu mu^T  (the reference's S_N; its covariance is c*C with
+//   c = (k_N+1)/(k_N (v_N-D+1))),  C = L L^T,  Winv = L^-1,  logdetC = 2 sum log L_jj.
+// LDS: A[D][D] + mu[D] + row[D].
+// ------------------------------------------------------------------------------------------
+int refresh_lds_bytes(int D) { return (D * D + 2 * D) * (int)sizeof(double); }
+
+__device__ __forceinline__ double student_const(const Dev &d, long long v) {
+    const double hd = 0.5 * (double)d.D;
+    return d.tab_lgam[v + d.D] - d.tab_lgam[v] - hd * d.tab_log[v] - hd * BGMM_LOG_PI;
+}
+
+__device__ __forceinline__ double seat_weight(const Dev &d, int n) {
+    if (n <= 0) return 0.0;
+    return d.use_power ? log(pow((double)n, d.power)) : log((double)n);
+}
+
+__device__ void refresh_slot(const Dev &d, int s, double *sm) {
+    const int D = d.D, Dp = d.Dp, tid = threadIdx.x;
+    double *A = sm;                // D*D, row major, lower triangle used
+    double *mu = sm + D * D;       // D
+    double *row = mu + D;          // D
+    const int n = d.n[s];
+    const double k_N = d.k0 + (double)n;
+    const double *m = d.m + (long long)s * D;
+    const double *S = d.S + (long long)s * D * D;
+
+    for (int a = tid; a < D; a += TPB) {
+        const double v = m[a] / k_N;
+        mu[a] = v;
+        d.mu[(long long)s * D + a] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += TPB) {
+        const int a = e / D, b = e % D;
+        if (b <= a) A[e] = S[e] - k_N * (mu[a] * mu[b]);
+    }
+    // --- Cholesky, right looking, 2 barriers per column ---
+    bool bad = false;
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int j = 0; j < D; ++j) {
+        __syncthreads();
+        const double djj = A[j * D + j];
+        if (!(djj > 0.0)) bad = true;
+        const double piv = sqrt(djj);
+        for (int i = j + 1 + tid; i < D; i += TPB) A[i * D + j] = A[i * D + j] / piv;
+        __syncthreads();
+        if (tid == 0) A[j * D + j] = piv;
+        for (int i = j + 1 + ty; i < D; i += 16) {
+            const double lij = A[i * D + j];
+            for (int l = j + 1 + tx; l <= i; l += 16) A[i * D + l] = fma(-lij, A[l * D + j], A[i * D + l]);
+        }
+    }
+    __syncthreads();
+    // logdetC (sequential, deterministic)
+    double logdetC = 0.0;
+    if (tid == 0) {
+        for (int j = 0; j < D; ++j) logdetC += log(A[j * D + j]);
+        logdetC *= 2.0;
+        if (bad || !(logdetC == logdetC)) atomicCAS(&d.ctrl->error, 0, -4);
+    }
+    // --- in-place inverse of the lower-triangular factor, row by row ---
+    // Winv[i][c] = -(sum_{t=c}^{i-1} L[i][t] Winv[t][c]) / L[i][i],  Winv[i][i] = 1/L[i][i]
+    int P = 1;
+    while (P < D) P <<= 1;                 // columns padded to a power of two
+    int tpc = TPB / P;                     // threads cooperating on one column
+    if (tpc < 1) tpc = 1;
+    if (tpc > 64) tpc = 64;
+    const int col = tid / tpc, part = tid % tpc;
+    for (int i = 0; i < D; ++i) {
+        for (int t = tid; t <= i; t += TPB) row[t] = A[i * D + t];
+        __syncthreads();
+        const double inv_d = 1.0 / row[i];
+        for (int c0 = 0; c0 <= i; c0 += TPB / tpc) {   // (one pass unless D > TPB/tpc)
+            const int c = c0 + col;
+            double acc = 0.0;
+            if (c < i)
+                for (int t = c + part; t < i; t += tpc) acc = fma(row[t], A[t * D + c], acc);
+            for (int o = tpc >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (part == 0) {
+                if (c < i) A[i * D + c] = -acc * inv_d;
+                else if (c == i) A[i * D + i] = inv_d;
+            }
+        }
+        __syncthreads();
+    }
+    // --- cvec = Winv mu, and the three output layouts ---
+    for (int j = tid; j < Dp; j += TPB) {
+        double acc = 0.0;
+        if (j < D)
+            for (int l = 0; l <= j; ++l) acc = fma(A[j * D + l], mu[l], acc);
+        d.cvec[(long long)s * Dp + j] = acc;
+    }
+    for (int e = tid; e < D * D; e += TPB) {
+        const int a = e / D, b = e % D;
+        d.Wrm[(long long)s * D * D + e] = (b <= a) ? A[e] : 0.0;
+    }
+    {
+        double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
+        const int nJ = Dp / 16;
+        for (int J = 0; J < nJ; ++J) {
+            const int base = 2 * J * (J + 1);
+            for (int e = tid; e < 4 * (J + 1) * 64; e += TPB) {
+                const int kk = e >> 6, lane = e & 63;
+                const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
+                wf[(base + kk) * 64 + lane] = (j < D && l <= j) ? -A[j * D + l] : 0.0;
+            }
+        }
+    }
+    // --- scalar constants ---
+    if (tid == 0) {
+        SlotConst c;
+        const double Dd = (double)D;
+        const long long v = d.v0 + n - D + 1;
+        const double cs = (k_N + 1.0) / (k_N * (double)v);
+        c.logdetC = logdetC;
+        c.A = student_const(d, v) - 0.5 * (Dd * log(cs) + logdetC);
+        c.half_vd = 0.5 * (double)(v + D);
+        c.inv_cv = 1.0 / (cs * (double)v);
+        c.logseat = seat_weight(d, n);
+        c.logseat1 = seat_weight(d, n - 1);
+        c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+        if (n >= 2) {
+            const double k1 = k_N - 1.0;
+            const long long v1 = v - 1;
+            const double c1 = k_N / (k1 * (double)v1);
+            const double a = k_N / k1;
+            c.a1 = a;
+            c.A1 = student_const(d, v1) - 0.5 * (Dd * log(c1) + logdetC);
+            c.half_vd1 = 0.5 * (double)(v1 + D);
+            c.coef1 = a * a / (c1 * (double)v1);
+        }
+        c.pad0 = 0.0; c.pad1 = 0.0;
+        d.sc[s] = c;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x < n) refresh_slot(d, slots ? slots[blockIdx.x] : (int)blockIdx.x, sm);
+}
+
+__global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const Ctrl *c = d.ctrl;
+    if ((int)blockIdx.x < c->n_refresh) refresh_slot(d, c->refresh[blockIdx.x], sm);
+}
+
+static void ensure_lds(const void *fn, int bytes) {
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) {
+    if (n <= 0) return;
+    const int lds = refresh_lds_bytes(d.D);
+    ensure_lds((const void *)refresh_list_kernel, lds);
+    hipLaunchKernelGGL(refresh_list_kernel, dim3(n), dim3(TPB), lds, st, d, slots, n);
+}
+
+void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
+    const int lds = refresh_lds_bytes(d.D);
+    ensure_lds((const void *)refresh_ctrl_kernel, lds);
+    hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
+}
+
+// ------------------------------------------------------------------------------------------
+// Window bookkeeping (thread 0 of the applier / sweep_begin only)
+// ------------------------------------------------------------------------------------------
+__device__ void set_chunks(const Dev &d, Job &j) {
+    const long long rows = j.win_hi - j.pos;
+    const long long rb = (rows + d.rows_per_block - 1) / d.rows_per_block;
+    const int nlist = (j.mode == MODE_FRESH) ? j.K : j.n_dirty;
+    long long ch = rb > 0 ? (1024 + rb - 1) / rb : 1;
+    if (ch > kMaxChunks) ch = kMaxChunks;
+    if (ch > nlist) ch = nlist;
+    if (ch < 1) ch = 1;
+    j.chunks = (int)ch;
+}
+
+__device__ void start_window(const Dev &d, Ctrl *c, long long pos) {
+    Job &j = c->job;
+    j.pos = pos;
+    j.win_base = pos;
+    long long hi = pos + c->win_size;
+    if (hi > c->n_visits) hi = c->n_visits;
+    j.win_hi = hi;
+    j.n_dirty = 0;
+    if (pos >= c->n_visits) {
+        j.mode = MODE_DONE;
+    } else {
+        j.mode = MODE_FRESH;
+        c->n_windows += 1;
+    }
+    set_chunks(d, j);
+}
+
+__global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
+    Ctrl *c = d.ctrl;
+    const int K = c->job.K;
+    // seating weights depend on the sweep's exponent
+    for (int j = threadIdx.x; j < K; j += TPB) {
+        const int s = d.perm[j];
+        d.sc[s].logseat = seat_weight(d, d.n[s]);
+        d.sc[s].logseat1 = seat_weight(d, d.n[s] - 1);
+    }
+    if (threadIdx.x == 0) {
+        c->n_visits = d.N;
+        c->first_mover = kNoMover;
+        c->n_refresh = 0;
+        c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
+        c->n_score_launches = 0; c->n_scored = 0;
+        c->last_mover = -1;
+        if (c->win_size < 256) c->win_size = 256;
+        if (c->win_size > c->win_cap) c->win_size = c->win_cap;
+        if (c->error == 0) start_window(d, c, 0);
+        else c->job.mode = MODE_DONE;
+    }
+}
+
+void launch_sweep_begin(const Dev &d, hipStream_t st) {
+    hipLaunchKernelGGL(sweep_begin_kernel, dim3(1), dim3(TPB), 0, st, d);
+}
+
+// ------------------------------------------------------------------------------------------
+// Moves.  `unseat` / `seat` update the label<->slot maps and counts (thread 0) and report
+// which slots need their (m, S) touched; the block then applies the rank-1 changes.
+// ------------------------------------------------------------------------------------------
+struct MovePlan {
+    long long i;
+    int sub_slot;     // slot to subtract x from (-1: none)
+    int add_slot;     // slot to add x to (-1: none)
+    int add_init;     // 1: add_slot is a freshly opened component (start from the prior)
+};
+
+// remove point i from its slot (del_item semantics).  Returns slot to subtract from, or -1.
+__device__ int plan_unseat(const Dev &d, Ctrl *c, long long i) {
+    const int h = d.z[i];
+    if (h < 0) return -1;
+    d.z[i] = -1;
+    const int nh = d.n[h] - 1;
+    d.n[h] = nh;
+    if (nh > 0) return h;
+    // swap-with-last delete of label lab (gaussian_components.py:188-205)
+    const int lab = d.label_of_slot[h];
+    const int last = c->job.K - 1;
+    const int s_last = d.perm[last];
+    d.perm[lab] = s_last;
+    d.label_of_slot[s_last] = lab;
+    d.perm[last] = h;
+    d.label_of_slot[h] = last;
+    c->job.K = last;
+    return -1;
+}
+
+// seat point i at label `lab` (add_item semantics); returns 0 or an error code
+__device__ int plan_seat(const Dev &d, Ctrl *c, long long i, int lab, MovePlan &mp) {
+    int K = c->job.K;
+    int t;
+    mp.add_init = 0;
+    if (lab >= K) {
+        if (K >= d.K_max) return -3;
+        t = d.perm[K];
+        d.label_of_slot[t] = K;
+        d.n[t] = 0;
+        c->job.K = K + 1;
+        mp.add_init = 1;
+    } else {
+        t = d.perm[lab];
+    }
+    d.n[t] += 1;
+    d.z[i] = t;
+    mp.add_slot = t;
+    return 0;
+}
+
+__device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
+    const int D = d.D;
+    const double *x = d.X + mp.i * D;
+    if (mp.sub_slot >= 0) {
+        double *m = d.m + (long long)mp.sub_slot * D;
+        double *S = d.S + (long long)mp.sub_slot * D * D;
+        for (int a = threadIdx.x; a < D; a += TPB) m[a] = __dsub_rn(m[a], x[a]);
+        for (int e = threadIdx.x; e < D * D; e += TPB)
+            S[e] = __dsub_rn(S[e], __dmul_rn(x[e / D], x[e % D]));
+    }
+    if (mp.add_slot >= 0) {
+        double *m = d.m + (long long)mp.add_slot * D;
+        double *S = d.S + (long long)mp.add_slot * D * D;
+        for (int a = threadIdx.x; a < D; a += TPB)
+            m[a] = __dadd_rn(mp.add_init ? d.prior_m[a] : m[a], x[a]);
+        for (int e = threadIdx.x; e < D * D; e += TPB)
+            S[e] = __dadd_rn(mp.add_init ? d.prior_S[e] : S[e], __dmul_rn(x[e / D], x[e % D]));
+    }
+}
+
+__device__ void set_refresh(Ctrl *c, const MovePlan &mp) {
+    int nr = 0;
+    if (mp.sub_slot >= 0) c->refresh[nr++] = mp.sub_slot;
+    if (mp.add_slot >= 0 && mp.add_slot != mp.sub_slot) c->refresh[nr++] = mp.add_slot;
+    c->n_refresh = nr;
+}
+
+__global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
+    __shared__ MovePlan mp;
+    __shared__ int do_move;
+    Ctrl *c = d.ctrl;
+    if (threadIdx.x == 0) {
+        do_move = 0;
+        c->n_refresh = 0;
+        Job &j = c->job;
+        if (j.mode != MODE_DONE) {
+            c->n_steps += 1;
+            c->n_score_launches += 1;
+            c->n_scored += (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
+            const unsigned long long fm = c->first_mover;
+            c->first_mover = kNoMover;
+            if (fm == kNoMover) {
+                // every visit of the window keeps its component: the state is untouched
+                c->lik_evals += (j.win_hi - j.pos) * (long long)j.K;
+                if (j.pos == j.win_base) {           // a clean window: be more optimistic
+                    long long w = 2ll * c->win_size;
+                    c->win_size = (int)(w > c->win_cap ? c->win_cap : w);
+                }
+                start_window(d, c, j.win_hi);
+            } else {
+                const long long p = (long long)fm;
+                c->lik_evals += (p - j.pos) * (long long)j.K;
+                mp.i = d.order ? d.order[p] : p;
+                const int lab = d.choice[p - j.win_base];
+                mp.sub_slot = plan_unseat(d, c, mp.i);
+                mp.add_slot = -1;
+                c->lik_evals += j.K;                 // K after the removal
+                const int rc = plan_seat(d, c, mp.i, lab, mp);
+                if (rc != 0) {
+                    atomicCAS(&c->error, 0, rc);
+                    j.mode = MODE_DONE;
+                } else {
+                    do_move = 1;
+                    set_refresh(c, mp);
+                    c->n_moves += 1;
+                    // adaptive window: about half the running mean distance between movers
+                    const double run = (double)(p - c->last_mover);
+                    c->last_mover = p;
+                    c->ema_run = 0.875 * c->ema_run + 0.125 * run;
+                    long long w = 256;
+                    while (w < c->win_cap && (double)w < 0.5 * c->ema_run) w <<= 1;
+                    if (w > c->win_cap) w = c->win_cap;
+                    c->win_size = (int)w;
+                    if (p + 1 >= j.win_hi) {
+                        start_window(d, c, p + 1);
+                    } else {
+                        j.pos = p + 1;
+                        j.mode = MODE_PARTIAL;
+                        j.n_dirty = c->n_refresh;
+                        j.dirty[0] = c->refresh[0];
+                        j.dirty[1] = c->refresh[1];
+                        set_chunks(d, j);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (do_move) apply_rank1(d, mp);
+}
+
+void launch_apply(const Dev &d, hipStream_t st) {
+    hipLaunchKernelGGL(apply_kernel, dim3(1), dim3(TPB), 0, st, d);
+}
+
+// op 0: del_item(i); op 1: add_item(i, label)
+__global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, int label) {
+    __shared__ MovePlan mp;
+    __shared__ int ok;
+    Ctrl *c = d.ctrl;
+    if (threadIdx.x == 0) {
+        mp.i = i; mp.sub_slot = -1; mp.add_slot = -1; mp.add_init = 0;
+        ok = 1;
+        if (op == 0) {
+            mp.sub_slot = plan_unseat(d, c, i);
+        } else {
+            const int rc = (label < 0 || label > c->job.K) ? -1 : plan_seat(d, c, i, label, mp);
+            if (rc != 0) { atomicCAS(&c->error, 0, rc); ok = 0; }
+        }
+        set_refresh(c, mp);
+        if (!ok) c->n_refresh = 0;
+    }
+    __syncthreads();
+    if (ok) apply_rank1(d, mp);
+}
+
+void launch_item_op(const Dev &d, int op, long long i, int label, hipStream_t st) {
+    hipLaunchKernelGGL(item_kernel, dim3(1), dim3(TPB), 0, st, d, op, i, label);
+}
+
+// ------------------------------------------------------------------------------------------
+// Read-outs
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void log_marg_kernel(Dev d, double *out_total, double *out_per_label) {
+    const Ctrl *c = d.ctrl;
+    const int K = c->job.K, D = d.D;
+    const double hd = 0.5 * (double)D;
+    const double logdetS0 = d.sc[d.K_max].logdetC;     // pseudo slot: C == S_0
+    for (int j = threadIdx.x; j < K; j += TPB) {
+        const int s = d.perm[j];
+        const int n = d.n[s];
+        const double k_N = d.k0 + (double)n;
+        const long long v_N = d.v0 + n;
+        double gs = 0.0;
+        for (int t = 1; t <= D; ++t) gs += d.tab_lgam[v_N + 1 - t] - d.tab_lgam[d.v0 + 1 - t];
+        out_per_label[j] = -(double)n * hd * BGMM_LOG_PI + hd * log(d.k0) - hd * log(k_N)
+                           + 0.5 * (double)d.v0 * logdetS0 - 0.5 * (double)v_N * d.sc[s].logdetC + gs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum_n = 0.0, sum_lf = 0.0, px = 0.0;
+        for (int j = 0; j < K; ++j) {
+            const int n = d.n[d.perm[j]];
+            sum_n += (double)n;
+            if (n > 0) sum_lf += lgamma((double)n);
+            px += out_per_label[j];
+        }
+        const double pz = (double)(K - 1) * d.log_alpha + lgamma(d.alpha) - lgamma(sum_n + d.alpha) + sum_lf;
+        *out_total = pz + px;
+    }
+}
+
+void launch_log_marg(const Dev &d, double *out_total, double *out_per_label, hipStream_t st) {
+    hipLaunchKernelGGL(log_marg_kernel, dim3(1), dim3(TPB), 0, st, d, out_total, out_per_label);
+}
+
+__global__ void labels_kernel(Dev d, long long *z_out, long long *counts_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z_out && i < d.N) {
+        const int s = d.z[i];
+        z_out[i] = s < 0 ? -1 : d.label_of_slot[s];
+    }
+    if (counts_out && i < d.ctrl->job.K) counts_out[i] = d.n[d.perm[i]];
+}
+
+void launch_labels(const Dev &d, long long *z_out, long long *counts_out, hipStream_t st) {
+    const long long n = d.N > d.K_max ? d.N : d.K_max;
+    hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, z_out, counts_out);
+}
+
+__global__ void prior_lp_kernel(Dev d, const double *__restrict__ qcol) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    const SlotConst c = d.sc[d.K_max];
+    d.log_prior[i] = c.A - c.half_vd * log(1.0 + qcol[i] * c.inv_cv);
+}
+
+void launch_prior_lp(const Dev &d, const double *qcol, hipStream_t st) {
+    hipLaunchKernelGGL(prior_lp_kernel, dim3((unsigned)((d.N + 255) / 256)), dim3(256), 0, st, d, qcol);
+}
+
+__global__ void post_pred_kernel(Dev d, const double *__restrict__ qrow, double *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.ctrl->job.K) return;
+    const int s = d.perm[j];
+    const SlotConst c = d.sc[s];
+    out[j] = c.A - c.half_vd * log(1.0 + qrow[s] * c.inv_cv);
+}
+
+void launch_post_pred(const Dev &d, const double *qrow, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(post_pred_kernel, dim3((unsigned)((d.K_max + 255) / 256)), dim3(256), 0, st, d, qrow, out);
+}
+
+// stats export in label order: m, S, logdet(covar), inv(covar) as the reference stores them
+__global__ __launch_bounds__(TPB) void export_stats_kernel(Dev d, double *m_out, double *S_out,
+                                                           double *logdet_out, double *inv_out) {
+    const int j = blockIdx.x;
+    if (j >= d.ctrl->job.K) return;
+    const int s = d.perm[j], D = d.D;
+    const int n = d.n[s];
+    const double k_N = d.k0 + (double)n;
+    const double cs = (k_N + 1.0) / (k_N * (double)(d.v0 + n - D + 1));
+    if (m_out) for (int a = threadIdx.x; a < D; a += TPB) m_out[(long long)j * D + a] = d.m[(long long)s * D + a];
+    if (S_out) for (int e = threadIdx.x; e < D * D; e += TPB) S_out[(long long)j * D * D + e] = d.S[(long long)s * D * D + e];
+    if (logdet_out && threadIdx.x == 0) logdet_out[j] = (double)D * log(cs) + d.sc[s].logdetC;
+    if (inv_out) {
+        const double *W = d.Wrm + (long long)s * D * D;
+        for (int e = threadIdx.x; e < D * D; e += TPB) {
+            const int a = e / D, b = e % D;
+            double acc = 0.0;
+            for (int t = (a > b ? a : b); t < D; ++t) acc = fma(W[t * D + a], W[t * D + b], acc);
+            inv_out[(long long)j * D * D + e] = acc / cs;
+        }
+    }
+}
+
+void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
+                         double *inv_out, hipStream_t st) {
+    if (K > 0) hipLaunchKernelGGL(export_stats_kernel, dim3(K), dim3(TPB), 0, st, d, m_out, S_out, logdet_out, inv_out);
+}
+
+void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st) {
+    const long long n = d.N > d.K_max ? d.N : d.K_max;
+    hipLaunchKernelGGL(init_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, z_in, K_init);
+}

@@ -1,0 +1,63 @@
+"""
+Per-sweep record keeping: the record_dict of reference pybgmm/gmm/gmm.py:45-118.
+
+``sample_time`` keeps the reference's meaning: wall time of the sweep only (the
+timer is restarted after the record is taken, igmm/crpmm.py:91-92).  ``log_marg``,
+``components`` and ``nk`` come from device state.  The clustering metrics
+(nmi / mi / vi / loss / bic) are SURVEY.md 8(f) "next" rows; until they are
+built on the device they are evaluated on the host only when
+``self.record_metrics`` is True and otherwise recorded as NaN.
+"""
+import logging
+import time
+
+import numpy as np
+
+from ..utils import metrics as _metrics
+
+logger = logging.getLogger(__name__)
+
+RECORD_KEYS = ("sample_time", "log_marg", "components", "nmi", "mi", "nk", "loss", "bic", "vi",
+               "alpha")
+
+
+class GMM(object):
+    record_metrics = True
+
+    def __init__(self):
+        pass
+
+    def label_switch(self, idx, nplist):
+        return np.array(nplist)[idx]
+
+    def setup_record_dict(self):
+        return dict((key, []) for key in RECORD_KEYS)
+
+    def update_record_dict(self, record_dict, i_iter, true_assignments, start_time):
+        record_dict["sample_time"].append(time.time() - start_time)
+        record_dict["log_marg"].append(self.log_marg())
+        K = self.components.K
+        record_dict["components"].append(K)
+        counts = self.components.counts[:K]
+        if self.record_metrics and true_assignments is not None:
+            z = self.components.assignments
+            nmi = _metrics.normalized_mutual_information(true_assignments, z)
+            mi = _metrics.mutual_information(true_assignments, z)
+            loss = _metrics.cluster_loss_inertia(self.components.X, z)
+            vi = _metrics.information_variation(true_assignments, z, base=2)
+        else:
+            nmi = mi = loss = vi = float("nan")
+        record_dict["nmi"].append(nmi)
+        record_dict["mi"].append(mi)
+        record_dict["nk"].append(str(counts))
+        record_dict["loss"].append(loss)
+        record_dict["bic"].append(loss)     # the reference records the same quantity twice (gmm.py:96-101)
+        record_dict["vi"].append(vi)
+        record_dict["alpha"].append(self.alpha)
+        if i_iter % 20 == 0:
+            info = "iteration: " + str(i_iter)
+            for key in sorted(record_dict):
+                info += ", " + key + ": " + str(record_dict[key][-1])
+            info += "."
+            logger.info(info)
+        return record_dict

@@ -1,0 +1,129 @@
+"""
+Base class of the infinite Gaussian mixture samplers -- the interface of reference
+pybgmm/igmm/igmm.py:37-227 (``IGMM``), with the components on the GPU.
+"""
+import math
+
+import numpy as np
+from scipy import stats
+from scipy.special import gammaln
+
+from ..gaussian.gaussian_components import GaussianComponents
+from ..gmm import GMM
+from ..utils import rng as _rng
+
+
+def compact_labels(z):
+    """Close gaps in a label vector keeping the order of the labels -- the net effect of
+    the reference's shift-down loop (igmm.py:89-94)."""
+    return np.unique(z, return_inverse=True)[1].astype(np.int64)
+
+
+class IGMM(GMM):
+    """
+    An infinite Gaussian mixture model.
+
+    X : N x D data.  kernel_prior : ``NIW``.  alpha : CRP concentration.
+    assignments : vector of initial labels (-1 = unassigned) or one of
+      "rand" (``np.random.randint(0, K, N)`` from the global stream),
+      "one-by-one" (only X[0] seated), "each-in-own".
+    K : initial number of components for "rand".  K_max : component slots.
+    covariance_type : "full" ("diag"/"fixed" are not built yet).
+    device : GPU ordinal (extension).  rng / nprng : ``random.Random`` /
+      ``np.random.RandomState`` to draw from instead of the process-global streams
+      (extension, used for one-chain-per-GPU runs).
+    """
+
+    def __init__(self, X, kernel_prior, alpha, save_path, assignments="rand", K=1, K_max=None,
+                 covariance_type="full", device=0, rng=None, nprng=None):
+        super(IGMM, self).__init__()
+        X = np.asarray(X)
+        if len(X.shape) < 2:
+            raise ValueError('X must be at least a 2-dimensional array.')
+        self.save_path = save_path
+        self.alpha = alpha
+        self.N, self.D = X.shape
+        self._rng = rng
+        self._nprng = np.random if nprng is None else nprng
+
+        if isinstance(assignments, str):
+            if assignments == "rand":
+                assignments = compact_labels(self._nprng.randint(0, K, self.N))
+            elif assignments == "one-by-one":
+                assignments = -1 * np.ones(self.N, dtype="int")
+                assignments[0] = 0
+            elif assignments == "each-in-own":
+                assignments = np.arange(self.N)
+            else:
+                raise ValueError("unknown assignments mode %r" % (assignments,))
+
+        if covariance_type == "full":
+            self.components = GaussianComponents(X, kernel_prior, assignments, K_max,
+                                                 device=device, alpha=alpha)
+        elif covariance_type in ("diag", "fixed"):
+            raise NotImplementedError(
+                "covariance_type=%r is a later row of the build (SURVEY.md 8f)" % covariance_type)
+        else:
+            assert False, "Invalid covariance type."
+
+    # ------------------------------------------------------------------ #
+    def setup_distribution_dict(self, num_saved):
+        return {"mean": np.zeros(shape=(num_saved, 0)),
+                "variance": np.zeros(shape=(num_saved, 0)),
+                "weights": np.zeros(shape=(num_saved, 0))}
+
+    def update_distribution_dict(self, distribution_dict, weight_first):
+        """Snapshot of MAP means / variances / Dirichlet weights with the reference's
+        label-switch ordering (igmm.py:128-197).  The matplotlib output of the
+        reference for D == 2 is not produced; the ``np.random`` Dirichlet draw is,
+        so the caller-visible stream stays aligned."""
+        K = self.components.K
+        means, sds = [], []
+        for k in range(K):
+            mu, sigma = self.components.map(k)
+            means.append(mu)
+            sds.append(sigma)
+        sds = np.array(sds).flatten()
+        means = np.array(means).flatten()
+        if weight_first:
+            weights = self.gibbs_weight()
+            idx = np.argsort(weights)
+        else:
+            idx = np.argsort(means)
+            weights = self.gibbs_weight()
+        means = self.label_switch(idx, means)
+        sds = self.label_switch(idx, sds)
+        weights = self.label_switch(idx, weights)
+        self.old_mean, self.old_sigma = means, sds
+        for key, val in (("mean", means), ("variance", sds), ("weights", weights)):
+            distribution_dict[key] = np.hstack((distribution_dict[key], val.reshape((val.shape[0], 1))))
+        return distribution_dict
+
+    def log_marg(self):
+        """log p(X, z) (igmm.py:199-215), evaluated on the device."""
+        return self.components._ctx.log_marg()
+
+    def log_marg_host(self):
+        """The same quantity assembled on the host from downloaded counts and the
+        per-component device marginals (cross-check for tests)."""
+        K = self.components.K
+        counts = self.components.counts[:K]
+        facts_ = gammaln(counts)
+        facts_[counts == 0] = 0
+        log_prob_z = ((K - 1) * math.log(self.alpha) + gammaln(self.alpha)
+                      - gammaln(np.sum(counts) + self.alpha) + np.sum(facts_))
+        return log_prob_z + self.components.log_marg()
+
+    def gibbs_weight(self):
+        K = self.components.K
+        Nk = self.components.counts[:K].tolist()
+        alpha = [Nk[cid] + self.alpha / K for cid in range(K)]
+        if self._nprng is np.random:
+            return stats.dirichlet(alpha).rvs(size=1).flatten()
+        return stats.dirichlet(alpha).rvs(size=1, random_state=self._nprng).flatten()
+
+    # ------------------------------------------------------------------ #
+    def _sweep(self, order=None, power=None):
+        """One device sweep fed from the caller's random streams."""
+        u = _rng.take_uniforms(self.N, self._rng)
+        self.components._ctx.sweep(u, order, power)

@@ -1,0 +1,250 @@
+"""
+Parity of the HIP path (through the C-ABI) with the reference.
+
+  * every golden trajectory captured from the reference (tests/golden), label for label,
+    sweep by sweep, with both likelihood kernels;
+  * the reference's own known-answer values;
+  * the C oracle on fresh seeded problems;
+  * at BASELINE sizes, size-independent properties (window-size independence,
+    kernel independence, determinism, statistics consistent with a from-scratch rebuild).
+Tolerances: integer trajectory bit-exact; log marginal 1e-6 relative (north_star), observed
+~1e-12; m / S bit-exact; logdet / inverse 1e-8.
+"""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from golden_util import ALL_CASES, Golden
+from pybgmm_amd.gaussian.gaussian_components import reference_tables
+
+pytestmark = pytest.mark.gpu
+
+LM_RTOL = 1e-6
+
+
+def make_ctx(g, kind=0, window=0, tables=True):
+    from pybgmm_amd import _lib
+    ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max,
+                       tables=reference_tables(g.v_0, g.N) if tables else None)
+    ctx.set_tuning(max_window=window, kernel_kind=kind)
+    ctx.set_assignments(g.z_init)
+    return ctx
+
+
+@pytest.mark.parametrize("kind", [1, 2], ids=["valu", "mfma"])
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_golden_trajectory(case, kind):
+    g = Golden(case)
+    ctx = make_ctx(g, kind)
+    npt.assert_allclose(ctx.log_prior()[:4096], g.d["cached_log_prior"], rtol=1e-11, atol=1e-11)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        z = ctx.assignments()
+        bad = np.nonzero(z != g.z[it])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        assert ctx.K == g.K[it]
+        npt.assert_array_equal(ctx.counts(), g.counts_at(it))
+        lm = ctx.log_marg()
+        assert abs(lm - g.log_marg[it]) <= LM_RTOL * abs(g.log_marg[it])
+        assert abs(lm - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it]), "observed accuracy regressed"
+    if "final_S" in g.d.files:
+        m, S, ld, iv = ctx.stats()
+        npt.assert_array_equal(m, g.d["final_m"])       # bit-exact sufficient statistics
+        npt.assert_array_equal(S, g.d["final_S"])
+        npt.assert_allclose(ld, g.d["final_logdet"], rtol=1e-8, atol=1e-8)
+        npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-7, atol=1e-9)
+    ctx.close()
+
+
+@pytest.mark.parametrize("window", [256, 1024])
+@pytest.mark.parametrize("case", ["c2twin_crpmm_2d", "c3rand_pcrpmm_16d", "each_in_own_50"])
+def test_window_size_does_not_change_trajectory(case, window):
+    g = Golden(case)
+    ctx = make_ctx(g, 0, window)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        npt.assert_array_equal(ctx.assignments(), g.z[it])
+    ctx.close()
+
+
+def test_libm_tables():
+    g = Golden("kat1_igmm_2d")
+    ctx = make_ctx(g, tables=False)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it])
+    npt.assert_array_equal(ctx.assignments(), g.z[-1])
+    ctx.close()
+
+
+def test_first_visit_probabilities():
+    """prob_z of the very first visit (reference probe) from log_post_pred + del_item."""
+    g = Golden("kat1_igmm_2d")
+    ctx = make_ctx(g)
+    p_ref, _u, _k = g.probes()[0]
+    ctx.del_item(0)
+    K = ctx.K
+    lp = np.zeros(K + 1)
+    lp[:K] = np.log(ctx.counts()) + ctx.log_post_pred(0)
+    lp[-1] = np.log(g.alpha) + ctx.log_prior()[0]
+    p = np.exp(lp - np.logaddexp.reduce(lp))
+    npt.assert_allclose(p, p_ref, rtol=1e-10, atol=1e-14)
+    ctx.close()
+
+
+# ---- the reference's component known answers (pybgmm/tests/test_gaussian_components.py) ----
+def test_component_known_answers():
+    from pybgmm_amd.gaussian import GaussianComponents
+    from pybgmm_amd.prior import NIW
+    X = np.array([[-0.3406, -0.0593, -0.0686]])
+    gmm = GaussianComponents(X, NIW(np.zeros(3), 0.05, 4, 0.001 * np.eye(3)))
+    npt.assert_almost_equal(gmm.log_prior(0), -0.472067277015)
+
+    X = np.array([[-0.3406, -0.3593, -0.0686], [-0.3381, 0.2993, 0.925], [-0.5, -0.101, 0.75]])
+    gmm = GaussianComponents(X, NIW(np.zeros(3), 0.05, 6, 0.5 * np.eye(3)), [0, 0, 0])
+    npt.assert_almost_equal(gmm.log_marg_k(0), -8.42365141729)
+
+    prior = NIW(m_0=np.array([0.0, 0.0]), k_0=2., v_0=5, S_0=5. * np.eye(2))
+    gmm = GaussianComponents(np.array([[1.2, 0.9], [-0.1, 0.8], [0.5, 0.4]]), prior)
+    gmm.add_item(0, 0)
+    gmm.add_item(1, 0)
+    npt.assert_almost_equal(gmm.log_post_pred_k(2, 0), -2.07325364088)
+    mu, sigma = gmm.map(0)
+    npt.assert_almost_equal(mu, [0.275, 0.425])
+    npt.assert_almost_equal(sigma, [[0.55886364, 0.04840909], [0.04840909, 0.52068182]])
+
+
+def test_add_del_item_roundtrip_and_delete_swap():
+    from pybgmm_amd.gaussian import GaussianComponents
+    from pybgmm_amd.prior import NIW
+    rs = np.random.RandomState(2)
+    X = rs.rand(11, 4)
+    prior = NIW(X.mean(axis=0), 0.05, 14, 0.5 * np.eye(4))
+    gmm = GaussianComponents(X, prior, [0, 0, 0, 1, 0, 1, 3, 4, 3, 2, -1])
+    assert gmm.K == 5
+    gmm.del_item(9)                       # label 2 was a singleton: label 4 moves into 2
+    assert gmm.K == 4
+    npt.assert_array_equal(gmm.assignments, [0, 0, 0, 1, 0, 1, 3, 2, 3, -1, -1])
+    npt.assert_array_equal(gmm.counts[:4], [4, 2, 1, 2])
+    gmm.add_item(10, 4)                   # opens a new component
+    assert gmm.K == 5 and gmm.assignments[10] == 4
+
+
+# ---- class level: seeds -> same trajectory as the reference classes ------------------------
+def test_crpmm_class_reproduces_reference_kat():
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    g = Golden("kat1_igmm_2d")
+    random.seed(1)
+    np.random.seed(1)
+    X, z_true = gendata.demo_mixture(100, 2, 4, rs=np.random)
+    npt.assert_array_equal(X, g.X)
+    prior = NIW(*gendata.demo_prior_params(2, v_0=5))
+    mm = CRPMM(X, prior, 1.0, None, assignments="rand", K=3)
+    npt.assert_array_equal(mm.components.assignments, g.z_init)
+    record, dist = mm.collapsed_gibbs_sampler(10, z_true, num_saved=0)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
+    assert record["components"] == list(g.K)
+    npt.assert_allclose(record["nmi"], g.d["rec_nmi"], rtol=1e-12)
+    assert [str(s) for s in record["nk"]] == [str(s) for s in g.d["rec_nk"]]
+    npt.assert_almost_equal(mm.log_marg(), -411.811711231)
+    npt.assert_allclose(mm.log_marg_host(), mm.log_marg(), rtol=1e-12)
+
+
+def test_pcrpmm_class_reproduces_reference():
+    import random
+    from pybgmm_amd.igmm import PCRPMM
+    from pybgmm_amd.prior import NIW
+    g = Golden("pcrp_burnin_2d")
+    random.seed(6)
+    np.random.seed(6)
+    mm = PCRPMM(g.X, NIW(*g.prior), g.alpha, None, assignments="rand", K=6, K_max=g.K_max)
+    npt.assert_array_equal(mm.components.assignments, g.z_init)
+    record, _ = mm.collapsed_gibbs_sampler(g.n_iter, g.d["true_assignments"], n_power=1.5,
+                                           power_burnin=1, num_saved=0)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
+
+
+def test_k_max_overflow_is_an_error():
+    from pybgmm_amd import _lib
+    g = Golden("each_in_own_50")
+    ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, 1e9, 50)   # huge alpha: always a new table
+    ctx.set_assignments(np.arange(50))
+    with pytest.raises(_lib.BGMMError) as ei:
+        for _ in range(3):
+            ctx.sweep(np.full(50, 0.999999))
+    assert ei.value.code == -3
+    ctx.close()
+
+
+# ---- oracle on fresh seeded problems --------------------------------------------------------
+@pytest.mark.parametrize("N,D,K,init", [(6000, 16, 40, "rand"), (3000, 32, 10, "rand"),
+                                        (5000, 64, 50, "true"), (1500, 128, 6, "rand"),
+                                        (4000, 5, 9, "rand")])
+def test_against_c_oracle(N, D, K, init):
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, z_true = gendata.synth_mixture(N, D, K, seed=100 + D)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D)
+    z0 = z_true if init == "true" else np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    us = rs.random_sample((2, N))
+    order = rs.permutation(N)
+    Kmax = 4 * K
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, Kmax)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, Kmax, tables=reference_tables(v_0, N))
+    ctx.set_assignments(z0)
+    for it in range(2):
+        power = 1.01 if it == 1 else None
+        o.sweep(us[it], order, power)
+        ctx.sweep(us[it], order, power)
+        npt.assert_array_equal(ctx.assignments(), o.z)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+    assert ctx.sweep_stats()["lik_evals"] > 0
+    ctx.close()
+
+
+# ---- BASELINE sizes: size-independent properties -------------------------------------------
+@pytest.mark.parametrize("N,D,K", [(100000, 2, 20), (1000000, 16, 100), (1000000, 64, 200)],
+                         ids=["C2", "C3", "C4"])
+def test_full_size_properties(N, D, K):
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, z_true = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(1)
+    u = rs.random_sample(N)
+    tabs = reference_tables(v_0, N)
+    # perturb the true labelling so that the sweep has real moves to make
+    z0 = z_true.copy()
+    flip = rs.choice(N, size=2000, replace=False)
+    z0[flip] = rs.randint(0, K, size=flip.size)
+    results = []
+    for kind, window in ((0, 0), (1 if D >= 24 else 2, 2048)):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
+        ctx.set_tuning(max_window=window, kernel_kind=kind)
+        ctx.set_assignments(z0)
+        ctx.sweep(u)
+        z = ctx.assignments()
+        c = ctx.counts()
+        lm = ctx.log_marg()
+        st = ctx.sweep_stats()
+        results.append((z, c, lm, st["moves"]))
+        assert c.sum() == N and z.min() >= 0 and z.max() == len(c) - 1
+        npt.assert_array_equal(np.bincount(z, minlength=len(c)), c)
+        if kind == 0:
+            # incremental statistics agree with a from-scratch rebuild of the same labelling
+            ctx2 = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
+            ctx2.set_assignments(z)
+            assert abs(ctx2.log_marg() - lm) <= 1e-9 * abs(lm)
+            ctx2.close()
+        ctx.close()
+    (za, ca, lma, mva), (zb, cb, lmb, mvb) = results
+    npt.assert_array_equal(za, zb)      # kernel kind and window size do not change the chain
+    assert mva == mvb and mva > 0
+    assert abs(lma - lmb) <= 1e-9 * abs(lma)

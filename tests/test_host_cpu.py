@@ -1,0 +1,136 @@
+"""CPU-side checks: host logic, the C-ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from pybgmm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "bgmm.h")).read()
+    declared = set(re.findall(r"\b(bgmm_[A-Za-z_0-9]+)\s*\(", hdr))
+    declared.discard("bgmm_ctx")
+    assert declared == set(_lib.SIGNATURES), declared.symmetric_difference(_lib.SIGNATURES)
+    L = _lib.load()
+    for name in declared:
+        assert hasattr(L, name), "libbgmm_hip.so does not export %s" % name
+    assert L.bgmm_version().decode().startswith("bgmm-hip")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pybgmm_amd import _lib
+    X = np.zeros((4, 2))
+    with pytest.raises(_lib.BGMMError) as ei:
+        _lib.Context(X, np.zeros(2), 1.0, 3, np.eye(2), 1.0, 4)
+    assert ei.value.code == -2
+
+
+def test_argument_validation_before_device():
+    from pybgmm_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    X = np.zeros((4, 2))
+    m, S = np.zeros(2), np.eye(2)
+    # v_0 < D
+    rc = L.bgmm_create(ctypes.byref(h), 0, 4, 2, 4, 0, X.ctypes.data, m.ctypes.data, 1.0, 1,
+                       S.ctypes.data, 1.0, None, None)
+    assert rc == -1 and b"v_0" in L.bgmm_last_error(None)
+    rc = L.bgmm_create(ctypes.byref(h), 0, 4, 2, 4, 1, X.ctypes.data, m.ctypes.data, 1.0, 3,
+                       S.ctypes.data, 1.0, None, None)
+    assert rc == -5
+    rc = L.bgmm_create(ctypes.byref(h), 0, 4, 300, 4, 0, X.ctypes.data, m.ctypes.data, 1.0, 300,
+                       S.ctypes.data, 1.0, None, None)
+    assert rc == -5
+
+
+def test_product_never_imports_oracle():
+    """The shipped path must not import, load or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "pybgmm_amd")
+    pat = re.compile(r"^\s*(from|import)\s+[\w.]*oracle|CDLL\([^)]*oracle|#include\s+[\"<][^\">]*oracle")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                for line in open(os.path.join(dirpath, f)):
+                    assert not pat.search(line), "%s refers to oracle/: %s" % (f, line)
+
+
+def test_take_uniforms_is_the_python_stream():
+    from pybgmm_amd.utils.rng import take_uniforms
+    random.seed(11)
+    a = [random.random() for _ in range(501)]
+    nxt = random.random()
+    random.seed(11)
+    b = take_uniforms(501)
+    npt.assert_array_equal(a, b)
+    assert random.random() == nxt
+    r1, r2 = random.Random(3), random.Random(3)
+    npt.assert_array_equal([r1.random() for _ in range(64)], take_uniforms(64, r2))
+    assert r1.random() == r2.random()
+
+
+def test_chain_rngs_equal_global_streams():
+    from pybgmm_amd.chains import chain_rngs
+    rng, nprng = chain_rngs(5, 2)
+    random.seed(7)
+    np.random.seed(7)
+    assert rng.random() == random.random()
+    npt.assert_array_equal(nprng.permutation(20), np.random.permutation(20))
+    npt.assert_array_equal(nprng.randint(0, 5, 9), np.random.randint(0, 5, 9))
+
+
+def test_compact_labels_equals_shift_down_loop():
+    from pybgmm_amd.igmm.igmm import compact_labels
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        K = rs.randint(1, 12)
+        z = rs.randint(0, K, rs.randint(1, 30))
+        want = z.copy()
+        for k in range(want.max()):            # the reference's loop (igmm.py:89-94), restated
+            while len(np.nonzero(want == k)[0]) == 0:
+                want[np.where(want > k)] -= 1
+            if want.max() == k:
+                break
+        npt.assert_array_equal(compact_labels(z), want)
+
+
+def test_rand_init_matches_golden_init():
+    """'rand' initialisation consumes np.random exactly like the reference (igmm.py:86-94)."""
+    from golden_util import Golden
+    from pybgmm_amd.igmm.igmm import compact_labels
+    for case, K in (("c2twin_crpmm_2d", 20), ("general_prior_3d", 4), ("c1_crpmm_1d", 3)):
+        g = Golden(case)
+        np.random.seed(int(g.d["seed_numpy"]))
+        npt.assert_array_equal(compact_labels(np.random.randint(0, K, g.N)), g.z_init)
+
+
+def test_error_conventions():
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    with pytest.raises(AssertionError):
+        NIW(np.zeros(3), 1.0, 2, np.eye(3))                 # v_0 < D (niw.py:21)
+    prior = NIW(np.zeros(2), 1.0, 3, np.eye(2))
+    with pytest.raises(ValueError):
+        CRPMM(np.zeros(5), prior, 1.0, None)                 # 1-D X (igmm.py:75-76)
+    with pytest.raises(AssertionError):
+        CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="banana")
+    with pytest.raises(NotImplementedError):
+        CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="diag")
+
+
+def test_synth_recipes_are_deterministic():
+    from pybgmm_amd.utils import gendata
+    X1, z1 = gendata.synth_mixture(300, 5, 7, seed=3)
+    X2, z2 = gendata.synth_mixture(300, 5, 7, seed=3)
+    npt.assert_array_equal(X1, X2)
+    npt.assert_array_equal(z1, z2)
+    assert X1.flags["C_CONTIGUOUS"] and X1.dtype == np.float64
+    assert np.bincount(z1).min() >= 300 // 7

@@ -1,0 +1,21 @@
+"""Host-side record-dict metrics against the values the reference recorded."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from golden_util import Golden
+from pybgmm_amd.utils import metrics
+
+
+@pytest.mark.parametrize("case", ["kat1_igmm_2d", "c1_crpmm_1d", "general_prior_3d",
+                                  "each_in_own_50", "c2twin_crpmm_2d"])
+def test_metrics_match_reference(case):
+    g = Golden(case)
+    zt = g.d["true_assignments"]
+    for it in range(g.n_iter):
+        z = g.z[it]
+        npt.assert_allclose(metrics.normalized_mutual_information(zt, z), g.d["rec_nmi"][it], rtol=1e-12, atol=1e-14)
+        npt.assert_allclose(metrics.mutual_information(zt, z), g.d["rec_mi"][it], rtol=1e-12, atol=1e-14)
+        npt.assert_allclose(metrics.information_variation(zt, z, base=2), g.d["rec_vi"][it], rtol=1e-11, atol=1e-12)
+        assert int(metrics.cluster_loss_inertia(g.X, z)) == int(g.d["rec_loss"][it])
+        assert g.d["rec_bic"][it] == g.d["rec_loss"][it]

@@ -1,0 +1,42 @@
+"""The C oracle against the reference's golden vectors and captured trajectories."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from golden_util import ALL_CASES, Golden
+from oracle import c_oracle
+
+
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_trajectory(case):
+    g = Golden(case)
+    o, out = c_oracle.run_chain(g)
+    for it in range(g.n_iter):
+        npt.assert_array_equal(out["z"][it], g.z[it], err_msg="sweep %d" % it)
+        assert out["K"][it] == g.K[it]
+        npt.assert_array_equal(out["counts"][it], g.counts_at(it))
+        assert abs(out["log_marg"][it] - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
+    if "final_S" in g.d.files:
+        m, S, ld, iv = o.stats()
+        # identical trajectory + unfused accumulation => identical sufficient statistics
+        npt.assert_array_equal(m, g.d["final_m"])
+        npt.assert_array_equal(S, g.d["final_S"])
+        npt.assert_allclose(ld, g.d["final_logdet"], rtol=1e-9, atol=1e-9)
+        npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-7, atol=1e-10)
+    npt.assert_allclose(o.log_prior[:4096], g.d["cached_log_prior"], rtol=1e-12)
+
+
+def test_libm_tables_give_same_trajectory():
+    g = Golden("kat1_igmm_2d")
+    _, out = c_oracle.run_chain(g, scipy_tables=False)
+    npt.assert_array_equal(out["z"][-1], g.z[-1])
+
+
+def test_component_kats():
+    # pybgmm/tests/test_gaussian_components.py:33,104 (expected values)
+    X = np.array([[-0.3406, -0.0593, -0.0686]])
+    o = c_oracle.COracle(X, np.zeros(3), 0.05, 4, 0.001 * np.eye(3), 1.0, [-1], 1)
+    npt.assert_almost_equal(o.log_prior[0], -0.472067277015)
+    X = np.array([[1.2, 0.9], [-0.1, 0.8], [0.5, 0.4]])
+    o = c_oracle.COracle(X, np.zeros(2), 2., 5, 5. * np.eye(2), 1.0, [0, 0, -1], 3)
+    npt.assert_almost_equal(o.log_post_pred(2)[0], -2.07325364088)
