@@ -171,12 +171,11 @@ def test_pcrpmm_class_reproduces_reference():
 def test_k_max_overflow_is_an_error():
     from pybgmm_amd import _lib
     g = Golden("each_in_own_50")
-    ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, 1e9, 50)   # huge alpha: always a new table
-    ctx.set_assignments(np.arange(50))
+    ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, 1e300, 3)  # huge alpha: always a new table
+    ctx.set_assignments(np.zeros(50, dtype=np.int64))
     with pytest.raises(_lib.BGMMError) as ei:
-        for _ in range(3):
-            ctx.sweep(np.full(50, 0.999999))
-    assert ei.value.code == -3
+        ctx.sweep(np.full(50, 0.999999))
+    assert ei.value.code == -3 and "K_max" in str(ei.value)
     ctx.close()
 
 
