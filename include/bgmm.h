@@ -85,6 +85,12 @@ int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, int32_t use
 int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
 int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
 
+/* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
+ * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no
+ * host-to-device traffic inside the call. */
+int bgmm_upload_streams(bgmm_ctx *ctx, int32_t n_sweeps, const double *u_all, const int64_t *order_all);
+int bgmm_sweep_resident(bgmm_ctx *ctx, int32_t index, int32_t use_power, double power);
+
 /* IGMM.log_marg (igmm/igmm.py:199-215) = CRP log P(z) + sum_k log_marg_k
  * (gaussian_components.py:253-289). */
 int bgmm_log_marg(bgmm_ctx *ctx, double *out);

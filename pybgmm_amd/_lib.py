@@ -32,6 +32,8 @@ SIGNATURES = {
     "bgmm_sweep": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
+    "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
+    "bgmm_sweep_resident": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     "bgmm_log_marg": (ctypes.c_int, [_vp, _f64]),
     "bgmm_log_marg_k": (ctypes.c_int, [_vp, ctypes.c_int32, _f64]),
     "bgmm_get_K": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -150,6 +152,18 @@ class Context(object):
     def sweep_staged(self, power=None):
         self._ck(self.L.bgmm_sweep_staged(self.h, 0 if power is None else 1,
                                           1.0 if power is None else float(power)))
+
+    def upload_streams(self, u_all, order_all=None):
+        u_all = np.ascontiguousarray(u_all, dtype=np.float64)
+        assert u_all.ndim == 2 and u_all.shape[1] == self.N
+        if order_all is not None:
+            order_all = np.ascontiguousarray(order_all, dtype=np.int64)
+            assert order_all.shape == u_all.shape
+        self._ck(self.L.bgmm_upload_streams(self.h, u_all.shape[0], _ptr(u_all), _ptr(order_all)))
+
+    def sweep_resident(self, index, power=None):
+        self._ck(self.L.bgmm_sweep_resident(self.h, int(index), 0 if power is None else 1,
+                                            1.0 if power is None else float(power)))
 
     @property
     def K(self):

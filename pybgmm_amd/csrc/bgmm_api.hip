@@ -39,6 +39,11 @@ struct bgmm_ctx {
     long long *d_order = nullptr;
     bool have_order = false;
     bool assigned = false;
+    double *res_u = nullptr;         // resident multi-sweep inputs
+    long long *res_order = nullptr;
+    int res_n = 0;
+    const double *cur_u = nullptr;   // inputs of the sweep being run
+    const long long *cur_order = nullptr;
     int kernel_kind = KERNEL_AUTO;
     int kind = KERNEL_VALU;          // resolved
     int win_rows = 0;                // allocated q / choice rows
@@ -128,6 +133,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->res_u) (void)hipFree(c->res_u);
+    if (c->res_order) (void)hipFree(c->res_order);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -337,6 +344,25 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
+    c->cur_u = c->d_u;
+    c->cur_order = order ? c->d_order : nullptr;
+    return 0;
+}
+
+extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *u_all, const int64_t *order_all) {
+    if (!c || !u_all || n_sweeps < 1) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->d.N;
+    if (c->res_u) { (void)hipFree(c->res_u); c->res_u = nullptr; }
+    if (c->res_order) { (void)hipFree(c->res_order); c->res_order = nullptr; }
+    c->res_n = 0;
+    CK(c, hipMalloc((void **)&c->res_u, sizeof(double) * N * n_sweeps));
+    CK(c, hipMemcpy(c->res_u, u_all, sizeof(double) * N * n_sweeps, hipMemcpyHostToDevice));
+    if (order_all) {
+        CK(c, hipMalloc((void **)&c->res_order, sizeof(long long) * N * n_sweeps));
+        CK(c, hipMemcpy(c->res_order, order_all, sizeof(long long) * N * n_sweeps, hipMemcpyHostToDevice));
+    }
+    c->res_n = n_sweeps;
     return 0;
 }
 
@@ -358,8 +384,9 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     Dev &d = c->d;
     d.use_power = use_power ? 1 : 0;
     d.power = use_power ? power : 1.0;
-    d.u = c->d_u;
-    d.order = c->have_order ? c->d_order : nullptr;
+    if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
+    d.u = c->cur_u;
+    d.order = c->cur_order;
     resolve_kind(c);
     hipStream_t st = c->stream;
     launch_sweep_begin(d, st);
@@ -396,6 +423,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
     return check_device_error(c);
+}
+
+extern "C" int bgmm_sweep_resident(bgmm_ctx *c, int32_t index, int32_t use_power, double power) {
+    if (!c) return BGMM_EINVAL;
+    if (index < 0 || index >= c->res_n) return fail(c, BGMM_EINVAL, "resident sweep index out of range");
+    c->cur_u = c->res_u + (size_t)index * c->d.N;
+    c->cur_order = c->res_order ? c->res_order + (size_t)index * c->d.N : nullptr;
+    return bgmm_sweep_staged(c, use_power, power);
 }
 
 extern "C" int bgmm_sweep(bgmm_ctx *c, const int64_t *order, const double *u, int32_t use_power, double power) {
