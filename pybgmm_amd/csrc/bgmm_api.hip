@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+int choice_rows_for(int K_max);
 void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st);
 void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
                          double *inv_out, hipStream_t st);
@@ -47,6 +48,7 @@ struct bgmm_ctx {
     int kernel_kind = KERNEL_AUTO;
     int kind = KERNEL_VALU;          // resolved
     int win_rows = 0;                // allocated q / choice rows
+    double last_move_rate = 0.0;     // movers per visit of the previous sweep
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev0, ev1;
@@ -182,11 +184,13 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, c->d_order, (size_t)N);
     // speculative window buffers: q rows bounded by ~1 GiB and by N
     long long rows = 32768;
-    while (rows > 1024 && (size_t)rows * d.ldq * sizeof(double) > ((size_t)1 << 30)) rows >>= 1;
+    while (rows > 1024 && (size_t)rows * d.nslots * sizeof(double) > ((size_t)1 << 30)) rows >>= 1;
     long long n_up = (N + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
     if (rows > n_up) rows = n_up;
     c->win_rows = (int)rows;
-    DALLOC(c, d.q, (size_t)rows * d.ldq);
+    d.qstride = rows;
+    d.choice_rows = choice_rows_for(K_max);
+    DALLOC(c, d.q, (size_t)rows * d.nslots);
     DALLOC(c, d.choice, (size_t)rows);
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
 
@@ -250,7 +254,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipMemcpy(c->util_job, &job, sizeof(Job), hipMemcpyHostToDevice));
     double *qcol;
     DALLOC(c, qcol, (size_t)N);
-    launch_score(d, c->kind, c->util_job, qcol, 1, 0, N, c->stream);
+    launch_score(d, c->kind, c->util_job, qcol, N, 0, N, c->stream);
     launch_prior_lp(d, qcol, c->stream);
     CK(c, hipGetLastError());
     int rc = fetch_ctrl(c);
@@ -391,12 +395,27 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     hipStream_t st = c->stream;
     launch_sweep_begin(d, st);
     long long steps_done = 0;
-    int T = 8;
+    // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
+    // Lower bound on the steps still needed: one per remaining window.  On top of that,
+    // one step per expected mover, estimated from the rate observed so far in this sweep
+    // (first chunk: from the previous sweep).
+    const long long N = d.N;
+    long long pos = 0;
+    int win = c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows;
+    double rate = c->last_move_rate;
     for (;;) {
+        const long long remaining = N - pos;
+        long long lb = (remaining + win - 1) / win;
+        long long extra = (long long)std::ceil(rate * (double)remaining * 1.1);
+        if (extra > 2048) extra = 2048;
+        long long Tl = lb + extra;
+        if (Tl < 1) Tl = 1;
+        if (Tl > 4096) Tl = 4096;
+        const int T = (int)Tl;
         if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
         for (int t = 0; t < T; ++t) {
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
-            launch_score(d, c->kind, &d.ctrl->job, d.q, d.ldq, -1, c->win_rows, st);
+            launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
             launch_choice(d, c->win_rows, st);
             launch_apply(d, st);
@@ -417,8 +436,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         }
         steps_done = h.n_steps;
         if (h.error != 0 || h.job.mode == MODE_DONE) break;
-        if (T < 256) T *= 2;
+        pos = h.job.pos;
+        win = h.win_size > 0 ? h.win_size : win;
+        rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
     }
+    c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
@@ -549,7 +571,7 @@ extern "C" int bgmm_log_post_pred(bgmm_ctx *c, int64_t i, double *out) {
     CK(c, hipStreamSynchronize(c->stream));
     Dev d = c->d;
     d.order = nullptr;
-    launch_score(d, c->kind, c->util_job, c->util_q, d.ldq, -1, 1, c->stream);
+    launch_score(d, c->kind, c->util_job, c->util_q, 1, -1, 1, c->stream);
     launch_post_pred(d, c->util_q, c->util_out, c->stream);
     CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));

@@ -16,7 +16,8 @@
 //                      B-operand fragments (block-lower-triangular, zero padded to Dp)
 //     cvec[s][Dp]      Winv * mu  (so that  Winv (mu - x) = cvec - Winv x)
 //     sc[s]            scalar constants of the Student-t predictive (SlotConst)
-//   q[Wmax][ldq]       quadratic forms (mu_s - x)^T C_s^{-1} (mu_s - x) of the current window
+//   q[nslots][Wmax]    quadratic forms (mu_s - x)^T C_s^{-1} (mu_s - x) of the current window,
+//                      slot major so that both kernels touch it in full 64/128-byte segments
 //   choice[Wmax] int32 drawn label of every visit of the current window
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,10 +30,10 @@ enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
 enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
 
 static constexpr unsigned long long kNoMover = ~0ull;
-static constexpr int kMaxChunks = 32;      // grid.y of the likelihood kernels
+static constexpr int kMaxChunks = 8;       // grid.y of the likelihood kernels
 static constexpr int kValuRows = 64;       // rows (visits) per block, VALU likelihood kernel
 static constexpr int kMfmaRows = 128;      // rows per block, MFMA likelihood kernel (4 waves x 2 x 16)
-static constexpr int kChoiceRows = 4;      // rows per block of the draw kernel (one wave per row)
+static constexpr int kChoiceRowsMax = 8;   // rows per block of the draw kernel (one wave per row)
 
 // Per-slot scalar constants.  As-is predictive of a point under slot s:
 //   lp = A - half_vd * log(1 + q * inv_cv)
@@ -79,6 +80,8 @@ struct Ctrl {
 struct Dev {
     long long N;
     int D, Dp, K_max, nslots, nfrag, ldq;
+    long long qstride;           // q[slot * qstride + window row]
+    int choice_rows;             // visits per block of the draw kernel
     int rows_per_block;          // of the active likelihood kernel (chunk policy)
     long long tab_len, v0;
     double k0, alpha, log_alpha;
@@ -115,7 +118,7 @@ void launch_labels(const Dev &d, long long *z_out, long long *counts_out, hipStr
 void launch_prior_lp(const Dev &d, const double *qcol, hipStream_t st);
 void launch_post_pred(const Dev &d, const double *qrow, double *out, hipStream_t st);
 
-void launch_score(const Dev &d, int kind, const Job *job, double *q, int ldq, int col_override,
-                  long long max_rows, hipStream_t st);
+void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride,
+                  int col_override, long long max_rows, hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 int refresh_lds_bytes(int D);

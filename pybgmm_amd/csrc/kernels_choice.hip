@@ -34,36 +34,53 @@ __device__ __forceinline__ double wave_scan(double v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * kChoiceRows) void choice_kernel(Dev d) {
-    extern __shared__ __attribute__((aligned(16))) double lpbuf_all[];   // [kChoiceRows][ldq + 1]
+// LDS tile: entry (j, r) at tile[j * R + r]; R = d.choice_rows visits per block, labels j < K,
+// plus one extra line (index K_max + 1) for the "new table" entry.  The block first stages the
+// q values of its R consecutive visits (slot-major q: R x 8 contiguous bytes per label), then
+// wave r turns column r into log scores in place.
+__global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];
     Ctrl *c = d.ctrl;
-    const Job job = c->job;
-    if (job.mode == MODE_DONE) return;
+    const int mode = c->job.mode;
+    if (mode == MODE_DONE) return;
+    const long long pos = c->job.pos, win_base = c->job.win_base, win_hi = c->job.win_hi;
+    const int K = c->job.K;
+    const int R = d.choice_rows;
+    const long long p0 = pos + (long long)blockIdx.x * R;
+    if (p0 >= win_hi) return;
+    for (int idx = threadIdx.x; idx < K * R; idx += blockDim.x) {
+        const int j = idx / R, r = idx - j * R;
+        const long long p = p0 + r;
+        tile[idx] = p < win_hi ? d.q[(long long)d.perm[j] * d.qstride + (p - win_base)] : 0.0;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long p = job.pos + (long long)blockIdx.x * kChoiceRows + w;
-    if (p >= job.win_hi) return;
-    double *lp = lpbuf_all + (long long)w * (d.ldq + 1);
+    const long long p = p0 + w;
+    if (p >= win_hi) return;
+    const int NEWIDX = d.K_max + 1;
 
     const long long i = d.order ? d.order[p] : p;
     const int h = d.z[i];
-    const int K = job.K;
     const int nh = h >= 0 ? d.n[h] : 0;
     const bool home_live = h >= 0 && nh >= 2;          // removal keeps the component
     const bool singleton = h >= 0 && nh == 1;          // removal deletes it (swap with last)
     const int lab_h = singleton ? d.label_of_slot[h] : -1;
     const int L = singleton ? K - 1 : K;               // labels after the removal
-    const double *__restrict__ qrow = d.q + (p - job.win_base) * (long long)d.ldq;
 
-    // pass 1: log scores into LDS, running max
+    // pass 1: log scores, in place.  Entry (j, w) is read and written by the one lane that
+    // owns label j; a deleted singleton's stand-in (entry K-1) is only ever read, because the
+    // new-table score has its own line NEWIDX.
     double mx = -INFINITY;
     for (int j = lane; j <= L; j += 64) {
         double v;
         if (j == L) {
             v = d.log_alpha + d.log_prior[i];
+            tile[NEWIDX * R + w] = v;
         } else {
-            const int s = (singleton && j == lab_h) ? d.perm[K - 1] : d.perm[j];
-            const double qv = qrow[s];
+            const int jj = (singleton && j == lab_h) ? K - 1 : j;
+            const int s = d.perm[jj];
+            const double qv = tile[jj * R + w];
             const SlotConst sc = d.sc[s];
             if (home_live && s == h) {
                 const double den = 1.0 - sc.a1 * qv;
@@ -72,15 +89,16 @@ __global__ __launch_bounds__(64 * kChoiceRows) void choice_kernel(Dev d) {
                 v = sc.logseat + sc.A - sc.half_vd * log(1.0 + qv * sc.inv_cv);
             }
         }
-        lp[j] = v;
         mx = fmax(mx, v);
+        if (j < L) tile[j * R + w] = v;
     }
     mx = wave_max(mx);
     // pass 2: exp and total
     double tot = 0.0;
     for (int j = lane; j <= L; j += 64) {
-        const double e = exp(lp[j] - mx);
-        lp[j] = e;
+        const int idx = (j == L ? NEWIDX : j) * R + w;
+        const double e = exp(tile[idx] - mx);
+        tile[idx] = e;
         tot += e;
     }
     tot = wave_sum(tot);
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(64 * kChoiceRows) void choice_kernel(Dev d) {
     int pick = L;                                        // fallback: last entry (utils.py:20)
     for (int j0 = 0; j0 <= L; j0 += 64) {
         const int j = j0 + lane;
-        const double pj = j <= L ? lp[j] / tot : 0.0;
+        const double pj = j <= L ? tile[(j == L ? NEWIDX : j) * R + w] / tot : 0.0;
         const double cum = carry + wave_scan(pj, lane);
         const bool hit = j <= L && (u - cum) < 0.0;
         const unsigned long long m = __ballot(hit);
@@ -98,20 +116,27 @@ __global__ __launch_bounds__(64 * kChoiceRows) void choice_kernel(Dev d) {
         carry = __shfl(cum, 63);
     }
     if (lane == 0) {
-        d.choice[p - job.win_base] = pick;
+        d.choice[p - win_base] = pick;
         const bool stay = home_live && pick < L && d.perm[pick] == h;
         if (!stay) atomicMin(&c->first_mover, (unsigned long long)p);
     }
 }
 
+int choice_rows_for(int K_max) {
+    int R = kChoiceRowsMax;
+    while (R > 1 && (long long)(K_max + 2) * R * (long long)sizeof(double) > 64 * 1024) R >>= 1;
+    return R;
+}
+
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st) {
     if (max_rows <= 0) return;
-    const unsigned gx = (unsigned)((max_rows + kChoiceRows - 1) / kChoiceRows);
-    const int lds = kChoiceRows * (d.ldq + 1) * (int)sizeof(double);
+    const int R = d.choice_rows;
+    const unsigned gx = (unsigned)((max_rows + R - 1) / R);
+    const int lds = (d.K_max + 2) * R * (int)sizeof(double);
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)choice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(choice_kernel, dim3(gx), dim3(64 * kChoiceRows), lds, st, d);
+    hipLaunchKernelGGL(choice_kernel, dim3(gx), dim3(64 * R), lds, st, d);
 }

@@ -17,31 +17,38 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-struct RowSpan {
-    long long p0;      // first visit of this block
-    long long hi;      // end of window
-    long long base;    // q row of visit p is p - base
+// The Job is read field by field (a by-value copy with a dynamically indexed dirty[] member
+// ends up in scratch memory).
+struct JobView {
+    long long pos, win_base, win_hi;
+    int mode, nlist, chunks, dirty0, dirty1;
 };
-
-// label t of the job's list -> slot
-__device__ __forceinline__ int job_slot(const Dev &d, const Job &job, int t) {
-    return job.mode == MODE_FRESH ? d.perm[t] : job.dirty[t];
+__device__ __forceinline__ JobView load_job(const Job *__restrict__ j) {
+    JobView v;
+    v.pos = j->pos; v.win_base = j->win_base; v.win_hi = j->win_hi;
+    v.mode = j->mode; v.chunks = j->chunks;
+    v.nlist = v.mode == MODE_FRESH ? j->K : j->n_dirty;
+    v.dirty0 = j->dirty[0]; v.dirty1 = j->dirty[1];
+    return v;
+}
+// entry t of the job's list -> slot
+__device__ __forceinline__ int job_slot(const Dev &d, const JobView &job, int t) {
+    return job.mode == MODE_FRESH ? d.perm[t] : (t == 0 ? job.dirty0 : job.dirty1);
 }
 
 // ------------------------------------------------------------------------------------------
-// VALU kernel
+// VALU kernel.  q is stored slot-major: q[col * qstride + row].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__restrict__ jobp,
-                                                         double *__restrict__ q, int ldq,
+                                                         double *__restrict__ q, long long qstride,
                                                          int col_override) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
-    const Job job = *jobp;
+    const JobView job = load_job(jobp);
     if (job.mode == MODE_DONE) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks) return;
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
     if (p0 >= job.win_hi) return;
-    const int nlist = job.mode == MODE_FRESH ? job.K : job.n_dirty;
     const int D = d.D;
 
     // stage the x tile transposed: xs[l][r]
@@ -60,8 +67,8 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long p = p0 + lane;
-    // labels of this chunk: chunk, chunk + chunks, ...; the 4 waves take them round robin
-    for (int t = chunk + job.chunks * w; t < nlist; t += job.chunks * 4) {
+    // entries of this chunk: chunk, chunk + chunks, ...; the 4 waves take them round robin
+    for (int t = chunk + job.chunks * w; t < job.nlist; t += job.chunks * 4) {
         const int s = job_slot(d, job, t);
         const double *__restrict__ W = d.Wrm + (long long)s * D * D;
         const double *__restrict__ cv = d.cvec + (long long)s * d.Dp;
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
             for (int l = 0; l <= j; ++l) acc = fma(-Wj[l], xs[l * kValuRows + lane], acc);
             qv = fma(acc, acc, qv);
         }
-        if (p < job.win_hi) q[(p - job.win_base) * ldq + (col_override >= 0 ? col_override : s)] = qv;
+        if (p < job.win_hi)
+            q[(long long)(col_override >= 0 ? col_override : s) * qstride + (p - job.win_base)] = qv;
     }
 }
 
@@ -82,19 +90,33 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
 //   A: lane holds A[i = lane&15][k = lane>>4]   -> x[row lane&15][4*kk + (lane>>4)]
 //   B: lane holds B[k = lane>>4][j = lane&15]   -> -Winv[16J + (lane&15)][4*kk + (lane>>4)]
 //   C/D: lane holds rows (lane>>4) + 4*r, r = 0..3, column lane&15
+// The B fragments of a slot are a flat list of NF = 2 NJ (NJ+1) 512-byte pieces.  They are
+// streamed through a register ring of PF pieces: the piece consumed by MFMA number f is
+// replaced at once by the load of piece f + PF (wrapping into the NEXT slot's list), so PF
+// loads are always in flight ahead of the matrix pipe.
 // ------------------------------------------------------------------------------------------
-template <int NJ, int RB>
-__global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
-                                                         double *__restrict__ q, int ldq,
-                                                         int col_override) {
-    const Job job = *jobp;
+constexpr int pick_pf(int nf) {
+    int best = 1;
+    for (int p = 1; p <= 24 && p <= nf; ++p)
+        if (nf % p == 0) best = p;
+    return best;
+}
+
+// MINW = waves per SIMD the register budget is planned for (2 up to D = 80; the D = 96..128
+// variants keep 2 x 16 rows of A fragments = 96..128 VGPRs and run one wave per SIMD).
+template <int NJ, int RB, int MINW>
+__global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
+                                                            double *__restrict__ q, long long qstride,
+                                                            int col_override) {
+    const JobView job = load_job(jobp);
     if (job.mode == MODE_DONE) return;
     const int chunk = blockIdx.y;
-    if (chunk >= job.chunks) return;
+    if (chunk >= job.chunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = 16 * RB;              // rows per wave
+    constexpr int NF = 2 * NJ * (NJ + 1);
+    constexpr int PF = pick_pf(NF);
     const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
     if (pb >= job.win_hi) return;
-    const int nlist = job.mode == MODE_FRESH ? job.K : job.n_dirty;
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,11 +139,26 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__res
         }
     }
 
-    const int nfrag64 = d.nfrag * 64;
-    for (int t = chunk; t < nlist; t += job.chunks) {
-        const int s = job_slot(d, job, t);
-        const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
-        const double *__restrict__ cv = d.cvec + (long long)s * d.Dp + lr;
+    const long long nfrag64 = (long long)NF * 64;
+    int t = chunk;
+    int s = job_slot(d, job, t);
+    const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
+    double ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = wf[i * 64];
+    double cj[NJ];
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) cj[J] = d.cvec[(long long)s * d.Dp + 16 * J + lr];
+
+    for (;;) {
+        const int tn = t + job.chunks;
+        const bool has_next = tn < job.nlist;
+        const int sn = has_next ? job_slot(d, job, tn) : s;
+        const double *__restrict__ wfn = d.Wfrag + (long long)sn * nfrag64 + lane;
+        double cjn[NJ];
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) cjn[J] = d.cvec[(long long)sn * d.Dp + 16 * J + lr];
+
         double qp[RB][4];
 #pragma unroll
         for (int R = 0; R < RB; ++R)
@@ -129,13 +166,14 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__res
             for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
 #pragma unroll
         for (int J = 0; J < NJ; ++J) {
-            const double cj = cv[16 * J];
             v4d acc[RB];
 #pragma unroll
-            for (int R = 0; R < RB; ++R) acc[R] = (v4d){cj, cj, cj, cj};
+            for (int R = 0; R < RB; ++R) acc[R] = (v4d){cj[J], cj[J], cj[J], cj[J]};
 #pragma unroll
             for (int kk = 0; kk < 4 * (J + 1); ++kk) {
-                const double b = wf[(2 * J * (J + 1) + kk) * 64];
+                const int f = 2 * J * (J + 1) + kk;          // folds to a constant when unrolled
+                const double b = ring[f % PF];
+                ring[f % PF] = (f + PF < NF) ? wf[(f + PF) * 64] : wfn[(f + PF - NF) * 64];
 #pragma unroll
                 for (int R = 0; R < RB; ++R)
                     acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], b, acc[R], 0, 0, 0);
@@ -145,8 +183,9 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qp[R][r] = fma(acc[R][r], acc[R][r], qp[R][r]);
         }
-        // sum over the 16 columns held by the 16 lanes of each (lane>>4) group
-        const int col = col_override >= 0 ? col_override : s;
+        // sum over the 16 columns held by the 16 lanes of each (lane>>4) group, then lane
+        // (lk, lr = r) stores row lk + 4r: 16 consecutive rows = one 128-byte segment
+        double *__restrict__ qcol = q + (long long)(col_override >= 0 ? col_override : s) * qstride;
 #pragma unroll
         for (int R = 0; R < RB; ++R) {
 #pragma unroll
@@ -156,43 +195,46 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(Dev d, const Job *__res
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                qp[R][r] = v;
+                const long long p = pw + R * 16 + lk + 4 * r;
+                if (lr == r && p < job.win_hi) qcol[p - job.win_base] = v;
             }
-            // lane with lr == r writes row lk + 4*r
-            const double mine = lr == 0 ? qp[R][0] : lr == 1 ? qp[R][1] : lr == 2 ? qp[R][2] : qp[R][3];
-            const long long p = pw + R * 16 + lk + 4 * lr;
-            if (lr < 4 && p < job.win_hi) q[(p - job.win_base) * ldq + col] = mine;
         }
+        if (!has_next) break;
+        t = tn;
+        s = sn;
+        wf = wfn;
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) cj[J] = cjn[J];
     }
 }
 
 // ------------------------------------------------------------------------------------------
 template <int NJ>
-static void launch_mfma(const Dev &d, const Job *job, double *q, int ldq, int col_override,
+static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                         long long max_rows, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
-                       ldq, col_override);
+    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 5 ? 2 : 1)>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
+                       qstride, col_override);
 }
 
-void launch_score(const Dev &d, int kind, const Job *job, double *q, int ldq, int col_override,
+void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
                   long long max_rows, hipStream_t st) {
     if (max_rows <= 0) return;
     if (kind == KERNEL_MFMA) {
         switch (d.Dp / 16) {
-            case 1: launch_mfma<1>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 2: launch_mfma<2>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 3: launch_mfma<3>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 4: launch_mfma<4>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 5: launch_mfma<5>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 6: launch_mfma<6>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 7: launch_mfma<7>(d, job, q, ldq, col_override, max_rows, st); return;
-            case 8: launch_mfma<8>(d, job, q, ldq, col_override, max_rows, st); return;
+            case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 2: launch_mfma<2>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 3: launch_mfma<3>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 4: launch_mfma<4>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 5: launch_mfma<5>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 6: launch_mfma<6>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 7: launch_mfma<7>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 8: launch_mfma<8>(d, job, q, qstride, col_override, max_rows, st); return;
             default: break;
         }
     }
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
     const int lds = d.D * kValuRows * (int)sizeof(double);
-    hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, ldq,
+    hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
                        col_override);
 }
