@@ -35,7 +35,8 @@ WORKLOADS = {
     "C2": (100000, 2, 20, "CRPMM"),
     "C5": (2000000, 128, 200, "PCRPMM"),
 }
-PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense FP64 matrix peak (spec); see DESIGN.md
+PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense FP64 matrix peak (spec); see DESIGN.md section 4
+SUSTAINED_FP64_MFMA_TFLOPS = 49.0 # pure v_mfma_f64_16x16x4 loop measured on the box (tools/mfma_f64_peak.hip)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -170,14 +171,23 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 24)
+            nJ = (D + 15) // 16
+            # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
+            # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
+            exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
+            executed = st["scored"] * exec_per_eval / (ms * 1e-3) / 1e12
             roofline = {
-                "kernel": "score_mfma_kernel" if (args.kernel == 2 or (args.kernel == 0 and D >= 24)) else "score_valu_kernel",
+                "kernel": "score_mfma_kernel" if is_mfma else "score_valu_kernel",
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
                 "traffic": traffic,
                 "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                 "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
                 "flops_per_lik_eval": flops_per_lik_eval(D),
+                "executed_tflops": round(executed, 3),
+                "executed_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
+                "executed_frac_of_sustained_mfma": round(executed / SUSTAINED_FP64_MFMA_TFLOPS, 4),
                 "hbm_gbps_algorithmic": round(st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9, 2),
                 "hbm_frac": round(st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
             }
