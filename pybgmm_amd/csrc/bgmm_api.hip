@@ -173,6 +173,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.Wfrag, ns * d.nfrag * 64);
     DALLOC(c, d.cvec, ns * d.Dp);
     DALLOC(c, d.n, ns);
+    DALLOC(c, d.nupd, ns);
     DALLOC(c, d.sc, ns);
     DALLOC(c, d.perm, ns);
     DALLOC(c, d.label_of_slot, ns);
@@ -221,6 +222,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipMemcpyAsync(dpS, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
     // pseudo slot K_max = the bare prior (n = 0): its refresh yields C = S_0, mu = m_0
     CK(c, hipMemsetAsync(d.n, 0, sizeof(int) * ns, c->stream));
+    CK(c, hipMemsetAsync(d.nupd, 0, sizeof(int) * ns, c->stream));
     CK(c, hipMemcpyAsync(d.m + (size_t)K_max * D, pm.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemcpyAsync(d.S + (size_t)K_max * DD, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemsetAsync(d.z, 0xff, sizeof(int) * N, c->stream));

@@ -28,6 +28,12 @@
 
 enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
 enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
+// how a slot's derived state (mu, Winv, cvec, constants) follows a change of (n, m, S)
+enum { REFRESH_SCRATCH = 0,   // Cholesky + inverse of S_N from scratch, O(D^3)
+       REFRESH_ADD = 1,       // rank-1 update of Winv: point refresh_i was added
+       REFRESH_SUB = 2,       // rank-1 downdate: point refresh_i was removed
+       REFRESH_NEW = 3 };     // new component: rank-1 update of the prior's factor (pseudo slot)
+static constexpr int kRefreshEvery = 64;   // rank-1 steps per slot between from-scratch rebuilds
 
 static constexpr unsigned long long kNoMover = ~0ull;
 static constexpr int kMaxChunks = 8;       // grid.y of the likelihood kernels
@@ -68,6 +74,8 @@ struct Ctrl {
     unsigned long long first_mover;
     int n_refresh;
     int refresh[2];
+    int refresh_kind[2];  // REFRESH_* : how the derived state of refresh[b] is rebuilt
+    long long refresh_i;  // data index of the point whose move caused the refresh
     int win_size;         // current adaptive window size
     int win_cap;          // upper bound (host tuning; <= allocated rows of q)
     int error;
@@ -92,6 +100,7 @@ struct Dev {
     const double *prior_m, *prior_S;
     double *m, *S, *mu, *Wrm, *Wfrag, *cvec;
     int *n;
+    int *nupd;                   // rank-1 updates since the slot's last from-scratch refresh
     SlotConst *sc;
     int *perm, *label_of_slot;
     Ctrl *ctrl;

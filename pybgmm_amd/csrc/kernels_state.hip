@@ -79,8 +79,129 @@ __device__ __forceinline__ double seat_weight(const Dev &d, int n) {
     return d.use_power ? log(pow((double)n, d.power)) : log((double)n);
 }
 
-__device__ void refresh_slot(const Dev &d, int s, double *sm) {
+// Everything that is written out once the inverse factor Winv (LDS, row major with leading
+// dimension ld, lower triangle valid), mu (LDS) and logdetC are known.
+__device__ void finish_slot(const Dev &d, int s, const double *A, int ld, const double *mu, double logdetC) {
     const int D = d.D, Dp = d.Dp, tid = threadIdx.x;
+    const int n = d.n[s];
+    const double k_N = d.k0 + (double)n;
+    for (int j = tid; j < Dp; j += TPB) {
+        double acc = 0.0;
+        if (j < D)
+            for (int l = 0; l <= j; ++l) acc = fma(A[j * ld + l], mu[l], acc);
+        d.cvec[(long long)s * Dp + j] = acc;
+    }
+    for (int e = tid; e < D * D; e += TPB) {
+        const int a = e / D, b = e % D;
+        d.Wrm[(long long)s * D * D + e] = (b <= a) ? A[a * ld + b] : 0.0;
+    }
+    {
+        double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
+        const int nJ = Dp / 16;
+        for (int J = 0; J < nJ; ++J) {
+            const int base = 2 * J * (J + 1);
+            for (int e = tid; e < 4 * (J + 1) * 64; e += TPB) {
+                const int kk = e >> 6, lane = e & 63;
+                const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
+                wf[(base + kk) * 64 + lane] = (j < D && l <= j) ? -A[j * ld + l] : 0.0;
+            }
+        }
+    }
+    if (tid == 0) {
+        SlotConst c;
+        const double Dd = (double)D;
+        const long long v = d.v0 + n - D + 1;
+        const double cs = (k_N + 1.0) / (k_N * (double)v);
+        c.logdetC = logdetC;
+        c.A = student_const(d, v) - 0.5 * (Dd * log(cs) + logdetC);
+        c.half_vd = 0.5 * (double)(v + D);
+        c.inv_cv = 1.0 / (cs * (double)v);
+        c.logseat = seat_weight(d, n);
+        c.logseat1 = seat_weight(d, n - 1);
+        c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+        if (n >= 2) {
+            const double k1 = k_N - 1.0;
+            const long long v1 = v - 1;
+            const double c1 = k_N / (k1 * (double)v1);
+            const double a = k_N / k1;
+            c.a1 = a;
+            c.A1 = student_const(d, v1) - 0.5 * (Dd * log(c1) + logdetC);
+            c.half_vd1 = 0.5 * (double)(v1 + D);
+            c.coef1 = a * a / (c1 * (double)v1);
+        }
+        c.pad0 = 0.0; c.pad1 = 0.0;
+        d.sc[s] = c;
+    }
+}
+
+// Rank-1 update of a slot's derived state after point i joined (a > 0) or left (a < 0) it.
+//   S_N' = S_N + a dd',  d = x_i - mu_old,  a = k/(k+1) (join, k = k_0 + n_before)
+//                                          a = -k/(k-1) (leave, k = k_0 + n_before)
+// With p = Winv d, P_i = sum_{k<=i} p_k^2 (s = P_{D-1}):  Winv' = T Winv,  T'T = I - a/(1+as) pp',
+//   T_ii = l_i = sqrt((1 + a P_{i-1}) / (1 + a P_i)),   T_ik = t_i p_k (k < i),
+//   t_i = -a p_i / ((1 + a P_i) l_i),    logdet S_N' = logdet S_N + log(1 + a s).
+// `src` is the slot whose (mu, Winv, logdetC) describe the state BEFORE the change (dst itself,
+// or the prior pseudo slot for a freshly opened component).  O(D^2), 5 barriers.
+// LDS: W[D][D+1] + 5 D + 2 doubles.
+__device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind, double *sm) {
+    const int D = d.D, ld = D + 1, tid = threadIdx.x;
+    double *W = sm;
+    double *dv = sm + D * ld, *pv = dv + D, *lv = pv + D, *tv = lv + D, *mu = tv + D;
+    double *s_total = mu + D;
+    const double logdet_src = d.sc[src].logdetC;      // read before anything of dst is rewritten
+    const int n_new = d.n[dst];
+    const double k_before = d.k0 + (double)(kind == REFRESH_SUB ? n_new + 1 : n_new - 1);
+    const double a = kind == REFRESH_SUB ? -k_before / (k_before - 1.0) : k_before / (k_before + 1.0);
+    const double *x = d.X + i * D;
+    const double *Wsrc = d.Wrm + (long long)src * D * D;
+    for (int e = tid; e < D * D; e += TPB) W[(e / D) * ld + (e % D)] = Wsrc[e];
+    for (int l = tid; l < D; l += TPB) {
+        dv[l] = x[l] - d.mu[(long long)src * D + l];
+        const double m_new = d.m[(long long)dst * D + l] / (d.k0 + (double)n_new);
+        mu[l] = m_new;
+        d.mu[(long long)dst * D + l] = m_new;
+    }
+    __syncthreads();
+    for (int r = tid; r < D; r += TPB) {
+        double acc = 0.0;
+        for (int l = 0; l <= r; ++l) acc = fma(W[r * ld + l], dv[l], acc);
+        pv[r] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double P = 0.0;
+        bool bad = false;
+        for (int r = 0; r < D; ++r) {
+            const double num = 1.0 + a * P;
+            P = fma(pv[r], pv[r], P);
+            const double den = 1.0 + a * P;
+            if (!(den > 0.0) || !(num > 0.0)) bad = true;
+            const double l = sqrt(num / den);
+            lv[r] = l;
+            tv[r] = -a * pv[r] / (den * l);
+        }
+        *s_total = P;
+        if (bad) atomicCAS(&d.ctrl->error, 0, -4);
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += TPB) {          // column j, rows j..D-1, running sum_{k<i} p_k W[k][j]
+        double r = 0.0;
+        for (int row = j; row < D; ++row) {
+            const double w = W[row * ld + j];
+            W[row * ld + j] = fma(tv[row], r, lv[row] * w);
+            r = fma(pv[row], w, r);
+        }
+    }
+    __syncthreads();
+    const double logdetC = logdet_src + log(1.0 + a * (*s_total));
+    finish_slot(d, dst, W, ld, mu, logdetC);
+    if (tid == 0) d.nupd[dst] += 1;
+}
+
+int rank1_lds_bytes(int D) { return (D * (D + 1) + 5 * D + 2) * (int)sizeof(double); }
+
+__device__ void refresh_slot(const Dev &d, int s, double *sm) {
+    const int D = d.D, tid = threadIdx.x;
     double *A = sm;                // D*D, row major, lower triangle used
     double *mu = sm + D * D;       // D
     double *row = mu + D;          // D
@@ -148,55 +269,8 @@ __device__ void refresh_slot(const Dev &d, int s, double *sm) {
         }
         __syncthreads();
     }
-    // --- cvec = Winv mu, and the three output layouts ---
-    for (int j = tid; j < Dp; j += TPB) {
-        double acc = 0.0;
-        if (j < D)
-            for (int l = 0; l <= j; ++l) acc = fma(A[j * D + l], mu[l], acc);
-        d.cvec[(long long)s * Dp + j] = acc;
-    }
-    for (int e = tid; e < D * D; e += TPB) {
-        const int a = e / D, b = e % D;
-        d.Wrm[(long long)s * D * D + e] = (b <= a) ? A[e] : 0.0;
-    }
-    {
-        double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
-        const int nJ = Dp / 16;
-        for (int J = 0; J < nJ; ++J) {
-            const int base = 2 * J * (J + 1);
-            for (int e = tid; e < 4 * (J + 1) * 64; e += TPB) {
-                const int kk = e >> 6, lane = e & 63;
-                const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
-                wf[(base + kk) * 64 + lane] = (j < D && l <= j) ? -A[j * D + l] : 0.0;
-            }
-        }
-    }
-    // --- scalar constants ---
-    if (tid == 0) {
-        SlotConst c;
-        const double Dd = (double)D;
-        const long long v = d.v0 + n - D + 1;
-        const double cs = (k_N + 1.0) / (k_N * (double)v);
-        c.logdetC = logdetC;
-        c.A = student_const(d, v) - 0.5 * (Dd * log(cs) + logdetC);
-        c.half_vd = 0.5 * (double)(v + D);
-        c.inv_cv = 1.0 / (cs * (double)v);
-        c.logseat = seat_weight(d, n);
-        c.logseat1 = seat_weight(d, n - 1);
-        c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
-        if (n >= 2) {
-            const double k1 = k_N - 1.0;
-            const long long v1 = v - 1;
-            const double c1 = k_N / (k1 * (double)v1);
-            const double a = k_N / k1;
-            c.a1 = a;
-            c.A1 = student_const(d, v1) - 0.5 * (Dd * log(c1) + logdetC);
-            c.half_vd1 = 0.5 * (double)(v1 + D);
-            c.coef1 = a * a / (c1 * (double)v1);
-        }
-        c.pad0 = 0.0; c.pad1 = 0.0;
-        d.sc[s] = c;
-    }
+    finish_slot(d, s, A, D, mu, logdetC);
+    if (tid == 0) d.nupd[s] = 0;
 }
 
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
@@ -207,7 +281,10 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
 __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = d.ctrl;
-    if ((int)blockIdx.x < c->n_refresh) refresh_slot(d, c->refresh[blockIdx.x], sm);
+    if ((int)blockIdx.x >= c->n_refresh) return;
+    const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
+    if (kind == REFRESH_SCRATCH) refresh_slot(d, s, sm);
+    else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
 
 static void ensure_lds(const void *fn, int bytes) {
@@ -222,7 +299,8 @@ void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) 
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
-    const int lds = refresh_lds_bytes(d.D);
+    const int l1 = refresh_lds_bytes(d.D), l2 = rank1_lds_bytes(d.D);
+    const int lds = l1 > l2 ? l1 : l2;
     ensure_lds((const void *)refresh_ctrl_kernel, lds);
     hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
 }
@@ -326,6 +404,7 @@ __device__ int plan_seat(const Dev &d, Ctrl *c, long long i, int lab, MovePlan &
         t = d.perm[K];
         d.label_of_slot[t] = K;
         d.n[t] = 0;
+        d.nupd[t] = 0;
         c->job.K = K + 1;
         mp.add_init = 1;
     } else {
@@ -357,10 +436,24 @@ __device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
     }
 }
 
-__device__ void set_refresh(Ctrl *c, const MovePlan &mp) {
+// rank1 = false: always rebuild from scratch (API item ops); else rank-1 steps with a
+// from-scratch rebuild every kRefreshEvery steps per slot
+__device__ void set_refresh(const Dev &d, Ctrl *c, const MovePlan &mp, bool rank1) {
     int nr = 0;
-    if (mp.sub_slot >= 0) c->refresh[nr++] = mp.sub_slot;
-    if (mp.add_slot >= 0 && mp.add_slot != mp.sub_slot) c->refresh[nr++] = mp.add_slot;
+    c->refresh_i = mp.i;
+    if (mp.sub_slot >= 0) {
+        c->refresh_kind[nr] = (rank1 && d.nupd[mp.sub_slot] < kRefreshEvery) ? REFRESH_SUB : REFRESH_SCRATCH;
+        c->refresh[nr++] = mp.sub_slot;
+    }
+    if (mp.add_slot >= 0 && mp.add_slot != mp.sub_slot) {
+        int kind = REFRESH_SCRATCH;
+        if (rank1) {
+            if (mp.add_init) kind = REFRESH_NEW;
+            else if (d.nupd[mp.add_slot] < kRefreshEvery) kind = REFRESH_ADD;
+        }
+        c->refresh_kind[nr] = kind;
+        c->refresh[nr++] = mp.add_slot;
+    }
     c->n_refresh = nr;
 }
 
@@ -400,7 +493,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     j.mode = MODE_DONE;
                 } else {
                     do_move = 1;
-                    set_refresh(c, mp);
+                    set_refresh(d, c, mp, true);
                     c->n_moves += 1;
                     // adaptive window: about half the running mean distance between movers
                     const double run = (double)(p - c->last_mover);
@@ -446,7 +539,7 @@ __global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, i
             const int rc = (label < 0 || label > c->job.K) ? -1 : plan_seat(d, c, i, label, mp);
             if (rc != 0) { atomicCAS(&c->error, 0, rc); ok = 0; }
         }
-        set_refresh(c, mp);
+        set_refresh(d, c, mp, false);
         if (!ok) c->n_refresh = 0;
     }
     __syncthreads();
