@@ -131,9 +131,10 @@ int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out6);
 int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
 int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 
-/* Tuning knobs (0 keeps the default): cap on the speculative window, forced likelihood
- * kernel (0 auto, 1 VALU, 2 MFMA). */
-int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind);
+/* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
+ * kernel (0 auto, 1 VALU, 2 MFMA); in-launch mover resolver (0 auto: when movers are dense,
+ * 1 never, 2 whenever it fits).  None of them changes the sampled trajectory. */
+int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode);
 
 /* Blocks until all work queued on the context's stream has finished. */
 int bgmm_synchronize(bgmm_ctx *ctx);

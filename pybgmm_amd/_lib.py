@@ -47,7 +47,7 @@ SIGNATURES = {
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
-    "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32]),
+    "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "bgmm_synchronize": (ctypes.c_int, [_vp]),
 }
 
@@ -231,8 +231,8 @@ class Context(object):
         self._ck(self.L.bgmm_get_kernel_timing(self.h, ctypes.byref(n), ctypes.byref(ms)))
         return int(n.value), float(ms.value)
 
-    def set_tuning(self, max_window=0, kernel_kind=0):
-        self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind)))
+    def set_tuning(self, max_window=0, kernel_kind=0, resolver_mode=0):
+        self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind), int(resolver_mode)))
 
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))

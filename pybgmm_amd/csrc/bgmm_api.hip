@@ -49,6 +49,10 @@ struct bgmm_ctx {
     int kind = KERNEL_VALU;          // resolved
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
+    int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
+    double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
+    int seat_use_power = 0;
+    double seat_power = 1.0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev0, ev1;
@@ -158,12 +162,15 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     resolve_kind(c);
 
     const size_t DD = (size_t)D * D, ns = (size_t)d.nslots;
-    double *dX, *dtl, *dtg, *dpm, *dpS;
+    double *dX, *dtl, *dtg, *dpm, *dpS, *dtG, *dtC, *dtS;
     DALLOC(c, dX, (size_t)N * D);
     DALLOC(c, d.log_prior, (size_t)N);
     DALLOC(c, d.z, (size_t)N);
     DALLOC(c, dtl, (size_t)d.tab_len);
     DALLOC(c, dtg, (size_t)d.tab_len);
+    DALLOC(c, dtG, (size_t)d.tab_len);
+    DALLOC(c, dtC, (size_t)N + 2);
+    DALLOC(c, dtS, (size_t)N + 2);
     DALLOC(c, dpm, (size_t)D);
     DALLOC(c, dpS, DD);
     DALLOC(c, d.m, ns * D);
@@ -196,6 +203,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
 
     d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
+    d.tabG = dtG; d.tabLogC = dtC; d.tabSeat = dtS;
+    c->tabSeat = dtS;
     CK(c, hipMemcpyAsync(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
 
     // tables: the reference's n = [1, 1, 2, ..., v_0+N+1] (gaussian_components.py:120-122)
@@ -243,6 +252,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipMemcpy(d.perm, ident.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
     CK(c, hipMemcpy(d.label_of_slot, ident.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
 
+    launch_build_tables(d, dtG, dtC, c->stream);
+    launch_build_seat_table(d, dtS, c->stream);       // plain CRP weights log(n) until a sweep says otherwise
+    c->seat_use_power = 0; c->seat_power = 1.0;
     // cached_log_prior: score every row against the pseudo slot, then the Student-t tail
     const int pslot = K_max;
     int *dslot;
@@ -395,6 +407,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.order = c->cur_order;
     resolve_kind(c);
     hipStream_t st = c->stream;
+    if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
+        launch_build_seat_table(d, c->tabSeat, st);
+        c->seat_use_power = d.use_power;
+        c->seat_power = d.power;
+    }
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
@@ -414,12 +431,17 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (Tl < 1) Tl = 1;
         if (Tl > 4096) Tl = 4096;
         const int T = (int)Tl;
+        // the resolver's LDS plan depends on the number of labels: re-planned every chunk
+        int res_R = 0, res_Kcap = 0, res_lds = 0;
+        const bool use_resolver = c->resolver_mode != 1 &&
+                                  resolve_plan(d, c->ctrl_host->job.K, &res_R, &res_Kcap, &res_lds);
         if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
         for (int t = 0; t < T; ++t) {
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
             launch_choice(d, c->win_rows, st);
+            if (use_resolver) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
             launch_refresh_ctrl(d, st);
         }
@@ -600,6 +622,14 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
 extern "C" int bgmm_add_item(bgmm_ctx *c, int64_t i, int32_t k) { return item_op(c, 1, i, k); }
 extern "C" int bgmm_del_item(bgmm_ctx *c, int64_t i) { return item_op(c, 0, i, 0); }
 
+extern "C" int bgmm_debug_prof(bgmm_ctx *c, int64_t *out8) {
+    if (!c || !out8) return BGMM_EINVAL;
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    for (int t = 0; t < 16; ++t) out8[t] = c->ctrl_host->prof[t];
+    return 0;
+}
+
 extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out6) {
     if (!c || !out6) return BGMM_EINVAL;
     for (int t = 0; t < 6; ++t) out6[t] = c->stats[t];
@@ -621,16 +651,19 @@ extern "C" int bgmm_get_kernel_timing(bgmm_ctx *c, int64_t *n_launches, double *
     return 0;
 }
 
-extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind) {
+extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode) {
     if (!c) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
+    if (resolver_mode < 0 || resolver_mode > 2) return fail(c, BGMM_EINVAL, "resolver_mode must be 0, 1 or 2");
     c->kernel_kind = kernel_kind;
+    c->resolver_mode = resolver_mode;
+    CK(c, hipMemcpy(&c->d.ctrl->dense_mode, &resolver_mode, sizeof(int), hipMemcpyHostToDevice));
     resolve_kind(c);
     if (max_window > 0) {
         int rc = fetch_ctrl(c);
         if (rc) return rc;
-        int cap = max_window < 256 ? 256 : max_window;
+        int cap = max_window < 64 ? 64 : max_window;
         if (cap > c->win_rows) cap = c->win_rows;
         c->ctrl_host->win_cap = cap;
         if (c->ctrl_host->win_size > cap) c->ctrl_host->win_size = cap;

@@ -79,10 +79,13 @@ struct Ctrl {
     int win_size;         // current adaptive window size
     int win_cap;          // upper bound (host tuning; <= allocated rows of q)
     int error;
+    int skip_apply;       // set by the resolver when it has consumed the step
+    int dense_mode;       // tuning: 0 auto, 1 never use the resolver, 2 always when it fits
     double ema_run;       // running mean distance between movers
     long long last_mover;
     // counters of the current sweep
     long long lik_evals, n_moves, n_windows, n_steps, n_score_launches, n_scored;
+    long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
 };
 
 struct Dev {
@@ -97,6 +100,9 @@ struct Dev {
     double *log_prior;
     int *z;
     const double *tab_lgam, *tab_log;
+    // derived tables (device built): tabG[v] = Student-t normaliser for v degrees of freedom,
+    // tabLogC[n] = log((k_N+1)/(k_N v_n)), tabSeat[n] = seating weight of a table with n guests
+    const double *tabG, *tabLogC, *tabSeat;
     const double *prior_m, *prior_S;
     double *m, *S, *mu, *Wrm, *Wfrag, *cvec;
     int *n;
@@ -120,6 +126,8 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st);  // explicit slots
 void launch_refresh_ctrl(const Dev &d, hipStream_t st);                          // ctrl->refresh[]
 void launch_sweep_begin(const Dev &d, hipStream_t st);
+void launch_build_tables(const Dev &d, double *tabG, double *tabLogC, hipStream_t st);
+void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st);
 void launch_apply(const Dev &d, hipStream_t st);
 void launch_item_op(const Dev &d, int op, long long i, int label, hipStream_t st); // add/del item
 void launch_log_marg(const Dev &d, double *out_total, double *out_per_label, hipStream_t st);
@@ -130,4 +138,6 @@ void launch_post_pred(const Dev &d, const double *qrow, double *out, hipStream_t
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride,
                   int col_override, long long max_rows, hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
+bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
+void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
 int refresh_lds_bytes(int D);

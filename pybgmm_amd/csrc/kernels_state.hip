@@ -10,6 +10,7 @@
 // Compiled with -ffp-contract=off: `m += x`, `S += x*x'` must round the product and the sum
 // separately so that the statistics stay bit-identical to numpy's.
 #include "bgmm_device.h"
+#include "slot_math.h"
 
 #define TPB 256
 
@@ -65,89 +66,38 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
 // Refresh: everything derived from (n, m, S) of one slot.
 //   C = S - k_N mu mu^T  (the reference's S_N; its covariance is c*C with
 //   c = (k_N+1)/(k_N (v_N-D+1))),  C = L L^T,  Winv = L^-1,  logdetC = 2 sum log L_jj.
-// LDS: A[D][D] + mu[D] + row[D].
+// Two routes (slot_math.h): from scratch, O(D^3); or a rank-1 change of Winv, O(D^2).
+// LDS: W[D][D+1] + 6 D + 4 doubles.
 // ------------------------------------------------------------------------------------------
-int refresh_lds_bytes(int D) { return (D * D + 2 * D) * (int)sizeof(double); }
+int refresh_lds_bytes(int D) { return (D * (D + 1) + 6 * D + 4) * (int)sizeof(double); }
 
-__device__ __forceinline__ double student_const(const Dev &d, long long v) {
-    const double hd = 0.5 * (double)d.D;
-    return d.tab_lgam[v + d.D] - d.tab_lgam[v] - hd * d.tab_log[v] - hd * BGMM_LOG_PI;
-}
-
-__device__ __forceinline__ double seat_weight(const Dev &d, int n) {
-    if (n <= 0) return 0.0;
-    return d.use_power ? log(pow((double)n, d.power)) : log((double)n);
-}
-
-// Everything that is written out once the inverse factor Winv (LDS, row major with leading
-// dimension ld, lower triangle valid), mu (LDS) and logdetC are known.
-__device__ void finish_slot(const Dev &d, int s, const double *A, int ld, const double *mu, double logdetC) {
-    const int D = d.D, Dp = d.Dp, tid = threadIdx.x;
-    const int n = d.n[s];
-    const double k_N = d.k0 + (double)n;
-    for (int j = tid; j < Dp; j += TPB) {
-        double acc = 0.0;
-        if (j < D)
-            for (int l = 0; l <= j; ++l) acc = fma(A[j * ld + l], mu[l], acc);
-        d.cvec[(long long)s * Dp + j] = acc;
-    }
+__device__ void refresh_slot(const Dev &d, int s, double *sm) {
+    const int D = d.D, ld = D + 1, tid = threadIdx.x;
+    double *A = sm;
+    double *mu = sm + D * ld, *row = mu + D;
+    double *scal = row + 5 * D;                    // [0] logdet, [1] bad flag (as int)
+    const double k_N = d.k0 + (double)d.n[s];
+    const double *m = d.m + (long long)s * D;
+    const double *S = d.S + (long long)s * D * D;
+    for (int a = tid; a < D; a += TPB) mu[a] = m[a] / k_N;
+    __syncthreads();
     for (int e = tid; e < D * D; e += TPB) {
         const int a = e / D, b = e % D;
-        d.Wrm[(long long)s * D * D + e] = (b <= a) ? A[a * ld + b] : 0.0;
+        if (b <= a) A[a * ld + b] = S[e] - k_N * (mu[a] * mu[b]);
     }
-    {
-        double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
-        const int nJ = Dp / 16;
-        for (int J = 0; J < nJ; ++J) {
-            const int base = 2 * J * (J + 1);
-            for (int e = tid; e < 4 * (J + 1) * 64; e += TPB) {
-                const int kk = e >> 6, lane = e & 63;
-                const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
-                wf[(base + kk) * 64 + lane] = (j < D && l <= j) ? -A[j * ld + l] : 0.0;
-            }
-        }
-    }
-    if (tid == 0) {
-        SlotConst c;
-        const double Dd = (double)D;
-        const long long v = d.v0 + n - D + 1;
-        const double cs = (k_N + 1.0) / (k_N * (double)v);
-        c.logdetC = logdetC;
-        c.A = student_const(d, v) - 0.5 * (Dd * log(cs) + logdetC);
-        c.half_vd = 0.5 * (double)(v + D);
-        c.inv_cv = 1.0 / (cs * (double)v);
-        c.logseat = seat_weight(d, n);
-        c.logseat1 = seat_weight(d, n - 1);
-        c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
-        if (n >= 2) {
-            const double k1 = k_N - 1.0;
-            const long long v1 = v - 1;
-            const double c1 = k_N / (k1 * (double)v1);
-            const double a = k_N / k1;
-            c.a1 = a;
-            c.A1 = student_const(d, v1) - 0.5 * (Dd * log(c1) + logdetC);
-            c.half_vd1 = 0.5 * (double)(v1 + D);
-            c.coef1 = a * a / (c1 * (double)v1);
-        }
-        c.pad0 = 0.0; c.pad1 = 0.0;
-        d.sc[s] = c;
-    }
+    chol_inverse<TPB>(A, ld, D, row, &scal[0], (int *)&scal[1], tid, true);
+    if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
+    write_slot<TPB>(d, s, A, ld, mu, scal[0], tid, nullptr, true);
+    if (tid == 0) d.nupd[s] = 0;
 }
 
-// Rank-1 update of a slot's derived state after point i joined (a > 0) or left (a < 0) it.
-//   S_N' = S_N + a dd',  d = x_i - mu_old,  a = k/(k+1) (join, k = k_0 + n_before)
-//                                          a = -k/(k-1) (leave, k = k_0 + n_before)
-// With p = Winv d, P_i = sum_{k<=i} p_k^2 (s = P_{D-1}):  Winv' = T Winv,  T'T = I - a/(1+as) pp',
-//   T_ii = l_i = sqrt((1 + a P_{i-1}) / (1 + a P_i)),   T_ik = t_i p_k (k < i),
-//   t_i = -a p_i / ((1 + a P_i) l_i),    logdet S_N' = logdet S_N + log(1 + a s).
-// `src` is the slot whose (mu, Winv, logdetC) describe the state BEFORE the change (dst itself,
-// or the prior pseudo slot for a freshly opened component).  O(D^2), 5 barriers.
-// LDS: W[D][D+1] + 5 D + 2 doubles.
+// Rank-1 route after point i joined (kind ADD / NEW) or left (SUB) slot dst; `src` holds the
+// state before the change (dst itself, or the prior pseudo slot for a new component).
 __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind, double *sm) {
     const int D = d.D, ld = D + 1, tid = threadIdx.x;
     double *W = sm;
-    double *dv = sm + D * ld, *pv = dv + D, *lv = pv + D, *tv = lv + D, *mu = tv + D;
-    double *s_total = mu + D;
+    double *mu = sm + D * ld, *dv = mu + D, *pv = dv + D, *lv = pv + D, *tv = lv + D;
+    double *scal = tv + 2 * D;
     const double logdet_src = d.sc[src].logdetC;      // read before anything of dst is rewritten
     const int n_new = d.n[dst];
     const double k_before = d.k0 + (double)(kind == REFRESH_SUB ? n_new + 1 : n_new - 1);
@@ -157,120 +107,13 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     for (int e = tid; e < D * D; e += TPB) W[(e / D) * ld + (e % D)] = Wsrc[e];
     for (int l = tid; l < D; l += TPB) {
         dv[l] = x[l] - d.mu[(long long)src * D + l];
-        const double m_new = d.m[(long long)dst * D + l] / (d.k0 + (double)n_new);
-        mu[l] = m_new;
-        d.mu[(long long)dst * D + l] = m_new;
+        mu[l] = d.m[(long long)dst * D + l] / (d.k0 + (double)n_new);
     }
     __syncthreads();
-    for (int r = tid; r < D; r += TPB) {
-        double acc = 0.0;
-        for (int l = 0; l <= r; ++l) acc = fma(W[r * ld + l], dv[l], acc);
-        pv[r] = acc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double P = 0.0;
-        bool bad = false;
-        for (int r = 0; r < D; ++r) {
-            const double num = 1.0 + a * P;
-            P = fma(pv[r], pv[r], P);
-            const double den = 1.0 + a * P;
-            if (!(den > 0.0) || !(num > 0.0)) bad = true;
-            const double l = sqrt(num / den);
-            lv[r] = l;
-            tv[r] = -a * pv[r] / (den * l);
-        }
-        *s_total = P;
-        if (bad) atomicCAS(&d.ctrl->error, 0, -4);
-    }
-    __syncthreads();
-    for (int j = tid; j < D; j += TPB) {          // column j, rows j..D-1, running sum_{k<i} p_k W[k][j]
-        double r = 0.0;
-        for (int row = j; row < D; ++row) {
-            const double w = W[row * ld + j];
-            W[row * ld + j] = fma(tv[row], r, lv[row] * w);
-            r = fma(pv[row], w, r);
-        }
-    }
-    __syncthreads();
-    const double logdetC = logdet_src + log(1.0 + a * (*s_total));
-    finish_slot(d, dst, W, ld, mu, logdetC);
+    rank1_inverse_factor<TPB>(W, ld, D, a, dv, pv, lv, tv, &scal[0], (int *)&scal[1], tid, true);
+    if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
+    write_slot<TPB>(d, dst, W, ld, mu, logdet_src + log(1.0 + a * scal[0]), tid, nullptr, true);
     if (tid == 0) d.nupd[dst] += 1;
-}
-
-int rank1_lds_bytes(int D) { return (D * (D + 1) + 5 * D + 2) * (int)sizeof(double); }
-
-__device__ void refresh_slot(const Dev &d, int s, double *sm) {
-    const int D = d.D, tid = threadIdx.x;
-    double *A = sm;                // D*D, row major, lower triangle used
-    double *mu = sm + D * D;       // D
-    double *row = mu + D;          // D
-    const int n = d.n[s];
-    const double k_N = d.k0 + (double)n;
-    const double *m = d.m + (long long)s * D;
-    const double *S = d.S + (long long)s * D * D;
-
-    for (int a = tid; a < D; a += TPB) {
-        const double v = m[a] / k_N;
-        mu[a] = v;
-        d.mu[(long long)s * D + a] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < D * D; e += TPB) {
-        const int a = e / D, b = e % D;
-        if (b <= a) A[e] = S[e] - k_N * (mu[a] * mu[b]);
-    }
-    // --- Cholesky, right looking, 2 barriers per column ---
-    bool bad = false;
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int j = 0; j < D; ++j) {
-        __syncthreads();
-        const double djj = A[j * D + j];
-        if (!(djj > 0.0)) bad = true;
-        const double piv = sqrt(djj);
-        for (int i = j + 1 + tid; i < D; i += TPB) A[i * D + j] = A[i * D + j] / piv;
-        __syncthreads();
-        if (tid == 0) A[j * D + j] = piv;
-        for (int i = j + 1 + ty; i < D; i += 16) {
-            const double lij = A[i * D + j];
-            for (int l = j + 1 + tx; l <= i; l += 16) A[i * D + l] = fma(-lij, A[l * D + j], A[i * D + l]);
-        }
-    }
-    __syncthreads();
-    // logdetC (sequential, deterministic)
-    double logdetC = 0.0;
-    if (tid == 0) {
-        for (int j = 0; j < D; ++j) logdetC += log(A[j * D + j]);
-        logdetC *= 2.0;
-        if (bad || !(logdetC == logdetC)) atomicCAS(&d.ctrl->error, 0, -4);
-    }
-    // --- in-place inverse of the lower-triangular factor, row by row ---
-    // Winv[i][c] = -(sum_{t=c}^{i-1} L[i][t] Winv[t][c]) / L[i][i],  Winv[i][i] = 1/L[i][i]
-    int P = 1;
-    while (P < D) P <<= 1;                 // columns padded to a power of two
-    int tpc = TPB / P;                     // threads cooperating on one column
-    if (tpc < 1) tpc = 1;
-    if (tpc > 64) tpc = 64;
-    const int col = tid / tpc, part = tid % tpc;
-    for (int i = 0; i < D; ++i) {
-        for (int t = tid; t <= i; t += TPB) row[t] = A[i * D + t];
-        __syncthreads();
-        const double inv_d = 1.0 / row[i];
-        for (int c0 = 0; c0 <= i; c0 += TPB / tpc) {   // (one pass unless D > TPB/tpc)
-            const int c = c0 + col;
-            double acc = 0.0;
-            if (c < i)
-                for (int t = c + part; t < i; t += tpc) acc = fma(row[t], A[t * D + c], acc);
-            for (int o = tpc >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (part == 0) {
-                if (c < i) A[i * D + c] = -acc * inv_d;
-                else if (c == i) A[i * D + i] = inv_d;
-            }
-        }
-        __syncthreads();
-    }
-    finish_slot(d, s, A, D, mu, logdetC);
-    if (tid == 0) d.nupd[s] = 0;
 }
 
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
@@ -299,8 +142,7 @@ void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) 
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
-    const int l1 = refresh_lds_bytes(d.D), l2 = rank1_lds_bytes(d.D);
-    const int lds = l1 > l2 ? l1 : l2;
+    const int lds = refresh_lds_bytes(d.D);
     ensure_lds((const void *)refresh_ctrl_kernel, lds);
     hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
 }
@@ -308,51 +150,41 @@ void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // Window bookkeeping (thread 0 of the applier / sweep_begin only)
 // ------------------------------------------------------------------------------------------
-__device__ void set_chunks(const Dev &d, Job &j) {
-    const long long rows = j.win_hi - j.pos;
-    const long long rb = (rows + d.rows_per_block - 1) / d.rows_per_block;
-    const int nlist = (j.mode == MODE_FRESH) ? j.K : j.n_dirty;
-    long long ch = rb > 0 ? (1024 + rb - 1) / rb : 1;
-    if (ch > kMaxChunks) ch = kMaxChunks;
-    if (ch > nlist) ch = nlist;
-    if (ch < 1) ch = 1;
-    j.chunks = (int)ch;
+// tabG[v], v = 1 .. tab_len-D-1;  tabLogC[n], n = 0 .. N+1 (log c1 of a slot with n is tabLogC[n-1])
+__global__ void build_tables_kernel(Dev d, double *tabG, double *tabLogC) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 1 && t + d.D < d.tab_len) tabG[t] = student_const(d, t);
+    if (t <= d.N + 1) tabLogC[t] = log(cov_scale(d, (int)t));
 }
-
-__device__ void start_window(const Dev &d, Ctrl *c, long long pos) {
-    Job &j = c->job;
-    j.pos = pos;
-    j.win_base = pos;
-    long long hi = pos + c->win_size;
-    if (hi > c->n_visits) hi = c->n_visits;
-    j.win_hi = hi;
-    j.n_dirty = 0;
-    if (pos >= c->n_visits) {
-        j.mode = MODE_DONE;
-    } else {
-        j.mode = MODE_FRESH;
-        c->n_windows += 1;
-    }
-    set_chunks(d, j);
+__global__ void build_seat_table_kernel(Dev d, double *tabSeat) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= d.N + 1) tabSeat[t] = seat_weight(d, (int)t);
+}
+void launch_build_tables(const Dev &d, double *tabG, double *tabLogC, hipStream_t st) {
+    hipLaunchKernelGGL(build_tables_kernel, dim3((unsigned)((d.tab_len + 255) / 256)), dim3(256), 0, st, d, tabG, tabLogC);
+}
+void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st) {
+    hipLaunchKernelGGL(build_seat_table_kernel, dim3((unsigned)((d.N + 2 + 255) / 256)), dim3(256), 0, st, d, tabSeat);
 }
 
 __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     const int K = c->job.K;
-    // seating weights depend on the sweep's exponent
+    // seating weights depend on the sweep's exponent (tabSeat was rebuilt by the host if it changed)
     for (int j = threadIdx.x; j < K; j += TPB) {
         const int s = d.perm[j];
-        d.sc[s].logseat = seat_weight(d, d.n[s]);
-        d.sc[s].logseat1 = seat_weight(d, d.n[s] - 1);
+        d.sc[s].logseat = d.tabSeat[d.n[s]];
+        d.sc[s].logseat1 = d.n[s] >= 1 ? d.tabSeat[d.n[s] - 1] : 0.0;
     }
     if (threadIdx.x == 0) {
         c->n_visits = d.N;
         c->first_mover = kNoMover;
         c->n_refresh = 0;
+        c->skip_apply = 0;
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
         c->last_mover = -1;
-        if (c->win_size < 256) c->win_size = 256;
+        if (c->win_size < 64) c->win_size = 64;
         if (c->win_size > c->win_cap) c->win_size = c->win_cap;
         if (c->error == 0) start_window(d, c, 0);
         else c->job.mode = MODE_DONE;
@@ -463,9 +295,11 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (threadIdx.x == 0) {
         do_move = 0;
-        c->n_refresh = 0;
         Job &j = c->job;
-        if (j.mode != MODE_DONE) {
+        c->n_refresh = 0;               // (a consumed or idle step must not re-run a refresh)
+        if (c->skip_apply) {
+            c->skip_apply = 0;          // the resolver already consumed this step
+        } else if (j.mode != MODE_DONE) {
             c->n_steps += 1;
             c->n_score_launches += 1;
             c->n_scored += (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
@@ -499,10 +333,12 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     const double run = (double)(p - c->last_mover);
                     c->last_mover = p;
                     c->ema_run = 0.875 * c->ema_run + 0.125 * run;
-                    long long w = 256;
-                    while (w < c->win_cap && (double)w < 0.5 * c->ema_run) w <<= 1;
-                    if (w > c->win_cap) w = c->win_cap;
+                    const long long w = window_for_rate(c);
                     c->win_size = (int)w;
+                    // movers are dense relative to what is left of this window: give up its tail
+                    // (it is re-scored later as part of a fresh, smaller window) instead of
+                    // re-evaluating all of it after every move
+                    if (j.win_hi - (p + 1) > 2 * w) j.win_hi = p + 1 + w;
                     if (p + 1 >= j.win_hi) {
                         start_window(d, c, p + 1);
                     } else {

@@ -1,0 +1,279 @@
+// Per-slot derived-state math shared by the state kernels and the in-launch mover resolver.
+// Everything here is written for a thread team of NT threads with team-local thread id `tid`
+// (a whole block, or one half of the resolver block); functions that contain barriers must be
+// called by ALL threads of the block (teams that have no work pass active = false).
+//
+// Reference behaviour restated: gaussian_components.py:319-331 (covariance refresh) and
+// :228-251 (the constants of the Student-t predictive it feeds).
+#pragma once
+#include "bgmm_device.h"
+
+__device__ __forceinline__ double student_const(const Dev &d, long long v) {
+    const double hd = 0.5 * (double)d.D;
+    return d.tab_lgam[v + d.D] - d.tab_lgam[v] - hd * d.tab_log[v] - hd * BGMM_LOG_PI;
+}
+
+__device__ __forceinline__ double seat_weight(const Dev &d, int n) {
+    if (n <= 0) return 0.0;
+    return d.use_power ? log(pow((double)n, d.power)) : log((double)n);
+}
+
+// scale of the predictive covariance: Sigma = cs * S_N with cs = (k_N+1)/(k_N (v_N-D+1))
+__device__ __forceinline__ double cov_scale(const Dev &d, int n) {
+    const double k_N = d.k0 + (double)n;
+    return (k_N + 1.0) / (k_N * (double)(d.v0 + n - d.D + 1));
+}
+
+// constants of the predictive for a slot with count n and logdet(S_N) = logdetC.  Everything
+// that depends on n alone comes from the device-built tables (no transcendental on this path:
+// it sits on the critical chain of every move).
+__device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC) {
+    SlotConst c;
+    const int D = d.D;
+    const double Dd = (double)D;
+    const double k_N = d.k0 + (double)n;
+    const long long v = d.v0 + n - D + 1;
+    const double g = d.tabG[v], lc = d.tabLogC[n], seat = d.tabSeat[n];
+    const double g1 = n >= 2 ? d.tabG[v - 1] : 0.0, lc1 = n >= 1 ? d.tabLogC[n - 1] : 0.0;
+    const double seat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
+    const double cs = (k_N + 1.0) / (k_N * (double)v);
+    c.logdetC = logdetC;
+    c.A = g - 0.5 * (Dd * lc + logdetC);
+    c.half_vd = 0.5 * (double)(v + D);
+    c.inv_cv = 1.0 / (cs * (double)v);
+    c.logseat = seat;
+    c.logseat1 = seat1;
+    c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+    if (n >= 2) {
+        const double k1 = k_N - 1.0;
+        const long long v1 = v - 1;
+        const double c1 = k_N / (k1 * (double)v1);
+        const double a = k_N / k1;
+        c.a1 = a;
+        c.A1 = g1 - 0.5 * (Dd * lc1 + logdetC);
+        c.half_vd1 = 0.5 * (double)(v1 + D);
+        c.coef1 = a * a / (c1 * (double)v1);
+    }
+    c.pad0 = 0.0; c.pad1 = 0.0;
+    return c;
+}
+
+// log score of one (visit, slot) pair from its quadratic form (seating weight included)
+__device__ __forceinline__ double slot_log_score(const SlotConst &sc, double qv, bool home_minus_one) {
+    if (home_minus_one) {
+        const double den = 1.0 - sc.a1 * qv;
+        return sc.logseat1 + sc.A1 - 0.5 * log(den) - sc.half_vd1 * log(1.0 + sc.coef1 * qv / den);
+    }
+    return sc.logseat + sc.A - sc.half_vd * log(1.0 + qv * sc.inv_cv);
+}
+
+// Write a slot's derived state from Winv (LDS, lower triangle, leading dimension ld) and mu
+// (LDS).  cv_lds (optional) receives cvec as well.  No barrier inside; the caller's data must
+// be complete (barrier before), and cv_lds is valid after the caller's next barrier.
+template <int NT>
+__device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, const double *mu,
+                                  double logdetC, int tid, double *cv_lds, bool active) {
+    if (!active) return;
+    const int D = d.D, Dp = d.Dp;
+    for (int j = tid; j < Dp; j += NT) {
+        double acc = 0.0;
+        if (j < D)
+            for (int l = 0; l <= j; ++l) acc = fma(W[j * ld + l], mu[l], acc);
+        d.cvec[(long long)s * Dp + j] = acc;
+        if (cv_lds && j < D) cv_lds[j] = acc;
+    }
+    for (int e = tid; e < D * D; e += NT) {
+        const int a = e / D, b = e - a * D;
+        d.Wrm[(long long)s * D * D + e] = (b <= a) ? W[a * ld + b] : 0.0;
+    }
+    double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
+    for (int e = tid; e < d.nfrag * 64; e += NT) {
+        const int f = e >> 6, lane = e & 63;
+        int J = 0;
+        while (2 * (J + 1) * (J + 2) <= f) ++J;
+        const int kk = f - 2 * J * (J + 1);
+        const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
+        wf[e] = (j < D && l <= j) ? -W[j * ld + l] : 0.0;
+    }
+    for (int l = tid; l < D; l += NT) d.mu[(long long)s * D + l] = mu[l];
+    if (tid == 0) d.sc[s] = make_consts(d, d.n[s], logdetC);
+}
+
+// In-place Cholesky (right looking) followed by the in-place inverse of the factor.
+// A: LDS, lower triangle of S_N on entry, Winv on exit.  rowbuf: D doubles of LDS scratch.
+// Returns (to every thread that reads *logdet_out after the final barrier) logdet S_N.
+// Contains barriers: all NT threads of the team's BLOCK must call it (block-wide barriers), with
+// active = false for teams that have nothing to do.
+template <int NT>
+__device__ inline void chol_inverse(double *A, int ld, int D, double *rowbuf, double *logdet_out,
+                                    int *bad_out, int tid, bool active) {
+    const int tx = tid & 15, ty = tid >> 4;
+    bool bad = false;
+    for (int j = 0; j < D; ++j) {
+        __syncthreads();
+        if (active) {
+            const double djj = A[j * ld + j];
+            if (!(djj > 0.0)) bad = true;
+            const double piv = sqrt(djj);
+            for (int i = j + 1 + tid; i < D; i += NT) A[i * ld + j] = A[i * ld + j] / piv;
+        }
+        __syncthreads();
+        if (active) {
+            if (tid == 0) A[j * ld + j] = sqrt(A[j * ld + j]);
+            for (int i = j + 1 + ty; i < D; i += NT / 16) {
+                const double lij = A[i * ld + j];
+                for (int l = j + 1 + tx; l <= i; l += 16) A[i * ld + l] = fma(-lij, A[l * ld + j], A[i * ld + l]);
+            }
+        }
+    }
+    __syncthreads();
+    if (active && tid == 0) {
+        double ldt = 0.0;
+        for (int j = 0; j < D; ++j) ldt += log(A[j * ld + j]);
+        ldt *= 2.0;
+        *logdet_out = ldt;
+        *bad_out = (bad || !(ldt == ldt)) ? 1 : 0;
+    }
+    // inverse, row by row: Winv[i][c] = -(sum_{t=c}^{i-1} L[i][t] Winv[t][c]) / L[i][i]
+    int P = 1;
+    while (P < D) P <<= 1;
+    int tpc = NT / P;
+    if (tpc < 1) tpc = 1;
+    if (tpc > 64) tpc = 64;
+    const int col = tid / tpc, part = tid % tpc;
+    for (int i = 0; i < D; ++i) {
+        if (active)
+            for (int t = tid; t <= i; t += NT) rowbuf[t] = A[i * ld + t];
+        __syncthreads();
+        if (active) {
+            const double inv_d = 1.0 / rowbuf[i];
+            for (int c0 = 0; c0 <= i; c0 += NT / tpc) {
+                const int c = c0 + col;
+                double acc = 0.0;
+                if (c < i)
+                    for (int t = c + part; t < i; t += tpc) acc = fma(rowbuf[t], A[t * ld + c], acc);
+                for (int o = tpc >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                if (part == 0) {
+                    if (c < i) A[i * ld + c] = -acc * inv_d;
+                    else if (c == i) A[i * ld + i] = inv_d;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Rank-1 change of the inverse factor held in LDS:
+//   S_N' = S_N + a dd',  p = Winv d,  P_i = sum_{k<=i} p_k^2,
+//   Winv' = T Winv,  T_ii = l_i = sqrt((1 + a P_{i-1})/(1 + a P_i)),  T_ik = t_i p_k (k < i),
+//   t_i = -a p_i / ((1 + a P_i) l_i),   logdet' = logdet + log(1 + a P_{D-1}).
+// W, dv (= x - mu_old), pv, lv, tv: LDS.  *s_out receives P_{D-1}; *bad_out is set on loss of
+// positive definiteness.  Barriers inside (block wide).
+template <int NT>
+__device__ inline void rank1_inverse_factor(double *W, int ld, int D, double a, const double *dv,
+                                            double *pv, double *lv, double *tv, double *s_out,
+                                            int *bad_out, int tid, bool active) {
+    // p = W d : 8 threads per row
+    if (active) {
+        for (int r0 = 0; r0 < D; r0 += NT / 8) {
+            const int r = r0 + (tid >> 3), part = tid & 7;
+            double acc = 0.0;
+            if (r < D)
+                for (int l = part; l <= r; l += 8) acc = fma(W[r * ld + l], dv[l], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            if (r < D && part == 0) pv[r] = acc;
+        }
+    }
+    __syncthreads();
+    if (active && D <= 64) {
+        // prefix sums of p^2 by the first wavefront of the team
+        if (tid < 64) {
+            const double v = tid < D ? pv[tid] * pv[tid] : 0.0;
+            double P = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(P, o);
+                if (tid >= o) P += t;
+            }
+            double Pm1 = __shfl_up(P, 1);
+            if (tid == 0) Pm1 = 0.0;
+            const double num = 1.0 + a * Pm1, den = 1.0 + a * P;
+            const bool badl = tid < D && (!(den > 0.0) || !(num > 0.0));
+            if (tid < D) {
+                const double l = sqrt(num / den);
+                lv[tid] = l;
+                tv[tid] = -a * pv[tid] / (den * l);
+            }
+            const unsigned long long anybad = __ballot(badl);
+            if (tid == D - 1) { *s_out = P; *bad_out = anybad ? 1 : 0; }
+        }
+    } else if (active && tid == 0) {
+        double P = 0.0;
+        bool bad = false;
+        for (int r = 0; r < D; ++r) {
+            const double num = 1.0 + a * P;
+            P = fma(pv[r], pv[r], P);
+            const double den = 1.0 + a * P;
+            if (!(den > 0.0) || !(num > 0.0)) bad = true;
+            const double l = sqrt(num / den);
+            lv[r] = l;
+            tv[r] = -a * pv[r] / (den * l);
+        }
+        *s_out = P;
+        *bad_out = bad ? 1 : 0;
+    }
+    __syncthreads();
+    if (active) {
+        for (int j = tid; j < D; j += NT) {        // column j: running sum_{k<i} p_k W[k][j]
+            double r = 0.0;
+            for (int row = j; row < D; ++row) {
+                const double w = W[row * ld + j];
+                W[row * ld + j] = fma(tv[row], r, lv[row] * w);
+                r = fma(pv[row], w, r);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Window bookkeeping (one thread)
+// ------------------------------------------------------------------------------------------
+__device__ inline void set_chunks(const Dev &d, Job &j) {
+    const long long rows = j.win_hi - j.pos;
+    const long long rb = (rows + d.rows_per_block - 1) / d.rows_per_block;
+    const int nlist = (j.mode == MODE_FRESH) ? j.K : j.n_dirty;
+    long long ch = rb > 0 ? (1024 + rb - 1) / rb : 1;
+    if (ch > kMaxChunks) ch = kMaxChunks;
+    if (ch > nlist) ch = nlist;
+    if (ch < 1) ch = 1;
+    j.chunks = (int)ch;
+}
+
+__device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
+    Job &j = c->job;
+    j.pos = pos;
+    j.win_base = pos;
+    long long hi = pos + c->win_size;
+    if (hi > c->n_visits) hi = c->n_visits;
+    j.win_hi = hi;
+    j.n_dirty = 0;
+    if (pos >= c->n_visits) {
+        j.mode = MODE_DONE;
+    } else {
+        j.mode = MODE_FRESH;
+        c->n_windows += 1;
+    }
+    set_chunks(d, j);
+}
+
+
+// window size from the running mean distance between movers: about half of it, a power of two
+__device__ inline long long window_for_rate(const Ctrl *c) {
+    long long w = 64;
+    while (w < c->win_cap && (double)w < 0.5 * c->ema_run) w <<= 1;
+    if (w > c->win_cap) w = c->win_cap;
+    return w;
+}

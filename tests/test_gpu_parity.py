@@ -22,11 +22,11 @@ pytestmark = pytest.mark.gpu
 LM_RTOL = 1e-6
 
 
-def make_ctx(g, kind=0, window=0, tables=True):
+def make_ctx(g, kind=0, window=0, tables=True, resolver=0):
     from pybgmm_amd import _lib
     ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max,
                        tables=reference_tables(g.v_0, g.N) if tables else None)
-    ctx.set_tuning(max_window=window, kernel_kind=kind)
+    ctx.set_tuning(max_window=window, kernel_kind=kind, resolver_mode=resolver)
     ctx.set_assignments(g.z_init)
     return ctx
 
@@ -50,6 +50,29 @@ def test_golden_trajectory(case, kind):
     if "final_S" in g.d.files:
         m, S, ld, iv = ctx.stats()
         npt.assert_array_equal(m, g.d["final_m"])       # bit-exact sufficient statistics
+        npt.assert_array_equal(S, g.d["final_S"])
+        npt.assert_allclose(ld, g.d["final_logdet"], rtol=1e-8, atol=1e-8)
+        npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-7, atol=1e-9)
+    ctx.close()
+
+
+@pytest.mark.parametrize("resolver", [1, 2], ids=["per-mover-kernels", "in-launch-resolver"])
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_golden_trajectory_both_mover_paths(case, resolver):
+    """Force the per-mover kernel chain (1) and the in-launch resolver (2): same chain."""
+    g = Golden(case)
+    ctx = make_ctx(g, 0, 0, resolver=resolver)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        z = ctx.assignments()
+        bad = np.nonzero(z != g.z[it])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        npt.assert_array_equal(ctx.counts(), g.counts_at(it))
+        lm = ctx.log_marg()
+        assert abs(lm - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
+    if "final_S" in g.d.files:
+        m, S, ld, iv = ctx.stats()
+        npt.assert_array_equal(m, g.d["final_m"])
         npt.assert_array_equal(S, g.d["final_S"])
         npt.assert_allclose(ld, g.d["final_logdet"], rtol=1e-8, atol=1e-8)
         npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-7, atol=1e-9)
