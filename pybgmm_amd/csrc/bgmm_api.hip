@@ -124,6 +124,9 @@ static void resolve_kind(bgmm_ctx *c) {
     if (k == KERNEL_MFMA && c->d.Dp / 16 > 8) k = KERNEL_VALU;
     c->kind = k;
     c->d.rows_per_block = (k == KERNEL_MFMA) ? kMfmaRows : kValuRows;
+    // 256 CUs x resident blocks per CU of the chosen kernel (see the MINW note in kernels_score.hip)
+    const int nJ = c->d.Dp / 16;
+    c->d.target_blocks = (k == KERNEL_MFMA) ? 256 * (nJ <= 4 ? 3 : (nJ <= 5 ? 2 : 1)) : 1024;
 }
 
 extern "C" const char *bgmm_version(void) { return "bgmm-hip 0.1 gfx950"; }

@@ -94,6 +94,7 @@ struct Dev {
     long long qstride;           // q[slot * qstride + window row]
     int choice_rows;             // visits per block of the draw kernel
     int rows_per_block;          // of the active likelihood kernel (chunk policy)
+    int target_blocks;           // blocks that fill the chip at the kernel's occupancy
     long long tab_len, v0;
     double k0, alpha, log_alpha;
     const double *X;

@@ -95,15 +95,34 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
 // replaced at once by the load of piece f + PF (wrapping into the NEXT slot's list), so PF
 // loads are always in flight ahead of the matrix pipe.
 // ------------------------------------------------------------------------------------------
+// Sum over the 16 lanes of a DPP row without touching the LDS crossbar: quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after the four steps every lane of the
+// row holds the row total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    return v;
+}
+
 constexpr int pick_pf(int nf) {
     int best = 1;
-    for (int p = 1; p <= 24 && p <= nf; ++p)
+    for (int p = 1; p <= 12 && p <= nf; ++p)
         if (nf % p == 0) best = p;
     return best;
 }
 
-// MINW = waves per SIMD the register budget is planned for (2 up to D = 80; the D = 96..128
-// variants keep 2 x 16 rows of A fragments = 96..128 VGPRs and run one wave per SIMD).
+// MINW = waves per SIMD the register budget is planned for: 3 up to D = 64 (168 VGPRs with a
+// 10..12-deep ring), 2 at D = 80, 1 for D = 96..128 (2 x 16 rows of A fragments alone are
+// 96..128 VGPRs).  bgmm_api.hip sizes the grid (label chunks) to a whole number of residency rounds.
 template <int NJ, int RB, int MINW>
 __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
                                                             double *__restrict__ q, long long qstride,
@@ -190,11 +209,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
         for (int R = 0; R < RB; ++R) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double v = qp[R][r];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                const double v = row16_sum(qp[R][r]);
                 const long long p = pw + R * 16 + lk + 4 * r;
                 if (lr == r && p < job.win_hi) qcol[p - job.win_base] = v;
             }
@@ -213,7 +228,7 @@ template <int NJ>
 static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                         long long max_rows, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 5 ? 2 : 1)>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
+    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
                        qstride, col_override);
 }
 

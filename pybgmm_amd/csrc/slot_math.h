@@ -245,7 +245,7 @@ __device__ inline void set_chunks(const Dev &d, Job &j) {
     const long long rows = j.win_hi - j.pos;
     const long long rb = (rows + d.rows_per_block - 1) / d.rows_per_block;
     const int nlist = (j.mode == MODE_FRESH) ? j.K : j.n_dirty;
-    long long ch = rb > 0 ? (1024 + rb - 1) / rb : 1;
+    long long ch = rb > 0 ? (d.target_blocks + rb - 1) / rb : 1;
     if (ch > kMaxChunks) ch = kMaxChunks;
     if (ch > nlist) ch = nlist;
     if (ch < 1) ch = 1;
