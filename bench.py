@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--init", default="true", choices=["true", "rand"])
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 VALU, 2 MFMA")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--prune", type=int, default=0, help="0 auto (exact pruning on), 1 off")
+    ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 off, 2 always")
     ap.add_argument("--cpu-visits", type=int, default=20000,
                     help="visits of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1)
@@ -114,7 +116,8 @@ def main():
     t0 = time.time()
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, device=local_rank,
                        tables=reference_tables(v_0, N))
-    ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel)
+    ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                   prune_mode=args.prune)
     ctx.set_assignments(z0)
     t_setup = time.time() - t0
     t0 = time.time()
@@ -176,9 +179,18 @@ def main():
             # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
             # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
             exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
-            executed = st["scored"] * exec_per_eval / (ms * 1e-3) / 1e12
+            pruning = bool(st["bound_blocks"] > 0)
+            if pruning:
+                # pruning kernel: a 16-visit block costs D/4 MFMAs per slot it bounds (the distance
+                # GEMM) plus 2 nJ (nJ+1) MFMAs per slot it scores in full; 2048 flop per MFMA
+                executed_flops = 2048.0 * (st["bound_blocks"] * (4 * nJ) / 16.0
+                                           + st["kept_blocks"] * 2 * nJ * (nJ + 1))
+            else:
+                executed_flops = st["scored"] * exec_per_eval
+            executed = executed_flops / (ms * 1e-3) / 1e12
             roofline = {
-                "kernel": "score_mfma_kernel" if is_mfma else "score_valu_kernel",
+                "kernel": ("score_mfma_prune_kernel" if pruning else "score_mfma_kernel") if is_mfma else "score_valu_kernel",
+                "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 4) if pruning else 1.0,
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
                 "traffic": traffic,
@@ -221,7 +233,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s D=%d N=%d K~%d, one independent chain per GPU, init=%s"
                                    % (args.workload, model, D, N, K, args.init),
-                       "parallelism": "replica_chains_x%d" % n_gpus},
+                       "parallelism": "replica_chains_x%d" % n_gpus,
+                       "exact_pruning": bool(args.prune == 0 and D >= 17 and args.kernel != 1)},
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
             "roofline": roofline,

@@ -122,19 +122,23 @@ int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
  *   sweep_stats: counters of the last sweep --
  *     [0] lik_evals = sum over visits of K at that visit, [1] visits that changed component,
  *     [2] speculative windows evaluated, [3] kernel steps issued, [4] likelihood-kernel launches
- *     that did work, [5] rows x components scored (incl. re-scores after moves).
+ *     that did work, [5] rows x components scored (incl. re-scores after moves; pruned pairs
+ *     count: they are decided, just not by the full quadratic form), [6] (16-visit block,
+ *     component) pairs the pruning kernel evaluated in full, [7] pairs it only bounded.
  *   kernel timing: when enabled, every likelihood-kernel launch is bracketed by HIP events on
  *     the context's own stream; get returns the number of timed launches that did work and the
  *     sum of their durations in milliseconds since the last reset.
  */
-int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out6);
+int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out8);
 int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
 int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
  * kernel (0 auto, 1 VALU, 2 MFMA); in-launch mover resolver (0 auto: when movers are dense,
- * 1 never, 2 whenever it fits).  None of them changes the sampled trajectory. */
-int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode);
+ * 1 never, 2 whenever it fits); exact pruning of components whose weight in a draw is provably
+ * below e^-80 (0 auto: on, 1 off).  None of them changes the sampled trajectory. */
+int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
+                    int32_t prune_mode);
 
 /* Blocks until all work queued on the context's stream has finished. */
 int bgmm_synchronize(bgmm_ctx *ctx);

@@ -47,7 +47,7 @@ SIGNATURES = {
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
-    "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "bgmm_synchronize": (ctypes.c_int, [_vp]),
 }
 
@@ -217,9 +217,10 @@ class Context(object):
 
     # -- measurement ---------------------------------------------------------
     def sweep_stats(self):
-        out = np.zeros(6, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._ck(self.L.bgmm_get_sweep_stats(self.h, _ptr(out)))
-        keys = ("lik_evals", "moves", "windows", "steps", "score_launches", "scored")
+        keys = ("lik_evals", "moves", "windows", "steps", "score_launches", "scored", "kept_blocks",
+                "bound_blocks")
         return dict(zip(keys, (int(v) for v in out)))
 
     def set_kernel_timing(self, on):
@@ -231,8 +232,9 @@ class Context(object):
         self._ck(self.L.bgmm_get_kernel_timing(self.h, ctypes.byref(n), ctypes.byref(ms)))
         return int(n.value), float(ms.value)
 
-    def set_tuning(self, max_window=0, kernel_kind=0, resolver_mode=0):
-        self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind), int(resolver_mode)))
+    def set_tuning(self, max_window=0, kernel_kind=0, resolver_mode=0, prune_mode=0):
+        self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind), int(resolver_mode),
+                                        int(prune_mode)))
 
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))

@@ -50,6 +50,7 @@ struct bgmm_ctx {
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
     int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
+    int prune_mode = 0;              // 0 auto (on for D >= 17 with the MFMA kernel), 1 off
     double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
     int seat_use_power = 0;
     double seat_power = 1.0;
@@ -58,7 +59,7 @@ struct bgmm_ctx {
     std::vector<hipEvent_t> ev0, ev1;
     long long timed_launches = 0;
     double timed_ms = 0.0;
-    long long stats[6] = {0, 0, 0, 0, 0, 0};
+    long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 #define CK(ctx, call)                                                                       \
@@ -161,7 +162,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.nfrag = bgmm_nfrag(d.Dp); d.ldq = d.nslots;
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
     d.tab_len = v_0 + N + 2;
-    d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr;
+    d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
     resolve_kind(c);
 
     const size_t DD = (size_t)D * D, ns = (size_t)d.nslots;
@@ -271,7 +272,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipMemcpy(c->util_job, &job, sizeof(Job), hipMemcpyHostToDevice));
     double *qcol;
     DALLOC(c, qcol, (size_t)N);
-    launch_score(d, c->kind, c->util_job, qcol, N, 0, N, c->stream);
+    launch_score(d, c->kind, c->util_job, qcol, N, 0, N, 0, c->stream);
     launch_prior_lp(d, qcol, c->stream);
     CK(c, hipGetLastError());
     int rc = fetch_ctrl(c);
@@ -409,6 +410,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.u = c->cur_u;
     d.order = c->cur_order;
     resolve_kind(c);
+    const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA && d.Dp >= 32;
+    d.prune_enabled = use_prune ? 1 : 0;
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
         launch_build_seat_table(d, c->tabSeat, st);
@@ -440,8 +443,13 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
                                   resolve_plan(d, c->ctrl_host->job.K, &res_R, &res_Kcap, &res_lds);
         if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
         for (int t = 0; t < T; ++t) {
+            // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
+            // only serves the re-scoring after a move; the events bracket the one that works in
+            // the steady state.
+            if (use_prune) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
-            launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, st);
+            if (use_prune) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, c->win_rows, st);
+            else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
             launch_choice(d, c->win_rows, st);
             if (use_resolver) launch_resolve(d, res_R, res_Kcap, res_lds, st);
@@ -471,6 +479,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
+    c->stats[6] = (long long)h.n_kept_blocks; c->stats[7] = (long long)h.n_bound_blocks;
     return check_device_error(c);
 }
 
@@ -598,7 +607,7 @@ extern "C" int bgmm_log_post_pred(bgmm_ctx *c, int64_t i, double *out) {
     CK(c, hipStreamSynchronize(c->stream));
     Dev d = c->d;
     d.order = nullptr;
-    launch_score(d, c->kind, c->util_job, c->util_q, 1, -1, 1, c->stream);
+    launch_score(d, c->kind, c->util_job, c->util_q, 1, -1, 1, 0, c->stream);
     launch_post_pred(d, c->util_q, c->util_out, c->stream);
     CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
@@ -633,9 +642,9 @@ extern "C" int bgmm_debug_prof(bgmm_ctx *c, int64_t *out8) {
     return 0;
 }
 
-extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out6) {
-    if (!c || !out6) return BGMM_EINVAL;
-    for (int t = 0; t < 6; ++t) out6[t] = c->stats[t];
+extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out8) {
+    if (!c || !out8) return BGMM_EINVAL;
+    for (int t = 0; t < 8; ++t) out8[t] = c->stats[t];
     return 0;
 }
 
@@ -654,13 +663,16 @@ extern "C" int bgmm_get_kernel_timing(bgmm_ctx *c, int64_t *n_launches, double *
     return 0;
 }
 
-extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode) {
+extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
+                               int32_t prune_mode) {
     if (!c) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
     if (resolver_mode < 0 || resolver_mode > 2) return fail(c, BGMM_EINVAL, "resolver_mode must be 0, 1 or 2");
+    if (prune_mode < 0 || prune_mode > 1) return fail(c, BGMM_EINVAL, "prune_mode must be 0 or 1");
     c->kernel_kind = kernel_kind;
     c->resolver_mode = resolver_mode;
+    c->prune_mode = prune_mode;
     CK(c, hipMemcpy(&c->d.ctrl->dense_mode, &resolver_mode, sizeof(int), hipMemcpyHostToDevice));
     resolve_kind(c);
     if (max_window > 0) {

@@ -51,7 +51,8 @@ struct SlotConst {
     double A1, half_vd1, coef1, a1;
     double logdetC;
     double logseat, logseat1;   // log(n^r), log((n-1)^r)   (r = 1 for the plain CRP)
-    double pad0, pad1;
+    double inv_lam;             // 1 / Lambda, Lambda >= lambda_max(S_N) (0: no bound known -> never pruned)
+    double mu2;                 // |mu|^2
 };
 
 // What a likelihood / draw kernel works on.  First member of Ctrl so that (const Job*)ctrl
@@ -65,7 +66,7 @@ struct Job {
     int n_dirty;
     int dirty[2];
     int chunks;           // label chunks per row block (<= kMaxChunks)
-    int pad;
+    int prune;            // fresh window scored by the pruning kernel (valid only while nothing moves)
 };
 
 struct Ctrl {
@@ -85,6 +86,8 @@ struct Ctrl {
     long long last_mover;
     // counters of the current sweep
     long long lik_evals, n_moves, n_windows, n_steps, n_score_launches, n_scored;
+    unsigned long long n_kept_blocks;   // (16-visit block, slot) pairs the pruning kernel scored in full
+    unsigned long long n_bound_blocks;  // (16-visit block, slot) pairs it bounded
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
 };
 
@@ -117,6 +120,7 @@ struct Dev {
     const long long *order;      // may be null (identity)
     int use_power;
     double power;
+    int prune_enabled;           // tuning: exact pruning of negligible components in fresh windows
 };
 
 __host__ __device__ inline int bgmm_nfrag(int Dp) { int nJ = Dp / 16; return 2 * nJ * (nJ + 1); }
@@ -137,7 +141,9 @@ void launch_prior_lp(const Dev &d, const double *qcol, hipStream_t st);
 void launch_post_pred(const Dev &d, const double *qrow, double *out, hipStream_t st);
 
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride,
-                  int col_override, long long max_rows, hipStream_t st);
+                  int col_override, long long max_rows, int skip_pruned_jobs, hipStream_t st);
+bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
+                         hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
             const int s = d.perm[jj];
             const double qv = tile[jj * R + w];
             const SlotConst sc = d.sc[s];
-            if (home_live && s == h) {
+            if (qv == INFINITY) {
+                v = -INFINITY;                      // pruned by the likelihood kernel: weight exactly 0
+            } else if (home_live && s == h) {
                 const double den = 1.0 - sc.a1 * qv;
                 v = sc.logseat1 + sc.A1 - 0.5 * log(den) - sc.half_vd1 * log(1.0 + sc.coef1 * qv / den);
             } else {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     double tot = 0.0;
     for (int j = lane; j <= L; j += 64) {
         const int idx = (j == L ? NEWIDX : j) * R + w;
-        const double e = exp(tile[idx] - mx);
+        const double e = tile[idx] == -INFINITY ? 0.0 : exp(tile[idx] - mx);
         tile[idx] = e;
         tot += e;
     }

@@ -29,7 +29,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 struct ResolveShared {
     int active, nrows, K, ncols, err, pad0;
     int slot[2], kind[2], src[2], col[2], bad[2];
-    double a[2], logdet_src[2], stot[2];
+    double a[2], logdet_src[2], stot[2], inv_lam_src[2], lam_new[2];
     long long sub_lo, i_move, lik, moves;
     double scnew[2][12];    // fresh SlotConst of the two touched slots (D1 reads them from LDS)
 };
@@ -53,7 +53,7 @@ enum { O_W, O_VEC, O_XS, O_ET, O_QP, O_RM, O_RE, O_RU, O_RI, O_RQ, O_RH, O_RP, O
 
 // byte offsets of the arrays inside the dynamic LDS block; returns the total size
 __host__ __device__ inline size_t resolve_offsets(int D, int R, int Kcap, int nslots, unsigned *o) {
-    size_t off = 512;                       // ResolveShared
+    size_t off = 768;                       // ResolveShared
     const int ld = D + 1;
     unsigned dummy[O_COUNT];
     if (!o) o = dummy;
@@ -192,12 +192,17 @@ __device__ void pick_row(const Dev &d, const ResolveLds &L, int R, int r, int la
 
 // Team-local outputs of one slot (HT threads): cvec (4 threads per row), Wrm, Wfrag, mu, consts.
 __device__ __forceinline__ void write_slot_team(const Dev &d, int s, const lds_f64 W, int ld, const lds_f64 mu,
-                                                double logdetC, int n_new, int ht, lds_f64 cv_lds,
+                                                double logdetC, double lam, int n_new, int ht, lds_f64 cv_lds,
                                                 lds_f64 sc_lds) {
     const int D = d.D, Dp = d.Dp;
     // the scalar constants first: their table loads are in flight while the team does the rest
     SlotConst sc_new;
-    if (ht == 0) sc_new = make_consts(d, n_new, logdetC);
+    if (ht < 64) {
+        double m2 = 0.0;
+        for (int l = ht; l < D; l += 64) m2 = fma(mu[l], mu[l], m2);
+        m2 = wsum(m2);
+        if (ht == 0) sc_new = make_consts(d, n_new, logdetC, lam, m2);
+    }
     for (int r0 = 0; r0 < Dp; r0 += HT / 4) {
         const int r = r0 + (ht >> 2), part = ht & 3;
         double acc = 0.0;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 const long long p = (long long)fm;
                 const double ema = 0.875 * c->ema_run + 0.125 * (double)(p - c->last_mover);
                 const bool dense = c->dense_mode == 2 || ema < 3.0 * (double)R;
-                if (dense && j.K + R + 2 <= Kcap) {
+                if (dense && !j.prune && j.K + R + 2 <= Kcap) {
                     S.active = 1;
                     S.sub_lo = p;
                     long long nr = j.win_hi - p;
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 const double kb = d.k0 + (double)(hf == 0 ? n_new + 1 : n_new - 1);
                 S.a[hf] = hf == 0 ? -kb / (kb - 1.0) : kb / (kb + 1.0);
                 S.logdet_src[hf] = L.ldetL[S.src[hf]];
+                S.inv_lam_src[hf] = d.sc[S.src[hf]].inv_lam;
             }
             const long long p = sub_lo + cur;
             c->ema_run = 0.875 * c->ema_run + 0.125 * (double)(p - c->last_mover);
@@ -504,6 +510,11 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 }
                 const unsigned long long anybad = __ballot(badl);
                 if (ht == D - 1) { S.stot[half] = P; S.bad[half] = anybad ? 1 : 0; }
+            } else if (act_r1 && ht < 128) {
+                double d2 = 0.0;                                  // |x - mu_old|^2 for the Lambda bound
+                for (int l = ht - 64; l < D; l += 64) d2 = fma(dv[l], dv[l], d2);
+                d2 = wsum(d2);
+                if (ht == 64) S.lam_new[half] = lam_after_rank1(S.inv_lam_src[half], S.a[half], d2);
             }
             lds_barrier();
             PROF(10);
@@ -537,10 +548,14 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
             lds_barrier();
             PROF(11);
         }
-        if (any_sc) chol_inverse<HT>((double *)Wh, ld, D, (double *)pv, (double *)&S.stot[half], (int *)&S.bad[half], ht, act_sc);
+        if (any_sc) {
+            __syncthreads();
+            gershgorin_bound<HT>((double *)Wh, ld, D, (double *)pv, (double *)&S.lam_new[half], ht, act_sc);
+            chol_inverse<HT>((double *)Wh, ld, D, (double *)pv, (double *)&S.stot[half], (int *)&S.bad[half], ht, act_sc);
+        }
         if (act) {
             const double logdetC = act_sc ? S.stot[half] : S.logdet_src[half] + log(1.0 + S.a[half] * S.stot[half]);
-            write_slot_team(d, myslot, Wh, ld, mu, logdetC, L.nL[myslot], ht, cv, (lds_f64)&S.scnew[half][0]);
+            write_slot_team(d, myslot, Wh, ld, mu, logdetC, S.lam_new[half], L.nL[myslot], ht, cv, (lds_f64)&S.scnew[half][0]);
             if (ht == 0) {
                 const int nu = act_sc ? 0 : L.nupdL[myslot] + 1;
                 L.nupdL[myslot] = nu;

@@ -17,11 +17,20 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// log score of a (visit, slot) pair from its exact quadratic form -- the formulas of the draw kernel
+__device__ __forceinline__ double slot_score_exact(const SlotConst &sc, double qv, bool home_minus_one) {
+    if (home_minus_one) {
+        const double den = 1.0 - sc.a1 * qv;
+        return sc.logseat1 + sc.A1 - 0.5 * log(den) - sc.half_vd1 * log(1.0 + sc.coef1 * qv / den);
+    }
+    return sc.logseat + sc.A - sc.half_vd * log(1.0 + qv * sc.inv_cv);
+}
+
 // The Job is read field by field (a by-value copy with a dynamically indexed dirty[] member
 // ends up in scratch memory).
 struct JobView {
     long long pos, win_base, win_hi;
-    int mode, nlist, chunks, dirty0, dirty1;
+    int mode, nlist, chunks, dirty0, dirty1, prune;
 };
 __device__ __forceinline__ JobView load_job(const Job *__restrict__ j) {
     JobView v;
@@ -29,6 +38,7 @@ __device__ __forceinline__ JobView load_job(const Job *__restrict__ j) {
     v.mode = j->mode; v.chunks = j->chunks;
     v.nlist = v.mode == MODE_FRESH ? j->K : j->n_dirty;
     v.dirty0 = j->dirty[0]; v.dirty1 = j->dirty[1];
+    v.prune = j->prune;
     return v;
 }
 // entry t of the job's list -> slot
@@ -41,10 +51,10 @@ __device__ __forceinline__ int job_slot(const Dev &d, const JobView &job, int t)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__restrict__ jobp,
                                                          double *__restrict__ q, long long qstride,
-                                                         int col_override) {
+                                                         int col_override, int skip_pruned_jobs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE) return;
+    if (job.mode == MODE_DONE || (skip_pruned_jobs && job.prune)) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks) return;
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
@@ -126,9 +136,9 @@ constexpr int pick_pf(int nf) {
 template <int NJ, int RB, int MINW>
 __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
                                                             double *__restrict__ q, long long qstride,
-                                                            int col_override) {
+                                                            int col_override, int skip_pruned_jobs) {
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE) return;
+    if (job.mode == MODE_DONE || (skip_pruned_jobs && job.prune)) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = 16 * RB;              // rows per wave
@@ -224,32 +234,274 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
 }
 
 // ------------------------------------------------------------------------------------------
+// MFMA kernel with EXACT pruning of negligible components (fresh windows only).
+//
+// For a slot s with Lambda_s >= lambda_max(S_N) (Gershgorin at every from-scratch refresh, raised by
+// a |d|^2 at every rank-1 addition; slot_math.h) the quadratic form is bounded from below by the
+// Euclidean distance:   q_s(x) = (mu-x)' S_N^-1 (mu-x) >= |mu - x|^2 / Lambda_s =: q_lb,   and
+//     lp_ub = logseat + A - half_vd * L(q_lb * inv_cv),     L(t) <= log(1 + t)  (cheap minorant)
+// is a rigorous upper bound of the component's log score for that visit.  |mu - x|^2 for 16
+// slots x 32 visits costs ONE v_mfma_f64_16x16x4 per slot and 16 visits (a [rows x D].[D x 16]
+// product against the means) -- 2.5 % of the full quadratic form at D = 64.
+// Every visit also has a lower bound M_lb of its maximum log score: the "new table" entry
+// log(alpha) + log_prior[i] (crpmm.py:74) to start with, raised by every exact score computed so
+// far.  A slot whose lp_ub < M_lb - kPruneMargin for all 32 visits of the wave, and that is
+// nobody's home, has weight exp(lp - max) < e^-80 ~ 2e-35 in each of those draws -- twenty orders
+// of magnitude below the rounding noise of the normaliser -- and is not scored: q = +inf is
+// stored, which the draw kernel turns into an exact zero weight.  The bound holds against the
+// frozen state only, which is why a pruned window ends at its first move (slot_math.h).
+// ------------------------------------------------------------------------------------------
+static constexpr double kPruneMargin = 80.0;
+
+// minorant of log(1 + t), t >= 0: 2t/(2+t) below 1, (e + m - 1) ln 2 above (1+t = m 2^e, 1 <= m < 2)
+__device__ __forceinline__ double log1p_lower(double t) {
+    if (t < 1.0) return 2.0 * t / (2.0 + t);
+    int e;
+    const double m = frexp(1.0 + t, &e);               // 1+t = m 2^e, 0.5 <= m < 1
+    return 0.6931471805599453 * ((double)(e - 1) + (2.0 * m - 1.0));
+}
+
+template <int NJ, int RB, int MINW>
+__global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
+                                                                  double *__restrict__ q, long long qstride) {
+    const JobView job = load_job(jobp);
+    if (job.mode != MODE_FRESH || !job.prune) return;
+    const int chunk = blockIdx.y;
+    if (chunk >= job.chunks || chunk >= job.nlist) return;
+    constexpr int ROWS_W = 16 * RB;
+    constexpr int NF = 2 * NJ * (NJ + 1);
+    const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
+    if (pb >= job.win_hi) return;
+    const int D = d.D;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long pw = pb + w * ROWS_W;
+    if (pw >= job.win_hi) return;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    double xf[RB][NJ * 4];
+#pragma unroll
+    for (int R = 0; R < RB; ++R) {
+        const long long p = pw + R * 16 + lr;
+        const bool live = p < job.win_hi;
+        const long long i = live ? (d.order ? d.order[p] : p) : 0;
+        const double *__restrict__ xrow = d.X + i * D;
+#pragma unroll
+        for (int kk = 0; kk < NJ * 4; ++kk) {
+            const int l = 4 * kk + lk;
+            xf[R][kk] = (live && l < D) ? xrow[l] : 0.0;
+        }
+    }
+    // Per accumulator element (visits lk + 4r of block R): |x|^2, the lower bound of the visit's best
+    // log score, its home slot (never pruned).  Dead rows can never keep a slot alive.
+    double x2[RB][4], Mlb[RB][4];
+    int home[RB][4];
+#pragma unroll
+    for (int R = 0; R < RB; ++R) {
+        // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes) ...
+        double part = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < NJ * 4; ++kk) part = fma(xf[R][kk], xf[R][kk], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        // ... re-distributed to the accumulator layout: rows lk + 4r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x2[R][r] = __shfl(part, lk + 4 * r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long p = pw + R * 16 + lk + 4 * r;
+            if (p < job.win_hi) {
+                const long long i = d.order ? d.order[p] : p;
+                Mlb[R][r] = d.log_alpha + d.log_prior[i];
+                home[R][r] = d.z[i];
+            } else {
+                Mlb[R][r] = INFINITY;
+                home[R][r] = -2;
+            }
+        }
+    }
+
+    const long long nfrag64 = (long long)NF * 64;
+    unsigned n_kept = 0, n_bound = 0;
+    // groups of 16 list entries: lane column lr <-> entry t0 + chunks * lr
+    for (int t0 = chunk; t0 < job.nlist; t0 += 16 * job.chunks) {
+        const int tl = t0 + job.chunks * lr;
+        const int sg = tl < job.nlist ? job_slot(d, job, tl) : -1;
+        // distances to the 16 means: G = X . Mu'  (B fragment: mu_sg[4kk + lk])
+        v4d accG[RB];
+#pragma unroll
+        for (int R = 0; R < RB; ++R) accG[R] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double *__restrict__ mup = d.mu + (long long)(sg >= 0 ? sg : 0) * D + lk;
+#pragma unroll
+        for (int kk = 0; kk < NJ * 4; ++kk) {
+            const double bm = (sg >= 0 && 4 * kk + lk < D) ? mup[4 * kk] : 0.0;
+#pragma unroll
+            for (int R = 0; R < RB; ++R)
+                accG[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bm, accG[R], 0, 0, 0);
+        }
+        bool need[RB];
+        {
+            const SlotConst *__restrict__ scp = d.sc + (sg >= 0 ? sg : 0);
+            const double base = scp->logseat + scp->A, hvd = scp->half_vd, icv = scp->inv_cv;
+            const double ilam = scp->inv_lam, mu2 = scp->mu2;
+#pragma unroll
+            for (int R = 0; R < RB; ++R) {
+                need[R] = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double nrm = x2[R][r] + mu2;
+                    double dist2 = nrm - 2.0 * accG[R][r] - 1e-9 * nrm;     // (rounding of the difference)
+                    dist2 = dist2 > 0.0 ? dist2 : 0.0;
+                    const double ub = base - hvd * log1p_lower(dist2 * ilam * icv);
+                    need[R] = need[R] || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
+                }
+                need[R] = need[R] && sg >= 0;
+            }
+        }
+        // fold the votes of the 4 lk lanes (and 4 r's) of every slot column
+        unsigned keepmask[RB];
+#pragma unroll
+        for (int R = 0; R < RB; ++R) {
+            const unsigned long long bl = __ballot(need[R]);
+            keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull);
+        }
+        // pruned (block of 16 visits, slot) pairs: exact zero weight downstream
+#pragma unroll
+        for (int R = 0; R < RB; ++R) {
+            if (sg >= 0 && !((keepmask[R] >> lr) & 1u)) {
+                double *__restrict__ qc = q + (long long)sg * qstride;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long p = pw + R * 16 + lk + 4 * r;
+                    if (p < job.win_hi) qc[p - job.win_base] = INFINITY;
+                }
+            }
+        }
+        // the slots somebody needs: full quadratic form, tiles fetched in batches of 8
+        unsigned todo = 0;
+#pragma unroll
+        for (int R = 0; R < RB; ++R) {
+            todo |= keepmask[R];
+            n_kept += __popc(keepmask[R]);
+        }
+        {
+            const int left = (job.nlist - t0 + job.chunks - 1) / job.chunks;
+            n_bound += RB * (left < 16 ? left : 16);
+        }
+        while (todo) {
+            const int jbit = __ffs(todo) - 1;
+            todo &= todo - 1;
+            const int s = __builtin_amdgcn_readlane(sg, jbit);
+            const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
+            const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
+            double qp[RB][4];
+#pragma unroll
+            for (int R = 0; R < RB; ++R)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+                const double cj = cvp[16 * J];
+                v4d acc[RB];
+#pragma unroll
+                for (int R = 0; R < RB; ++R) acc[R] = (v4d){cj, cj, cj, cj};
+#pragma unroll
+                for (int k0 = 0; k0 < 4 * (J + 1); k0 += 8) {
+                    double bb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k0 + k < 4 * (J + 1)) bb[k] = wf[(2 * J * (J + 1) + k0 + k) * 64];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k0 + k < 4 * (J + 1)) {
+#pragma unroll
+                            for (int R = 0; R < RB; ++R)
+                                acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][k0 + k], bb[k], acc[R], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int R = 0; R < RB; ++R)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qp[R][r] = fma(acc[R][r], acc[R][r], qp[R][r]);
+            }
+            const SlotConst scs = d.sc[s];
+            const int ns = d.n[s];
+            double *__restrict__ qcol = q + (long long)s * qstride;
+#pragma unroll
+            for (int R = 0; R < RB; ++R) {
+                const bool kept = (keepmask[R] >> jbit) & 1u;      // else this block's column holds +inf
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = row16_sum(qp[R][r]);
+                    const long long p = pw + R * 16 + lk + 4 * r;
+                    if (kept && lr == r && p < job.win_hi) qcol[p - job.win_base] = v;
+                    // an exact score is a lower bound of the visit's maximum (the home component
+                    // counts with its one-point-removed form, exactly as the draw kernel scores it)
+                    if (p < job.win_hi) {
+                        const bool own = home[R][r] == s;
+                        if (!own || ns >= 2) Mlb[R][r] = fmax(Mlb[R][r], slot_score_exact(scs, v, own));
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&d.ctrl->n_kept_blocks, (unsigned long long)n_kept);
+        atomicAdd(&d.ctrl->n_bound_blocks, (unsigned long long)n_bound);
+    }
+}
+
+template <int NJ>
+static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
+                              hipStream_t st) {
+    const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
+    hipLaunchKernelGGL((score_mfma_prune_kernel<NJ, 2, (NJ <= 5 ? 2 : 1)>), dim3(gx, kMaxChunks),
+                       dim3(256), 0, st, d, job, q, qstride);
+}
+
+// Fresh-window scoring with pruning (D >= 17 so that there is more than one block of factor rows)
+bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
+                         hipStream_t st) {
+    if (max_rows <= 0) return true;
+    switch (d.Dp / 16) {
+        case 2: launch_mfma_prune<2>(d, job, q, qstride, max_rows, st); return true;
+        case 3: launch_mfma_prune<3>(d, job, q, qstride, max_rows, st); return true;
+        case 4: launch_mfma_prune<4>(d, job, q, qstride, max_rows, st); return true;
+        case 5: launch_mfma_prune<5>(d, job, q, qstride, max_rows, st); return true;
+        case 6: launch_mfma_prune<6>(d, job, q, qstride, max_rows, st); return true;
+        case 7: launch_mfma_prune<7>(d, job, q, qstride, max_rows, st); return true;
+        case 8: launch_mfma_prune<8>(d, job, q, qstride, max_rows, st); return true;
+        default: return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 template <int NJ>
 static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
-                        long long max_rows, hipStream_t st) {
+                        long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
     hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
-                       qstride, col_override);
+                       qstride, col_override, skip_pruned_jobs);
 }
 
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
-                  long long max_rows, hipStream_t st) {
+                  long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
     if (kind == KERNEL_MFMA) {
         switch (d.Dp / 16) {
-            case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 2: launch_mfma<2>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 3: launch_mfma<3>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 4: launch_mfma<4>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 5: launch_mfma<5>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 6: launch_mfma<6>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 7: launch_mfma<7>(d, job, q, qstride, col_override, max_rows, st); return;
-            case 8: launch_mfma<8>(d, job, q, qstride, col_override, max_rows, st); return;
+            case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 2: launch_mfma<2>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 3: launch_mfma<3>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 4: launch_mfma<4>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 5: launch_mfma<5>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 6: launch_mfma<6>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 7: launch_mfma<7>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
+            case 8: launch_mfma<8>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
             default: break;
         }
     }
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
     const int lds = d.D * kValuRows * (int)sizeof(double);
     hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
-                       col_override);
+                       col_override, skip_pruned_jobs);
 }

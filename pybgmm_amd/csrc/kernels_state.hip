@@ -85,9 +85,11 @@ __device__ void refresh_slot(const Dev &d, int s, double *sm) {
         const int a = e / D, b = e % D;
         if (b <= a) A[a * ld + b] = S[e] - k_N * (mu[a] * mu[b]);
     }
+    __syncthreads();
+    gershgorin_bound<TPB>(A, ld, D, row, &scal[2], tid, true);
     chol_inverse<TPB>(A, ld, D, row, &scal[0], (int *)&scal[1], tid, true);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
-    write_slot<TPB>(d, s, A, ld, mu, scal[0], tid, nullptr, true);
+    write_slot<TPB>(d, s, A, ld, mu, scal[0], scal[2], tid, nullptr, true);
     if (tid == 0) d.nupd[s] = 0;
 }
 
@@ -99,6 +101,7 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     double *mu = sm + D * ld, *dv = mu + D, *pv = dv + D, *lv = pv + D, *tv = lv + D;
     double *scal = tv + 2 * D;
     const double logdet_src = d.sc[src].logdetC;      // read before anything of dst is rewritten
+    const double inv_lam_src = d.sc[src].inv_lam;
     const int n_new = d.n[dst];
     const double k_before = d.k0 + (double)(kind == REFRESH_SUB ? n_new + 1 : n_new - 1);
     const double a = kind == REFRESH_SUB ? -k_before / (k_before - 1.0) : k_before / (k_before + 1.0);
@@ -112,7 +115,10 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     __syncthreads();
     rank1_inverse_factor<TPB>(W, ld, D, a, dv, pv, lv, tv, &scal[0], (int *)&scal[1], tid, true);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
-    write_slot<TPB>(d, dst, W, ld, mu, logdet_src + log(1.0 + a * scal[0]), tid, nullptr, true);
+    double d2 = 0.0;
+    if (tid == 0) for (int l = 0; l < D; ++l) d2 = fma(dv[l], dv[l], d2);
+    write_slot<TPB>(d, dst, W, ld, mu, logdet_src + log(1.0 + a * scal[0]), lam_after_rank1(inv_lam_src, a, d2),
+                    tid, nullptr, true);
     if (tid == 0) d.nupd[dst] += 1;
 }
 
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->skip_apply = 0;
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
+        c->n_kept_blocks = 0; c->n_bound_blocks = 0;
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
         if (c->win_size > c->win_cap) c->win_size = c->win_cap;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     // (it is re-scored later as part of a fresh, smaller window) instead of
                     // re-evaluating all of it after every move
                     if (j.win_hi - (p + 1) > 2 * w) j.win_hi = p + 1 + w;
-                    if (p + 1 >= j.win_hi) {
+                    if (p + 1 >= j.win_hi || j.prune) {      // (a pruned window ends at its first move)
                         start_window(d, c, p + 1);
                     } else {
                         j.pos = p + 1;

@@ -27,7 +27,7 @@ __device__ __forceinline__ double cov_scale(const Dev &d, int n) {
 // constants of the predictive for a slot with count n and logdet(S_N) = logdetC.  Everything
 // that depends on n alone comes from the device-built tables (no transcendental on this path:
 // it sits on the critical chain of every move).
-__device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC) {
+__device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC, double lam, double mu2) {
     SlotConst c;
     const int D = d.D;
     const double Dd = (double)D;
@@ -54,7 +54,8 @@ __device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC) {
         c.half_vd1 = 0.5 * (double)(v1 + D);
         c.coef1 = a * a / (c1 * (double)v1);
     }
-    c.pad0 = 0.0; c.pad1 = 0.0;
+    c.inv_lam = (lam > 0.0 && lam < 1e300) ? 1.0 / lam : 0.0;
+    c.mu2 = mu2;
     return c;
 }
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ double slot_log_score(const SlotConst &sc, double qv,
 // be complete (barrier before), and cv_lds is valid after the caller's next barrier.
 template <int NT>
 __device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, const double *mu,
-                                  double logdetC, int tid, double *cv_lds, bool active) {
+                                  double logdetC, double lam, int tid, double *cv_lds, bool active) {
     if (!active) return;
     const int D = d.D, Dp = d.Dp;
     for (int j = tid; j < Dp; j += NT) {
@@ -96,7 +97,38 @@ __device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, 
         wf[e] = (j < D && l <= j) ? -W[j * ld + l] : 0.0;
     }
     for (int l = tid; l < D; l += NT) d.mu[(long long)s * D + l] = mu[l];
-    if (tid == 0) d.sc[s] = make_consts(d, d.n[s], logdetC);
+    if (tid == 0) {
+        double mu2 = 0.0;
+        for (int l = 0; l < D; ++l) mu2 = fma(mu[l], mu[l], mu2);
+        d.sc[s] = make_consts(d, d.n[s], logdetC, lam, mu2);
+    }
+}
+
+// Gershgorin bound of lambda_max of the symmetric matrix whose lower triangle is in A (LDS):
+// max_i sum_j |A_ij|.  One barrier; result in *out (LDS) for every thread after it.
+template <int NT>
+__device__ inline void gershgorin_bound(const double *A, int ld, int D, double *rowbuf, double *out,
+                                        int tid, bool active) {
+    if (active)
+        for (int i = tid; i < D; i += NT) {
+            double sacc = 0.0;
+            for (int j = 0; j < D; ++j) sacc += fabs(j <= i ? A[i * ld + j] : A[j * ld + i]);
+            rowbuf[i] = sacc;
+        }
+    __syncthreads();
+    if (active && tid == 0) {
+        double mx = 0.0;
+        for (int i = 0; i < D; ++i) mx = fmax(mx, rowbuf[i]);
+        *out = mx;
+    }
+}
+
+// Lambda after a rank-1 change S_N' = S_N + a dd':  lambda_max grows by at most a |d|^2 (a > 0)
+// and cannot grow when a < 0.
+__device__ __forceinline__ double lam_after_rank1(double inv_lam_old, double a, double d2) {
+    if (!(inv_lam_old > 0.0)) return 0.0;                 // unknown stays unknown
+    const double lam = 1.0 / inv_lam_old;
+    return a > 0.0 ? lam + a * d2 : lam;
 }
 
 // In-place Cholesky (right looking) followed by the in-place inverse of the factor.
@@ -260,11 +292,16 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     if (hi > c->n_visits) hi = c->n_visits;
     j.win_hi = hi;
     j.n_dirty = 0;
+    j.prune = 0;
     if (pos >= c->n_visits) {
         j.mode = MODE_DONE;
     } else {
         j.mode = MODE_FRESH;
         c->n_windows += 1;
+        // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
+        // score and promote a pruned component), so they are used while moves are sparse; the
+        // mover-dense path (resolver) always works on complete scores.
+        j.prune = (d.prune_enabled && d.Dp >= 32 && c->ema_run >= 256.0) ? 1 : 0;
     }
     set_chunks(d, j);
 }

@@ -22,11 +22,11 @@ pytestmark = pytest.mark.gpu
 LM_RTOL = 1e-6
 
 
-def make_ctx(g, kind=0, window=0, tables=True, resolver=0):
+def make_ctx(g, kind=0, window=0, tables=True, resolver=0, prune=0):
     from pybgmm_amd import _lib
     ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max,
                        tables=reference_tables(g.v_0, g.N) if tables else None)
-    ctx.set_tuning(max_window=window, kernel_kind=kind, resolver_mode=resolver)
+    ctx.set_tuning(max_window=window, kernel_kind=kind, resolver_mode=resolver, prune_mode=prune)
     ctx.set_assignments(g.z_init)
     return ctx
 
@@ -76,6 +76,19 @@ def test_golden_trajectory_both_mover_paths(case, resolver):
         npt.assert_array_equal(S, g.d["final_S"])
         npt.assert_allclose(ld, g.d["final_logdet"], rtol=1e-8, atol=1e-8)
         npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-7, atol=1e-9)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prune", [0, 1], ids=["pruned", "unpruned"])
+@pytest.mark.parametrize("case", ["c4twin_crpmm_64d", "c4rand_crpmm_64d", "c3twin_pcrpmm_16d", "c3rand_pcrpmm_16d"])
+def test_pruning_does_not_change_trajectory(case, prune):
+    """Exact pruning of negligible components (MFMA kernel, forced also at D=16) on and off."""
+    g = Golden(case)
+    ctx = make_ctx(g, kind=2, prune=prune, resolver=1)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        npt.assert_array_equal(ctx.assignments(), g.z[it])
+        assert abs(ctx.log_marg() - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
     ctx.close()
 
 
@@ -247,9 +260,9 @@ def test_full_size_properties(N, D, K):
     flip = rs.choice(N, size=2000, replace=False)
     z0[flip] = rs.randint(0, K, size=flip.size)
     results = []
-    for kind, window in ((0, 0), (1 if D >= 24 else 2, 2048)):
+    for kind, window, prune in ((0, 0, 0), (1 if D >= 24 else 2, 2048, 1)):
         ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
-        ctx.set_tuning(max_window=window, kernel_kind=kind)
+        ctx.set_tuning(max_window=window, kernel_kind=kind, prune_mode=prune)
         ctx.set_assignments(z0)
         ctx.sweep(u)
         z = ctx.assignments()
