@@ -160,49 +160,65 @@ def main():
     K_final = ctx.K
 
     # --- likelihood-kernel roofline: one more sweep with HIP events around every launch ---
-    roofline = None
-    if not args.no_kernel_timing:
+    def kernel_roofline(prune_mode):
+        """One extra sweep with the likelihood kernel bracketed by HIP events (on the library's
+        stream).  prune_mode 0 = as benchmarked, 1 = force the full evaluation of every pair."""
+        ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                       prune_mode=prune_mode)
+        ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))          # settle the window policy
         ctx.set_kernel_timing(True)
         ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
         n_launch, ms = ctx.kernel_timing()
         st = ctx.sweep_stats()
         ctx.set_kernel_timing(False)
-        if n_launch > 0 and ms > 0:
-            flops = st["scored"] * flops_per_lik_eval(D)
-            achieved = flops / (ms * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 24)
-            nJ = (D + 15) // 16
-            # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
-            # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
-            exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
-            pruning = bool(st["bound_blocks"] > 0)
-            if pruning:
-                # pruning kernel: a 16-visit block costs D/4 MFMAs per slot it bounds (the distance
-                # GEMM) plus 2 nJ (nJ+1) MFMAs per slot it scores in full; 2048 flop per MFMA
-                executed_flops = 2048.0 * (st["bound_blocks"] * (4 * nJ) / 16.0
-                                           + st["kept_blocks"] * 2 * nJ * (nJ + 1))
-            else:
-                executed_flops = st["scored"] * exec_per_eval
-            executed = executed_flops / (ms * 1e-3) / 1e12
-            roofline = {
-                "kernel": ("score_mfma_prune_kernel" if pruning else "score_mfma_kernel") if is_mfma else "score_valu_kernel",
-                "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 4) if pruning else 1.0,
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
-                "traffic": traffic,
-                "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
-                "flops_per_lik_eval": flops_per_lik_eval(D),
-                "executed_tflops": round(executed, 3),
-                "executed_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
-                "executed_frac_of_sustained_mfma": round(executed / SUSTAINED_FP64_MFMA_TFLOPS, 4),
-                "hbm_gbps_algorithmic": round(st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9, 2),
-                "hbm_frac": round(st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
-            }
+        if n_launch <= 0 or ms <= 0:
+            return None
+        flops = st["scored"] * flops_per_lik_eval(D)
+        achieved = flops / (ms * 1e-3) / 1e12
+        is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 24)
+        nJ = (D + 15) // 16
+        # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
+        # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
+        exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
+        pruning = bool(st["bound_blocks"] > 0)
+        if pruning:
+            # pruning kernel: a 16-visit block costs D/4 MFMAs per slot it bounds (the distance
+            # GEMM) plus 2 nJ (nJ+1) MFMAs per slot it scores in full; 2048 flop per MFMA
+            executed_flops = 2048.0 * (st["bound_blocks"] * (4 * nJ) / 16.0
+                                       + st["kept_blocks"] * 2 * nJ * (nJ + 1))
+        else:
+            executed_flops = st["scored"] * exec_per_eval
+        executed = executed_flops / (ms * 1e-3) / 1e12
+        hbm = st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch_pruned" if pruning else "hbm_bytes_per_launch")
+        return {
+            "kernel": ("score_mfma_prune_kernel" if pruning else "score_mfma_kernel") if is_mfma else "score_valu_kernel",
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
+            "traffic": traffic,
+            "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
+            "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
+            "flops_per_lik_eval": flops_per_lik_eval(D),
+            "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 4) if pruning else 1.0,
+            "executed_tflops": round(executed, 3),
+            "executed_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
+            "executed_frac_of_sustained_mfma": round(executed / SUSTAINED_FP64_MFMA_TFLOPS, 4),
+            "hbm_gbps_algorithmic": round(hbm, 2), "hbm_frac": round(hbm / PEAK_HBM_GBPS, 5),
+        }
+
+    roofline = roofline_full = None
+    if not args.no_kernel_timing:
+        roofline = kernel_roofline(args.prune)
+        if roofline and roofline["kernel"] == "score_mfma_prune_kernel":
+            # the same kernel family with pruning off: every (visit, component) pair through the
+            # full quadratic form -- the MFMA-efficiency number
+            roofline_full = kernel_roofline(1)
+        ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                       prune_mode=args.prune)
 
     # --- the one collective: final label gather (RCCL over xGMI), outside the timed region ---
     t0 = time.time()
@@ -238,6 +254,7 @@ def main():
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
             "roofline": roofline,
+            "roofline_full_evaluation": roofline_full,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
                       "K_final": K_final, "log_marg_rank0": log_marg,

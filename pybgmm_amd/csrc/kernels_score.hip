@@ -399,25 +399,27 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             for (int R = 0; R < RB; ++R)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
+            // software pipeline over the slot's NF tiles: a ring of PFK loads in flight
+            constexpr int PFK = NF < 16 ? NF : 16;
+            double ringk[PFK];
+#pragma unroll
+            for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
+            double cjk[NJ];
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
-                const double cj = cvp[16 * J];
                 v4d acc[RB];
 #pragma unroll
-                for (int R = 0; R < RB; ++R) acc[R] = (v4d){cj, cj, cj, cj};
+                for (int R = 0; R < RB; ++R) acc[R] = (v4d){cjk[J], cjk[J], cjk[J], cjk[J]};
 #pragma unroll
-                for (int k0 = 0; k0 < 4 * (J + 1); k0 += 8) {
-                    double bb[8];
+                for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                    const int f = 2 * J * (J + 1) + kk;          // constant after unrolling
+                    const double b = ringk[f % PFK];
+                    if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k0 + k < 4 * (J + 1)) bb[k] = wf[(2 * J * (J + 1) + k0 + k) * 64];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k0 + k < 4 * (J + 1)) {
-#pragma unroll
-                            for (int R = 0; R < RB; ++R)
-                                acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][k0 + k], bb[k], acc[R], 0, 0, 0);
-                        }
+                    for (int R = 0; R < RB; ++R)
+                        acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], b, acc[R], 0, 0, 0);
                 }
 #pragma unroll
                 for (int R = 0; R < RB; ++R)
