@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,7 +51,7 @@ struct bgmm_ctx {
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
     int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
-    int prune_mode = 0;              // 0 auto (on for D >= 17 with the MFMA kernel), 1 off
+    int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off
     double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
     int seat_use_power = 0;
     double seat_power = 1.0;
@@ -195,8 +196,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, c->d_u, (size_t)N);
     DALLOC(c, c->d_order, (size_t)N);
     // speculative window buffers: q rows bounded by ~1 GiB and by N
-    long long rows = 32768;
-    while (rows > 1024 && (size_t)rows * d.nslots * sizeof(double) > ((size_t)1 << 30)) rows >>= 1;
+    // speculative window: up to 128 Ki visits, q bounded by ~4 GiB (288 GB of HBM per GPU)
+    long long rows = 131072;
+    if (const char *e = getenv("BGMM_WIN_ROWS")) { long long v = atoll(e); if (v >= 1024) rows = v; }
+    while (rows > 1024 && (size_t)rows * d.nslots * sizeof(double) > ((size_t)4 << 30)) rows >>= 1;
     long long n_up = (N + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
     if (rows > n_up) rows = n_up;
     c->win_rows = (int)rows;
@@ -204,6 +207,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.choice_rows = choice_rows_for(K_max);
     DALLOC(c, d.q, (size_t)rows * d.nslots);
     DALLOC(c, d.choice, (size_t)rows);
+    DALLOC(c, d.wperm, (size_t)rows);
+    DALLOC(c, d.bucket_bins, ns + 4);
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
 
     d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
@@ -410,7 +415,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.u = c->cur_u;
     d.order = c->cur_order;
     resolve_kind(c);
-    const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA && d.Dp >= 32;
+    const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA;
     d.prune_enabled = use_prune ? 1 : 0;
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
@@ -446,7 +451,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
-            if (use_prune) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
+            if (use_prune) {
+                launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
+                launch_bucket_rows(d, c->win_rows, st);
+            }
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (use_prune) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, c->win_rows, st);
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 0, st);

@@ -116,6 +116,8 @@ struct Dev {
     Ctrl *ctrl;
     double *q;
     int *choice;
+    int *bucket_bins;            // nslots + 2 counters of the per-window bucket sort
+    int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;
     const long long *order;      // may be null (identity)
     int use_power;
@@ -145,6 +147,7 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
+void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
 int refresh_lds_bytes(int D);

@@ -46,18 +46,21 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     const long long pos = c->job.pos, win_base = c->job.win_base, win_hi = c->job.win_hi;
     const int K = c->job.K;
     const int R = d.choice_rows;
-    const long long p0 = pos + (long long)blockIdx.x * R;
-    if (p0 >= win_hi) return;
+    // q row index of this block's first visit: the window row itself, or -- in a pruned window,
+    // which is evaluated grouped by home component -- the evaluation position (visit = wperm[k])
+    const bool sorted = c->job.prune != 0;
+    const long long k0 = (pos - win_base) + (long long)blockIdx.x * R;
+    const long long kend = win_hi - win_base;
+    if (k0 >= kend) return;
     for (int idx = threadIdx.x; idx < K * R; idx += blockDim.x) {
         const int j = idx / R, r = idx - j * R;
-        const long long p = p0 + r;
-        tile[idx] = p < win_hi ? d.q[(long long)d.perm[j] * d.qstride + (p - win_base)] : 0.0;
+        tile[idx] = k0 + r < kend ? d.q[(long long)d.perm[j] * d.qstride + (k0 + r)] : 0.0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long p = p0 + w;
-    if (p >= win_hi) return;
+    if (k0 + w >= kend) return;
+    const long long p = win_base + (sorted ? (long long)d.wperm[k0 + w] : k0 + w);
     const int NEWIDX = d.K_max + 1;
 
     const long long i = d.order ? d.order[p] : p;

@@ -261,6 +261,9 @@ __device__ __forceinline__ double log1p_lower(double t) {
     return 0.6931471805599453 * ((double)(e - 1) + (2.0 * m - 1.0));
 }
 
+// In a pruned window the visits are evaluated in the order of d.wperm (grouped by home component,
+// kernels_state.hip: bucket_rows_kernel), so that the visits of one wave mostly share a home and
+// need the same one or two components in full.  q is indexed by that evaluation position.
 template <int NJ, int RB, int MINW>
 __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
                                                                   double *__restrict__ q, long long qstride) {
@@ -270,20 +273,22 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     if (chunk >= job.chunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = 16 * RB;
     constexpr int NF = 2 * NJ * (NJ + 1);
-    const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
-    if (pb >= job.win_hi) return;
+    const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
+    const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
+    if (kb >= nrows) return;
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long pw = pb + w * ROWS_W;
-    if (pw >= job.win_hi) return;
+    const long long kw = kb + w * ROWS_W;                         // first evaluation position of the wave
+    if (kw >= nrows) return;
     const int lr = lane & 15, lk = lane >> 4;
 
     double xf[RB][NJ * 4];
 #pragma unroll
     for (int R = 0; R < RB; ++R) {
-        const long long p = pw + R * 16 + lr;
-        const bool live = p < job.win_hi;
+        const long long k = kw + R * 16 + lr;
+        const bool live = k < nrows;
+        const long long p = live ? job.win_base + d.wperm[k] : 0;
         const long long i = live ? (d.order ? d.order[p] : p) : 0;
         const double *__restrict__ xrow = d.X + i * D;
 #pragma unroll
@@ -309,8 +314,9 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
         for (int r = 0; r < 4; ++r) x2[R][r] = __shfl(part, lk + 4 * r);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long p = pw + R * 16 + lk + 4 * r;
-            if (p < job.win_hi) {
+            const long long k = kw + R * 16 + lk + 4 * r;
+            if (k < nrows) {
+                const long long p = job.win_base + d.wperm[k];
                 const long long i = d.order ? d.order[p] : p;
                 Mlb[R][r] = d.log_alpha + d.log_prior[i];
                 home[R][r] = d.z[i];
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                 double *__restrict__ qc = q + (long long)sg * qstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long long p = pw + R * 16 + lk + 4 * r;
-                    if (p < job.win_hi) qc[p - job.win_base] = INFINITY;
+                    const long long k = kw + R * 16 + lk + 4 * r;
+                    if (k < nrows) qc[k] = INFINITY;
                 }
             }
         }
@@ -435,11 +441,11 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double v = row16_sum(qp[R][r]);
-                    const long long p = pw + R * 16 + lk + 4 * r;
-                    if (kept && lr == r && p < job.win_hi) qcol[p - job.win_base] = v;
+                    const long long k = kw + R * 16 + lk + 4 * r;
+                    if (kept && lr == r && k < nrows) qcol[k] = v;
                     // an exact score is a lower bound of the visit's maximum (the home component
                     // counts with its one-point-removed form, exactly as the draw kernel scores it)
-                    if (p < job.win_hi) {
+                    if (k < nrows) {
                         const bool own = home[R][r] == s;
                         if (!own || ns >= 2) Mlb[R][r] = fmax(Mlb[R][r], slot_score_exact(scs, v, own));
                     }
@@ -461,11 +467,12 @@ static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long
                        dim3(256), 0, st, d, job, q, qstride);
 }
 
-// Fresh-window scoring with pruning (D >= 17 so that there is more than one block of factor rows)
+// Fresh-window scoring with pruning
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st) {
     if (max_rows <= 0) return true;
     switch (d.Dp / 16) {
+        case 1: launch_mfma_prune<1>(d, job, q, qstride, max_rows, st); return true;
         case 2: launch_mfma_prune<2>(d, job, q, qstride, max_rows, st); return true;
         case 3: launch_mfma_prune<3>(d, job, q, qstride, max_rows, st); return true;
         case 4: launch_mfma_prune<4>(d, job, q, qstride, max_rows, st); return true;

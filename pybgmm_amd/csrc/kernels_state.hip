@@ -198,6 +198,96 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
     }
 }
 
+// Evaluation order of a pruned window: its visits grouped by home component -- a counting sort
+// in three small launches (count per block -> exclusive prefix -> scatter).  wperm[k] = window
+// row of the k-th visit in evaluation order.  The order INSIDE a bucket depends on atomic
+// arrival order; that only changes which visits share a tile, never a visit's result.
+// d.bucket_bins: nslots + 2 global counters (bin b = home slot b - 1; bin 0 = unassigned).
+#define BUCKET_ROWS 1024
+__global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
+    extern __shared__ int bins[];
+    const Ctrl *c = d.ctrl;
+    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    const long long base = c->job.win_base;
+    const int nrows = (int)(c->job.win_hi - base);
+    const int r0 = blockIdx.x * BUCKET_ROWS;
+    if (r0 >= nrows) return;
+    const int nb = d.nslots + 1;
+    for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0;
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r0 + BUCKET_ROWS && r < nrows; r += 256) {
+        const long long p = base + r;
+        const long long i = d.order ? d.order[p] : p;
+        atomicAdd(&bins[d.z[i] + 1], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256)
+        if (bins[b]) atomicAdd(&d.bucket_bins[b], bins[b]);
+}
+
+__global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
+    __shared__ int wsum_[16];
+    const Ctrl *c = d.ctrl;
+    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    const int nb = d.nslots + 1;
+    // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
+    const int per = (nb + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    int local = 0;
+    for (int b = lo; b < hi; ++b) local += d.bucket_bins[b];
+    int incl = local;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum_[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum_[k];
+    int run = woff + incl - local;
+    for (int b = lo; b < hi; ++b) { const int v = d.bucket_bins[b]; d.bucket_bins[b] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
+    extern __shared__ int lds[];                  // [nb] local counts, then [nb] reserved bases
+    const Ctrl *c = d.ctrl;
+    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    const long long base = c->job.win_base;
+    const int nrows = (int)(c->job.win_hi - base);
+    const int r0 = blockIdx.x * BUCKET_ROWS;
+    if (r0 >= nrows) return;
+    const int nb = d.nslots + 1;
+    int *cnt = lds, *res = lds + nb;
+    for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
+    __syncthreads();
+    int myb[BUCKET_ROWS / 256], myk[BUCKET_ROWS / 256];
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
+        const int r = r0 + threadIdx.x + t * 256;
+        myb[t] = -1;
+        if (r < nrows) {
+            const long long p = base + r;
+            const long long i = d.order ? d.order[p] : p;
+            myb[t] = d.z[i] + 1;
+            myk[t] = atomicAdd(&cnt[myb[t]], 1);          // rank inside (block, bucket)
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256)
+        res[b] = cnt[b] ? atomicAdd(&d.bucket_bins[b], cnt[b]) : 0;     // reserve this block's range
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t)
+        if (myb[t] >= 0) d.wperm[res[myb[t]] + myk[t]] = r0 + threadIdx.x + t * 256;
+}
+
+void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
+    const int nb = d.nslots + 1;
+    const unsigned g = (unsigned)((max_rows + BUCKET_ROWS - 1) / BUCKET_ROWS);
+    (void)hipMemsetAsync(d.bucket_bins, 0, sizeof(int) * (nb + 1), st);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), nb * (int)sizeof(int), st, d);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
+}
+
 void launch_sweep_begin(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(sweep_begin_kernel, dim3(1), dim3(TPB), 0, st, d);
 }

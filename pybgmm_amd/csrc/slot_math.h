@@ -301,7 +301,7 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
         // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
         // score and promote a pruned component), so they are used while moves are sparse; the
         // mover-dense path (resolver) always works on complete scores.
-        j.prune = (d.prune_enabled && d.Dp >= 32 && c->ema_run >= 256.0) ? 1 : 0;
+        j.prune = (d.prune_enabled && c->ema_run >= 256.0) ? 1 : 0;
     }
     set_chunks(d, j);
 }
