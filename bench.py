@@ -175,7 +175,7 @@ def main():
             return None
         flops = st["scored"] * flops_per_lik_eval(D)
         achieved = flops / (ms * 1e-3) / 1e12
-        is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 24)
+        is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 12)
         nJ = (D + 15) // 16
         # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
         # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
@@ -250,7 +250,7 @@ def main():
             "config": {"workload": "%s: %s D=%d N=%d K~%d, one independent chain per GPU, init=%s"
                                    % (args.workload, model, D, N, K, args.init),
                        "parallelism": "replica_chains_x%d" % n_gpus,
-                       "exact_pruning": bool(args.prune == 0 and D >= 17 and args.kernel != 1)},
+                       "exact_pruning": bool(args.prune == 0 and args.kernel != 1 and (D >= 12 or args.kernel == 2))},
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
             "roofline": roofline,

@@ -122,7 +122,7 @@ static int fetch_ctrl(bgmm_ctx *c) {
 
 static void resolve_kind(bgmm_ctx *c) {
     int k = c->kernel_kind;
-    if (k == KERNEL_AUTO) k = (c->d.D >= 24) ? KERNEL_MFMA : KERNEL_VALU;
+    if (k == KERNEL_AUTO) k = (c->d.D >= 12) ? KERNEL_MFMA : KERNEL_VALU;
     if (k == KERNEL_MFMA && c->d.Dp / 16 > 8) k = KERNEL_VALU;
     c->kind = k;
     c->d.rows_per_block = (k == KERNEL_MFMA) ? kMfmaRows : kValuRows;
