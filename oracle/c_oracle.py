@@ -31,7 +31,7 @@ def lib():
         L.go_create.restype = ctypes.c_void_p
         L.go_create.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _f64p, _f64p,
                                 ctypes.c_double, ctypes.c_int64, _f64p, ctypes.c_double,
-                                ctypes.c_void_p, ctypes.c_void_p]
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.go_destroy.argtypes = [ctypes.c_void_p]
         L.go_set_assignments.argtypes = [ctypes.c_void_p, _i64p]
         L.go_sweep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _f64p, ctypes.c_int,
@@ -58,12 +58,15 @@ def host_tables(v_0, N):
 
 
 class COracle(object):
-    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, z_init, K_max=None, scipy_tables=True):
+    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, z_init, K_max=None, scipy_tables=True,
+                 cov_type="full"):
         self.X = np.ascontiguousarray(X, dtype=np.float64)
         self.N, self.D = self.X.shape
         self.K_max = self.N if K_max is None else int(K_max)
         m_0 = np.ascontiguousarray(m_0, dtype=np.float64)
         S_0 = np.ascontiguousarray(S_0, dtype=np.float64)
+        self.diag = cov_type == "diag"
+        assert S_0.shape == ((self.D,) if self.diag else (self.D, self.D))
         L = lib()
         if scipy_tables:
             self._tabs = host_tables(v_0, self.N)
@@ -71,7 +74,7 @@ class COracle(object):
         else:
             tl = tg = None
         self.h = L.go_create(self.N, self.D, self.K_max, self.X, m_0, float(k_0), int(v_0), S_0,
-                             float(alpha), tl, tg)
+                             float(alpha), tl, tg, 1 if self.diag else 0)
         rc = L.go_set_assignments(self.h, np.ascontiguousarray(z_init, dtype=np.int64))
         assert rc == 0, "invalid initial assignment vector"
         self.lik_evals = ctypes.c_int64(0)
@@ -119,8 +122,9 @@ class COracle(object):
 
     def stats(self):
         K, D = self.K, self.D
-        m, S = np.empty((K, D)), np.empty((K, D, D))
-        ld, iv = np.empty(K), np.empty((K, D, D))
+        blk = (D,) if self.diag else (D, D)
+        m, S = np.empty((K, D)), np.empty((K,) + blk)
+        ld, iv = np.empty(K), np.empty((K,) + blk)
         lib().go_get_stats(self.h, m.ctypes.data, S.ctypes.data, ld.ctypes.data, iv.ctypes.data)
         return m, S, ld, iv
 
@@ -132,7 +136,8 @@ class COracle(object):
 
 def run_chain(g, n_iter=None, scipy_tables=True):
     """Run a Golden case through the C oracle; returns (oracle, per-sweep dict)."""
-    o = COracle(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.z_init, g.K_max, scipy_tables)
+    o = COracle(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.z_init, g.K_max, scipy_tables,
+                cov_type=g.cov_type)
     out = {"z": [], "K": [], "counts": [], "log_marg": []}
     for it in range(g.n_iter if n_iter is None else n_iter):
         o.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))

@@ -1,7 +1,7 @@
 /*
  * ORACLE (test infrastructure, not product code) -- plain-C restatement of the
  * reference's collapsed-Gibbs reassignment path (CRP / pCRP Gaussian mixture,
- * NIW prior, full covariance).  Scalar, single threaded, one visit at a time,
+ * NIW prior; full covariance, and -- SURVEY 8f rank 1 -- diagonal covariance).  Scalar, single threaded, one visit at a time,
  * with the reference's algorithmic structure: component statistics cached and
  * restored around every visit, covariance log-determinant and inverse rebuilt
  * FROM SCRATCH (LU with partial pivoting) on every removal and every move, a
@@ -34,6 +34,8 @@
 
 typedef struct {
     int64_t N, D, K_max, K;
+    int diag;                   /* covariance_type="diag": S, inv are D-vectors (gaussian_components_diag.py) */
+    int64_t SD;                 /* entries of one second-moment block: D*D or D */
     const double *X;            /* borrowed, N x D row major */
     double *m0, *S0;
     double k0, alpha;
@@ -117,6 +119,21 @@ static double slogdet_of(go_t *g, const double *a) {
 
 static void refresh_cov(go_t *g, int64_t k) {
     int64_t D = g->D;
+    if (g->diag) {              /* gaussian_components_diag.py:325-338 */
+        double k_N = g->k0 + (double)g->n[k];
+        double v_N = (double)(g->v0 + g->n[k]);
+        double scale = (k_N + 1.) / (k_N * v_N);
+        const double *m = g->m + k * D, *S = g->S + k * D;
+        double lp = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double mean = m[a] / k_N;
+            double var = scale * (S[a] - k_N * (mean * mean));
+            lp += log(var);
+            g->inv[k * D + a] = 1. / var;
+        }
+        g->logdet[k] = lp;
+        return;
+    }
     double k_N = g->k0 + (double)g->n[k];
     double v_N = (double)(g->v0 + g->n[k]);
     double scale = (k_N + 1.) / (k_N * (v_N - (double)D + 1.));
@@ -133,18 +150,22 @@ static void refresh_cov(go_t *g, int64_t k) {
 static void seat(go_t *g, int64_t i, int64_t k) {
     int64_t D = g->D;
     const double *x = g->X + i * D;
-    double *m = g->m + k * D, *S = g->S + k * D * D;
+    double *m = g->m + k * D, *S = g->S + k * g->SD;
     if (k == g->K) {
         g->K += 1;
         memcpy(m, g->prior_m, sizeof(double) * D);
-        memcpy(S, g->prior_S, sizeof(double) * D * D);
+        memcpy(S, g->prior_S, sizeof(double) * g->SD);
     }
     for (int64_t a = 0; a < D; ++a) m[a] += x[a];
-    for (int64_t a = 0; a < D; ++a)
-        for (int64_t b = 0; b < D; ++b) {
-            double o = x[a] * x[b];
-            S[a * D + b] += o;
-        }
+    if (g->diag) {
+        for (int64_t a = 0; a < D; ++a) { double o = x[a] * x[a]; S[a] += o; }
+    } else {
+        for (int64_t a = 0; a < D; ++a)
+            for (int64_t b = 0; b < D; ++b) {
+                double o = x[a] * x[b];
+                S[a * D + b] += o;
+            }
+    }
     g->n[k] += 1;
     refresh_cov(g, k);
     g->z[i] = k;
@@ -156,16 +177,16 @@ static void drop_component(go_t *g, int64_t k) {
     int64_t last = g->K;
     if (k != last) {
         memcpy(g->m + k * D, g->m + last * D, sizeof(double) * D);
-        memcpy(g->S + k * D * D, g->S + last * D * D, sizeof(double) * D * D);
+        memcpy(g->S + k * g->SD, g->S + last * g->SD, sizeof(double) * g->SD);
         g->logdet[k] = g->logdet[last];
-        memcpy(g->inv + k * D * D, g->inv + last * D * D, sizeof(double) * D * D);
+        memcpy(g->inv + k * g->SD, g->inv + last * g->SD, sizeof(double) * g->SD);
         g->n[k] = g->n[last];
         for (int64_t i = 0; i < g->N; ++i) if (g->z[i] == last) g->z[i] = k;
     }
     memset(g->m + last * D, 0, sizeof(double) * D);
-    memset(g->S + last * D * D, 0, sizeof(double) * D * D);
+    memset(g->S + last * g->SD, 0, sizeof(double) * g->SD);
     g->logdet[last] = 0.;
-    memset(g->inv + last * D * D, 0, sizeof(double) * D * D);
+    memset(g->inv + last * g->SD, 0, sizeof(double) * g->SD);
     g->n[last] = 0;
 }
 
@@ -177,19 +198,32 @@ static void unseat(go_t *g, int64_t i) {
     g->z[i] = -1;
     if (g->n[k] == 0) { drop_component(g, k); return; }
     const double *x = g->X + i * D;
-    double *m = g->m + k * D, *S = g->S + k * D * D;
+    double *m = g->m + k * D, *S = g->S + k * g->SD;
     for (int64_t a = 0; a < D; ++a) m[a] -= x[a];
-    for (int64_t a = 0; a < D; ++a)
-        for (int64_t b = 0; b < D; ++b) {
-            double o = x[a] * x[b];
-            S[a * D + b] -= o;
-        }
+    if (g->diag) {
+        for (int64_t a = 0; a < D; ++a) { double o = x[a] * x[a]; S[a] -= o; }
+    } else {
+        for (int64_t a = 0; a < D; ++a)
+            for (int64_t b = 0; b < D; ++b) {
+                double o = x[a] * x[b];
+                S[a * D + b] -= o;
+            }
+    }
     refresh_cov(g, k);
 }
 
 static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
                         double logdet, const double *inv, int64_t nu, double *delta) {
     int64_t D = g->D;
+    if (g->diag) {              /* product of univariate Student-t: gaussian_components_diag.py:340-354 */
+        double acc = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double dl = x[a] - mu_num[a] / k_N;
+            acc += log(1. + 1. / (double)nu * (dl * dl) * inv[a]);
+        }
+        return (double)D * (g->tab_lgam[nu + 1] - g->tab_lgam[nu] - 0.5 * g->tab_log[nu] - 0.5 * LOG_PI)
+               - 0.5 * logdet - ((double)nu + 1.) / 2. * acc;
+    }
     for (int64_t a = 0; a < D; ++a) delta[a] = mu_num[a] / k_N - x[a];
     double q = 0.0;
     for (int64_t a = 0; a < D; ++a) {
@@ -205,11 +239,12 @@ static double student_t(const go_t *g, const double *x, const double *mu_num, do
 /* ------------------------------------------------------------------------- */
 void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const double *m0,
                 double k0, int64_t v0, const double *S0, double alpha,
-                const double *tab_lgam, const double *tab_log) {
+                const double *tab_lgam, const double *tab_log, int diag) {
     go_t *g = (go_t *)calloc(1, sizeof(go_t));
     g->N = N; g->D = D; g->K_max = K_max; g->X = X; g->k0 = k0; g->v0 = v0; g->alpha = alpha;
+    g->diag = diag; g->SD = diag ? D : D * D;
     g->m0 = (double *)malloc(sizeof(double) * D); memcpy(g->m0, m0, sizeof(double) * D);
-    g->S0 = (double *)malloc(sizeof(double) * D * D); memcpy(g->S0, S0, sizeof(double) * D * D);
+    g->S0 = (double *)malloc(sizeof(double) * D * D); memcpy(g->S0, S0, sizeof(double) * g->SD);
     g->tab_len = v0 + N + 2;
     g->tab_lgam = (double *)malloc(sizeof(double) * g->tab_len);
     g->tab_log = (double *)malloc(sizeof(double) * g->tab_len);
@@ -221,12 +256,16 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->prior_m = (double *)malloc(sizeof(double) * D);
     g->prior_S = (double *)malloc(sizeof(double) * D * D);
     for (int64_t a = 0; a < D; ++a) g->prior_m[a] = k0 * m0[a];
-    for (int64_t a = 0; a < D; ++a)
-        for (int64_t b = 0; b < D; ++b) {
-            double o = m0[a] * m0[b];
-            double ko = k0 * o;
-            g->prior_S[a * D + b] = S0[a * D + b] + ko;
-        }
+    if (diag) {
+        for (int64_t a = 0; a < D; ++a) { double o = m0[a] * m0[a]; double ko = k0 * o; g->prior_S[a] = S0[a] + ko; }
+    } else {
+        for (int64_t a = 0; a < D; ++a)
+            for (int64_t b = 0; b < D; ++b) {
+                double o = m0[a] * m0[b];
+                double ko = k0 * o;
+                g->prior_S[a * D + b] = S0[a * D + b] + ko;
+            }
+    }
     g->m = (double *)calloc(K_max * D, sizeof(double));
     g->S = (double *)calloc(K_max * D * D, sizeof(double));
     g->inv = (double *)calloc(K_max * D * D, sizeof(double));
@@ -245,6 +284,13 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->delta = (double *)malloc(sizeof(double) * D);
     g->tmp = (double *)malloc(sizeof(double) * D);
 
+    if (diag) {                 /* gaussian_components_diag.py:205-212 */
+        double sc = (k0 + 1.) / (k0 * (double)v0), lp = 0.0;
+        for (int64_t a = 0; a < D; ++a) { double var = sc * S0[a]; lp += log(var); g->save_inv[a] = 1. / var; }
+        for (int64_t i = 0; i < N; ++i)
+            g->log_prior[i] = student_t(g, X + i * D, m0, 1.0, lp, g->save_inv, v0, g->delta);
+        return g;
+    }
     /* prior predictive of every point */
     int64_t nu0 = v0 - D + 1;
     double scale = (k0 + 1) / (k0 * (double)nu0);
@@ -301,8 +347,8 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         double save_logdet = 0.; int64_t save_n = 0;
         if (k_old >= 0) {
             memcpy(g->save_m, g->m + k_old * D, sizeof(double) * D);
-            memcpy(g->save_S, g->S + k_old * D * D, sizeof(double) * D * D);
-            memcpy(g->save_inv, g->inv + k_old * D * D, sizeof(double) * D * D);
+            memcpy(g->save_S, g->S + k_old * g->SD, sizeof(double) * g->SD);
+            memcpy(g->save_inv, g->inv + k_old * g->SD, sizeof(double) * g->SD);
             save_logdet = g->logdet[k_old]; save_n = g->n[k_old];
         }
         unseat(g, i);
@@ -312,9 +358,9 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         double top = -INFINITY;
         for (int64_t k = 0; k < K; ++k) {
             double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
-            int64_t nu = g->v0 + g->n[k] - D + 1;
+            int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
             g->lp[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
-                                     g->inv + k * D * D, nu, g->delta);
+                                     g->inv + k * g->SD, nu, g->delta);
             if (g->lp[k] > top) top = g->lp[k];
         }
         g->lp[K] = log_alpha + g->log_prior[i];
@@ -330,8 +376,8 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         }
         if (k_new == k_old && g->K == K_old) {
             memcpy(g->m + k_old * D, g->save_m, sizeof(double) * D);
-            memcpy(g->S + k_old * D * D, g->save_S, sizeof(double) * D * D);
-            memcpy(g->inv + k_old * D * D, g->save_inv, sizeof(double) * D * D);
+            memcpy(g->S + k_old * g->SD, g->save_S, sizeof(double) * g->SD);
+            memcpy(g->inv + k_old * g->SD, g->save_inv, sizeof(double) * g->SD);
             g->logdet[k_old] = save_logdet; g->n[k_old] = save_n;
             g->z[i] = k_old;
         } else {
@@ -351,9 +397,26 @@ double go_log_marg(void *h) {
         if (g->n[k] > 0) sum_lf += lgamma((double)g->n[k]);
     }
     double log_pz = (double)(K - 1) * log(g->alpha) + lgamma(g->alpha) - lgamma(sum_n + g->alpha) + sum_lf;
-    double ld_S0 = slogdet_of(g, g->S0);
     double hd = (double)D / 2.;
     double log_px = 0.;
+    if (g->diag) {              /* gaussian_components_diag.py:261-284 */
+        double lS0 = 0.;
+        for (int64_t a = 0; a < D; ++a) lS0 += log(g->S0[a]);
+        for (int64_t k = 0; k < K; ++k) {
+            double k_N = g->k0 + (double)g->n[k];
+            int64_t v_N = g->v0 + g->n[k];
+            double lSN = 0.;
+            for (int64_t a = 0; a < D; ++a) {
+                double mean = g->m[k * D + a] / k_N;
+                lSN += log(g->S[k * D + a] - k_N * (mean * mean));
+            }
+            log_px += -(double)g->n[k] * hd * LOG_PI + hd * log(g->k0) - hd * log(k_N)
+                      + (double)g->v0 / 2. * lS0 - (double)v_N / 2. * lSN
+                      + (double)D * (g->tab_lgam[v_N] - g->tab_lgam[g->v0]);
+        }
+        return log_pz + log_px;
+    }
+    double ld_S0 = slogdet_of(g, g->S0);
     for (int64_t k = 0; k < K; ++k) {
         double k_N = g->k0 + (double)g->n[k];
         int64_t v_N = g->v0 + g->n[k];
@@ -378,14 +441,14 @@ void go_get_log_prior(void *h, double *out) { go_t *g = (go_t *)h; memcpy(out, g
 void go_get_stats(void *h, double *m, double *S, double *logdet, double *inv) {
     go_t *g = (go_t *)h; int64_t D = g->D, K = g->K;
     if (m) memcpy(m, g->m, sizeof(double) * K * D);
-    if (S) memcpy(S, g->S, sizeof(double) * K * D * D);
+    if (S) memcpy(S, g->S, sizeof(double) * K * g->SD);
     if (logdet) memcpy(logdet, g->logdet, sizeof(double) * K);
-    if (inv) memcpy(inv, g->inv, sizeof(double) * K * D * D);
+    if (inv) memcpy(inv, g->inv, sizeof(double) * K * g->SD);
 }
 /* Student-t predictive of X[i] under every current component (no removal). */
 void go_log_post_pred(void *h, int64_t i, double *out) {
     go_t *g = (go_t *)h; int64_t D = g->D;
     for (int64_t k = 0; k < g->K; ++k)
         out[k] = student_t(g, g->X + i * D, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
-                           g->inv + k * D * D, g->v0 + g->n[k] - D + 1, g->delta);
+                           g->inv + k * g->SD, g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1, g->delta);
 }

@@ -212,7 +212,13 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
         out["rec_nk"] = np.array(record["nk"])
     if store_X:
         out["X"] = np.asarray(X, dtype=np.float64)
-    if comp.K * D * D <= 40000:
+    if cov_type == "diag":
+        Kf = comp.K
+        out["final_m"] = np.array(comp.m_N_numerators[:Kf])
+        out["final_S"] = np.array(comp.S_N_partials[:Kf])
+        out["final_logdet"] = np.array(comp.log_prod_vars[:Kf])      # log prod of predictive variances
+        out["final_inv"] = np.array(comp.inv_vars[:Kf])
+    elif comp.K * D * D <= 40000:
         Kf = comp.K
         out["final_m"] = np.array(comp.m_N_numerators[:Kf])
         out["final_S"] = np.array(comp.S_N_partials[:Kf])
@@ -377,6 +383,47 @@ def case_d12():
              true_assignments=z_true, skip_metrics=True)
 
 
+# ---- diagonal covariance: S_0 is a D-vector ------------------------- #
+def diag_prior(D, v_0=None):
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D, v_0=v_0)
+    return m_0, k_0, v_0, np.ascontiguousarray(np.diag(S_0))
+
+
+def case_diag_kat():
+    X, z_true = kat_data(1, 2, 100, 4)
+    run_case("diag_kat_2d", "CRPMM", X, diag_prior(2, v_0=5), 1.0, "rand", 3, None, 10, (1, 1),
+             true_assignments=z_true, reseed_before_model=False, cov_type="diag")
+
+
+def case_diag_each_in_own():
+    X, z_true = gendata.synth_mixture(30, 2, 3, seed=41)
+    run_case("diag_each_in_own_30", "CRPMM", X, diag_prior(2), 1.0, "each-in-own", 1, None, 3, (4, 4),
+             true_assignments=z_true, cov_type="diag")
+
+
+def case_diag_pcrp():
+    X, z_true = gendata.synth_mixture(600, 16, 10, seed=42)
+    run_case("diag_pcrp_16d", "PCRPMM", X, diag_prior(16), 1.0, "rand", 10, 80, 3, (5, 5),
+             sampler_kwargs=dict(n_power=1.1, power_burnin=0), true_assignments=z_true,
+             skip_metrics=True, cov_type="diag")
+
+
+def case_diag_general():
+    X, z_true = gendata.synth_mixture(300, 5, 6, seed=43)
+    X = X + np.array([4.0, -2.0, 0.0, 7.5, 1.0])
+    m_0 = np.array([3.5, -1.0, 0.5, 7.0, 0.0])
+    S_0 = np.array([2.0, 0.7, 1.3, 5.0, 0.9])
+    run_case("diag_general_5d", "CRPMM", X, (m_0, 0.3, 7, S_0), 2.5, "rand", 5, 60, 4, (6, 6),
+             true_assignments=z_true, cov_type="diag")
+
+
+def case_diag_64d():
+    X, z_true = gendata.synth_mixture(800, 64, 8, seed=44)
+    run_case("diag_crpmm_64d", "CRPMM", X, diag_prior(64), 1.0, "rand", 8, 64, 2, (7, 7),
+             true_assignments=z_true, store_X=False, skip_metrics=True, cov_type="diag",
+             recipe="synth_mixture(800,64,8,seed=44)")
+
+
 CASES = {
     "kat1": case_kat1, "kat3": case_kat3, "kat4": case_kat4, "c1": case_c1,
     "c2twin": case_c2_twin, "c3twin": case_c3_twin, "c3rand": case_c3_rand,
@@ -384,6 +431,8 @@ CASES = {
     "each_in_own": case_each_in_own, "one_by_one": case_one_by_one,
     "pcrp_burnin": case_pcrp_burnin, "pcrp_flagoff": case_pcrp_flag_off,
     "general_prior": case_general_prior, "d12": case_d12,
+    "diag_kat": case_diag_kat, "diag_each_in_own": case_diag_each_in_own, "diag_pcrp": case_diag_pcrp,
+    "diag_general": case_diag_general, "diag_64d": case_diag_64d,
 }
 
 

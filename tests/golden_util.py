@@ -8,7 +8,9 @@ from pybgmm_amd.utils import gendata
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+_EVERY = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+ALL_CASES = [c for c in _EVERY if not c.startswith("diag_")]          # full covariance
+DIAG_CASES = [c for c in _EVERY if c.startswith("diag_")]             # covariance_type="diag"
 # cases whose reference trajectory is short enough for the pure-numpy oracle
 SMALL_CASES = ["kat1_igmm_2d", "kat3_each_in_own", "kat4_log_marg", "each_in_own_50",
                "one_by_one_50", "pcrp_burnin_2d", "pcrp_flagoff_3d", "general_prior_3d"]
@@ -25,6 +27,7 @@ class Golden(object):
             setattr(self, key, float(d[key]))
         self.flag_power = bool(d["flag_power"])
         self.model = str(d["model"])
+        self.cov_type = str(d["cov_type"])
         self.m_0, self.S_0 = d["m_0"], d["S_0"]
         self.z_init = d["z_init"]
         self.u, self.order = d["u"], d["order"]

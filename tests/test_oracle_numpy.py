@@ -4,7 +4,7 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
-from golden_util import SMALL_CASES, Golden
+from golden_util import DIAG_CASES, SMALL_CASES, Golden
 from oracle.gibbs_numpy import NumpyGibbsOracle, run_chain
 
 
@@ -26,6 +26,48 @@ def test_trajectory_bitexact(case):
         npt.assert_array_equal(o.logdet[:K], g.d["final_logdet"])
         npt.assert_array_equal(o.inv[:K], g.d["final_inv"])
     npt.assert_array_equal(o.log_prior[:4096], g.d["cached_log_prior"])
+
+
+@pytest.mark.parametrize("case", [c for c in DIAG_CASES if c != "diag_crpmm_64d"])
+def test_diag_trajectory_bitexact(case):
+    g = Golden(case)
+    o, out = run_chain(g.X, g.prior, g.alpha, g.z_init, g.K_max, g.u, g.order,
+                       g.n_power, g.power_burnin, g.flag_power, cov_type="diag")
+    for it in range(g.n_iter):
+        npt.assert_array_equal(out["z"][it], g.z[it], err_msg="sweep %d" % it)
+        npt.assert_array_equal(out["counts"][it], g.counts_at(it))
+        assert out["log_marg"][it] == g.log_marg[it]
+    K = g.K[-1]
+    npt.assert_array_equal(o.m[:K], g.d["final_m"])
+    npt.assert_array_equal(o.S[:K], g.d["final_S"])
+    npt.assert_array_equal(o.logdet[:K], g.d["final_logdet"])
+    npt.assert_array_equal(o.inv[:K], g.d["final_inv"])
+    npt.assert_array_equal(o.log_prior[:4096], g.d["cached_log_prior"])
+
+
+def test_diag_matches_univariate_student_t():
+    """The analytic cross-check of pybgmm/tests/test_gaussian_components_diag.py:17-72: the
+    predictive is a product of univariate Student-t densities (Murphy, bayesGauss p. 26)."""
+    from scipy.special import gammaln
+    from oracle.gibbs_numpy import NumpyGibbsOracleDiag
+
+    def t_logpdf(x, mu, var, v):
+        c = gammaln((v + 1) / 2.) - gammaln(v / 2.) - 0.5 * (np.log(v) + np.log(np.pi) + np.log(var))
+        return c - (v + 1) / 2. * np.log(1 + 1. / v * (x - mu) ** 2 / var)
+
+    rs = np.random.RandomState(1)
+    X = 5 * rs.rand(10, 3) - 1
+    m_0, k_0, v_0, S_0 = 5 * rs.rand(3) - 2, rs.randint(15), 4, 2 * rs.rand(3) + 3
+    o = NumpyGibbsOracleDiag(X, m_0, k_0 + 1, v_0, S_0, 1.0, np.zeros(10, dtype=np.int64), None)
+    k0 = k_0 + 1
+    var0 = S_0 * (k0 + 1) / (k0 * v_0)
+    npt.assert_almost_equal(o.log_prior[0], np.sum(t_logpdf(X[0], m_0, var0, v_0)))
+    k_N, v_N = k0 + 10, v_0 + 10
+    m_N = (k0 * m_0 + X.sum(axis=0)) / k_N
+    S_N = S_0 + k0 * m_0 ** 2 + (X ** 2).sum(axis=0) - k_N * m_N ** 2
+    var = S_N * (k_N + 1) / (k_N * v_N)
+    npt.assert_almost_equal(o.predictive_k(0, 0), np.sum(t_logpdf(X[0], m_N, var, v_N)))
+    npt.assert_almost_equal(o.predictive_all(0)[0], o.predictive_k(0, 0))
 
 
 def test_probes_first_visits():
