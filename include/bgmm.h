@@ -39,7 +39,10 @@ enum {
     BGMM_EUNSUPPORTED = -5
 };
 
-enum { BGMM_COV_FULL = 0 };   /* covariance_type="full" (igmm.py:104-105); diag/fixed: next rows */
+enum { BGMM_COV_FULL = 0,      /* covariance_type="full"  (igmm.py:104-105, gaussian/gaussian_components.py)      */
+       BGMM_COV_DIAG = 1 };    /* covariance_type="diag"  (igmm.py:106-107, gaussian/gaussian_components_diag.py):
+                                  S_0 is a D-vector; per-slot S / inverse blocks are D-vectors too; `logdet_out`
+                                  of bgmm_get_stats is log_prod_vars, `inv_out` is inv_vars                       */
 
 /* Library / build identification, e.g. "bgmm-hip 0.1 gfx950". */
 const char *bgmm_version(void);

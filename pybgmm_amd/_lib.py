@@ -89,7 +89,7 @@ def _ptr(a):
 class Context(object):
     """One chain on one GPU.  Thin, argument-checked wrapper over the C-ABI."""
 
-    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, device=0, tables=None):
+    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, device=0, tables=None, cov_type="full"):
         L = load()
         self.L = L
         self.X = np.ascontiguousarray(X, dtype=np.float64)
@@ -97,6 +97,10 @@ class Context(object):
         self.K_max = int(K_max)
         m_0 = np.ascontiguousarray(m_0, dtype=np.float64)
         S_0 = np.ascontiguousarray(S_0, dtype=np.float64)
+        self.cov_type = cov_type
+        self.diag = cov_type == "diag"
+        assert cov_type in ("full", "diag")
+        assert S_0.shape == ((self.D,) if self.diag else (self.D, self.D)), "S_0 has the wrong shape"
         if int(v_0) != v_0:
             raise ValueError("v_0 must be integer valued (the reference indexes its "
                              "log/gammaln tables with it)")
@@ -106,7 +110,7 @@ class Context(object):
             tg = np.ascontiguousarray(tables[1], dtype=np.float64)
             assert tl.shape == (int(v_0) + self.N + 2,) and tg.shape == tl.shape
         h = _vp()
-        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max, 0,
+        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max, 1 if self.diag else 0,
                            _ptr(self.X), _ptr(m_0), float(k_0), int(v_0), _ptr(S_0), float(alpha),
                            _ptr(tl), _ptr(tg))
         if rc != 0:
@@ -183,9 +187,10 @@ class Context(object):
 
     def stats(self, want_inv=True):
         K, D = self.K, self.D
-        m, S = np.empty((K, D)), np.empty((K, D, D))
+        blk = (D,) if self.diag else (D, D)
+        m, S = np.empty((K, D)), np.empty((K,) + blk)
         ld = np.empty(K)
-        iv = np.empty((K, D, D)) if want_inv else None
+        iv = np.empty((K,) + blk) if want_inv else None
         self._ck(self.L.bgmm_get_stats(self.h, _ptr(m), _ptr(S), _ptr(ld), _ptr(iv)))
         return m, S, ld, iv
 

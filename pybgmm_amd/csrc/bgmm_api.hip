@@ -122,6 +122,7 @@ static int fetch_ctrl(bgmm_ctx *c) {
 
 static void resolve_kind(bgmm_ctx *c) {
     int k = c->kernel_kind;
+    if (c->d.cov_type == COV_DIAG) k = KERNEL_VALU;      // (the diag likelihood kernel has the VALU geometry)
     if (k == KERNEL_AUTO) k = (c->d.D >= 12) ? KERNEL_MFMA : KERNEL_VALU;
     if (k == KERNEL_MFMA && c->d.Dp / 16 > 8) k = KERNEL_VALU;
     c->kind = k;
@@ -151,7 +152,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     delete c;
 }
 
-static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_max,
+static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
                        const double *X, const double *m_0, double k_0, int64_t v_0,
                        const double *S_0, double alpha, const double *lgamma_tab,
                        const double *log_tab) {
@@ -159,6 +160,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipSetDevice(device));
     CK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     Dev &d = c->d;
+    d.cov_type = cov_type;
     d.N = N; d.D = D; d.Dp = (D + 15) / 16 * 16; d.K_max = K_max; d.nslots = K_max + 1;
     d.nfrag = bgmm_nfrag(d.Dp); d.ldq = d.nslots;
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
@@ -166,7 +168,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
     resolve_kind(c);
 
-    const size_t DD = (size_t)D * D, ns = (size_t)d.nslots;
+    const bool diag = cov_type == COV_DIAG;
+    const size_t DD = diag ? (size_t)D : (size_t)D * D, ns = (size_t)d.nslots;   // second-moment block
+    const size_t WW = diag ? 1 : (size_t)D * D;                                   // factor block (full only)
     double *dX, *dtl, *dtg, *dpm, *dpS, *dtG, *dtC, *dtS;
     DALLOC(c, dX, (size_t)N * D);
     DALLOC(c, d.log_prior, (size_t)N);
@@ -181,8 +185,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.m, ns * D);
     DALLOC(c, d.S, ns * DD);
     DALLOC(c, d.mu, ns * D);
-    DALLOC(c, d.Wrm, ns * DD);
-    DALLOC(c, d.Wfrag, ns * d.nfrag * 64);
+    DALLOC(c, d.Wrm, ns * WW);
+    DALLOC(c, d.Wfrag, diag ? 64 : ns * d.nfrag * 64);
+    DALLOC(c, d.dw, ns * D);
     DALLOC(c, d.cvec, ns * d.Dp);
     DALLOC(c, d.n, ns);
     DALLOC(c, d.nupd, ns);
@@ -230,12 +235,20 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     // k_0*m_0  and  S_0 + k_0*outer(m_0, m_0)
     std::vector<double> pm(D), pS(DD);
     for (int a = 0; a < D; ++a) pm[a] = k_0 * m_0[a];
-    for (int a = 0; a < D; ++a)
-        for (int b = 0; b < D; ++b) {
-            volatile double o = m_0[a] * m_0[b];
+    if (diag) {      // S_0 is a D-vector: S_0 + k_0*square(m_0)   (gaussian_components_diag.py:170)
+        for (int a = 0; a < D; ++a) {
+            volatile double o = m_0[a] * m_0[a];
             volatile double ko = k_0 * o;
-            pS[(size_t)a * D + b] = S_0[(size_t)a * D + b] + ko;
+            pS[a] = S_0[a] + ko;
         }
+    } else {
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b < D; ++b) {
+                volatile double o = m_0[a] * m_0[b];
+                volatile double ko = k_0 * o;
+                pS[(size_t)a * D + b] = S_0[(size_t)a * D + b] + ko;
+            }
+    }
     CK(c, hipMemcpyAsync(dpm, pm.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemcpyAsync(dpS, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
     // pseudo slot K_max = the bare prior (n = 0): its refresh yields C = S_0, mu = m_0
@@ -292,18 +305,21 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
                            const double *log_tab) {
     if (!out) return BGMM_EINVAL;
     *out = nullptr;
-    if (cov_type != BGMM_COV_FULL) return fail(nullptr, BGMM_EUNSUPPORTED, "only covariance_type=\"full\" is implemented");
+    if (cov_type != BGMM_COV_FULL && cov_type != BGMM_COV_DIAG)
+        return fail(nullptr, BGMM_EUNSUPPORTED, "covariance_type must be full (0) or diag (1)");
     if (!X || !m_0 || !S_0 || N < 1 || D < 1 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
     if (D > BGMM_MAX_D) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 128 is not supported yet");
     if (N >= (1ll << 31) - 256) return fail(nullptr, BGMM_EUNSUPPORTED, "N must fit int32");
-    if (v_0 < D) return fail(nullptr, BGMM_EINVAL, "v_0 must be larger or equal to dimension of data");
+    if (v_0 < D && cov_type == BGMM_COV_FULL)
+        return fail(nullptr, BGMM_EINVAL, "v_0 must be larger or equal to dimension of data");
+    if (v_0 < 1) return fail(nullptr, BGMM_EINVAL, "v_0 must be positive");
     if (!(k_0 > 0) || !(alpha > 0)) return fail(nullptr, BGMM_EINVAL, "k_0 and alpha must be positive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BGMM_EDEVICE, "no HIP device visible: libbgmm_hip.so has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(nullptr, BGMM_EINVAL, "device index out of range");
     bgmm_ctx *c = new bgmm_ctx();
-    const int rc = create_impl(c, device, N, D, K_max, X, m_0, k_0, v_0, S_0, alpha, lgamma_tab, log_tab);
+    const int rc = create_impl(c, device, N, D, K_max, cov_type, X, m_0, k_0, v_0, S_0, alpha, lgamma_tab, log_tab);
     if (rc != 0) {
         g_create_error = c->err;
         bgmm_destroy(c);
@@ -550,7 +566,7 @@ extern "C" int bgmm_get_stats(bgmm_ctx *c, double *m_out, double *S_out, double 
     if (rc) return rc;
     const int K = c->ctrl_host->job.K, D = c->d.D;
     if (K == 0) return 0;
-    const size_t DD = (size_t)D * D;
+    const size_t DD = c->d.cov_type == COV_DIAG ? (size_t)D : (size_t)D * D;
     double *dm = nullptr, *dS = nullptr, *dl = nullptr, *di = nullptr;
     hipError_t e = hipSuccess;
     if (m_out && e == hipSuccess) e = hipMalloc((void **)&dm, sizeof(double) * K * D);

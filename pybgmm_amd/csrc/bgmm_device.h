@@ -28,6 +28,7 @@
 
 enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
 enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
+enum { COV_FULL = 0, COV_DIAG = 1 };
 // how a slot's derived state (mu, Winv, cvec, constants) follows a change of (n, m, S)
 enum { REFRESH_SCRATCH = 0,   // Cholesky + inverse of S_N from scratch, O(D^3)
        REFRESH_ADD = 1,       // rank-1 update of Winv: point refresh_i was added
@@ -41,7 +42,9 @@ static constexpr int kValuRows = 64;       // rows (visits) per block, VALU like
 static constexpr int kMfmaRows = 128;      // rows per block, MFMA likelihood kernel (4 waves x 2 x 16)
 static constexpr int kChoiceRowsMax = 8;   // rows per block of the draw kernel (one wave per row)
 
-// Per-slot scalar constants.  As-is predictive of a point under slot s:
+// Per-slot scalar constants.  (Diagonal covariance uses A = D*(lgamma terms) - 0.5 log prod var,
+// half_vd = (v_N+1)/2, logdetC = sum log S_N,d, A1 = log prod var, the seating weights; rest 0.)
+// As-is predictive of a point under slot s:
 //   lp = A - half_vd * log(1 + q * inv_cv)
 // "Home" predictive (the visited point removed from its own component; Sherman-Morrison
 // on the frozen factor, with s = q the as-is quadratic form):
@@ -93,6 +96,7 @@ struct Ctrl {
 
 struct Dev {
     long long N;
+    int cov_type;                // 0 full covariance, 1 diagonal (S and dw are D-vectors per slot)
     int D, Dp, K_max, nslots, nfrag, ldq;
     long long qstride;           // q[slot * qstride + window row]
     int choice_rows;             // visits per block of the draw kernel
@@ -109,6 +113,7 @@ struct Dev {
     const double *tabG, *tabLogC, *tabSeat;
     const double *prior_m, *prior_S;
     double *m, *S, *mu, *Wrm, *Wfrag, *cvec;
+    double *dw;                  // diag: per-dimension weights 1 / (v_N var_d) of the univariate Student-t
     int *n;
     int *nupd;                   // rank-1 updates since the slot's last from-scratch refresh
     SlotConst *sc;

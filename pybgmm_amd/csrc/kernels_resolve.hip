@@ -649,7 +649,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
 
 // Largest sub-window (rows) whose working set fits in LDS for the current number of labels.
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out) {
-    if (d.D > 64) return false;
+    if (d.D > 64 || d.cov_type != COV_FULL) return false;
     for (int R = 64; R >= 8; R >>= 1) {
         const int Kcap = (K_now + 2 * R + 8 + 7) & ~7;     // room for labels opened by the caller's chunk
         const size_t bytes = resolve_offsets(d.D, R, Kcap, d.nslots, nullptr);

@@ -493,9 +493,13 @@ static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstri
                        qstride, col_override, skip_pruned_jobs);
 }
 
+void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
+                       long long max_rows, hipStream_t st);
+
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
                   long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
+    if (d.cov_type == COV_DIAG) { launch_score_diag(d, job, q, qstride, col_override, max_rows, st); return; }
     if (kind == KERNEL_MFMA) {
         switch (d.Dp / 16) {
             case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
@@ -513,4 +517,94 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
     const int lds = d.D * kValuRows * (int)sizeof(double);
     hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
                        col_override, skip_pruned_jobs);
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal covariance (reference gaussian_components_diag.py:231-259):
+// the predictive is a product of univariate Student-t densities,
+//     lp = D (lgamma((v+1)/2) - lgamma(v/2) - log(v)/2 - log(pi)/2) - log(prod var)/2
+//          - (v+1)/2 sum_d log(1 + (x_d - mu_d)^2 / (v var_d)),          v = v_N,
+// i.e. D logarithms per (visit, component): an FP64 VALU kernel.  Lane = visit, x tile
+// transposed in LDS, means / weights of the slot wave-uniform.  It stores the log density
+// itself (not a quadratic form); for the visit's own component it stores the
+// one-point-removed form, rebuilt from (n-1, m-x, S-x^2) exactly as del_item does
+// (gaussian_components_diag.py:178-193).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__restrict__ jobp,
+                                                         double *__restrict__ q, long long qstride,
+                                                         int col_override, int home_correction) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
+    const JobView job = load_job(jobp);
+    if (job.mode == MODE_DONE) return;
+    const int chunk = blockIdx.y;
+    if (chunk >= job.chunks) return;
+    const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
+    if (p0 >= job.win_hi) return;
+    const int D = d.D;
+    for (int e = threadIdx.x; e < kValuRows * D; e += 256) {
+        const int r = e / D, l = e % D;
+        const long long p = p0 + r;
+        double v = 0.0;
+        if (p < job.win_hi) {
+            const long long i = d.order ? d.order[p] : p;
+            v = d.X[i * D + l];
+        }
+        xs[l * kValuRows + r] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p = p0 + lane;
+    const bool live = p < job.win_hi;
+    // (utility jobs -- log_prior, log_post_pred -- score every slot as it is)
+    int home = -1;
+    if (live && home_correction) {
+        const long long i = d.order ? d.order[p] : p;
+        home = d.z[i];
+    }
+    const double hlp = 0.5 * BGMM_LOG_PI;
+    for (int t = chunk + job.chunks * w; t < job.nlist; t += job.chunks * 4) {
+        const int s = job_slot(d, job, t);
+        const double *__restrict__ mu = d.mu + (long long)s * D;
+        const double *__restrict__ dw = d.dw + (long long)s * D;
+        const SlotConst *__restrict__ scp = d.sc + s;
+        double acc = 0.0;
+        for (int l = 0; l < D; ++l) {
+            const double dl = xs[l * kValuRows + lane] - mu[l];
+            acc += log(1.0 + dl * dl * dw[l]);
+        }
+        double lp = scp->A - scp->half_vd * acc;
+        const int ns = d.n[s];
+        if (home == s && ns >= 2) {
+            // the visited point removed from its own component
+            const double *__restrict__ mS = d.m + (long long)s * D;
+            const double *__restrict__ SS = d.S + (long long)s * D;
+            const double k1 = d.k0 + (double)(ns - 1);
+            const long long v1 = d.v0 + ns - 1;
+            const double scale1 = (k1 + 1.0) / (k1 * (double)v1), inv_v1 = 1.0 / (double)v1;
+            double lpv = 0.0, a1 = 0.0;
+            for (int l = 0; l < D; ++l) {
+                const double x = xs[l * kValuRows + lane];
+                const double m1 = __dsub_rn(mS[l], x);
+                const double S1 = __dsub_rn(SS[l], __dmul_rn(x, x));
+                const double mean = m1 / k1;
+                const double var = scale1 * (S1 - k1 * (mean * mean));
+                const double dl = x - mean;
+                lpv += log(var);
+                a1 += log(1.0 + inv_v1 * (dl * dl) * (1.0 / var));
+            }
+            lp = (double)D * (d.tab_lgam[v1 + 1] - d.tab_lgam[v1] - 0.5 * d.tab_log[v1] - hlp)
+                 - 0.5 * lpv - 0.5 * (double)(v1 + 1) * a1;
+        }
+        if (live) q[(long long)(col_override >= 0 ? col_override : s) * qstride + (p - job.win_base)] = lp;
+    }
+}
+
+void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
+                       long long max_rows, hipStream_t st) {
+    if (max_rows <= 0) return;
+    const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
+    const int lds = d.D * kValuRows * (int)sizeof(double);
+    hipLaunchKernelGGL(score_diag_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
+                       col_override, job == &d.ctrl->job ? 1 : 0);
 }

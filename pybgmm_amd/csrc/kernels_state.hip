@@ -22,6 +22,20 @@ __global__ __launch_bounds__(TPB) void init_stats_kernel(Dev d, const int *__res
     const int k = blockIdx.x;                 // initial label == slot
     const int D = d.D;
     const long long lo = offsets[k], hi = offsets[k + 1];
+    if (d.cov_type == COV_DIAG) {             // gaussian_components_diag.py:162-176: S += square(x)
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            double accS = d.prior_S[a], accm = d.prior_m[a];
+            for (long long t = lo; t < hi; ++t) {
+                const double x = d.X[(long long)members[t] * D + a];
+                accS = __dadd_rn(accS, __dmul_rn(x, x));
+                accm = __dadd_rn(accm, x);
+            }
+            d.S[(long long)k * D + a] = accS;
+            d.m[(long long)k * D + a] = accm;
+        }
+        if (threadIdx.x == 0) d.n[k] = (int)(hi - lo);
+        return;
+    }
     for (int e = threadIdx.x; e < D * D; e += TPB) {
         const int a = e / D, b = e % D;
         double acc = d.prior_S[e];
@@ -69,7 +83,10 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
 // Two routes (slot_math.h): from scratch, O(D^3); or a rank-1 change of Winv, O(D^2).
 // LDS: W[D][D+1] + 6 D + 4 doubles.
 // ------------------------------------------------------------------------------------------
-int refresh_lds_bytes(int D) { return (D * (D + 1) + 6 * D + 4) * (int)sizeof(double); }
+int refresh_lds_bytes(int D) {
+    const int full = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double), diag = 2 * 256 * (int)sizeof(double);
+    return full > diag ? full : diag;
+}
 
 __device__ void refresh_slot(const Dev &d, int s, double *sm) {
     const int D = d.D, ld = D + 1, tid = threadIdx.x;
@@ -124,7 +141,10 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
 
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if ((int)blockIdx.x < n) refresh_slot(d, slots ? slots[blockIdx.x] : (int)blockIdx.x, sm);
+    if ((int)blockIdx.x >= n) return;
+    const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
+    if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
+    else refresh_slot(d, s, sm);
 }
 
 __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
@@ -132,7 +152,8 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
     if ((int)blockIdx.x >= c->n_refresh) return;
     const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
-    if (kind == REFRESH_SCRATCH) refresh_slot(d, s, sm);
+    if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
+    else if (kind == REFRESH_SCRATCH) refresh_slot(d, s, sm);
     else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
 
@@ -348,6 +369,22 @@ __device__ int plan_seat(const Dev &d, Ctrl *c, long long i, int lab, MovePlan &
 __device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
     const int D = d.D;
     const double *x = d.X + mp.i * D;
+    if (d.cov_type == COV_DIAG) {
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            const double xx = __dmul_rn(x[a], x[a]);
+            if (mp.sub_slot >= 0) {
+                const long long o = (long long)mp.sub_slot * D + a;
+                d.m[o] = __dsub_rn(d.m[o], x[a]);
+                d.S[o] = __dsub_rn(d.S[o], xx);
+            }
+            if (mp.add_slot >= 0) {
+                const long long o = (long long)mp.add_slot * D + a;
+                d.m[o] = __dadd_rn(mp.add_init ? d.prior_m[a] : d.m[o], x[a]);
+                d.S[o] = __dadd_rn(mp.add_init ? d.prior_S[a] : d.S[o], xx);
+            }
+        }
+        return;
+    }
     if (mp.sub_slot >= 0) {
         double *m = d.m + (long long)mp.sub_slot * D;
         double *S = d.S + (long long)mp.sub_slot * D * D;
@@ -370,6 +407,7 @@ __device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
 __device__ void set_refresh(const Dev &d, Ctrl *c, const MovePlan &mp, bool rank1) {
     int nr = 0;
     c->refresh_i = mp.i;
+    if (d.cov_type == COV_DIAG) rank1 = false;      // the diag refresh is O(D) anyway
     if (mp.sub_slot >= 0) {
         c->refresh_kind[nr] = (rank1 && d.nupd[mp.sub_slot] < kRefreshEvery) ? REFRESH_SUB : REFRESH_SCRATCH;
         c->refresh[nr++] = mp.sub_slot;
@@ -497,7 +535,9 @@ __global__ __launch_bounds__(TPB) void log_marg_kernel(Dev d, double *out_total,
         const double k_N = d.k0 + (double)n;
         const long long v_N = d.v0 + n;
         double gs = 0.0;
-        for (int t = 1; t <= D; ++t) gs += d.tab_lgam[v_N + 1 - t] - d.tab_lgam[d.v0 + 1 - t];
+        if (d.cov_type == COV_DIAG) gs = (double)D * (d.tab_lgam[v_N] - d.tab_lgam[d.v0]);
+        else
+            for (int t = 1; t <= D; ++t) gs += d.tab_lgam[v_N + 1 - t] - d.tab_lgam[d.v0 + 1 - t];
         out_per_label[j] = -(double)n * hd * BGMM_LOG_PI + hd * log(d.k0) - hd * log(k_N)
                            + 0.5 * (double)d.v0 * logdetS0 - 0.5 * (double)v_N * d.sc[s].logdetC + gs;
     }
@@ -536,6 +576,7 @@ void launch_labels(const Dev &d, long long *z_out, long long *counts_out, hipStr
 __global__ void prior_lp_kernel(Dev d, const double *__restrict__ qcol) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
+    if (d.cov_type == COV_DIAG) { d.log_prior[i] = qcol[i]; return; }   // the diag kernel emits log densities
     const SlotConst c = d.sc[d.K_max];
     d.log_prior[i] = c.A - c.half_vd * log(1.0 + qcol[i] * c.inv_cv);
 }
@@ -548,6 +589,7 @@ __global__ void post_pred_kernel(Dev d, const double *__restrict__ qrow, double 
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= d.ctrl->job.K) return;
     const int s = d.perm[j];
+    if (d.cov_type == COV_DIAG) { out[j] = qrow[s]; return; }
     const SlotConst c = d.sc[s];
     out[j] = c.A - c.half_vd * log(1.0 + qrow[s] * c.inv_cv);
 }
@@ -564,6 +606,15 @@ __global__ __launch_bounds__(TPB) void export_stats_kernel(Dev d, double *m_out,
     const int s = d.perm[j], D = d.D;
     const int n = d.n[s];
     const double k_N = d.k0 + (double)n;
+    if (d.cov_type == COV_DIAG) {        // m, S (K x D), log_prod_vars, inv_vars (K x D)
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            if (m_out) m_out[(long long)j * D + a] = d.m[(long long)s * D + a];
+            if (S_out) S_out[(long long)j * D + a] = d.S[(long long)s * D + a];
+            if (inv_out) inv_out[(long long)j * D + a] = d.dw[(long long)s * D + a] * (double)(d.v0 + n);
+        }
+        if (logdet_out && threadIdx.x == 0) logdet_out[j] = d.sc[s].A1;
+        return;
+    }
     const double cs = (k_N + 1.0) / (k_N * (double)(d.v0 + n - D + 1));
     if (m_out) for (int a = threadIdx.x; a < D; a += TPB) m_out[(long long)j * D + a] = d.m[(long long)s * D + a];
     if (S_out) for (int e = threadIdx.x; e < D * D; e += TPB) S_out[(long long)j * D * D + e] = d.S[(long long)s * D * D + e];

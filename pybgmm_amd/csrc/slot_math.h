@@ -314,3 +314,50 @@ __device__ inline long long window_for_rate(const Ctrl *c) {
     if (w > c->win_cap) w = c->win_cap;
     return w;
 }
+
+// ------------------------------------------------------------------------------------------
+// Diagonal covariance (reference gaussian_components_diag.py:325-338): everything derived from
+// (n, m[D], S[D]) of one slot.  red: 2*NT doubles of LDS.  Barriers inside.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int tid) {
+    const int D = d.D;
+    const int n = d.n[s];
+    const double k_N = d.k0 + (double)n;
+    const long long v_N = d.v0 + n;
+    const double scale = (k_N + 1.0) / (k_N * (double)v_N);
+    const double inv_v = 1.0 / (double)v_N;
+    double lpv = 0.0, lsn = 0.0;
+    bool bad = false;
+    for (int l = tid; l < D; l += NT) {
+        const double mean = d.m[(long long)s * D + l] / k_N;
+        const double sn = d.S[(long long)s * D + l] - k_N * (mean * mean);
+        const double var = scale * sn;
+        if (!(sn > 0.0)) bad = true;
+        d.mu[(long long)s * D + l] = mean;
+        d.dw[(long long)s * D + l] = (1.0 / var) * inv_v;
+        lpv += log(var);
+        lsn += log(sn);
+    }
+    red[tid] = lpv;
+    red[NT + tid] = lsn;
+    if (bad) atomicCAS(&d.ctrl->error, 0, -4);
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int t = 0; t < NT; ++t) { a += red[t]; b += red[NT + t]; }
+        SlotConst c;
+        c.A = (double)D * (d.tab_lgam[v_N + 1] - d.tab_lgam[v_N] - 0.5 * d.tab_log[v_N] - 0.5 * BGMM_LOG_PI) - 0.5 * a;
+        c.half_vd = 0.5 * (double)(v_N + 1);
+        c.inv_cv = 0.0;
+        c.A1 = a;                 // log prod of the predictive variances (reference log_prod_vars)
+        c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+        c.logdetC = b;            // sum_d log S_N,d (log_marg_k)
+        c.logseat = d.tabSeat[n];
+        c.logseat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
+        c.inv_lam = 0.0; c.mu2 = 0.0;
+        d.sc[s] = c;
+        d.nupd[s] = 0;
+    }
+    __syncthreads();
+}

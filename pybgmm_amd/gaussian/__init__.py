@@ -1,3 +1,3 @@
-from .gaussian_components import GaussianComponents
+from .gaussian_components import GaussianComponents, GaussianComponentsDiag
 
-__all__ = ["GaussianComponents"]
+__all__ = ["GaussianComponents", "GaussianComponentsDiag"]

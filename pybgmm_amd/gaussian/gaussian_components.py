@@ -37,6 +37,8 @@ class GaussianComponents(object):
     """``alpha`` (extension): CRP concentration used by the sweep kernel for the
     "open a new table" score; the reference keeps it on the sampler object."""
 
+    _cov_type = "full"
+
     def __init__(self, X, prior, assignments=None, K_max=None, device=0, alpha=1.0):
         X = np.asarray(X)
         self.X = X
@@ -56,11 +58,19 @@ class GaussianComponents(object):
         assert K_init <= self.K_max, "initial assignments use more than K_max components"
         self._cached_log_pi = np.log(np.pi)
         self._cached_gammaln_by_2, self._cached_log_v = reference_tables(prior.v_0, self.N)
+        self._check_prior(prior)
         self._ctx = _lib.Context(X, prior.m_0, prior.k_0, prior.v_0, prior.S_0,
                                  alpha, self.K_max, device=device,
-                                 tables=(self._cached_gammaln_by_2, self._cached_log_v))
+                                 tables=(self._cached_gammaln_by_2, self._cached_log_v),
+                                 cov_type=self._cov_type)
         self._log_prior = None
         self._ctx.set_assignments(z)
+
+    def _check_prior(self, prior):
+        pass
+
+    def _block(self):
+        return (self.D, self.D)
 
     # --- attributes of the reference class, served from the device ------------------
     @property
@@ -89,7 +99,7 @@ class GaussianComponents(object):
 
     @property
     def S_N_partials(self):
-        return self._padded(self._ctx.stats(False)[1], (self.D, self.D))
+        return self._padded(self._ctx.stats(False)[1], self._block())
 
     @property
     def logdet_covars(self):
@@ -97,7 +107,7 @@ class GaussianComponents(object):
 
     @property
     def inv_covars(self):
-        return self._padded(self._ctx.stats(True)[3], (self.D, self.D))
+        return self._padded(self._ctx.stats(True)[3], self._block())
 
     @property
     def cached_log_prior(self):
@@ -153,3 +163,34 @@ class GaussianComponents(object):
 
     def rand_k(self, k):
         raise NotImplementedError("posterior parameter draws (plots) are outside the Gibbs hot path")
+
+
+class GaussianComponentsDiag(GaussianComponents):
+    """
+    Diagonal-covariance components: the interface of the reference's
+    ``pybgmm/gaussian/gaussian_components_diag.py:19`` ``GaussianComponentsDiag``.  ``prior.S_0``
+    is a D-vector; ``S_N_partials`` / ``inv_vars`` are K_max x D, ``log_prod_vars`` K_max.
+    The predictive is a product of univariate Student-t densities with ``v_N`` degrees of freedom.
+    """
+    _cov_type = "diag"
+
+    def _check_prior(self, prior):
+        assert len(np.asarray(prior.S_0).shape) == 1, "For diagonal covariance, S_0 needs to be vector."
+
+    def _block(self):
+        return (self.D,)
+
+    @property
+    def log_prod_vars(self):
+        return self._padded(self._ctx.stats(False)[2], ())
+
+    @property
+    def inv_vars(self):
+        return self._padded(self._ctx.stats(True)[3], (self.D,))
+
+    # the full-covariance names do not exist on the reference's diag class
+    logdet_covars = property(lambda self: (_ for _ in ()).throw(AttributeError("logdet_covars")))
+    inv_covars = property(lambda self: (_ for _ in ()).throw(AttributeError("inv_covars")))
+
+    def map(self, k):
+        raise NotImplementedError("the reference's diagonal class has no map()")

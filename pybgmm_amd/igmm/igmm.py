@@ -8,7 +8,7 @@ import numpy as np
 from scipy import stats
 from scipy.special import gammaln
 
-from ..gaussian.gaussian_components import GaussianComponents
+from ..gaussian.gaussian_components import GaussianComponents, GaussianComponentsDiag
 from ..gmm import GMM
 from ..utils import rng as _rng
 
@@ -28,7 +28,7 @@ class IGMM(GMM):
       "rand" (``np.random.randint(0, K, N)`` from the global stream),
       "one-by-one" (only X[0] seated), "each-in-own".
     K : initial number of components for "rand".  K_max : component slots.
-    covariance_type : "full" ("diag"/"fixed" are not built yet).
+    covariance_type : "full" or "diag" ("fixed" is not built yet).
     device : GPU ordinal (extension).  rng / nprng : ``random.Random`` /
       ``np.random.RandomState`` to draw from instead of the process-global streams
       (extension, used for one-chain-per-GPU runs).
@@ -60,7 +60,10 @@ class IGMM(GMM):
         if covariance_type == "full":
             self.components = GaussianComponents(X, kernel_prior, assignments, K_max,
                                                  device=device, alpha=alpha)
-        elif covariance_type in ("diag", "fixed"):
+        elif covariance_type == "diag":
+            self.components = GaussianComponentsDiag(X, kernel_prior, assignments, K_max,
+                                                     device=device, alpha=alpha)
+        elif covariance_type == "fixed":
             raise NotImplementedError(
                 "covariance_type=%r is a later row of the build (SURVEY.md 8f)" % covariance_type)
         else:

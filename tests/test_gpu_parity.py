@@ -14,7 +14,7 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
-from golden_util import ALL_CASES, Golden
+from golden_util import ALL_CASES, DIAG_CASES, Golden
 from pybgmm_amd.gaussian.gaussian_components import reference_tables
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +25,7 @@ LM_RTOL = 1e-6
 def make_ctx(g, kind=0, window=0, tables=True, resolver=0, prune=0):
     from pybgmm_amd import _lib
     ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max,
-                       tables=reference_tables(g.v_0, g.N) if tables else None)
+                       tables=reference_tables(g.v_0, g.N) if tables else None, cov_type=g.cov_type)
     ctx.set_tuning(max_window=window, kernel_kind=kind, resolver_mode=resolver, prune_mode=prune)
     ctx.set_assignments(g.z_init)
     return ctx
@@ -283,3 +283,108 @@ def test_full_size_properties(N, D, K):
     npt.assert_array_equal(za, zb)      # kernel kind and window size do not change the chain
     assert mva == mvb and mva > 0
     assert abs(lma - lmb) <= 1e-9 * abs(lma)
+
+
+# ---- covariance_type="diag"  -------------------------------------------
+@pytest.mark.parametrize("window", [0, 64])
+@pytest.mark.parametrize("case", DIAG_CASES)
+def test_diag_golden_trajectory(case, window):
+    g = Golden(case)
+    ctx = make_ctx(g, window=window)
+    npt.assert_allclose(ctx.log_prior()[:4096], g.d["cached_log_prior"], rtol=1e-11, atol=1e-11)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        z = ctx.assignments()
+        bad = np.nonzero(z != g.z[it])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        npt.assert_array_equal(ctx.counts(), g.counts_at(it))
+        assert abs(ctx.log_marg() - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
+    m, S, lpv, iv = ctx.stats()
+    npt.assert_array_equal(m, g.d["final_m"])
+    npt.assert_array_equal(S, g.d["final_S"])
+    npt.assert_allclose(lpv, g.d["final_logdet"], rtol=1e-10, atol=1e-10)
+    npt.assert_allclose(iv, g.d["final_inv"], rtol=1e-10)
+    ctx.close()
+
+
+def test_diag_class_reproduces_reference():
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    g = Golden("diag_kat_2d")
+    random.seed(1)
+    np.random.seed(1)
+    X, z_true = gendata.demo_mixture(100, 2, 4, rs=np.random)
+    mm = CRPMM(X, NIW(*g.prior), 1.0, None, assignments="rand", K=3, covariance_type="diag")
+    record, _ = mm.collapsed_gibbs_sampler(10, z_true, num_saved=0)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
+    K = mm.components.K
+    npt.assert_allclose(mm.components.log_prod_vars[:K], g.d["final_logdet"], rtol=1e-10)
+    npt.assert_allclose(mm.components.inv_vars[:K], g.d["final_inv"], rtol=1e-10)
+    assert mm.components.S_N_partials.shape == (mm.components.K_max, 2)
+
+
+def test_diag_components_match_univariate_student_t():
+    """The analytic checks of pybgmm/tests/test_gaussian_components_diag.py (prior predictive,
+    posterior predictive, del_item, log_marg_k) against scipy's formulas, on the device."""
+    from scipy.special import gammaln
+    from pybgmm_amd.gaussian import GaussianComponentsDiag
+    from pybgmm_amd.prior import NIW
+
+    def t_logpdf(x, mu, var, v):
+        c = gammaln((v + 1) / 2.) - gammaln(v / 2.) - 0.5 * (np.log(v) + np.log(np.pi) + np.log(var))
+        return c - (v + 1) / 2. * np.log(1 + 1. / v * (x - mu) ** 2 / var)
+
+    rs = np.random.RandomState(1)
+    N, D = 10, 3
+    X = 5 * rs.rand(N, D) - 1
+    m_0, k_0, v_0, S_0 = 5 * rs.rand(D) - 2, float(rs.randint(15) + 1), 4, 2 * rs.rand(D) + 3
+    gmm = GaussianComponentsDiag(X, NIW(m_0, k_0, v_0, S_0), np.zeros(N, dtype=int))
+    var0 = S_0 * (k_0 + 1) / (k_0 * v_0)
+    npt.assert_almost_equal(gmm.log_prior(0), np.sum(t_logpdf(X[0], m_0, var0, v_0)))
+
+    def posterior(Xs):
+        n = len(Xs)
+        k_N, v_N = k_0 + n, v_0 + n
+        m_N = (k_0 * m_0 + Xs.sum(axis=0)) / k_N
+        S_N = S_0 + k_0 * m_0 ** 2 + (Xs ** 2).sum(axis=0) - k_N * m_N ** 2
+        return k_N, v_N, m_N, S_N
+
+    k_N, v_N, m_N, S_N = posterior(X)
+    npt.assert_almost_equal(gmm.log_post_pred_k(0, 0),
+                            np.sum(t_logpdf(X[0], m_N, S_N * (k_N + 1) / (k_N * v_N), v_N)))
+    lm = (-N * D / 2. * np.log(np.pi) + D / 2. * np.log(k_0) - D / 2. * np.log(k_N)
+          + v_0 / 2. * np.log(S_0).sum() - v_N / 2. * np.log(S_N).sum()
+          + D * (gammaln(v_N / 2.) - gammaln(v_0 / 2.)))
+    npt.assert_almost_equal(gmm.log_marg_k(0), lm)
+    gmm.del_item(N - 1)
+    k_N, v_N, m_N, S_N = posterior(X[:-1])
+    npt.assert_almost_equal(gmm.log_post_pred_k(0, 0),
+                            np.sum(t_logpdf(X[0], m_N, S_N * (k_N + 1) / (k_N * v_N), v_N)))
+
+
+@pytest.mark.parametrize("N,D,K", [(5000, 16, 30), (3000, 64, 12)])
+def test_diag_against_c_oracle(N, D, K):
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, _ = gendata.synth_mixture(N, D, K, seed=300 + D)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    S_0 = np.ascontiguousarray(np.diag(S_0))
+    rs = np.random.RandomState(D)
+    z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    us = rs.random_sample((2, N))
+    order = rs.permutation(N)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, cov_type="diag")
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N), cov_type="diag")
+    ctx.set_assignments(z0)
+    for it in range(2):
+        power = 1.05 if it == 1 else None
+        o.sweep(us[it], order, power)
+        ctx.sweep(us[it], order, power)
+        npt.assert_array_equal(ctx.assignments(), o.z)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+    ctx.close()

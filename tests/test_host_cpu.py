@@ -44,7 +44,7 @@ def test_argument_validation_before_device():
     rc = L.bgmm_create(ctypes.byref(h), 0, 4, 2, 4, 0, X.ctypes.data, m.ctypes.data, 1.0, 1,
                        S.ctypes.data, 1.0, None, None)
     assert rc == -1 and b"v_0" in L.bgmm_last_error(None)
-    rc = L.bgmm_create(ctypes.byref(h), 0, 4, 2, 4, 1, X.ctypes.data, m.ctypes.data, 1.0, 3,
+    rc = L.bgmm_create(ctypes.byref(h), 0, 4, 2, 4, 7, X.ctypes.data, m.ctypes.data, 1.0, 3,
                        S.ctypes.data, 1.0, None, None)
     assert rc == -5
     rc = L.bgmm_create(ctypes.byref(h), 0, 4, 300, 4, 0, X.ctypes.data, m.ctypes.data, 1.0, 300,
@@ -123,6 +123,8 @@ def test_error_conventions():
     with pytest.raises(AssertionError):
         CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="banana")
     with pytest.raises(NotImplementedError):
+        CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="fixed")
+    with pytest.raises(AssertionError):                       # gaussian_components_diag.py:92
         CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="diag")
 
 
