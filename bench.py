@@ -45,7 +45,7 @@ def flops_per_lik_eval(D):
     return 2.0 * D * D + 3.0 * D + 12.0
 
 
-def cpu_baseline(D, K, seed, budget_visits):
+def cpu_baseline(D, K, seed, budget_visits, cov="full"):
     """C oracle (oracle/gibbs_oracle.c, scalar, 1 thread) on a down-sized twin of the
     workload: same D, K, prior, init-at-truth; per-visit cost does not depend on N."""
     from oracle import c_oracle
@@ -53,8 +53,10 @@ def cpu_baseline(D, K, seed, budget_visits):
     n_cpu = max(4 * K, budget_visits)
     X, z_true = gendata.synth_mixture(n_cpu, D, K, seed)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    if cov == "diag":
+        S_0 = np.ascontiguousarray(np.diag(S_0))
     t0 = time.time()
-    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z_true, 4 * K, scipy_tables=False)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z_true, 4 * K, scipy_tables=False, cov_type=cov)
     t_init = time.time() - t0
     u = np.random.RandomState(seed).random_sample(n_cpu)
     t0 = time.time()
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 off, 2 always")
     ap.add_argument("--cpu-visits", type=int, default=20000,
                     help="visits of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cov", default="full", choices=["full", "diag"],
+                    help="covariance_type (diag: SURVEY 8f rank 1, not a BASELINE config)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -99,6 +103,8 @@ def main():
     N, D, K, model = WORKLOADS[args.workload]
     X, z_true = gendata.synth_mixture(N, D, K, seed=args.seed)          # replicated data set
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    if args.cov == "diag":
+        S_0 = np.ascontiguousarray(np.diag(S_0))
     n_sweeps = args.warmup + args.steps
     # chain c: its own uniform (and permutation) streams, seeds seed + c
     rs = np.random.RandomState(1000 + args.seed + rank)
@@ -115,7 +121,7 @@ def main():
 
     t0 = time.time()
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, device=local_rank,
-                       tables=reference_tables(v_0, N))
+                       tables=reference_tables(v_0, N), cov_type=args.cov)
     ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
                    prune_mode=args.prune)
     ctx.set_assignments(z0)
@@ -173,9 +179,18 @@ def main():
         ctx.set_kernel_timing(False)
         if n_launch <= 0 or ms <= 0:
             return None
+        if args.cov == "diag":
+            # D logarithms per (visit, component): an FP64 VALU / transcendental kernel, no MFMA
+            logs = st["scored"] * float(D)
+            return {"kernel": "score_diag_kernel", "bound": "valu-transcendental",
+                    "achieved": round(logs / (ms * 1e-3) / 1e9, 2), "peak": None, "unit": "Glog/s",
+                    "frac": None, "traffic": None, "launches": n_launch,
+                    "avg_launch_ms": round(ms / n_launch, 4),
+                    "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
+                    "note": "covariance_type=diag is a SURVEY 8f row, not a BASELINE config"}
         flops = st["scored"] * flops_per_lik_eval(D)
         achieved = flops / (ms * 1e-3) / 1e12
-        is_mfma = args.kernel == 2 or (args.kernel == 0 and D >= 12)
+        is_mfma = (args.kernel == 2 or (args.kernel == 0 and D >= 12)) and args.cov == "full"
         nJ = (D + 15) // 16
         # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
         # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
@@ -196,7 +211,8 @@ def main():
             tj = json.load(open(tpath))
             traffic = tj.get("hbm_bytes_per_launch_pruned" if pruning else "hbm_bytes_per_launch")
         return {
-            "kernel": ("score_mfma_prune_kernel" if pruning else "score_mfma_kernel") if is_mfma else "score_valu_kernel",
+            "kernel": "score_diag_kernel" if args.cov == "diag" else
+                      (("score_mfma_prune_kernel" if pruning else "score_mfma_kernel") if is_mfma else "score_valu_kernel"),
             "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
             "traffic": traffic,
@@ -228,7 +244,7 @@ def main():
 
     cpu = None
     if rank == 0 and n_gpus == 1 and args.cpu_visits > 0:
-        per_visit, n_cpu, t_init, cpu_lik = cpu_baseline(D, K, args.seed + 7, args.cpu_visits)
+        per_visit, n_cpu, t_init, cpu_lik = cpu_baseline(D, K, args.seed + 7, args.cpu_visits, args.cov)
         cpu = {"value": round(1.0 / (per_visit * N), 8), "unit": "sweeps/s", "cores": 1,
                "kind": "port",
                "sample": "%d visits of one sweep on a N=%d twin (same D=%d, K=%d, prior, init at truth); "
@@ -247,8 +263,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s D=%d N=%d K~%d, one independent chain per GPU, init=%s"
-                                   % (args.workload, model, D, N, K, args.init),
+            "config": {"workload": "%s: %s D=%d N=%d K~%d%s, one independent chain per GPU, init=%s"
+                                   % (args.workload, model, D, N, K,
+                                      " covariance_type=diag" if args.cov == "diag" else "", args.init),
                        "parallelism": "replica_chains_x%d" % n_gpus,
                        "exact_pruning": bool(args.prune == 0 and args.kernel != 1 and (D >= 12 or args.kernel == 2))},
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
