@@ -121,6 +121,17 @@ int bgmm_add_item(bgmm_ctx *ctx, int64_t i, int32_t k);
 int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
 
 /*
+ * Per-sweep clustering metrics of the record dict (gmm/gmm.py:85-104), SURVEY.md 8f rank 2.
+ *   bgmm_contingency: table[t * K + k] = #{i : true_idx[i] == t and label(i) == k}, the K_true x K
+ *     contingency table from which mutual_information / normalized_mutual_information /
+ *     information_variation (infopy/infopy.py:31-119) follow; true_idx holds 0..K_true-1.
+ *   bgmm_cluster_dispersion: out[k] = sum_{i in k} |x_i - mean_k|^2 from the component's sufficient
+ *     statistics -- what utils.cluster_loss_inertia (utils/utils.py:31-88) takes the square root of.
+ */
+int bgmm_contingency(bgmm_ctx *ctx, const int64_t *true_idx, int32_t K_true, int64_t *table_out);
+int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
+
+/*
  * Measurement hooks.
  *   sweep_stats: counters of the last sweep --
  *     [0] lik_evals = sum over visits of K at that visit, [1] visits that changed component,

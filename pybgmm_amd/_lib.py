@@ -44,6 +44,8 @@ SIGNATURES = {
     "bgmm_log_post_pred": (ctypes.c_int, [_vp, ctypes.c_int64, _vp]),
     "bgmm_add_item": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32]),
     "bgmm_del_item": (ctypes.c_int, [_vp, ctypes.c_int64]),
+    "bgmm_contingency": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, _vp]),
+    "bgmm_cluster_dispersion": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
@@ -219,6 +221,21 @@ class Context(object):
 
     def del_item(self, i):
         self._ck(self.L.bgmm_del_item(self.h, int(i)))
+
+    # -- record-dict metrics --------------------------------------------------
+    def contingency(self, true_idx, K_true):
+        """K_true x K table of (true class, current label) counts."""
+        true_idx = np.ascontiguousarray(true_idx, dtype=np.int64)
+        assert true_idx.shape == (self.N,)
+        K = self.K
+        table = np.zeros((int(K_true), max(K, 1)), dtype=np.int64)
+        self._ck(self.L.bgmm_contingency(self.h, _ptr(true_idx), int(K_true), _ptr(table)))
+        return table[:, :K]
+
+    def cluster_dispersion(self):
+        out = np.empty(max(self.K, 1), dtype=np.float64)
+        self._ck(self.L.bgmm_cluster_dispersion(self.h, _ptr(out)))
+        return out[:self.K]
 
     # -- measurement ---------------------------------------------------------
     def sweep_stats(self):

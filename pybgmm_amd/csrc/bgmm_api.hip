@@ -21,6 +21,9 @@
 #include <vector>
 
 int choice_rows_for(int K_max);
+void launch_contingency(const Dev &d, const long long *true_idx, int K_true, unsigned long long *table,
+                        hipStream_t st);
+void launch_dispersion(const Dev &d, double *out, hipStream_t st);
 void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st);
 void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
                          double *inv_out, hipStream_t st);
@@ -611,6 +614,43 @@ extern "C" int bgmm_log_marg_k(bgmm_ctx *c, int32_t k, double *out) {
     if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
     launch_log_marg(c->d, c->util_out, c->util_out + 8, c->stream);
     CK(c, hipMemcpyAsync(out, c->util_out + 8 + k, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bgmm_contingency(bgmm_ctx *c, const int64_t *true_idx, int32_t K_true, int64_t *table_out) {
+    if (!c || !true_idx || !table_out || K_true < 1) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const int K = c->ctrl_host->job.K;
+    if (K == 0) return 0;
+    long long *dt = nullptr;
+    unsigned long long *dtab = nullptr;
+    const size_t cells = (size_t)K_true * K;
+    hipError_t e = hipMalloc((void **)&dt, sizeof(long long) * c->d.N);
+    if (e == hipSuccess) e = hipMalloc((void **)&dtab, sizeof(unsigned long long) * cells);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, true_idx, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dtab, 0, sizeof(unsigned long long) * cells, c->stream);
+    if (e == hipSuccess) {
+        launch_contingency(c->d, dt, K_true, dtab, c->stream);
+        e = hipMemcpyAsync(table_out, dtab, sizeof(long long) * cells, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dt); (void)hipFree(dtab);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_cluster_dispersion(bgmm_ctx *c, double *out) {
+    if (!c || !out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const int K = c->ctrl_host->job.K;
+    if (K == 0) return 0;
+    launch_dispersion(c->d, c->util_out, c->stream);
+    CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -639,3 +639,43 @@ void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStre
     const long long n = d.N > d.K_max ? d.N : d.K_max;
     hipLaunchKernelGGL(init_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, z_in, K_init);
 }
+
+
+// ---- record-dict metrics --------------------------------------------
+__global__ void contingency_kernel(Dev d, const long long *__restrict__ true_idx, int K_true,
+                                   unsigned long long *__restrict__ table) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    const int s = d.z[i];
+    const long long t = true_idx[i];
+    if (s < 0 || t < 0 || t >= K_true) return;
+    atomicAdd(&table[t * d.ctrl->job.K + d.label_of_slot[s]], 1ull);
+}
+
+void launch_contingency(const Dev &d, const long long *true_idx, int K_true, unsigned long long *table,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(contingency_kernel, dim3((unsigned)((d.N + 255) / 256)), dim3(256), 0, st, d, true_idx,
+                       K_true, table);
+}
+
+// sum_i |x_i - mean|^2 = sum_d (sum x_d^2 - (sum x_d)^2 / n), with the prior's share removed from
+// the stored statistics (m = k_0 m_0 + sum x,  S_dd = S_0,dd + k_0 m_0,d^2 + sum x_d^2)
+__global__ __launch_bounds__(256) void dispersion_kernel(Dev d, double *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.ctrl->job.K) return;
+    const int s = d.perm[j], D = d.D;
+    const double n = (double)d.n[s];
+    const long long sd = d.cov_type == COV_DIAG ? 1 : (long long)D + 1;      // stride of the diagonal
+    const long long blk = d.cov_type == COV_DIAG ? (long long)D : (long long)D * D;
+    double acc = 0.0;
+    for (int a = 0; a < D; ++a) {
+        const double sx = d.m[(long long)s * D + a] - d.prior_m[a];
+        const double sxx = d.S[(long long)s * blk + a * sd] - d.prior_S[a * sd];
+        acc += sxx - sx * sx / n;
+    }
+    out[j] = acc > 0.0 ? acc : 0.0;
+}
+
+void launch_dispersion(const Dev &d, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(dispersion_kernel, dim3((unsigned)((d.K_max + 255) / 256)), dim3(256), 0, st, d, out);
+}

@@ -4,14 +4,14 @@ Per-sweep record keeping: the record_dict of reference pybgmm/gmm/gmm.py:45-118.
 ``sample_time`` keeps the reference's meaning: wall time of the sweep only (the
 timer is restarted after the record is taken, igmm/crpmm.py:91-92).  ``log_marg``,
 ``components`` and ``nk`` come from device state.  The clustering metrics
-(nmi / mi / vi / loss / bic) are SURVEY.md 8(f) "next" rows; until they are
-built on the device they are evaluated on the host only when
-``self.record_metrics`` is True and otherwise recorded as NaN.
+(nmi / mi / vi / loss / bic) come from a device contingency-table kernel
+and the components' sufficient statistics when ``self.record_metrics`` is True, and are
+recorded as NaN otherwise.
 """
 import logging
 import time
 
-import numpy as np
+import numpy as np  # noqa: F401
 
 from ..utils import metrics as _metrics
 
@@ -33,6 +33,30 @@ class GMM(object):
     def setup_record_dict(self):
         return dict((key, []) for key in RECORD_KEYS)
 
+    def _clustering_metrics(self, true_assignments):
+        """nmi, mi, vi (base 2) and the int-truncated inertia of the current labelling.  With the
+        components on the GPU the label vector never leaves the device: a contingency-table
+        kernel and the sufficient statistics provide everything; labels
+        sort like ``np.unique`` on both sides, so the values equal the host formulas'."""
+        ctx = getattr(self.components, "_ctx", None)
+        if ctx is None:
+            z = self.components.assignments
+            return (_metrics.normalized_mutual_information(true_assignments, z),
+                    _metrics.mutual_information(true_assignments, z),
+                    _metrics.information_variation(true_assignments, z, base=2),
+                    _metrics.cluster_loss_inertia(self.components.X, z))
+        t = np.asarray(true_assignments)
+        cache = getattr(self, "_true_idx_cache", None)
+        if cache is None or cache[0] is not true_assignments:
+            _metrics._check(t, t)
+            uniq, idx = np.unique(t, return_inverse=True)
+            cache = (true_assignments, idx.astype(np.int64), len(uniq))
+            self._true_idx_cache = cache
+        table = ctx.contingency(cache[1], cache[2])
+        nmi, mi, vi = _metrics.table_metrics(table)
+        loss = _metrics.loss_from_dispersion(ctx.cluster_dispersion())
+        return nmi, mi, vi, loss
+
     def update_record_dict(self, record_dict, i_iter, true_assignments, start_time):
         record_dict["sample_time"].append(time.time() - start_time)
         record_dict["log_marg"].append(self.log_marg())
@@ -40,11 +64,7 @@ class GMM(object):
         record_dict["components"].append(K)
         counts = self.components.counts[:K]
         if self.record_metrics and true_assignments is not None:
-            z = self.components.assignments
-            nmi = _metrics.normalized_mutual_information(true_assignments, z)
-            mi = _metrics.mutual_information(true_assignments, z)
-            loss = _metrics.cluster_loss_inertia(self.components.X, z)
-            vi = _metrics.information_variation(true_assignments, z, base=2)
+            nmi, mi, vi, loss = self._clustering_metrics(true_assignments)
         else:
             nmi = mi = loss = vi = float("nan")
         record_dict["nmi"].append(nmi)

@@ -82,3 +82,49 @@ def cluster_loss_inertia(x, assignments):
         dist = np.sqrt(np.sum(np.square(x_k - mean)))
         total = total + np.asarray(dist).astype(labels.dtype)   # int truncation, as the reference
     return total
+
+
+# ---- the same quantities from a contingency table (device path) ------- #
+def _entropy_from_counts(counts, n, base=E):
+    total = 0
+    for c in counts:
+        if c == 0:
+            continue
+        p_i = c / float(n)
+        total -= p_i * math.log(p_i, base)
+    return total
+
+
+def table_metrics(table):
+    """(nmi, mi, vi_base2) from a K_true x K contingency table whose rows / columns are ordered by
+    increasing label value -- the values ``normalized_mutual_information``,
+    ``mutual_information`` and ``information_variation(base=2)`` return for the label vectors."""
+    table = np.asarray(table, dtype=np.int64)
+    n = int(table.sum())
+    ca, cb = table.sum(axis=1), table.sum(axis=0)
+
+    def mi(base):
+        acc = 0.0
+        for r in range(table.shape[0]):
+            if ca[r] == 0:
+                continue
+            px = ca[r] / n
+            for c in np.nonzero(table[r])[0]:
+                pxy = table[r, c] / n
+                py = cb[c] / n
+                acc += pxy * math.log((pxy / (px * py)), base)
+        return acc
+
+    mi_e = mi(E)
+    nmi = mi_e / max(np.sqrt(_entropy_from_counts(ca, n) * _entropy_from_counts(cb, n)), 1e-10)
+    vi = _entropy_from_counts(ca, n, 2) + _entropy_from_counts(cb, n, 2) - 2 * mi(2)
+    return nmi, mi_e, vi
+
+
+def loss_from_dispersion(dispersion, dtype=np.int64):
+    """``cluster_loss_inertia``: per-cluster sqrt of the summed squared distances to the mean,
+    truncated to integers (the reference stores them in an int array) and summed."""
+    total = np.zeros((), dtype=dtype)
+    for v in np.sqrt(np.asarray(dispersion, dtype=np.float64)):
+        total = total + np.asarray(v).astype(dtype)
+    return total

@@ -183,10 +183,33 @@ def test_crpmm_class_reproduces_reference_kat():
     npt.assert_array_equal(mm.components.assignments, g.z[-1])
     npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
     assert record["components"] == list(g.K)
+    # record-dict metrics through the device contingency / dispersion kernels
     npt.assert_allclose(record["nmi"], g.d["rec_nmi"], rtol=1e-12)
+    npt.assert_allclose(record["mi"], g.d["rec_mi"], rtol=1e-12)
+    npt.assert_allclose(record["vi"], g.d["rec_vi"], rtol=1e-11, atol=1e-12)
+    assert [int(v) for v in record["loss"]] == [int(v) for v in g.d["rec_loss"]]
+    assert [int(v) for v in record["bic"]] == [int(v) for v in g.d["rec_bic"]]
     assert [str(s) for s in record["nk"]] == [str(s) for s in g.d["rec_nk"]]
     npt.assert_almost_equal(mm.log_marg(), -411.811711231)
     npt.assert_allclose(mm.log_marg_host(), mm.log_marg(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("case,K", [("c1_crpmm_1d", 3), ("general_prior_3d", 4), ("c2twin_crpmm_2d", 20)])
+def test_record_metrics_match_reference(case, K):
+    """nmi / mi / vi / loss of every sweep, device route, against what the reference recorded."""
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    g = Golden(case)
+    random.seed(int(g.d["seed_random"]))
+    np.random.seed(int(g.d["seed_numpy"]))
+    mm = CRPMM(g.X, NIW(*g.prior), g.alpha, None, assignments="rand", K=K, K_max=g.K_max)
+    record, _ = mm.collapsed_gibbs_sampler(g.n_iter, g.d["true_assignments"], num_saved=0)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    npt.assert_allclose(record["nmi"], g.d["rec_nmi"], rtol=1e-11, atol=1e-13)
+    npt.assert_allclose(record["mi"], g.d["rec_mi"], rtol=1e-11, atol=1e-13)
+    npt.assert_allclose(record["vi"], g.d["rec_vi"], rtol=1e-10, atol=1e-11)
+    assert [int(v) for v in record["loss"]] == [int(v) for v in g.d["rec_loss"]]
 
 
 def test_pcrpmm_class_reproduces_reference():

@@ -19,3 +19,23 @@ def test_metrics_match_reference(case):
         npt.assert_allclose(metrics.information_variation(zt, z, base=2), g.d["rec_vi"][it], rtol=1e-11, atol=1e-12)
         assert int(metrics.cluster_loss_inertia(g.X, z)) == int(g.d["rec_loss"][it])
         assert g.d["rec_bic"][it] == g.d["rec_loss"][it]
+
+
+@pytest.mark.parametrize("case", ["kat1_igmm_2d", "c1_crpmm_1d", "general_prior_3d", "c2twin_crpmm_2d"])
+def test_table_route_equals_label_route(case):
+    """The device path's formulas (contingency table + per-cluster dispersion) against the values
+    the reference recorded."""
+    g = Golden(case)
+    zt = g.d["true_assignments"]
+    ut, it_ = np.unique(zt, return_inverse=True)
+    for it in range(g.n_iter):
+        z = g.z[it]
+        uz, iz = np.unique(z, return_inverse=True)
+        table = np.zeros((len(ut), len(uz)), dtype=np.int64)
+        np.add.at(table, (it_, iz), 1)
+        nmi, mi, vi = metrics.table_metrics(table)
+        npt.assert_allclose(nmi, g.d["rec_nmi"][it], rtol=1e-12, atol=1e-14)
+        npt.assert_allclose(mi, g.d["rec_mi"][it], rtol=1e-12, atol=1e-14)
+        npt.assert_allclose(vi, g.d["rec_vi"][it], rtol=1e-11, atol=1e-12)
+        disp = np.array([np.sum(np.square(g.X[z == k] - g.X[z == k].mean(axis=0))) for k in uz])
+        assert int(metrics.loss_from_dispersion(disp)) == int(g.d["rec_loss"][it])
