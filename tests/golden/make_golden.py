@@ -93,7 +93,7 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
     """
     import pybgmm.gmm.gmm as ref_gmm
     import pybgmm.utils.utils as ref_utils
-    from pybgmm.igmm import CRPMM, PCRPMM
+    from pybgmm.igmm import ADAPCRPMM, CRPMM, PCRPMM
     from pybgmm.prior import NIW
 
     sampler_kwargs = dict(sampler_kwargs or {})
@@ -103,7 +103,7 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
 
     m_0, k_0, v_0, S_0 = prior_params
     prior = NIW(m_0, k_0, v_0, S_0)
-    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM, "ADAPCRPMM": ADAPCRPMM}[model]
     init = assignments if isinstance(assignments, str) else list(assignments)
     mm = cls(X, prior, alpha, None, assignments=init, K=K, K_max=K_max,
              covariance_type=cov_type)
@@ -194,6 +194,10 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
         "n_power": float(sampler_kwargs.get("n_power", 1.01 if model == "PCRPMM" else 1.0)),
         "power_burnin": int(sampler_kwargs.get("power_burnin", 0)),
         "flag_power": bool(sampler_kwargs.get("flag_power", model == "PCRPMM")),
+        "adap_r_up": float(sampler_kwargs.get("r_up", 1.3)),
+        "adap_perct": float(sampler_kwargs.get("adapcrp_perct", 0.04)),
+        "adap_burnin": int(sampler_kwargs.get("adapcrp_burnin", 0)),
+        "adap_flag": bool(sampler_kwargs.get("flag_adapcrp", model == "ADAPCRPMM")),
         "u": u,
         "order": (np.stack(orders) if orders else np.zeros((0, N), dtype=np.int64)),
         "z": np.stack(snaps["z"]), "K": np.array(snaps["K"], dtype=np.int64),
@@ -424,6 +428,15 @@ def case_diag_64d():
              recipe="synth_mixture(800,64,8,seed=44)")
 
 
+def case_adap():
+    # the sweep exponent adapts to the share of small clusters
+    # (adapcrp_burnin=-1: with the reference's default 0 its first sweep dies on an unbound local)
+    X, z_true = gendata.synth_mixture(400, 2, 5, seed=51)
+    run_case("adap_2d", "ADAPCRPMM", X, gendata.demo_prior_params(2), 1.0, "rand", 12, 80, 6, (11, 11),
+             sampler_kwargs=dict(r_up=1.4, adapcrp_perct=0.08, adapcrp_burnin=-1),
+             true_assignments=z_true)
+
+
 CASES = {
     "kat1": case_kat1, "kat3": case_kat3, "kat4": case_kat4, "c1": case_c1,
     "c2twin": case_c2_twin, "c3twin": case_c3_twin, "c3rand": case_c3_rand,
@@ -432,7 +445,7 @@ CASES = {
     "pcrp_burnin": case_pcrp_burnin, "pcrp_flagoff": case_pcrp_flag_off,
     "general_prior": case_general_prior, "d12": case_d12,
     "diag_kat": case_diag_kat, "diag_each_in_own": case_diag_each_in_own, "diag_pcrp": case_diag_pcrp,
-    "diag_general": case_diag_general, "diag_64d": case_diag_64d,
+    "diag_general": case_diag_general, "diag_64d": case_diag_64d, "adap": case_adap,
 }
 
 

@@ -9,7 +9,7 @@ from pybgmm_amd.utils import gendata
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 _EVERY = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
-ALL_CASES = [c for c in _EVERY if not c.startswith("diag_")]          # full covariance
+ALL_CASES = [c for c in _EVERY if not c.startswith("diag_")]          # full covariance (incl. ADAPCRPMM)
 DIAG_CASES = [c for c in _EVERY if c.startswith("diag_")]             # covariance_type="diag"
 # cases whose reference trajectory is short enough for the pure-numpy oracle
 SMALL_CASES = ["kat1_igmm_2d", "kat3_each_in_own", "kat4_log_marg", "each_in_own_50",
@@ -46,11 +46,25 @@ class Golden(object):
     def prior(self):
         return (self.m_0, self.k_0, self.v_0, self.S_0)
 
+    def _adap_power(self, it):
+        """ADAPCRPMM (igmm/adapcrpmm.py:100-104): 1 + (r_up - 1) * share of clusters holding at most
+        N * perct points, from the counts BEFORE sweep ``it``."""
+        z = self.z_init if it == 0 else self.z[it - 1]
+        nk = np.bincount(z[z >= 0])
+        small = np.sum(nk <= self.N * float(self.d["adap_perct"])) * 1.0 / len(nk)
+        return 1.0 + (float(self.d["adap_r_up"]) - 1.0) * small
+
     def sweep_order(self, it):
+        if self.model == "ADAPCRPMM":
+            # a permutation is drawn only in the sweeps whose exponent exceeds 1
+            used = [t for t in range(self.n_iter) if self._adap_power(t) > 1]
+            return self.order[used.index(it)] if it in used else None
         return self.order[it] if self.order.shape[0] else None
 
     def sweep_power(self, it):
         """pCRP exponent active in sweep ``it`` (None = plain CRP weights)."""
+        if self.model == "ADAPCRPMM":
+            return self._adap_power(it) if it > int(self.d["adap_burnin"]) else None
         return self.n_power if (self.flag_power and it > self.power_burnin) else None
 
     def counts_at(self, it):

@@ -212,6 +212,27 @@ def test_record_metrics_match_reference(case, K):
     assert [int(v) for v in record["loss"]] == [int(v) for v in g.d["rec_loss"]]
 
 
+def test_adapcrpmm_class_reproduces_reference():
+    """per-sweep exponent from the share of small clusters."""
+    import random
+    from pybgmm_amd.igmm import ADAPCRPMM
+    from pybgmm_amd.prior import NIW
+    g = Golden("adap_2d")
+    random.seed(11)
+    np.random.seed(11)
+    mm = ADAPCRPMM(g.X, NIW(*g.prior), g.alpha, None, assignments="rand", K=12, K_max=g.K_max)
+    npt.assert_array_equal(mm.components.assignments, g.z_init)
+    record, _ = mm.collapsed_gibbs_sampler(g.n_iter, g.d["true_assignments"], r_up=1.4,
+                                           adapcrp_perct=0.08, adapcrp_burnin=-1, num_saved=0)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    assert record["components"] == list(g.K)
+    npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
+    npt.assert_allclose(record["nmi"], g.d["rec_nmi"], rtol=1e-11)
+    mm2 = ADAPCRPMM(g.X, NIW(*g.prior), g.alpha, None, assignments=g.z_init, K_max=g.K_max)
+    with pytest.raises(UnboundLocalError):            # the reference's default burn-in does the same
+        mm2.collapsed_gibbs_sampler(1, g.d["true_assignments"], num_saved=0)
+
+
 def test_pcrpmm_class_reproduces_reference():
     import random
     from pybgmm_amd.igmm import PCRPMM
