@@ -65,8 +65,9 @@ class COracle(object):
         self.K_max = self.N if K_max is None else int(K_max)
         m_0 = np.ascontiguousarray(m_0, dtype=np.float64)
         S_0 = np.ascontiguousarray(S_0, dtype=np.float64)
-        self.diag = cov_type == "diag"
-        assert S_0.shape == ((self.D,) if self.diag else (self.D, self.D))
+        self.diag = cov_type in ("diag", "fixed")           # D-vector statistics
+        self.cov_code = {"full": 0, "diag": 1, "fixed": 2}[cov_type]
+        assert S_0.shape == {"full": (self.D, self.D), "diag": (self.D,), "fixed": (2 * self.D,)}[cov_type]
         L = lib()
         if scipy_tables:
             self._tabs = host_tables(v_0, self.N)
@@ -74,7 +75,7 @@ class COracle(object):
         else:
             tl = tg = None
         self.h = L.go_create(self.N, self.D, self.K_max, self.X, m_0, float(k_0), int(v_0), S_0,
-                             float(alpha), tl, tg, 1 if self.diag else 0)
+                             float(alpha), tl, tg, self.cov_code)
         rc = L.go_set_assignments(self.h, np.ascontiguousarray(z_init, dtype=np.int64))
         assert rc == 0, "invalid initial assignment vector"
         self.lik_evals = ctypes.c_int64(0)

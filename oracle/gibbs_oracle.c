@@ -34,7 +34,9 @@
 
 typedef struct {
     int64_t N, D, K_max, K;
-    int diag;                   /* covariance_type="diag": S, inv are D-vectors (gaussian_components_diag.py) */
+    int diag;                   /* 1: covariance_type="diag" (gaussian_components_diag.py), 2: "fixed"
+                                   (gaussian_components_fixedvar.py); S, inv are D-vectors in both */
+    double *prec, *prec0;       /* fixed: 1/var and 1/var_0 (D each); m0 holds mu_0 */
     int64_t SD;                 /* entries of one second-moment block: D*D or D */
     const double *X;            /* borrowed, N x D row major */
     double *m0, *S0;
@@ -119,6 +121,17 @@ static double slogdet_of(go_t *g, const double *a) {
 
 static void refresh_cov(go_t *g, int64_t k) {
     int64_t D = g->D;
+    if (g->diag == 2) {         /* gaussian_components_fixedvar.py:282-291 */
+        double lp = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double pN = g->S[k * D + a];
+            double pp = pN * g->prec[a] / (pN + g->prec[a]);
+            lp += log(pp);
+            g->inv[k * D + a] = pp;
+        }
+        g->logdet[k] = lp;
+        return;
+    }
     if (g->diag) {              /* gaussian_components_diag.py:325-338 */
         double k_N = g->k0 + (double)g->n[k];
         double v_N = (double)(g->v0 + g->n[k]);
@@ -155,6 +168,13 @@ static void seat(go_t *g, int64_t i, int64_t k) {
         g->K += 1;
         memcpy(m, g->prior_m, sizeof(double) * D);
         memcpy(S, g->prior_S, sizeof(double) * g->SD);
+    }
+    if (g->diag == 2) {         /* gaussian_components_fixedvar.py:146-162 */
+        for (int64_t a = 0; a < D; ++a) { double px = g->prec[a] * x[a]; m[a] += px; S[a] += g->prec[a]; }
+        g->n[k] += 1;
+        refresh_cov(g, k);
+        g->z[i] = k;
+        return;
     }
     for (int64_t a = 0; a < D; ++a) m[a] += x[a];
     if (g->diag) {
@@ -199,6 +219,11 @@ static void unseat(go_t *g, int64_t i) {
     if (g->n[k] == 0) { drop_component(g, k); return; }
     const double *x = g->X + i * D;
     double *m = g->m + k * D, *S = g->S + k * g->SD;
+    if (g->diag == 2) {
+        for (int64_t a = 0; a < D; ++a) { double px = g->prec[a] * x[a]; m[a] -= px; S[a] -= g->prec[a]; }
+        refresh_cov(g, k);
+        return;
+    }
     for (int64_t a = 0; a < D; ++a) m[a] -= x[a];
     if (g->diag) {
         for (int64_t a = 0; a < D; ++a) { double o = x[a] * x[a]; S[a] -= o; }
@@ -215,6 +240,15 @@ static void unseat(go_t *g, int64_t i) {
 static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
                         double logdet, const double *inv, int64_t nu, double *delta) {
     int64_t D = g->D;
+    if (g->diag == 2) {         /* product of univariate normals: gaussian_components_fixedvar.py:293-303;
+                                   mu_num / k_N is the mean (callers pass k_N = 1 and a ready mean) */
+        double acc = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double dl = x[a] - mu_num[a] / k_N;
+            acc += (dl * dl) * inv[a];
+        }
+        return -0.5 * (double)D * log(2. * 3.14159265358979323846) + 0.5 * logdet - 0.5 * acc;
+    }
     if (g->diag) {              /* product of univariate Student-t: gaussian_components_diag.py:340-354 */
         double acc = 0.0;
         for (int64_t a = 0; a < D; ++a) {
@@ -244,8 +278,9 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->N = N; g->D = D; g->K_max = K_max; g->X = X; g->k0 = k0; g->v0 = v0; g->alpha = alpha;
     g->diag = diag; g->SD = diag ? D : D * D;
     g->m0 = (double *)malloc(sizeof(double) * D); memcpy(g->m0, m0, sizeof(double) * D);
-    g->S0 = (double *)malloc(sizeof(double) * D * D); memcpy(g->S0, S0, sizeof(double) * g->SD);
+    g->S0 = (double *)malloc(sizeof(double) * (D * D + 2 * D)); memcpy(g->S0, S0, sizeof(double) * (diag == 2 ? 2 * D : g->SD));
     g->tab_len = v0 + N + 2;
+    if (g->tab_len < 4) g->tab_len = 4;
     g->tab_lgam = (double *)malloc(sizeof(double) * g->tab_len);
     g->tab_log = (double *)malloc(sizeof(double) * g->tab_len);
     for (int64_t t = 0; t < g->tab_len; ++t) {
@@ -256,7 +291,16 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->prior_m = (double *)malloc(sizeof(double) * D);
     g->prior_S = (double *)malloc(sizeof(double) * D * D);
     for (int64_t a = 0; a < D; ++a) g->prior_m[a] = k0 * m0[a];
-    if (diag) {
+    if (diag == 2) {            /* S0 = [var ; var_0]; a new component starts at (precision_0 mu_0, precision_0) */
+        g->prec = (double *)malloc(sizeof(double) * D);
+        g->prec0 = (double *)malloc(sizeof(double) * D);
+        for (int64_t a = 0; a < D; ++a) {
+            g->prec[a] = 1. / S0[a];
+            g->prec0[a] = 1. / S0[D + a];
+            g->prior_m[a] = g->prec0[a] * m0[a];
+            g->prior_S[a] = g->prec0[a];
+        }
+    } else if (diag) {
         for (int64_t a = 0; a < D; ++a) { double o = m0[a] * m0[a]; double ko = k0 * o; g->prior_S[a] = S0[a] + ko; }
     } else {
         for (int64_t a = 0; a < D; ++a)
@@ -284,6 +328,13 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->delta = (double *)malloc(sizeof(double) * D);
     g->tmp = (double *)malloc(sizeof(double) * D);
 
+    if (diag == 2) {            /* gaussian_components_fixedvar.py:205-212: N(mu_0, precision_0) */
+        double lp = 0.0;
+        for (int64_t a = 0; a < D; ++a) lp += log(g->prec0[a]);
+        for (int64_t i = 0; i < N; ++i)
+            g->log_prior[i] = student_t(g, X + i * D, m0, 1.0, lp, g->prec0, 0, g->delta);
+        return g;
+    }
     if (diag) {                 /* gaussian_components_diag.py:205-212 */
         double sc = (k0 + 1.) / (k0 * (double)v0), lp = 0.0;
         for (int64_t a = 0; a < D; ++a) { double var = sc * S0[a]; lp += log(var); g->save_inv[a] = 1. / var; }
@@ -312,6 +363,7 @@ void go_destroy(void *h) {
     free(g->prior_S); free(g->m); free(g->S); free(g->inv); free(g->logdet); free(g->n);
     free(g->z); free(g->log_prior); free(g->lu); free(g->col); free(g->piv); free(g->lp);
     free(g->save_m); free(g->save_S); free(g->save_inv); free(g->delta); free(g->tmp);
+    free(g->prec); free(g->prec0);
     free(g);
 }
 
@@ -359,6 +411,10 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         for (int64_t k = 0; k < K; ++k) {
             double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
             int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
+            if (g->diag == 2) {
+                for (int64_t a = 0; a < D; ++a) g->tmp[a] = g->m[k * D + a] / g->S[k * D + a];
+                g->lp[k] = w + student_t(g, x, g->tmp, 1.0, g->logdet[k], g->inv + k * D, 0, g->delta);
+            } else
             g->lp[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
                                      g->inv + k * g->SD, nu, g->delta);
             if (g->lp[k] > top) top = g->lp[k];
@@ -399,6 +455,22 @@ double go_log_marg(void *h) {
     double log_pz = (double)(K - 1) * log(g->alpha) + lgamma(g->alpha) - lgamma(sum_n + g->alpha) + sum_lf;
     double hd = (double)D / 2.;
     double log_px = 0.;
+    if (g->diag == 2) {         /* gaussian_components_fixedvar.py:248-270: sums over the members of k */
+        for (int64_t k = 0; k < K; ++k) {
+            double Nk = (double)g->n[k];
+            for (int64_t a = 0; a < D; ++a) {
+                double sx = 0., sxx = 0.;
+                for (int64_t i = 0; i < g->N; ++i)
+                    if (g->z[i] == k) { double x = g->X[i * D + a]; sx += x; sxx += x * x; }
+                double p = g->prec[a], p0 = g->prec0[a], mu0 = g->m0[a];
+                double den = Nk / p0 + 1. / p;
+                log_px += (Nk - 1.) / 2. * log(p) - 0.5 * Nk * log(2. * 3.14159265358979323846)
+                          - 0.5 * log(den) - 0.5 * p * sxx - 0.5 * p0 * (mu0 * mu0)
+                          + 0.5 * ((sx * sx) * p / p0 + (mu0 * mu0) * p0 / p + 2. * sx * mu0) / den;
+            }
+        }
+        return log_pz + log_px;
+    }
     if (g->diag) {              /* gaussian_components_diag.py:261-284 */
         double lS0 = 0.;
         for (int64_t a = 0; a < D; ++a) lS0 += log(g->S0[a]);
@@ -449,6 +521,10 @@ void go_get_stats(void *h, double *m, double *S, double *logdet, double *inv) {
 void go_log_post_pred(void *h, int64_t i, double *out) {
     go_t *g = (go_t *)h; int64_t D = g->D;
     for (int64_t k = 0; k < g->K; ++k)
+        if (g->diag == 2) {
+            for (int64_t a = 0; a < D; ++a) g->tmp[a] = g->m[k * D + a] / g->S[k * D + a];
+            out[k] = student_t(g, g->X + i * D, g->tmp, 1.0, g->logdet[k], g->inv + k * D, 0, g->delta);
+        } else
         out[k] = student_t(g, g->X + i * D, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
                            g->inv + k * g->SD, g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1, g->delta);
 }

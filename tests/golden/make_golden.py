@@ -101,8 +101,15 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
         random.seed(seeds[0])
         np.random.seed(seeds[1])
 
-    m_0, k_0, v_0, S_0 = prior_params
-    prior = NIW(m_0, k_0, v_0, S_0)
+    if cov_type == "fixed":
+        from pybgmm.gaussian.gaussian_components_fixedvar import FixedVarPrior
+        fv_var, fv_mu_0, fv_var_0 = prior_params
+        prior = FixedVarPrior(fv_var, fv_mu_0, fv_var_0)
+        # stored in the fixture through the NIW slots: m_0 = mu_0, S_0 = [var ; var_0], k_0 / v_0 unused
+        m_0, k_0, v_0, S_0 = fv_mu_0, 1.0, 1, np.concatenate([fv_var, fv_var_0])
+    else:
+        m_0, k_0, v_0, S_0 = prior_params
+        prior = NIW(m_0, k_0, v_0, S_0)
     cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM, "ADAPCRPMM": ADAPCRPMM}[model]
     init = assignments if isinstance(assignments, str) else list(assignments)
     mm = cls(X, prior, alpha, None, assignments=init, K=K, K_max=K_max,
@@ -216,7 +223,13 @@ def run_case(name, model, X, prior_params, alpha, assignments, K, K_max, n_iter,
         out["rec_nk"] = np.array(record["nk"])
     if store_X:
         out["X"] = np.asarray(X, dtype=np.float64)
-    if cov_type == "diag":
+    if cov_type == "fixed":
+        Kf = comp.K
+        out["final_m"] = np.array(comp.mu_N_numerators[:Kf])
+        out["final_S"] = np.array(comp.precision_Ns[:Kf])
+        out["final_logdet"] = np.array(comp.log_prod_precision_preds[:Kf])
+        out["final_inv"] = np.array(comp.precision_preds[:Kf])
+    elif cov_type == "diag":
         Kf = comp.K
         out["final_m"] = np.array(comp.m_N_numerators[:Kf])
         out["final_S"] = np.array(comp.S_N_partials[:Kf])
@@ -428,6 +441,29 @@ def case_diag_64d():
              recipe="synth_mixture(800,64,8,seed=44)")
 
 
+# ---- fixed-variance components ------------------------------------------ #
+def case_fixed_2d():
+    X, z_true = gendata.synth_mixture(300, 2, 5, seed=61)
+    prior = (np.array([0.49, 0.6]), np.array([0.5, -0.3]), np.array([16.0, 12.0]))   # var, mu_0, var_0
+    run_case("fixed_2d", "CRPMM", X, prior, 1.0, "rand", 6, 60, 5, (12, 12),
+             true_assignments=z_true, cov_type="fixed")
+
+
+def case_fixed_each_in_own():
+    X, z_true = gendata.synth_mixture(30, 3, 3, seed=62)
+    prior = (0.49 * np.ones(3), np.zeros(3), 16.0 * np.ones(3))
+    run_case("fixed_each_in_own_30", "CRPMM", X, prior, 1.5, "each-in-own", 1, None, 3, (13, 13),
+             true_assignments=z_true, cov_type="fixed")
+
+
+def case_fixed_pcrp_16d():
+    X, z_true = gendata.synth_mixture(500, 16, 8, seed=63)
+    prior = (0.49 * np.ones(16), np.zeros(16), 16.0 * np.ones(16))
+    run_case("fixed_pcrp_16d", "PCRPMM", X, prior, 1.0, "rand", 8, 80, 3, (14, 14),
+             sampler_kwargs=dict(n_power=1.1, power_burnin=0), true_assignments=z_true,
+             skip_metrics=True, cov_type="fixed")
+
+
 def case_adap():
     # the sweep exponent adapts to the share of small clusters
     # (adapcrp_burnin=-1: with the reference's default 0 its first sweep dies on an unbound local)
@@ -446,6 +482,7 @@ CASES = {
     "general_prior": case_general_prior, "d12": case_d12,
     "diag_kat": case_diag_kat, "diag_each_in_own": case_diag_each_in_own, "diag_pcrp": case_diag_pcrp,
     "diag_general": case_diag_general, "diag_64d": case_diag_64d, "adap": case_adap,
+    "fixed_2d": case_fixed_2d, "fixed_each_in_own": case_fixed_each_in_own, "fixed_pcrp": case_fixed_pcrp_16d,
 }
 
 

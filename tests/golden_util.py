@@ -9,8 +9,9 @@ from pybgmm_amd.utils import gendata
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 _EVERY = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
-ALL_CASES = [c for c in _EVERY if not c.startswith("diag_")]          # full covariance (incl. ADAPCRPMM)
+ALL_CASES = [c for c in _EVERY if not c.startswith(("diag_", "fixed_"))]   # full covariance (incl. ADAPCRPMM)
 DIAG_CASES = [c for c in _EVERY if c.startswith("diag_")]             # covariance_type="diag"
+FIXED_CASES = [c for c in _EVERY if c.startswith("fixed_")]           # covariance_type="fixed"
 # cases whose reference trajectory is short enough for the pure-numpy oracle
 SMALL_CASES = ["kat1_igmm_2d", "kat3_each_in_own", "kat4_log_marg", "each_in_own_50",
                "one_by_one_50", "pcrp_burnin_2d", "pcrp_flagoff_3d", "general_prior_3d"]

@@ -3,11 +3,11 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
-from golden_util import ALL_CASES, DIAG_CASES, Golden
+from golden_util import ALL_CASES, DIAG_CASES, FIXED_CASES, Golden
 from oracle import c_oracle
 
 
-@pytest.mark.parametrize("case", ALL_CASES + DIAG_CASES)
+@pytest.mark.parametrize("case", ALL_CASES + DIAG_CASES + FIXED_CASES)
 def test_trajectory(case):
     g = Golden(case)
     o, out = c_oracle.run_chain(g)

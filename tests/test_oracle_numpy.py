@@ -4,7 +4,7 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
-from golden_util import DIAG_CASES, SMALL_CASES, Golden
+from golden_util import DIAG_CASES, FIXED_CASES, SMALL_CASES, Golden
 from oracle.gibbs_numpy import NumpyGibbsOracle, run_chain
 
 
@@ -33,6 +33,23 @@ def test_diag_trajectory_bitexact(case):
     g = Golden(case)
     o, out = run_chain(g.X, g.prior, g.alpha, g.z_init, g.K_max, g.u, g.order,
                        g.n_power, g.power_burnin, g.flag_power, cov_type="diag")
+    for it in range(g.n_iter):
+        npt.assert_array_equal(out["z"][it], g.z[it], err_msg="sweep %d" % it)
+        npt.assert_array_equal(out["counts"][it], g.counts_at(it))
+        assert out["log_marg"][it] == g.log_marg[it]
+    K = g.K[-1]
+    npt.assert_array_equal(o.m[:K], g.d["final_m"])
+    npt.assert_array_equal(o.S[:K], g.d["final_S"])
+    npt.assert_array_equal(o.logdet[:K], g.d["final_logdet"])
+    npt.assert_array_equal(o.inv[:K], g.d["final_inv"])
+    npt.assert_array_equal(o.log_prior[:4096], g.d["cached_log_prior"])
+
+
+@pytest.mark.parametrize("case", FIXED_CASES)
+def test_fixed_trajectory_bitexact(case):
+    g = Golden(case)
+    o, out = run_chain(g.X, g.prior, g.alpha, g.z_init, g.K_max, g.u, g.order,
+                       g.n_power, g.power_burnin, g.flag_power, cov_type="fixed")
     for it in range(g.n_iter):
         npt.assert_array_equal(out["z"][it], g.z[it], err_msg="sweep %d" % it)
         npt.assert_array_equal(out["counts"][it], g.counts_at(it))
