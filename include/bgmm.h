@@ -43,6 +43,10 @@ enum { BGMM_COV_FULL = 0,      /* covariance_type="full"  (igmm.py:104-105, gaus
        BGMM_COV_DIAG = 1 };    /* covariance_type="diag"  (igmm.py:106-107, gaussian/gaussian_components_diag.py):
                                   S_0 is a D-vector; per-slot S / inverse blocks are D-vectors too; `logdet_out`
                                   of bgmm_get_stats is log_prod_vars, `inv_out` is inv_vars                       */
+enum { BGMM_COV_FIXED = 2 };   /* covariance_type="fixed" (igmm.py:108-109, gaussian/gaussian_components_fixedvar.py):
+                                  FixedVarPrior(var, mu_0, var_0) is passed as m_0 = mu_0, S_0 = [var[D] ; var_0[D]]
+                                  (k_0, v_0 ignored: pass 1, 1); bgmm_get_stats returns mu_N_numerators,
+                                  precision_Ns, log_prod_precision_preds, precision_preds                           */
 
 /* Library / build identification, e.g. "bgmm-hip 0.1 gfx950". */
 const char *bgmm_version(void);

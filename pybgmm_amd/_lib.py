@@ -100,9 +100,10 @@ class Context(object):
         m_0 = np.ascontiguousarray(m_0, dtype=np.float64)
         S_0 = np.ascontiguousarray(S_0, dtype=np.float64)
         self.cov_type = cov_type
-        self.diag = cov_type == "diag"
-        assert cov_type in ("full", "diag")
-        assert S_0.shape == ((self.D,) if self.diag else (self.D, self.D)), "S_0 has the wrong shape"
+        assert cov_type in ("full", "diag", "fixed")
+        self.diag = cov_type != "full"                      # per-slot blocks are D-vectors
+        want = {"full": (self.D, self.D), "diag": (self.D,), "fixed": (2 * self.D,)}[cov_type]
+        assert S_0.shape == want, "S_0 has the wrong shape"
         if int(v_0) != v_0:
             raise ValueError("v_0 must be integer valued (the reference indexes its "
                              "log/gammaln tables with it)")
@@ -112,7 +113,8 @@ class Context(object):
             tg = np.ascontiguousarray(tables[1], dtype=np.float64)
             assert tl.shape == (int(v_0) + self.N + 2,) and tg.shape == tl.shape
         h = _vp()
-        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max, 1 if self.diag else 0,
+        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max,
+                           {"full": 0, "diag": 1, "fixed": 2}[cov_type],
                            _ptr(self.X), _ptr(m_0), float(k_0), int(v_0), _ptr(S_0), float(alpha),
                            _ptr(tl), _ptr(tg))
         if rc != 0:

@@ -125,7 +125,7 @@ static int fetch_ctrl(bgmm_ctx *c) {
 
 static void resolve_kind(bgmm_ctx *c) {
     int k = c->kernel_kind;
-    if (c->d.cov_type == COV_DIAG) k = KERNEL_VALU;      // (the diag likelihood kernel has the VALU geometry)
+    if (c->d.cov_type != COV_FULL) k = KERNEL_VALU;      // (the diag / fixed likelihood kernel has the VALU geometry)
     if (k == KERNEL_AUTO) k = (c->d.D >= 12) ? KERNEL_MFMA : KERNEL_VALU;
     if (k == KERNEL_MFMA && c->d.Dp / 16 > 8) k = KERNEL_VALU;
     c->kind = k;
@@ -171,8 +171,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
     resolve_kind(c);
 
-    const bool diag = cov_type == COV_DIAG;
-    const size_t DD = diag ? (size_t)D : (size_t)D * D, ns = (size_t)d.nslots;   // second-moment block
+    const bool diag = cov_type != COV_FULL;                  // D-vector statistics (diag and fixed)
+    const bool fixed = cov_type == COV_FIXED;
+    const size_t DD = fixed ? (size_t)2 * D : diag ? (size_t)D : (size_t)D * D, ns = (size_t)d.nslots;   // second-moment block
     const size_t WW = diag ? 1 : (size_t)D * D;                                   // factor block (full only)
     double *dX, *dtl, *dtg, *dpm, *dpS, *dtG, *dtC, *dtS;
     DALLOC(c, dX, (size_t)N * D);
@@ -221,6 +222,12 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
 
     d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
     d.tabG = dtG; d.tabLogC = dtC; d.tabSeat = dtS;
+    {   // mu_0 on the device (fixed-variance log marginal)
+        double *dmu0;
+        DALLOC(c, dmu0, (size_t)D);
+        CK(c, hipMemcpyAsync(dmu0, m_0, sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+        d.fv_mu0 = dmu0;
+    }
     c->tabSeat = dtS;
     CK(c, hipMemcpyAsync(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
 
@@ -238,7 +245,14 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     // k_0*m_0  and  S_0 + k_0*outer(m_0, m_0)
     std::vector<double> pm(D), pS(DD);
     for (int a = 0; a < D; ++a) pm[a] = k_0 * m_0[a];
-    if (diag) {      // S_0 is a D-vector: S_0 + k_0*square(m_0)   (gaussian_components_diag.py:170)
+    if (fixed) {     // S_0 = [var ; var_0]: a new component starts at (precision_0 mu_0, precision_0)
+        for (int a = 0; a < D; ++a) {
+            const double p = 1.0 / S_0[a], p0 = 1.0 / S_0[D + a];
+            pm[a] = p0 * m_0[a];
+            pS[a] = p0;
+            pS[D + a] = p;
+        }
+    } else if (diag) {      // S_0 is a D-vector: S_0 + k_0*square(m_0)   (gaussian_components_diag.py:170)
         for (int a = 0; a < D; ++a) {
             volatile double o = m_0[a] * m_0[a];
             volatile double ko = k_0 * o;
@@ -258,7 +272,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     CK(c, hipMemsetAsync(d.n, 0, sizeof(int) * ns, c->stream));
     CK(c, hipMemsetAsync(d.nupd, 0, sizeof(int) * ns, c->stream));
     CK(c, hipMemcpyAsync(d.m + (size_t)K_max * D, pm.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
-    CK(c, hipMemcpyAsync(d.S + (size_t)K_max * DD, pS.data(), sizeof(double) * DD, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(d.S + (size_t)K_max * DD, pS.data(), sizeof(double) * (fixed ? (size_t)D : DD), hipMemcpyHostToDevice, c->stream));
+    if (fixed) CK(c, hipMemsetAsync(d.S + (size_t)K_max * DD + D, 0, sizeof(double) * D, c->stream));
     CK(c, hipMemsetAsync(d.z, 0xff, sizeof(int) * N, c->stream));
     CK(c, hipMemsetAsync(d.ctrl, 0, sizeof(Ctrl), c->stream));
     CK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope below
@@ -308,8 +323,8 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
                            const double *log_tab) {
     if (!out) return BGMM_EINVAL;
     *out = nullptr;
-    if (cov_type != BGMM_COV_FULL && cov_type != BGMM_COV_DIAG)
-        return fail(nullptr, BGMM_EUNSUPPORTED, "covariance_type must be full (0) or diag (1)");
+    if (cov_type != BGMM_COV_FULL && cov_type != BGMM_COV_DIAG && cov_type != BGMM_COV_FIXED)
+        return fail(nullptr, BGMM_EUNSUPPORTED, "covariance_type must be full (0), diag (1) or fixed (2)");
     if (!X || !m_0 || !S_0 || N < 1 || D < 1 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
     if (D > BGMM_MAX_D) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 128 is not supported yet");
     if (N >= (1ll << 31) - 256) return fail(nullptr, BGMM_EUNSUPPORTED, "N must fit int32");
@@ -569,7 +584,7 @@ extern "C" int bgmm_get_stats(bgmm_ctx *c, double *m_out, double *S_out, double 
     if (rc) return rc;
     const int K = c->ctrl_host->job.K, D = c->d.D;
     if (K == 0) return 0;
-    const size_t DD = c->d.cov_type == COV_DIAG ? (size_t)D : (size_t)D * D;
+    const size_t DD = c->d.cov_type != COV_FULL ? (size_t)D : (size_t)D * D;
     double *dm = nullptr, *dS = nullptr, *dl = nullptr, *di = nullptr;
     hipError_t e = hipSuccess;
     if (m_out && e == hipSuccess) e = hipMalloc((void **)&dm, sizeof(double) * K * D);

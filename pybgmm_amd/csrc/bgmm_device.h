@@ -28,7 +28,7 @@
 
 enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
 enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
-enum { COV_FULL = 0, COV_DIAG = 1 };
+enum { COV_FULL = 0, COV_DIAG = 1, COV_FIXED = 2 };
 // how a slot's derived state (mu, Winv, cvec, constants) follows a change of (n, m, S)
 enum { REFRESH_SCRATCH = 0,   // Cholesky + inverse of S_N from scratch, O(D^3)
        REFRESH_ADD = 1,       // rank-1 update of Winv: point refresh_i was added
@@ -96,7 +96,10 @@ struct Ctrl {
 
 struct Dev {
     long long N;
-    int cov_type;                // 0 full covariance, 1 diagonal (S and dw are D-vectors per slot)
+    int cov_type;                // 0 full covariance, 1 diagonal (S and dw are D-vectors per slot),
+                                 // 2 fixed variance (m = mu_N numerators, S = [precision_N[D], sum x^2[D]],
+                                 //   prior_m = precision_0 mu_0, prior_S = [precision_0[D], precision[D]])
+    const double *fv_mu0;        // fixed variance: mu_0
     int D, Dp, K_max, nslots, nfrag, ldq;
     long long qstride;           // q[slot * qstride + window row]
     int choice_rows;             // visits per block of the draw kernel

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
             const int s = d.perm[jj];
             const double qv = tile[jj * R + w];
             const SlotConst sc = d.sc[s];
-            if (d.cov_type == COV_DIAG) {
-                // the diag likelihood kernel stores log densities (home row: one-point-removed form)
+            if (d.cov_type != COV_FULL) {
+                // the diag / fixed likelihood kernels store log densities (home row: one-point-removed form)
                 v = ((home_live && s == h) ? sc.logseat1 : sc.logseat) + qv;
             } else if (qv == INFINITY) {
                 v = -INFINITY;                      // pruned by the likelihood kernel: weight exactly 0

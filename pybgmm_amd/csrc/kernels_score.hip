@@ -499,7 +499,7 @@ void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstrid
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
                   long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
-    if (d.cov_type == COV_DIAG) { launch_score_diag(d, job, q, qstride, col_override, max_rows, st); return; }
+    if (d.cov_type != COV_FULL) { launch_score_diag(d, job, q, qstride, col_override, max_rows, st); return; }
     if (kind == KERNEL_MFMA) {
         switch (d.Dp / 16) {
             case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
@@ -568,14 +568,38 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
         const double *__restrict__ mu = d.mu + (long long)s * D;
         const double *__restrict__ dw = d.dw + (long long)s * D;
         const SlotConst *__restrict__ scp = d.sc + s;
+        const bool fixed = d.cov_type == COV_FIXED;
         double acc = 0.0;
-        for (int l = 0; l < D; ++l) {
-            const double dl = xs[l * kValuRows + lane] - mu[l];
-            acc += log(1.0 + dl * dl * dw[l]);
+        if (fixed) {                // product of normals: sum (x - mu)^2 * predictive precision
+            for (int l = 0; l < D; ++l) {
+                const double dl = xs[l * kValuRows + lane] - mu[l];
+                acc += (dl * dl) * dw[l];
+            }
+        } else {
+            for (int l = 0; l < D; ++l) {
+                const double dl = xs[l * kValuRows + lane] - mu[l];
+                acc += log(1.0 + dl * dl * dw[l]);
+            }
         }
         double lp = scp->A - scp->half_vd * acc;
         const int ns = d.n[s];
-        if (home == s && ns >= 2) {
+        if (fixed && home == s && ns >= 2) {
+            // gaussian_components_fixedvar.py:164-176: numerator -= p x, precision_N -= p
+            const double *__restrict__ mS = d.m + (long long)s * D;
+            const double *__restrict__ SS = d.S + (long long)s * 2 * D;
+            double lpp = 0.0, a1 = 0.0;
+            for (int l = 0; l < D; ++l) {
+                const double x = xs[l * kValuRows + lane];
+                const double p = d.prior_S[D + l];
+                const double mn = __dsub_rn(mS[l], __dmul_rn(p, x));
+                const double pN = __dsub_rn(SS[l], p);
+                const double pp = pN * p / (pN + p);
+                const double dl = x - mn / pN;
+                lpp += log(pp);
+                a1 += (dl * dl) * pp;
+            }
+            lp = -0.5 * (double)D * log(2.0 * 3.14159265358979323846) + 0.5 * lpp - 0.5 * a1;
+        } else if (home == s && ns >= 2) {
             // the visited point removed from its own component
             const double *__restrict__ mS = d.m + (long long)s * D;
             const double *__restrict__ SS = d.S + (long long)s * D;

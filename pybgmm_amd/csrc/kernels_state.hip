@@ -22,6 +22,23 @@ __global__ __launch_bounds__(TPB) void init_stats_kernel(Dev d, const int *__res
     const int k = blockIdx.x;                 // initial label == slot
     const int D = d.D;
     const long long lo = offsets[k], hi = offsets[k + 1];
+    if (d.cov_type == COV_FIXED) {            // gaussian_components_fixedvar.py:146-162
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            double mn = d.prior_m[a], pN = d.prior_S[a], sq = 0.0;
+            const double p = d.prior_S[D + a];
+            for (long long t = lo; t < hi; ++t) {
+                const double x = d.X[(long long)members[t] * D + a];
+                mn = __dadd_rn(mn, __dmul_rn(p, x));
+                pN = __dadd_rn(pN, p);
+                sq = __dadd_rn(sq, __dmul_rn(x, x));
+            }
+            d.m[(long long)k * D + a] = mn;
+            d.S[(long long)k * 2 * D + a] = pN;
+            d.S[(long long)k * 2 * D + D + a] = sq;
+        }
+        if (threadIdx.x == 0) d.n[k] = (int)(hi - lo);
+        return;
+    }
     if (d.cov_type == COV_DIAG) {             // gaussian_components_diag.py:162-176: S += square(x)
         for (int a = threadIdx.x; a < D; a += TPB) {
             double accS = d.prior_S[a], accm = d.prior_m[a];
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
     if ((int)blockIdx.x >= n) return;
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
+    else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
     else refresh_slot(d, s, sm);
 }
 
@@ -153,6 +171,7 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     if ((int)blockIdx.x >= c->n_refresh) return;
     const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
+    else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
     else if (kind == REFRESH_SCRATCH) refresh_slot(d, s, sm);
     else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
@@ -369,6 +388,25 @@ __device__ int plan_seat(const Dev &d, Ctrl *c, long long i, int lab, MovePlan &
 __device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
     const int D = d.D;
     const double *x = d.X + mp.i * D;
+    if (d.cov_type == COV_FIXED) {
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            const double p = d.prior_S[D + a];
+            const double px = __dmul_rn(p, x[a]), xx = __dmul_rn(x[a], x[a]);
+            if (mp.sub_slot >= 0) {
+                const long long o = (long long)mp.sub_slot * D + a, o2 = (long long)mp.sub_slot * 2 * D + a;
+                d.m[o] = __dsub_rn(d.m[o], px);
+                d.S[o2] = __dsub_rn(d.S[o2], p);
+                d.S[o2 + D] = __dsub_rn(d.S[o2 + D], xx);
+            }
+            if (mp.add_slot >= 0) {
+                const long long o = (long long)mp.add_slot * D + a, o2 = (long long)mp.add_slot * 2 * D + a;
+                d.m[o] = __dadd_rn(mp.add_init ? d.prior_m[a] : d.m[o], px);
+                d.S[o2] = __dadd_rn(mp.add_init ? d.prior_S[a] : d.S[o2], p);
+                d.S[o2 + D] = __dadd_rn(mp.add_init ? 0.0 : d.S[o2 + D], xx);
+            }
+        }
+        return;
+    }
     if (d.cov_type == COV_DIAG) {
         for (int a = threadIdx.x; a < D; a += TPB) {
             const double xx = __dmul_rn(x[a], x[a]);
@@ -407,7 +445,7 @@ __device__ void apply_rank1(const Dev &d, const MovePlan &mp) {
 __device__ void set_refresh(const Dev &d, Ctrl *c, const MovePlan &mp, bool rank1) {
     int nr = 0;
     c->refresh_i = mp.i;
-    if (d.cov_type == COV_DIAG) rank1 = false;      // the diag refresh is O(D) anyway
+    if (d.cov_type != COV_FULL) rank1 = false;      // the diag / fixed refresh is O(D) anyway
     if (mp.sub_slot >= 0) {
         c->refresh_kind[nr] = (rank1 && d.nupd[mp.sub_slot] < kRefreshEvery) ? REFRESH_SUB : REFRESH_SCRATCH;
         c->refresh[nr++] = mp.sub_slot;
@@ -532,6 +570,21 @@ __global__ __launch_bounds__(TPB) void log_marg_kernel(Dev d, double *out_total,
     for (int j = threadIdx.x; j < K; j += TPB) {
         const int s = d.perm[j];
         const int n = d.n[s];
+        if (d.cov_type == COV_FIXED) {      // gaussian_components_fixedvar.py:248-270 from the slot's sums
+            const double Nk = (double)n;
+            double acc = 0.0;
+            for (int a = 0; a < D; ++a) {
+                const double p = d.prior_S[D + a], p0 = d.prior_S[a], mu0 = d.fv_mu0[a];
+                const double sx = (d.m[(long long)s * D + a] - d.prior_m[a]) / p;
+                const double sxx = d.S[(long long)s * 2 * D + D + a];
+                const double den = Nk / p0 + 1.0 / p;
+                acc += (Nk - 1.0) / 2.0 * log(p) - 0.5 * Nk * log(2.0 * 3.14159265358979323846)
+                       - 0.5 * log(den) - 0.5 * p * sxx - 0.5 * p0 * (mu0 * mu0)
+                       + 0.5 * ((sx * sx) * p / p0 + (mu0 * mu0) * p0 / p + 2.0 * sx * mu0) / den;
+            }
+            out_per_label[j] = acc;
+            continue;
+        }
         const double k_N = d.k0 + (double)n;
         const long long v_N = d.v0 + n;
         double gs = 0.0;
@@ -576,7 +629,7 @@ void launch_labels(const Dev &d, long long *z_out, long long *counts_out, hipStr
 __global__ void prior_lp_kernel(Dev d, const double *__restrict__ qcol) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
-    if (d.cov_type == COV_DIAG) { d.log_prior[i] = qcol[i]; return; }   // the diag kernel emits log densities
+    if (d.cov_type != COV_FULL) { d.log_prior[i] = qcol[i]; return; }   // these kernels emit log densities
     const SlotConst c = d.sc[d.K_max];
     d.log_prior[i] = c.A - c.half_vd * log(1.0 + qcol[i] * c.inv_cv);
 }
@@ -589,7 +642,7 @@ __global__ void post_pred_kernel(Dev d, const double *__restrict__ qrow, double 
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= d.ctrl->job.K) return;
     const int s = d.perm[j];
-    if (d.cov_type == COV_DIAG) { out[j] = qrow[s]; return; }
+    if (d.cov_type != COV_FULL) { out[j] = qrow[s]; return; }
     const SlotConst c = d.sc[s];
     out[j] = c.A - c.half_vd * log(1.0 + qrow[s] * c.inv_cv);
 }
@@ -606,6 +659,15 @@ __global__ __launch_bounds__(TPB) void export_stats_kernel(Dev d, double *m_out,
     const int s = d.perm[j], D = d.D;
     const int n = d.n[s];
     const double k_N = d.k0 + (double)n;
+    if (d.cov_type == COV_FIXED) {       // mu_N_numerators, precision_Ns, log_prod_precision_preds, precision_preds
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            if (m_out) m_out[(long long)j * D + a] = d.m[(long long)s * D + a];
+            if (S_out) S_out[(long long)j * D + a] = d.S[(long long)s * 2 * D + a];
+            if (inv_out) inv_out[(long long)j * D + a] = d.dw[(long long)s * D + a];
+        }
+        if (logdet_out && threadIdx.x == 0) logdet_out[j] = d.sc[s].A1;
+        return;
+    }
     if (d.cov_type == COV_DIAG) {        // m, S (K x D), log_prod_vars, inv_vars (K x D)
         for (int a = threadIdx.x; a < D; a += TPB) {
             if (m_out) m_out[(long long)j * D + a] = d.m[(long long)s * D + a];
@@ -668,6 +730,14 @@ __global__ __launch_bounds__(256) void dispersion_kernel(Dev d, double *__restri
     const long long sd = d.cov_type == COV_DIAG ? 1 : (long long)D + 1;      // stride of the diagonal
     const long long blk = d.cov_type == COV_DIAG ? (long long)D : (long long)D * D;
     double acc = 0.0;
+    if (d.cov_type == COV_FIXED) {
+        for (int a = 0; a < D; ++a) {
+            const double sx = (d.m[(long long)s * D + a] - d.prior_m[a]) / d.prior_S[D + a];
+            acc += d.S[(long long)s * 2 * D + D + a] - sx * sx / n;
+        }
+        out[j] = acc > 0.0 ? acc : 0.0;
+        return;
+    }
     for (int a = 0; a < D; ++a) {
         const double sx = d.m[(long long)s * D + a] - d.prior_m[a];
         const double sxx = d.S[(long long)s * blk + a * sd] - d.prior_S[a * sd];

@@ -361,3 +361,42 @@ __device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int t
     }
     __syncthreads();
 }
+
+// ------------------------------------------------------------------------------------------
+// Fixed-variance components (reference gaussian_components_fixedvar.py:282-291): predictive
+// precision pN p / (pN + p) per dimension; the bare prior (pseudo slot K_max) is scored with
+// precision_0 itself, as the reference's log_prior does (:205-212).  red: NT doubles of LDS.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__device__ inline void refresh_fixed_slot(const Dev &d, int s, double *red, int tid) {
+    const int D = d.D;
+    const int n = d.n[s];
+    double lpp = 0.0;
+    for (int l = tid; l < D; l += NT) {
+        const double pN = d.S[(long long)s * 2 * D + l];
+        const double p = d.prior_S[D + l];
+        const double pp = s == d.K_max ? pN : pN * p / (pN + p);
+        d.mu[(long long)s * D + l] = d.m[(long long)s * D + l] / pN;
+        d.dw[(long long)s * D + l] = pp;
+        lpp += log(pp);
+    }
+    red[tid] = lpp;
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0;
+        for (int t = 0; t < NT; ++t) a += red[t];
+        SlotConst c;
+        c.A = -0.5 * (double)D * log(2.0 * 3.14159265358979323846) + 0.5 * a;
+        c.half_vd = 0.5;
+        c.inv_cv = 0.0;
+        c.A1 = a;                 // log prod of the predictive precisions
+        c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+        c.logdetC = 0.0;
+        c.logseat = d.tabSeat[n];
+        c.logseat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
+        c.inv_lam = 0.0; c.mu2 = 0.0;
+        d.sc[s] = c;
+        d.nupd[s] = 0;
+    }
+    __syncthreads();
+}

@@ -1,3 +1,4 @@
 from .gaussian_components import GaussianComponents, GaussianComponentsDiag
+from .gaussian_components_fixedvar import FixedVarPrior, GaussianComponentsFixedVar
 
-__all__ = ["GaussianComponents", "GaussianComponentsDiag"]
+__all__ = ["GaussianComponents", "GaussianComponentsDiag", "GaussianComponentsFixedVar", "FixedVarPrior"]

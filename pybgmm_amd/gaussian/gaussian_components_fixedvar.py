@@ -1,0 +1,84 @@
+"""
+Fixed-variance Gaussian components: the interface of the reference's
+``pybgmm/gaussian/gaussian_components_fixedvar.py:18`` ``GaussianComponentsFixedVar`` and
+``FixedVarPrior`` (:304-311).  Mean-only conjugate update with a known per-dimension variance;
+the predictive is a product of univariate normals.  Statistics live on the GPU.
+"""
+import numpy as np
+
+from .. import _lib
+from .gaussian_components import GaussianComponents, default_K_max
+
+
+class FixedVarPrior(object):
+    """The prior parameters for a fixed diagonal covariance multivariate Gaussian."""
+
+    def __init__(self, var, mu_0, var_0):
+        self.var = var
+        self.mu_0 = mu_0
+        self.var_0 = var_0
+
+
+class GaussianComponentsFixedVar(GaussianComponents):
+    _cov_type = "fixed"
+
+    def __init__(self, X, prior, assignments=None, K_max=None, device=0, alpha=1.0):
+        X = np.asarray(X)
+        self.X = X
+        self.prior = prior
+        self.N, self.D = X.shape
+        self.precision = 1. / np.asarray(prior.var, dtype=np.float64)
+        self.mu_0 = np.asarray(prior.mu_0, dtype=np.float64)
+        self.precision_0 = 1. / np.asarray(prior.var_0, dtype=np.float64)
+        if assignments is None:
+            z = -1 * np.ones(self.N, dtype=np.int64)
+        else:
+            z = np.asarray(assignments, dtype=np.int64)
+            assert (self.N,) == z.shape
+            assert set(z.tolist()).difference([-1]) == set(range(int(z.max()) + 1))
+        K_init = int(z.max()) + 1
+        if K_max is None:
+            K_max = default_K_max(self.N, K_init)
+        self.K_max = int(K_max)
+        assert K_init <= self.K_max, "initial assignments use more than K_max components"
+        S_0 = np.concatenate([np.broadcast_to(np.asarray(prior.var, dtype=np.float64), (self.D,)),
+                              np.broadcast_to(np.asarray(prior.var_0, dtype=np.float64), (self.D,))])
+        self._ctx = _lib.Context(X, np.broadcast_to(self.mu_0, (self.D,)), 1.0, 1, S_0, alpha, self.K_max,
+                                 device=device, cov_type="fixed")
+        self._log_prior = None
+        self._ctx.set_assignments(z)
+
+    def _block(self):
+        return (self.D,)
+
+    @property
+    def mu_N_numerators(self):
+        return self._padded(self._ctx.stats(False)[0], (self.D,))
+
+    @property
+    def precision_Ns(self):
+        return self._padded(self._ctx.stats(False)[1], (self.D,))
+
+    @property
+    def log_prod_precision_preds(self):
+        return self._padded(self._ctx.stats(False)[2], ())
+
+    @property
+    def precision_preds(self):
+        return self._padded(self._ctx.stats(True)[3], (self.D,))
+
+    def _no(name):
+        return property(lambda self: (_ for _ in ()).throw(AttributeError(name)))
+
+    m_N_numerators = _no("m_N_numerators")
+    S_N_partials = _no("S_N_partials")
+    logdet_covars = _no("logdet_covars")
+    inv_covars = _no("inv_covars")
+    del _no
+
+    def cache_component_stats(self, k):
+        m, pN, lpp, pp = self._ctx.stats(True)
+        return (m[k].copy(), pN[k].copy(), lpp[k], pp[k].copy(), int(self._ctx.counts()[k]))
+
+    def map(self, k):
+        raise NotImplementedError("the reference's fixed-variance class has no map()")

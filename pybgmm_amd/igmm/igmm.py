@@ -9,6 +9,7 @@ from scipy import stats
 from scipy.special import gammaln
 
 from ..gaussian.gaussian_components import GaussianComponents, GaussianComponentsDiag
+from ..gaussian.gaussian_components_fixedvar import GaussianComponentsFixedVar
 from ..gmm import GMM
 from ..utils import rng as _rng
 
@@ -28,7 +29,7 @@ class IGMM(GMM):
       "rand" (``np.random.randint(0, K, N)`` from the global stream),
       "one-by-one" (only X[0] seated), "each-in-own".
     K : initial number of components for "rand".  K_max : component slots.
-    covariance_type : "full" or "diag" ("fixed" is not built yet).
+    covariance_type : "full", "diag" or "fixed" (the latter with a ``FixedVarPrior``).
     device : GPU ordinal (extension).  rng / nprng : ``random.Random`` /
       ``np.random.RandomState`` to draw from instead of the process-global streams
       (extension, used for one-chain-per-GPU runs).
@@ -64,8 +65,8 @@ class IGMM(GMM):
             self.components = GaussianComponentsDiag(X, kernel_prior, assignments, K_max,
                                                      device=device, alpha=alpha)
         elif covariance_type == "fixed":
-            raise NotImplementedError(
-                "covariance_type=%r is a later row of the build (SURVEY.md 8f)" % covariance_type)
+            self.components = GaussianComponentsFixedVar(X, kernel_prior, assignments, K_max,
+                                                         device=device, alpha=alpha)
         else:
             assert False, "Invalid covariance type."
 

@@ -122,8 +122,6 @@ def test_error_conventions():
         CRPMM(np.zeros(5), prior, 1.0, None)                 # 1-D X (igmm.py:75-76)
     with pytest.raises(AssertionError):
         CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="banana")
-    with pytest.raises(NotImplementedError):
-        CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="fixed")
     with pytest.raises(AssertionError):                       # gaussian_components_diag.py:92
         CRPMM(np.zeros((5, 2)), prior, 1.0, None, covariance_type="diag")
 
