@@ -217,6 +217,17 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.q, (size_t)rows * d.nslots);
     DALLOC(c, d.choice, (size_t)rows);
     DALLOC(c, d.wperm, (size_t)rows);
+    {
+        const size_t ng = ((size_t)d.nslots + 15) / 16;
+        DALLOC(c, d.pr_mufrag, ng * (size_t)(d.Dp / 4) * 64);
+        DALLOC(c, d.pr_const, ng * 128);
+        DALLOC(c, d.pr_slot, ng * 16);
+        DALLOC(c, d.wvisit, (size_t)rows);
+        DALLOC(c, d.pr_counts, 512);
+        CK(c, hipMemsetAsync(d.pr_counts, 0, 512 * sizeof(unsigned long long), c->stream));
+    }
+    d.keep_stride = (d.nslots + 63) / 64;
+    DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
     DALLOC(c, d.bucket_bins, ns + 4);
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
 
@@ -451,6 +462,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA;
     d.prune_enabled = use_prune ? 1 : 0;
+    { const char *e = getenv("BGMM_DEBUG_FLAGS"); d.debug_flags = e ? atoi(e) : 0; }
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
         launch_build_seat_table(d, c->tabSeat, st);
@@ -494,6 +506,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
             launch_choice(d, c->win_rows, st);
+            if (use_prune) launch_choice_sparse(d, c->win_rows, st);
             if (use_resolver) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
             launch_refresh_ctrl(d, st);
@@ -507,6 +520,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             for (long long t = 0; t < worked && t < T; ++t) {
                 float ms = 0.f;
                 CK(c, hipEventElapsedTime(&ms, c->ev0[(size_t)t], c->ev1[(size_t)t]));
+                if (d.debug_flags && c->timed_launches == 0) fprintf(stderr, "[bgmm debug] first launch %.4f ms\n", ms);
                 c->timed_ms += (double)ms;
                 c->timed_launches += 1;
             }

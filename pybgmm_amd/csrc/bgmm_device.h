@@ -18,6 +18,10 @@
 //     sc[s]            scalar constants of the Student-t predictive (SlotConst)
 //   q[nslots][Wmax]    quadratic forms (mu_s - x)^T C_s^{-1} (mu_s - x) of the current window,
 //                      slot major so that both kernels touch it in full 64/128-byte segments
+//                      A PRUNED window (kernels_score.hip) reuses the same buffer block-sparse:
+//                      qb[(block * nslots + label) * 16 + v] for the 16 visits of an evaluation
+//                      block, only the (block, label) lines the pruning kernel kept are written,
+//   keep64[Wmax/16][keep_stride]  bit `label` of a block's mask = "that line holds exact scores"
 //   choice[Wmax] int32 drawn label of every visit of the current window
 #pragma once
 #include <hip/hip_runtime.h>
@@ -125,11 +129,23 @@ struct Dev {
     double *q;
     int *choice;
     int *bucket_bins;            // nslots + 2 counters of the per-window bucket sort
+    unsigned long long *keep64;  // pruned windows: per 16-visit block, bitmask over labels of the kept q lines
+    int keep_stride;             // 64-bit words per block of keep64
+    // pruned windows: per group of 16 labels (label-ordered, rebuilt at the start of every pruned
+    // window by prune_tables_kernel): the means pre-swizzled into MFMA B fragments
+    // pr_mufrag[G][Dp/4][64] (lane (lk, lr) of fragment kk = mu[perm[16G + lr]][4kk + lk]), the bound
+    // constants pr_const[G][4][16] = {logseat + A, half_vd, inv_lam * inv_cv, |mu|^2} and the slot
+    // ids pr_slot[G][16] (-1 beyond the last label)
+    double *pr_mufrag, *pr_const;
+    int *pr_slot;
+    long long *wvisit;           // pruned windows: data index of the k-th row in evaluation order
+    unsigned long long *pr_counts;  // 2 x 256 spread counters (kept, bound) of the pruning kernel
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;
     const long long *order;      // may be null (identity)
     int use_power;
     double power;
+    int debug_flags;             // (development probes; 0 in production)
     int prune_enabled;           // tuning: exact pruning of negligible components in fresh windows
 };
 
@@ -155,6 +171,7 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
+void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   // pruned windows
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);

@@ -42,13 +42,10 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double tile[];
     Ctrl *c = d.ctrl;
     const int mode = c->job.mode;
-    if (mode == MODE_DONE) return;
+    if (mode == MODE_DONE || c->job.prune) return;      // (pruned windows: choice_sparse_kernel)
     const long long pos = c->job.pos, win_base = c->job.win_base, win_hi = c->job.win_hi;
     const int K = c->job.K;
     const int R = d.choice_rows;
-    // q row index of this block's first visit: the window row itself, or -- in a pruned window,
-    // which is evaluated grouped by home component -- the evaluation position (visit = wperm[k])
-    const bool sorted = c->job.prune != 0;
     const long long k0 = (pos - win_base) + (long long)blockIdx.x * R;
     const long long kend = win_hi - win_base;
     if (k0 >= kend) return;
@@ -60,7 +57,7 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (k0 + w >= kend) return;
-    const long long p = win_base + (sorted ? (long long)d.wperm[k0 + w] : k0 + w);
+    const long long p = win_base + k0 + w;
     const int NEWIDX = d.K_max + 1;
 
     const long long i = d.order ? d.order[p] : p;
@@ -88,8 +85,6 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
             if (d.cov_type != COV_FULL) {
                 // the diag / fixed likelihood kernels store log densities (home row: one-point-removed form)
                 v = ((home_live && s == h) ? sc.logseat1 : sc.logseat) + qv;
-            } else if (qv == INFINITY) {
-                v = -INFINITY;                      // pruned by the likelihood kernel: weight exactly 0
             } else if (home_live && s == h) {
                 const double den = 1.0 - sc.a1 * qv;
                 v = sc.logseat1 + sc.A1 - 0.5 * log(den) - sc.half_vd1 * log(1.0 + sc.coef1 * qv / den);
@@ -105,7 +100,7 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     double tot = 0.0;
     for (int j = lane; j <= L; j += 64) {
         const int idx = (j == L ? NEWIDX : j) * R + w;
-        const double e = tile[idx] == -INFINITY ? 0.0 : exp(tile[idx] - mx);
+        const double e = exp(tile[idx] - mx);
         tile[idx] = e;
         tot += e;
     }
@@ -128,6 +123,129 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
         const bool stay = home_live && pick < L && d.perm[pick] == h;
         if (!stay) atomicMin(&c->first_mover, (unsigned long long)p);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Draw kernel of a PRUNED window: one thread per visit, evaluation order (visit = wperm[k]).
+// The 16 visits of evaluation block b share the block's label mask keep64[b][..]; the exact
+// quadratic forms of a kept label are the 128-byte line qb[(b*nslots + label)*16 .. +16].
+// Labels whose bit is clear were bounded below e^-80 of the visit's best weight by the pruning
+// kernel and enter with weight exactly 0.  The arithmetic follows the reference literally:
+//   prob = exp(lp - (max + log(sum exp(lp - max))))       crpmm.py:75 with scipy's logsumexp
+//   u -= prob[j] in label order, first u < 0 wins, else the last index    utils.py:15-20
+// ------------------------------------------------------------------------------------------
+struct SparseVisit {
+    const Dev *d;
+    const unsigned long long *mask;
+    const double *qline;       // + label * 16
+    int K, h, lab_h;
+    bool home_live, singleton;
+};
+
+// exact log score (seating weight + predictive) of old label t for this visit, or false if pruned
+__device__ __forceinline__ bool sparse_score(const SparseVisit &sv, int t, double &v) {
+    if (!((sv.mask[t >> 6] >> (t & 63)) & 1ull)) return false;
+    const Dev &d = *sv.d;
+    const int s = d.perm[t];
+    const double qv = sv.qline[(long long)t * 16];
+    const SlotConst *__restrict__ sc = d.sc + s;
+    if (sv.home_live && s == sv.h) {
+        const double a1 = sc->a1, den = 1.0 - a1 * qv;
+        v = sc->logseat1 + sc->A1 - 0.5 * log(den) - sc->half_vd1 * log(1.0 + sc->coef1 * qv / den);
+    } else {
+        v = sc->logseat + sc->A - sc->half_vd * log(1.0 + qv * sc->inv_cv);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
+    Ctrl *c = d.ctrl;
+    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    const long long win_base = c->job.win_base;
+    const long long nrows = c->job.win_hi - win_base;
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nrows) return;
+    const int K = c->job.K;
+    const long long p = win_base + d.wperm[k];
+    const long long i = d.order ? d.order[p] : p;
+    SparseVisit sv;
+    sv.d = &d;
+    sv.K = K;
+    sv.h = d.z[i];
+    const int nh = sv.h >= 0 ? d.n[sv.h] : 0;
+    sv.home_live = sv.h >= 0 && nh >= 2;
+    sv.singleton = sv.h >= 0 && nh == 1;
+    sv.lab_h = sv.singleton ? d.label_of_slot[sv.h] : -1;
+    const long long b = k >> 4;
+    sv.mask = d.keep64 + b * d.keep_stride;
+    sv.qline = d.q + (b * (long long)d.nslots) * 16 + (k & 15);
+    const int L = sv.singleton ? K - 1 : K;              // labels after the removal
+    const int nw = (K + 63) >> 6;
+    const double vnew = d.log_alpha + d.log_prior[i];
+
+    // Post-removal label j is old label j, except that a deleted singleton's place lab_h is taken
+    // by old label K-1 (swap with last).  Without a singleton the kept labels are walked by bit
+    // scan; the singleton case (rare) walks all L labels.
+    double mx = vnew, tot = 0.0, v;
+    int pick = L;
+    if (!sv.singleton) {
+        for (int wi = 0; wi < nw; ++wi) {
+            unsigned long long m = sv.mask[wi];
+            if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+            while (m) {
+                const int t = wi * 64 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (sparse_score(sv, t, v)) mx = fmax(mx, v);
+            }
+        }
+        for (int wi = 0; wi < nw; ++wi) {
+            unsigned long long m = sv.mask[wi];
+            if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+            while (m) {
+                const int t = wi * 64 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (sparse_score(sv, t, v)) tot += exp(v - mx);
+            }
+        }
+        tot += exp(vnew - mx);
+        const double lse = log(tot) + mx;
+        double uu = d.u[p];
+        bool done = false;
+        for (int wi = 0; wi < nw && !done; ++wi) {
+            unsigned long long m = sv.mask[wi];
+            if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+            while (m) {
+                const int t = wi * 64 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (sparse_score(sv, t, v)) {
+                    uu -= exp(v - lse);
+                    if (uu < 0.0) { pick = t; done = true; break; }
+                }
+            }
+        }
+        // (the new-table entry is the last index: it wins either by u < 0 or as the fallback)
+    } else {
+        for (int j = 0; j < L; ++j)
+            if (sparse_score(sv, j == sv.lab_h ? K - 1 : j, v)) mx = fmax(mx, v);
+        for (int j = 0; j < L; ++j)
+            if (sparse_score(sv, j == sv.lab_h ? K - 1 : j, v)) tot += exp(v - mx);
+        tot += exp(vnew - mx);
+        const double lse = log(tot) + mx;
+        double uu = d.u[p];
+        for (int j = 0; j < L; ++j)
+            if (sparse_score(sv, j == sv.lab_h ? K - 1 : j, v)) {
+                uu -= exp(v - lse);
+                if (uu < 0.0) { pick = j; break; }
+            }
+    }
+    d.choice[p - win_base] = pick;
+    const bool stay = sv.home_live && pick < L && d.perm[pick] == sv.h;
+    if (!stay) atomicMin(&c->first_mover, (unsigned long long)p);
+}
+
+void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st) {
+    if (max_rows <= 0) return;
+    hipLaunchKernelGGL(choice_sparse_kernel, dim3((unsigned)((max_rows + 255) / 256)), dim3(256), 0, st, d);
 }
 
 int choice_rows_for(int K_max) {

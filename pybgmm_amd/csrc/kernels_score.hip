@@ -14,6 +14,7 @@
 //                       initialised with cvec so the MFMA chain directly yields
 //                       y = cvec - Winv x; q = sum y^2 by a 16-lane DPP/shuffle reduction.
 #include "bgmm_device.h"
+#include <type_traits>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -247,32 +248,54 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
 // log(alpha) + log_prior[i] (crpmm.py:74) to start with, raised by every exact score computed so
 // far.  A slot whose lp_ub < M_lb - kPruneMargin for all 32 visits of the wave, and that is
 // nobody's home, has weight exp(lp - max) < e^-80 ~ 2e-35 in each of those draws -- twenty orders
-// of magnitude below the rounding noise of the normaliser -- and is not scored: q = +inf is
-// stored, which the draw kernel turns into an exact zero weight.  The bound holds against the
+// of magnitude below the rounding noise of the normaliser -- and is not scored: nothing is
+// written for it, which the draw kernel treats as an exact zero weight.  The bound holds against the
 // frozen state only, which is why a pruned window ends at its first move (slot_math.h).
 // ------------------------------------------------------------------------------------------
 static constexpr double kPruneMargin = 80.0;
 
-// minorant of log(1 + t), t >= 0: 2t/(2+t) below 1, (e + m - 1) ln 2 above (1+t = m 2^e, 1 <= m < 2)
+// minorant of log(1 + t), t >= 0:  1 + t = m 2^e with 0.5 <= m < 1, and log is concave, so
+// log(m) >= (2m - 2) ln 2 (its chord over [0.5, 1]):  log(1 + t) >= (e + 2m - 2) ln 2.
+// No division, no branch; at most 0.06 below the logarithm.
 __device__ __forceinline__ double log1p_lower(double t) {
-    if (t < 1.0) return 2.0 * t / (2.0 + t);
-    int e;
-    const double m = frexp(1.0 + t, &e);               // 1+t = m 2^e, 0.5 <= m < 1
-    return 0.6931471805599453 * ((double)(e - 1) + (2.0 * m - 1.0));
+    const double y = 1.0 + t;
+    const double m = __builtin_amdgcn_frexp_mant(y);
+    const int e = __builtin_amdgcn_frexp_exp(y);
+    return 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
 }
 
-// In a pruned window the visits are evaluated in the order of d.wperm (grouped by home component,
-// kernels_state.hip: bucket_rows_kernel), so that the visits of one wave mostly share a home and
-// need the same one or two components in full.  q is indexed by that evaluation position.
+// In a pruned window the visits are evaluated in the order of d.wvisit (grouped by home component,
+// kernels_state.hip: bucket_*_kernel), so that the visits of one wave mostly share a home and
+// need the same one or two components in full.  The output is block-sparse: for every 16-visit
+// evaluation block b a bitmask over labels (d.keep64) says which components were scored in full,
+// and only those (block, label) lines -- 16 quadratic forms, 128 bytes -- are written to
+// qb[(b * nslots + label) * 16 + v].  The draw kernel for pruned windows (choice_sparse_kernel)
+// reads nothing else.  Labels are handed out in groups of 16 (group G = labels 16G .. 16G+15,
+// one MFMA column each), group G to chunk G % chunks; everything a group needs comes from the
+// label-ordered tables prune_tables_kernel built for this window (coalesced 512-byte fragments).
+//
+// The bound is evaluated in two levels: first on the leading 32 dimensions only
+// (|mu - x|^2 >= sum_{l<32} (mu_l - x_l)^2: 8 MFMAs per block and group), and only for groups in
+// which some (visit, label) survives that on all Dp dimensions (the remaining Dp/4 - 4 MFMAs).
+//
+// The 32 rows of a wave are staged through LDS (row-contiguous 512-byte global loads, then the
+// A fragments x[row lr][4kk + lk] are read back; row stride Ds = 4 mod 32 doubles).
+__host__ __device__ constexpr int prune_row_stride(int Dp) { return ((Dp + 27) / 32) * 32 + 4; }
+
 template <int NJ, int RB, int MINW>
 __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
                                                                   double *__restrict__ q, long long qstride) {
+    extern __shared__ __attribute__((aligned(16))) double xs_all[];
     const JobView job = load_job(jobp);
     if (job.mode != MODE_FRESH || !job.prune) return;
     const int chunk = blockIdx.y;
-    if (chunk >= job.chunks || chunk >= job.nlist) return;
+    const int ngroups = (job.nlist + 15) >> 4;
+    if (chunk >= job.chunks || chunk >= ngroups) return;
     constexpr int ROWS_W = 16 * RB;
     constexpr int NF = 2 * NJ * (NJ + 1);
+    constexpr int NKK = NJ * 4;
+    constexpr int NK0 = NKK < 8 ? NKK : 8;                        // fragments of the level-0 bound (32 dimensions)
+    constexpr int Ds = prune_row_stride(NJ * 16);
     const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
     const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
     if (kb >= nrows) return;
@@ -280,139 +303,116 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long kw = kb + w * ROWS_W;                         // first evaluation position of the wave
-    if (kw >= nrows) return;
     const int lr = lane & 15, lk = lane >> 4;
 
-    double xf[RB][NJ * 4];
-#pragma unroll
-    for (int R = 0; R < RB; ++R) {
-        const long long k = kw + R * 16 + lr;
-        const bool live = k < nrows;
-        const long long p = live ? job.win_base + d.wperm[k] : 0;
-        const long long i = live ? (d.order ? d.order[p] : p) : 0;
-        const double *__restrict__ xrow = d.X + i * D;
-#pragma unroll
-        for (int kk = 0; kk < NJ * 4; ++kk) {
-            const int l = 4 * kk + lk;
-            xf[R][kk] = (live && l < D) ? xrow[l] : 0.0;
-        }
-    }
-    // Per accumulator element (visits lk + 4r of block R): |x|^2, the lower bound of the visit's best
-    // log score, its home slot (never pruned).  Dead rows can never keep a slot alive.
-    double x2[RB][4], Mlb[RB][4];
+    const long long nfrag64 = (long long)NF * 64;
+    const long long blk0 = kw >> 4;                                // evaluation block of R = 0
+    // ---- stage the wave's rows: lane r < 32 owns the data index of row r
+    double *__restrict__ xs = xs_all + w * (ROWS_W * Ds);
+    const long long kmine = kw + (lane & (ROWS_W - 1));
+    const long long imine = kmine < nrows ? d.wvisit[kmine] : -1;
+    // gathers behind the bound (accumulator layout: visits lk + 4r of block R), issued before the rows
+    double Mlb[RB][4];
     int home[RB][4];
 #pragma unroll
-    for (int R = 0; R < RB; ++R) {
-        // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes) ...
-        double part = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < NJ * 4; ++kk) part = fma(xf[R][kk], xf[R][kk], part);
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        // ... re-distributed to the accumulator layout: rows lk + 4r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x2[R][r] = __shfl(part, lk + 4 * r);
+    for (int R = 0; R < RB; ++R)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long k = kw + R * 16 + lk + 4 * r;
-            if (k < nrows) {
-                const long long p = job.win_base + d.wperm[k];
-                const long long i = d.order ? d.order[p] : p;
-                Mlb[R][r] = d.log_alpha + d.log_prior[i];
-                home[R][r] = d.z[i];
-            } else {
-                Mlb[R][r] = INFINITY;
-                home[R][r] = -2;
+            const long long i = __shfl(imine, R * 16 + lk + 4 * r);
+            Mlb[R][r] = i >= 0 ? d.log_alpha + d.log_prior[i] : INFINITY;   // dead rows never keep a slot alive
+            home[R][r] = i >= 0 ? d.z[i] : -2;
+        }
+    const int hmine = imine >= 0 ? d.z[imine] : -2;                // home slot of row (lane & 31)
+    {
+        // all row loads in flight at once (unconditional, clamped addresses), then the LDS writes
+        constexpr int NP = (NJ * 16 + 63) / 64;
+        double tmp[ROWS_W][NP];
+#pragma unroll
+        for (int row = 0; row < ROWS_W; ++row) {
+            const long long i = __shfl(imine, row);
+            const double *__restrict__ xrow = d.X + (i >= 0 ? i : 0) * D;
+#pragma unroll
+            for (int pss = 0; pss < NP; ++pss) {
+                const int l = pss * 64 + lane;
+                tmp[row][pss] = xrow[l < D ? l : 0];
             }
+        }
+#pragma unroll
+        for (int row = 0; row < ROWS_W; ++row) {
+            const long long i = __shfl(imine, row);
+#pragma unroll
+            for (int pss = 0; pss < NP; ++pss) {
+                const int l = pss * 64 + lane;
+                const double v = (i >= 0 && l < D) ? tmp[row][pss] : 0.0;
+                if (NJ * 16 >= (pss + 1) * 64 || l < NJ * 16) xs[row * Ds + l] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (kw >= nrows) return;
+    double xf[RB][NKK];
+#pragma unroll
+    for (int R = 0; R < RB; ++R)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) xf[R][kk] = xs[(R * 16 + lr) * Ds + 4 * kk + lk];
+
+    unsigned short *__restrict__ keep16 = (unsigned short *)d.keep64;
+    unsigned n_kept = 0, n_bound = 0;
+
+    // Work list of the wave (reuses its staging area in LDS -- the rows live in registers now):
+    // entries  slot | label << 12.. are packed as two ints {slot, label | store0 << 30 | store1 << 31}.
+    // The kernel alternates between "score everything on the list exactly" and "bound groups of
+    // labels until the list is full", so that the two register-hungry parts are never live together.
+    int *__restrict__ wlist = (int *)xs;
+    constexpr int LIST_CAP = (ROWS_W * Ds * 8) / 8 - 16;           // entries (2 ints each), 16 spare per group
+    int n_list = 0;
+
+    // ---- the home components first (the visits are grouped by home: mostly one or two per wave),
+    // so that every bound below is taken against a tight Mlb.  Their q lines are stored for both
+    // blocks; the group loop skips them.  Up to 4 distinct homes; the rest is found by the loop.
+    int done0 = -1, done1 = -1, done2 = -1, done3 = -1;
+    {
+        unsigned long long pending = __ballot(lane < ROWS_W && hmine >= 0);
+#pragma unroll 1
+        for (int it = 0; it < 4 && pending; ++it) {
+            const int first = __ffsll((long long)pending) - 1;
+            const int s = __builtin_amdgcn_readfirstlane(__shfl(hmine, first));
+            pending &= ~__ballot(lane < ROWS_W && hmine == s);
+            wlist[2 * n_list] = s;
+            wlist[2 * n_list + 1] = d.label_of_slot[s] | (3 << 30);
+            ++n_list;
+            if (it == 0) done0 = s; else if (it == 1) done1 = s; else if (it == 2) done2 = s; else done3 = s;
         }
     }
 
-    const long long nfrag64 = (long long)NF * 64;
-    unsigned n_kept = 0, n_bound = 0;
-    // groups of 16 list entries: lane column lr <-> entry t0 + chunks * lr
-    for (int t0 = chunk; t0 < job.nlist; t0 += 16 * job.chunks) {
-        const int tl = t0 + job.chunks * lr;
-        const int sg = tl < job.nlist ? job_slot(d, job, tl) : -1;
-        // distances to the 16 means: G = X . Mu'  (B fragment: mu_sg[4kk + lk])
-        v4d accG[RB];
-#pragma unroll
-        for (int R = 0; R < RB; ++R) accG[R] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double *__restrict__ mup = d.mu + (long long)(sg >= 0 ? sg : 0) * D + lk;
-#pragma unroll
-        for (int kk = 0; kk < NJ * 4; ++kk) {
-            const double bm = (sg >= 0 && 4 * kk + lk < D) ? mup[4 * kk] : 0.0;
-#pragma unroll
-            for (int R = 0; R < RB; ++R)
-                accG[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bm, accG[R], 0, 0, 0);
-        }
-        bool need[RB];
-        {
-            const SlotConst *__restrict__ scp = d.sc + (sg >= 0 ? sg : 0);
-            const double base = scp->logseat + scp->A, hvd = scp->half_vd, icv = scp->inv_cv;
-            const double ilam = scp->inv_lam, mu2 = scp->mu2;
-#pragma unroll
-            for (int R = 0; R < RB; ++R) {
-                need[R] = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double nrm = x2[R][r] + mu2;
-                    double dist2 = nrm - 2.0 * accG[R][r] - 1e-9 * nrm;     // (rounding of the difference)
-                    dist2 = dist2 > 0.0 ? dist2 : 0.0;
-                    const double ub = base - hvd * log1p_lower(dist2 * ilam * icv);
-                    need[R] = need[R] || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
-                }
-                need[R] = need[R] && sg >= 0;
-            }
-        }
-        // fold the votes of the 4 lk lanes (and 4 r's) of every slot column
-        unsigned keepmask[RB];
-#pragma unroll
-        for (int R = 0; R < RB; ++R) {
-            const unsigned long long bl = __ballot(need[R]);
-            keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull);
-        }
-        // pruned (block of 16 visits, slot) pairs: exact zero weight downstream
-#pragma unroll
-        for (int R = 0; R < RB; ++R) {
-            if (sg >= 0 && !((keepmask[R] >> lr) & 1u)) {
-                double *__restrict__ qc = q + (long long)sg * qstride;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long k = kw + R * 16 + lk + 4 * r;
-                    if (k < nrows) qc[k] = INFINITY;
-                }
-            }
-        }
-        // the slots somebody needs: full quadratic form, tiles fetched in batches of 8
-        unsigned todo = 0;
-#pragma unroll
-        for (int R = 0; R < RB; ++R) {
-            todo |= keepmask[R];
-            n_kept += __popc(keepmask[R]);
-        }
-        {
-            const int left = (job.nlist - t0 + job.chunks - 1) / job.chunks;
-            n_bound += RB * (left < 16 ? left : 16);
-        }
-        while (todo) {
-            const int jbit = __ffs(todo) - 1;
-            todo &= todo - 1;
-            const int s = __builtin_amdgcn_readlane(sg, jbit);
+    int G = chunk;
+    bool tables_ready = false;
+    double x2[RB][4], x2p[RB][4];
+#pragma unroll 1
+    for (;;) {
+        // ================= exact quadratic forms of the listed (slot, label) entries =================
+#pragma unroll 1
+        for (int e = 0; e < n_list; ++e) {
+            const int s = __builtin_amdgcn_readfirstlane(wlist[2 * e]);
+            const int lf = __builtin_amdgcn_readfirstlane(wlist[2 * e + 1]);
+            const int label = lf & 0x3FFFFFFF;
             const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
             const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
-            double qp[RB][4];
-#pragma unroll
-            for (int R = 0; R < RB; ++R)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
             // software pipeline over the slot's NF tiles: a ring of PFK loads in flight
-            constexpr int PFK = NF < 16 ? NF : 16;
+            constexpr int PFK = NF < 20 ? NF : 20;
             double ringk[PFK];
 #pragma unroll
             for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
             double cjk[NJ];
 #pragma unroll
             for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
+            const SlotConst scs = d.sc[s];
+            const int ns = d.n[s];
+            double qp[RB][4];
+#pragma unroll
+            for (int R = 0; R < RB; ++R)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
                 v4d acc[RB];
@@ -421,41 +421,171 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
                 for (int kk = 0; kk < 4 * (J + 1); ++kk) {
                     const int f = 2 * J * (J + 1) + kk;          // constant after unrolling
-                    const double b = ringk[f % PFK];
+                    const double bfr = ringk[f % PFK];
                     if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
 #pragma unroll
                     for (int R = 0; R < RB; ++R)
-                        acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], b, acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bfr, acc[R], 0, 0, 0);
                 }
 #pragma unroll
                 for (int R = 0; R < RB; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) qp[R][r] = fma(acc[R][r], acc[R][r], qp[R][r]);
             }
-            const SlotConst scs = d.sc[s];
-            const int ns = d.n[s];
-            double *__restrict__ qcol = q + (long long)s * qstride;
 #pragma unroll
             for (int R = 0; R < RB; ++R) {
-                const bool kept = (keepmask[R] >> jbit) & 1u;      // else this block's column holds +inf
+                double v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double v = row16_sum(qp[R][r]);
-                    const long long k = kw + R * 16 + lk + 4 * r;
-                    if (kept && lr == r && k < nrows) qcol[k] = v;
+                    v[r] = row16_sum(qp[R][r]);                   // visit lk + 4r, in all 16 lanes of the row
                     // an exact score is a lower bound of the visit's maximum (the home component
-                    // counts with its one-point-removed form, exactly as the draw kernel scores it)
-                    if (k < nrows) {
-                        const bool own = home[R][r] == s;
-                        if (!own || ns >= 2) Mlb[R][r] = fmax(Mlb[R][r], slot_score_exact(scs, v, own));
-                    }
+                    // counts with its one-point-removed form, exactly as the draw kernel scores it);
+                    // dead rows have Mlb = +inf already
+                    const bool own = home[R][r] == s;
+                    if (!own || ns >= 2) Mlb[R][r] = fmax(Mlb[R][r], slot_score_exact(scs, v[r], own));
                 }
+                // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr
+                const double mine = lr == 0 ? v[0] : (lr == 1 ? v[1] : (lr == 2 ? v[2] : v[3]));
+                if (((lf >> (30 + R)) & 1) && lr < 4 && kw + R * 16 < nrows)
+                    q[((blk0 + R) * (long long)d.nslots + label) * 16 + lk + 4 * lr] = mine;
+            }
+        }
+        n_list = 0;
+        if (G >= ngroups) break;
+
+        // ================= bounds, group by group, until the list is full =================
+        if (!tables_ready) {
+            tables_ready = true;
+            // |x|^2 per accumulator element (all dimensions; leading 32 only)
+#pragma unroll
+            for (int R = 0; R < RB; ++R) {
+                // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes) ...
+                double part0 = 0.0, part = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NK0; ++kk) part0 = fma(xf[R][kk], xf[R][kk], part0);
+#pragma unroll
+                for (int kk = NK0; kk < NKK; ++kk) part = fma(xf[R][kk], xf[R][kk], part);
+                part += part0;
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                part0 += __shfl_xor(part0, 16);
+                part0 += __shfl_xor(part0, 32);
+                // ... re-distributed to the accumulator layout: rows lk + 4r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    x2[R][r] = __shfl(part, lk + 4 * r);
+                    x2p[R][r] = __shfl(part0, lk + 4 * r);
+                }
+            }
+        }
+        // Software pipeline over the groups: the level-0 fragments + constants of the next group are
+        // in flight while this one is being bounded.
+        struct GroupConst { double base, hvd, tcoef, mu2, mu2p; };
+        auto load_group = [&](int Gq, int &sg_o, double (&bm_o)[NK0], GroupConst &gc_o) {
+            const bool in = Gq < ngroups;
+            const int Gc = in ? Gq : chunk;
+            sg_o = in ? d.pr_slot[Gc * 16 + lr] : -1;
+            const double *__restrict__ mf = d.pr_mufrag + (long long)Gc * (NKK * 64) + lane;
+#pragma unroll
+            for (int kk = 0; kk < NK0; ++kk) bm_o[kk] = mf[kk * 64];
+            const double *__restrict__ g = d.pr_const + (long long)Gc * 128 + lr;
+            gc_o.base = g[0]; gc_o.hvd = g[16]; gc_o.tcoef = g[32]; gc_o.mu2 = g[48]; gc_o.mu2p = g[64];
+        };
+        int sg_next;
+        double bm_next[NK0];
+        GroupConst gc_next;
+        load_group(G, sg_next, bm_next, gc_next);
+#pragma unroll 1
+        for (; G < ngroups && n_list <= LIST_CAP; G += job.chunks) {
+            const int sg = sg_next;
+            const GroupConst gc = gc_next;
+            double bm[NK0];
+#pragma unroll
+            for (int kk = 0; kk < NK0; ++kk) bm[kk] = bm_next[kk];
+            load_group(G + job.chunks, sg_next, bm_next, gc_next);
+            // distances to the 16 means: X . Mu'  (B fragment: mu_sg[4kk + lk]); leading dimensions
+            v4d accG[RB];
+#pragma unroll
+            for (int R = 0; R < RB; ++R) accG[R] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < NK0; ++kk)
+#pragma unroll
+                for (int R = 0; R < RB; ++R)
+                    accG[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bm[kk], accG[R], 0, 0, 0);
+            bool need[RB];
+            bool any0 = false;
+#pragma unroll
+            for (int R = 0; R < RB; ++R) {
+                need[R] = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double nrm = x2p[R][r] + gc.mu2p;
+                    double dist2 = fma(-2.0, accG[R][r], nrm) - 1e-9 * nrm;     // (rounding of the difference)
+                    dist2 = dist2 > 0.0 ? dist2 : 0.0;
+                    const double ub = gc.base - gc.hvd * log1p_lower(dist2 * gc.tcoef);
+                    need[R] = need[R] || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
+                }
+                need[R] = need[R] && sg >= 0;
+                any0 = any0 || need[R];
+            }
+            if (NKK > NK0 && __ballot(any0) != 0ull) {
+                // somebody survives the leading-dimension bound: the distance on all dimensions
+                const double *__restrict__ mf = d.pr_mufrag + (long long)G * (NKK * 64) + lane;
+                double bmr[NKK > NK0 ? NKK - NK0 : 1];
+#pragma unroll
+                for (int kk = NK0; kk < NKK; ++kk) bmr[kk - NK0] = mf[kk * 64];
+#pragma unroll
+                for (int kk = NK0; kk < NKK; ++kk)
+#pragma unroll
+                    for (int R = 0; R < RB; ++R)
+                        accG[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bmr[kk - NK0], accG[R], 0, 0, 0);
+#pragma unroll
+                for (int R = 0; R < RB; ++R) {
+                    bool nd = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double nrm = x2[R][r] + gc.mu2;
+                        double dist2 = fma(-2.0, accG[R][r], nrm) - 1e-9 * nrm;
+                        dist2 = dist2 > 0.0 ? dist2 : 0.0;
+                        const double ub = gc.base - gc.hvd * log1p_lower(dist2 * gc.tcoef);
+                        nd = nd || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
+                    }
+                    need[R] = need[R] && nd;
+                }
+            }
+            // fold the votes of the 4 lk lanes (and 4 r's) of every label column; publish the block's
+            // 16 mask bits of this group (every (block, group) is written exactly once per window)
+            unsigned keepmask[RB];
+#pragma unroll
+            for (int R = 0; R < RB; ++R) {
+                const unsigned long long bl = __ballot(need[R]);
+                keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull);
+                if (lane == 0 && kw + R * 16 < nrows)
+                    keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = (unsigned short)keepmask[R];
+                n_kept += __popc(keepmask[R]);
+            }
+            {
+                const int left = job.nlist - 16 * G;
+                n_bound += RB * (left < 16 ? left : 16);
+            }
+            // the labels somebody needs go on the list (the homes scored up front are done already)
+            unsigned todo = keepmask[0] | keepmask[RB - 1];
+            while (todo) {
+                const int jbit = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const int s = __builtin_amdgcn_readlane(sg, jbit);
+                if (s == done0 || s == done1 || s == done2 || s == done3) continue;
+                wlist[2 * n_list] = s;
+                wlist[2 * n_list + 1] = (16 * G + jbit) | (((keepmask[0] >> jbit) & 1u) << 30)
+                                        | (((keepmask[RB - 1] >> jbit) & 1u) << 31);
+                ++n_list;
             }
         }
     }
     if (lane == 0) {
-        atomicAdd(&d.ctrl->n_kept_blocks, (unsigned long long)n_kept);
-        atomicAdd(&d.ctrl->n_bound_blocks, (unsigned long long)n_bound);
+        // (counters spread over 256 addresses; apply_kernel folds them)
+        atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
+        atomicAdd(&d.pr_counts[256 + (blockIdx.x & 255)], (unsigned long long)n_bound);
     }
 }
 
@@ -463,8 +593,14 @@ template <int NJ>
 static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    hipLaunchKernelGGL((score_mfma_prune_kernel<NJ, 2, (NJ <= 5 ? 2 : 1)>), dim3(gx, kMaxChunks),
-                       dim3(256), 0, st, d, job, q, qstride);
+    constexpr int lds = 4 * 32 * prune_row_stride(NJ * 16) * (int)sizeof(double);
+    auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }
 
 // Fresh-window scoring with pruning

@@ -316,7 +316,44 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < BUCKET_ROWS / 256; ++t)
-        if (myb[t] >= 0) d.wperm[res[myb[t]] + myk[t]] = r0 + threadIdx.x + t * 256;
+        if (myb[t] >= 0) {
+            const int r = r0 + threadIdx.x + t * 256;
+            const int k = res[myb[t]] + myk[t];
+            const long long p = base + r;
+            d.wperm[k] = r;
+            d.wvisit[k] = d.order ? d.order[p] : p;
+        }
+}
+
+// Label-ordered tables of the pruning kernel for the frozen state of this window (bgmm_device.h).
+__global__ __launch_bounds__(64) void prune_tables_kernel(Dev d) {
+    const Ctrl *c = d.ctrl;
+    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    const int K = c->job.K, G = blockIdx.x;
+    if (16 * G >= K) return;
+    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    const int t = 16 * G + lr;
+    const int s = t < K ? d.perm[t] : -1;
+    const int nkk = d.Dp / 4, D = d.D;
+    for (int kk = 0; kk < nkk; ++kk) {
+        const int l = 4 * kk + lk;
+        d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
+    }
+    if (lk == 0) {
+        const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
+        double *g = d.pr_const + (long long)G * 128 + lr;
+        g[0] = sc->logseat + sc->A;
+        g[16] = sc->half_vd;
+        g[32] = sc->inv_lam * sc->inv_cv;
+        g[48] = sc->mu2;
+        double m2p = 0.0;                        // |mu|^2 over the leading 32 dimensions (level-0 bound)
+        for (int l = 0; l < 32 && l < D; ++l) {
+            const double v = s >= 0 ? d.mu[(long long)s * D + l] : 0.0;
+            m2p += v * v;
+        }
+        g[64] = m2p;
+        d.pr_slot[G * 16 + lr] = s;
+    }
 }
 
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
@@ -326,6 +363,7 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
     hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), nb * (int)sizeof(int), st, d);
     hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(1024), 0, st, d);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
+    hipLaunchKernelGGL(prune_tables_kernel, dim3((unsigned)((d.nslots + 15) / 16)), dim3(64), 0, st, d);
 }
 
 void launch_sweep_begin(const Dev &d, hipStream_t st) {
@@ -466,6 +504,23 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     __shared__ MovePlan mp;
     __shared__ int do_move;
     Ctrl *c = d.ctrl;
+    if (c->job.mode == MODE_FRESH && c->job.prune && !c->skip_apply) {
+        // fold (and clear) the pruning kernel's spread counters of this window
+        __shared__ unsigned long long cnt_red[2 * TPB];
+        cnt_red[threadIdx.x] = d.pr_counts[threadIdx.x];
+        cnt_red[TPB + threadIdx.x] = d.pr_counts[256 + threadIdx.x];
+        d.pr_counts[threadIdx.x] = 0;
+        d.pr_counts[256 + threadIdx.x] = 0;
+        __syncthreads();
+        for (int o = TPB / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                cnt_red[threadIdx.x] += cnt_red[threadIdx.x + o];
+                cnt_red[TPB + threadIdx.x] += cnt_red[TPB + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { c->n_kept_blocks += cnt_red[0]; c->n_bound_blocks += cnt_red[TPB]; }
+    }
     if (threadIdx.x == 0) {
         do_move = 0;
         Job &j = c->job;

@@ -280,6 +280,12 @@ __device__ inline void set_chunks(const Dev &d, Job &j) {
     long long ch = rb > 0 ? (d.target_blocks + rb - 1) / rb : 1;
     if (ch > kMaxChunks) ch = kMaxChunks;
     if (ch > nlist) ch = nlist;
+    if (j.prune) {
+        // the pruning kernel hands out GROUPS of 16 labels; a wave's fixed cost (its 32 rows of X,
+        // the gathers behind Mlb) is paid once per chunk, so as few chunks as fill the chip
+        const long long ngroups = (nlist + 15) / 16;
+        if (ch > ngroups) ch = ngroups;
+    }
     if (ch < 1) ch = 1;
     j.chunks = (int)ch;
 }
