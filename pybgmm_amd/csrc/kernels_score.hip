@@ -27,6 +27,16 @@ __device__ __forceinline__ double slot_score_exact(const SlotConst &sc, double q
     return sc.logseat + sc.A - sc.half_vd * log(1.0 + qv * sc.inv_cv);
 }
 
+// Cheap LOWER bound of the same score (log(1 + t) <= t; for the home form -0.5 log(den) >= 0 because
+// 0 < den <= 1): what the pruning kernel raises a visit's best-score bound with.
+__device__ __forceinline__ double slot_score_lower(const SlotConst &sc, double qv, bool home_minus_one) {
+    if (home_minus_one) {
+        const double den = 1.0 - sc.a1 * qv;
+        return den > 0.0 ? sc.logseat1 + sc.A1 - sc.half_vd1 * (sc.coef1 * qv / den) : -INFINITY;
+    }
+    return sc.logseat + sc.A - sc.half_vd * (qv * sc.inv_cv);
+}
+
 // The Job is read field by field (a by-value copy with a dynamically indexed dirty[] member
 // ends up in scratch memory).
 struct JobView {
@@ -122,6 +132,13 @@ __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_mov_f64<0x141>(v);
     v += dpp_mov_f64<0x140>(v);
     return v;
+}
+
+constexpr int pick_ring(int nf, int cap) {
+    int best = 1;
+    for (int p = 1; p <= cap && p <= nf; ++p)
+        if (nf % p == 0) best = p;
+    return best;
 }
 
 constexpr int pick_pf(int nf) {
@@ -254,6 +271,12 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
 // ------------------------------------------------------------------------------------------
 static constexpr double kPruneMargin = 80.0;
 
+__device__ __forceinline__ long long readlane64(long long v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 // minorant of log(1 + t), t >= 0:  1 + t = m 2^e with 0.5 <= m < 1, and log is concave, so
 // log(m) >= (2m - 2) ln 2 (its chord over [0.5, 1]):  log(1 + t) >= (e + 2m - 2) ln 2.
 // No division, no branch; at most 0.06 below the logarithm.
@@ -299,6 +322,14 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
     const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
     if (kb >= nrows) return;
+    const bool probe = (d.debug_flags & 1024) && (threadIdx.x & 255) == 0 && (blockIdx.x == 0 || blockIdx.x == 600) && chunk == 0;
+    long long *pr = d.ctrl->prof + (blockIdx.x == 0 ? 0 : 8);
+    if (probe) { pr[0] = wall_clock64(); pr[5] = 0; pr[6] = 0; }
+    if ((d.debug_flags & 2048) && threadIdx.x == 0 && chunk == 0 && job.win_base == 0) {
+        const int bx = blockIdx.x;
+        const int slot = bx == 0 ? 0 : bx == 255 ? 1 : bx == 256 ? 2 : bx == 511 ? 3 : bx == 512 ? 4 : bx == 700 ? 5 : bx == 1023 ? 6 : -1;
+        if (slot >= 0) d.ctrl->prof[8 + slot] = wall_clock64();
+    }
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -311,25 +342,52 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     double *__restrict__ xs = xs_all + w * (ROWS_W * Ds);
     const long long kmine = kw + (lane & (ROWS_W - 1));
     const long long imine = kmine < nrows ? d.wvisit[kmine] : -1;
-    // gathers behind the bound (accumulator layout: visits lk + 4r of block R), issued before the rows
-    double Mlb[RB][4];
-    int home[RB][4];
-#pragma unroll
-    for (int R = 0; R < RB; ++R)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long i = __shfl(imine, R * 16 + lk + 4 * r);
-            Mlb[R][r] = i >= 0 ? d.log_alpha + d.log_prior[i] : INFINITY;   // dead rows never keep a slot alive
-            home[R][r] = i >= 0 ? d.z[i] : -2;
-        }
+    // gathers behind the bound, one value per row of the wave: the lower bound of the visit's best log
+    // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
+    // (wave-private side arrays behind the staging area; accumulator element (R, r) of lane (lk, .)
+    // is row 16 R + lk + 4 r).
+    double *__restrict__ sideM = xs_all + 4 * (ROWS_W * Ds) + w * 128;       // Mlb[32]
+    double *__restrict__ sideX2 = sideM + 32;                                 // |x|^2, all dimensions
+    double *__restrict__ sideX2p = sideM + 64;                                // |x|^2, leading dimensions
+    int *__restrict__ sideH = (int *)(sideM + 96);                            // home slot
     const int hmine = imine >= 0 ? d.z[imine] : -2;                // home slot of row (lane & 31)
+    if (lane < ROWS_W) {
+        sideM[lane] = imine >= 0 ? d.log_alpha + d.log_prior[imine] : INFINITY;   // dead rows never keep a slot alive
+        sideH[lane] = hmine;
+    }
+    // ---- the home components come first (the visits are grouped by home: mostly one or two per
+    // wave), so that every bound below is taken against a tight Mlb.  Their q lines are stored for
+    // both blocks; the group loop skips them.  Up to 4 distinct homes; the rest is found by the loop.
+    int done0 = -1, done1 = -1, done2 = -1, done3 = -1;
+    int lab0 = 0, lab1 = 0, lab2 = 0, lab3 = 0, n_home = 0;
+    {
+        unsigned long long pending = __ballot(lane < ROWS_W && hmine >= 0);
+#pragma unroll 1
+        for (int it = 0; it < 4 && pending; ++it) {
+            const int first = __ffsll((long long)pending) - 1;
+            const int s = __builtin_amdgcn_readfirstlane(__shfl(hmine, first));
+            pending &= ~__ballot(lane < ROWS_W && hmine == s);
+            const int lab = d.label_of_slot[s];
+            if (it == 0) { done0 = s; lab0 = lab; } else if (it == 1) { done1 = s; lab1 = lab; }
+            else if (it == 2) { done2 = s; lab2 = lab; } else { done3 = s; lab3 = lab; }
+            ++n_home;
+        }
+    }
+    // the first ring of inverse-factor tiles of the first home travels together with the rows
+    constexpr int PFK = pick_ring(NF, 20);
+    double ringk[PFK];
+    {
+        const double *__restrict__ wf = d.Wfrag + (long long)(done0 >= 0 ? done0 : 0) * nfrag64 + lane;
+#pragma unroll
+        for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
+    }
     {
         // all row loads in flight at once (unconditional, clamped addresses), then the LDS writes
         constexpr int NP = (NJ * 16 + 63) / 64;
         double tmp[ROWS_W][NP];
 #pragma unroll
         for (int row = 0; row < ROWS_W; ++row) {
-            const long long i = __shfl(imine, row);
+            const long long i = readlane64(imine, row);
             const double *__restrict__ xrow = d.X + (i >= 0 ? i : 0) * D;
 #pragma unroll
             for (int pss = 0; pss < NP; ++pss) {
@@ -339,7 +397,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
         }
 #pragma unroll
         for (int row = 0; row < ROWS_W; ++row) {
-            const long long i = __shfl(imine, row);
+            const long long i = readlane64(imine, row);
 #pragma unroll
             for (int pss = 0; pss < NP; ++pss) {
                 const int l = pss * 64 + lane;
@@ -356,38 +414,25 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) xf[R][kk] = xs[(R * 16 + lr) * Ds + 4 * kk + lk];
 
+    if (probe) pr[1] = wall_clock64() + ((long long)(xf[0][0]) & 1);
     unsigned short *__restrict__ keep16 = (unsigned short *)d.keep64;
     unsigned n_kept = 0, n_bound = 0;
 
     // Work list of the wave (reuses its staging area in LDS -- the rows live in registers now):
-    // entries  slot | label << 12.. are packed as two ints {slot, label | store0 << 30 | store1 << 31}.
-    // The kernel alternates between "score everything on the list exactly" and "bound groups of
-    // labels until the list is full", so that the two register-hungry parts are never live together.
+    // two ints per entry {slot, label | store0 << 30 | store1 << 31}.  The kernel alternates between
+    // "score everything on the list exactly" and "bound groups of labels until the list is full", so
+    // that the two register-hungry parts are never live together.
     int *__restrict__ wlist = (int *)xs;
-    constexpr int LIST_CAP = (ROWS_W * Ds * 8) / 8 - 16;           // entries (2 ints each), 16 spare per group
-    int n_list = 0;
-
-    // ---- the home components first (the visits are grouped by home: mostly one or two per wave),
-    // so that every bound below is taken against a tight Mlb.  Their q lines are stored for both
-    // blocks; the group loop skips them.  Up to 4 distinct homes; the rest is found by the loop.
-    int done0 = -1, done1 = -1, done2 = -1, done3 = -1;
-    {
-        unsigned long long pending = __ballot(lane < ROWS_W && hmine >= 0);
-#pragma unroll 1
-        for (int it = 0; it < 4 && pending; ++it) {
-            const int first = __ffsll((long long)pending) - 1;
-            const int s = __builtin_amdgcn_readfirstlane(__shfl(hmine, first));
-            pending &= ~__ballot(lane < ROWS_W && hmine == s);
-            wlist[2 * n_list] = s;
-            wlist[2 * n_list + 1] = d.label_of_slot[s] | (3 << 30);
-            ++n_list;
-            if (it == 0) done0 = s; else if (it == 1) done1 = s; else if (it == 2) done2 = s; else done3 = s;
-        }
-    }
+    constexpr int LIST_CAP = ROWS_W * Ds - 16;                     // entries; 16 spare per group
+    int n_list = n_home;
+    if (n_home > 0) { wlist[0] = done0; wlist[1] = lab0 | (3 << 30); }
+    if (n_home > 1) { wlist[2] = done1; wlist[3] = lab1 | (3 << 30); }
+    if (n_home > 2) { wlist[4] = done2; wlist[5] = lab2 | (3 << 30); }
+    if (n_home > 3) { wlist[6] = done3; wlist[7] = lab3 | (3 << 30); }
+    bool ring_ready = n_home > 0;                                  // ringk holds the first tiles of entry 0
 
     int G = chunk;
     bool tables_ready = false;
-    double x2[RB][4], x2p[RB][4];
 #pragma unroll 1
     for (;;) {
         // ================= exact quadratic forms of the listed (slot, label) entries =================
@@ -398,11 +443,16 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             const int label = lf & 0x3FFFFFFF;
             const double *__restrict__ wf = d.Wfrag + (long long)s * nfrag64 + lane;
             const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
-            // software pipeline over the slot's NF tiles: a ring of PFK loads in flight
-            constexpr int PFK = NF < 20 ? NF : 20;
-            double ringk[PFK];
+            // software pipeline over the slot's NF tiles: a ring of PFK loads in flight, refilled with
+            // the NEXT entry's first tiles as this entry's run out (NF is a multiple of PFK)
+            if (!ring_ready) {
 #pragma unroll
-            for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
+                for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
+            }
+            const bool has_next = e + 1 < n_list;
+            const int s_next = has_next ? __builtin_amdgcn_readfirstlane(wlist[2 * e + 2]) : s;
+            const double *__restrict__ wf_next = d.Wfrag + (long long)s_next * nfrag64 + lane;
+            ring_ready = has_next;
             double cjk[NJ];
 #pragma unroll
             for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
@@ -423,6 +473,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     const int f = 2 * J * (J + 1) + kk;          // constant after unrolling
                     const double bfr = ringk[f % PFK];
                     if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
+                    else if (has_next) ringk[f % PFK] = wf_next[(f + PFK - NF) * 64];
 #pragma unroll
                     for (int R = 0; R < RB; ++R)
                         acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bfr, acc[R], 0, 0, 0);
@@ -438,11 +489,14 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = row16_sum(qp[R][r]);                   // visit lk + 4r, in all 16 lanes of the row
-                    // an exact score is a lower bound of the visit's maximum (the home component
-                    // counts with its one-point-removed form, exactly as the draw kernel scores it);
-                    // dead rows have Mlb = +inf already
-                    const bool own = home[R][r] == s;
-                    if (!own || ns >= 2) Mlb[R][r] = fmax(Mlb[R][r], slot_score_exact(scs, v[r], own));
+                    // a lower bound of this score is a lower bound of the visit's maximum (the home
+                    // component counts with its one-point-removed form, as the draw kernel scores
+                    // it); dead rows have Mlb = +inf already
+                    if (lr == 0) {
+                        const int row = R * 16 + lk + 4 * r;
+                        const bool own = sideH[row] == s;
+                        if (!own || ns >= 2) sideM[row] = fmax(sideM[row], slot_score_lower(scs, v[r], own));
+                    }
                 }
                 // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr
                 const double mine = lr == 0 ? v[0] : (lr == 1 ? v[1] : (lr == 2 ? v[2] : v[3]));
@@ -450,16 +504,18 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     q[((blk0 + R) * (long long)d.nslots + label) * 16 + lk + 4 * lr] = mine;
             }
         }
+        if (probe) { const long long t = wall_clock64() + ((long long)sideM[0] & 1); if (pr[5] == 0) pr[2] = t; pr[5] += n_list; }
         n_list = 0;
+        ring_ready = false;                 // (already so: the last entry has no successor)
         if (G >= ngroups) break;
 
         // ================= bounds, group by group, until the list is full =================
         if (!tables_ready) {
             tables_ready = true;
-            // |x|^2 per accumulator element (all dimensions; leading 32 only)
+            // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes): all
+            // dimensions and leading dimensions only
 #pragma unroll
             for (int R = 0; R < RB; ++R) {
-                // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes) ...
                 double part0 = 0.0, part = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < NK0; ++kk) part0 = fma(xf[R][kk], xf[R][kk], part0);
@@ -470,12 +526,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                 part += __shfl_xor(part, 32);
                 part0 += __shfl_xor(part0, 16);
                 part0 += __shfl_xor(part0, 32);
-                // ... re-distributed to the accumulator layout: rows lk + 4r
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    x2[R][r] = __shfl(part, lk + 4 * r);
-                    x2p[R][r] = __shfl(part0, lk + 4 * r);
-                }
+                if (lk == 0) { sideX2[R * 16 + lr] = part; sideX2p[R * 16 + lr] = part0; }
             }
         }
         // Software pipeline over the groups: the level-0 fragments + constants of the next group are
@@ -519,11 +570,12 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                 need[R] = false;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double nrm = x2p[R][r] + gc.mu2p;
+                    const int row = R * 16 + lk + 4 * r;
+                    const double nrm = sideX2p[row] + gc.mu2p;
                     double dist2 = fma(-2.0, accG[R][r], nrm) - 1e-9 * nrm;     // (rounding of the difference)
                     dist2 = dist2 > 0.0 ? dist2 : 0.0;
                     const double ub = gc.base - gc.hvd * log1p_lower(dist2 * gc.tcoef);
-                    need[R] = need[R] || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
+                    need[R] = need[R] || (ub >= sideM[row] - kPruneMargin) || (sideH[row] == sg);
                 }
                 need[R] = need[R] && sg >= 0;
                 any0 = any0 || need[R];
@@ -544,11 +596,12 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     bool nd = false;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double nrm = x2[R][r] + gc.mu2;
+                        const int row = R * 16 + lk + 4 * r;
+                        const double nrm = sideX2[row] + gc.mu2;
                         double dist2 = fma(-2.0, accG[R][r], nrm) - 1e-9 * nrm;
                         dist2 = dist2 > 0.0 ? dist2 : 0.0;
                         const double ub = gc.base - gc.hvd * log1p_lower(dist2 * gc.tcoef);
-                        nd = nd || (ub >= Mlb[R][r] - kPruneMargin) || (home[R][r] == sg);
+                        nd = nd || (ub >= sideM[row] - kPruneMargin) || (sideH[row] == sg);
                     }
                     need[R] = need[R] && nd;
                 }
@@ -582,6 +635,8 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             }
         }
     }
+    if (probe) pr[4] = wall_clock64();
+    if ((d.debug_flags & 2048) && threadIdx.x == 0 && chunk == 0 && job.win_base == 0 && blockIdx.x == 1023) d.ctrl->prof[15] = wall_clock64();
     if (lane == 0) {
         // (counters spread over 256 addresses; apply_kernel folds them)
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
@@ -593,7 +648,7 @@ template <int NJ>
 static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    constexpr int lds = 4 * 32 * prune_row_stride(NJ * 16) * (int)sizeof(double);
+    constexpr int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * 128) * (int)sizeof(double);
     auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {

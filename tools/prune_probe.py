@@ -27,5 +27,7 @@ for f in flags:
     ctx.L.bgmm_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     ctx.L.bgmm_debug_prof(ctx.h, out)
     v = list(out)
-    print('probe ticks(10ns): blk0', [v[i] - v[0] for i in range(1, 5)], 'lvl1+kept+nkept', v[6], v[5], v[7], 'blk1000', [v[8 + i] - v[8] for i in range(1, 5)], v[14], v[13], v[15])
+    print('probe ticks(10ns): blk0 start->staged %d ->homes done %d ->end %d listed %d | blk600 %d %d %d listed %d' % (v[1]-v[0], v[2]-v[0], v[4]-v[0], v[5], v[9]-v[8], v[10]-v[8], v[12]-v[8], v[13]))
+    if int(f) & 2048:
+        print('block start ticks rel. to block 0: b255 %d b256 %d b511 %d b512 %d b700 %d b1023 %d; b1023 end %d' % tuple(v[i] - v[8] for i in (9, 10, 11, 12, 13, 14, 15)))
     ctx.close()
