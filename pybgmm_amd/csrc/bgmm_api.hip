@@ -229,6 +229,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
     DALLOC(c, d.bucket_bins, ns + 4);
+    CK(c, hipMemsetAsync(d.bucket_bins, 0, sizeof(int) * (ns + 4), c->stream));
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
 
     d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
@@ -461,7 +462,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.order = c->cur_order;
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA;
-    d.prune_enabled = use_prune ? 1 : 0;
+    d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
     { const char *e = getenv("BGMM_DEBUG_FLAGS"); d.debug_flags = e ? atoi(e) : 0; }
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
@@ -479,6 +480,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     long long pos = 0;
     int win = c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows;
     double rate = c->last_move_rate;
+    bool first_batch = true;               // (sweep_begin has just opened a fresh window at visit 0)
     for (;;) {
         const long long remaining = N - pos;
         long long lb = (remaining + win - 1) / win;
@@ -487,27 +489,38 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         long long Tl = lb + extra;
         if (Tl < 1) Tl = 1;
         if (Tl > 4096) Tl = 4096;
-        const int T = (int)Tl;
+        int T = (int)Tl;
         // the resolver's LDS plan depends on the number of labels: re-planned every chunk
         int res_R = 0, res_Kcap = 0, res_lds = 0;
         const bool use_resolver = c->resolver_mode != 1 &&
                                   resolve_plan(d, c->ctrl_host->job.K, &res_R, &res_Kcap, &res_lds);
         if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
+        // Which kernel set this batch of steps needs (bgmm_device.h: Dev::prune_enabled).  Far inside
+        // the sparse-mover regime only the pruned-window kernels are queued, far inside the dense
+        // one only the dense ones; in between both, and the device picks per window.
+        int pmode = 0;
+        if (use_prune) {
+            const Ctrl &hc = *c->ctrl_host;
+            const bool fresh = first_batch || hc.job.mode == MODE_FRESH;
+            pmode = (hc.ema_run >= 2048.0 && fresh) ? 2 : (hc.ema_run < 64.0 ? 0 : 1);
+        }
+        first_batch = false;
+        d.prune_enabled = pmode;
+        // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
+        if (pmode == 2 && rate > 0.0 && T > lb + 64) T = (int)(lb + 64);
         for (int t = 0; t < T; ++t) {
             // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
-            if (use_prune) {
-                launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
-                launch_bucket_rows(d, c->win_rows, st);
-            }
+            if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
+            if (pmode >= 1) launch_bucket_rows(d, c->win_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
-            if (use_prune) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, c->win_rows, st);
+            if (pmode >= 1) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, c->win_rows, st);
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
-            launch_choice(d, c->win_rows, st);
-            if (use_prune) launch_choice_sparse(d, c->win_rows, st);
-            if (use_resolver) launch_resolve(d, res_R, res_Kcap, res_lds, st);
+            if (pmode <= 1) launch_choice(d, c->win_rows, st);
+            if (pmode >= 1) launch_choice_sparse(d, c->win_rows, st);
+            if (use_resolver && pmode <= 1) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
             launch_refresh_ctrl(d, st);
         }

@@ -146,8 +146,16 @@ struct Dev {
     int use_power;
     double power;
     int debug_flags;             // (development probes; 0 in production)
-    int prune_enabled;           // tuning: exact pruning of negligible components in fresh windows
+    int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
+                                 // queued steps: 0 never (only the dense kernels are launched), 1 the device
+                                 // decides per window (job.prune; both kernel sets are launched), 2 every
+                                 // window (only the pruned-window kernels are launched)
 };
+
+// Is the (fresh) window described by (mode, prune flag) evaluated by the pruned-window kernels?
+__host__ __device__ inline bool job_is_pruned(const Dev &d, int mode, int prune_flag) {
+    return mode == MODE_FRESH && (d.prune_enabled == 2 || (d.prune_enabled == 1 && prune_flag != 0));
+}
 
 __host__ __device__ inline int bgmm_nfrag(int Dp) { int nJ = Dp / 16; return 2 * nJ * (nJ + 1); }
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * kChoiceRowsMax) void choice_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double tile[];
     Ctrl *c = d.ctrl;
     const int mode = c->job.mode;
-    if (mode == MODE_DONE || c->job.prune) return;      // (pruned windows: choice_sparse_kernel)
+    if (mode == MODE_DONE || job_is_pruned(d, mode, c->job.prune)) return;      // (pruned windows: choice_sparse_kernel)
     const long long pos = c->job.pos, win_base = c->job.win_base, win_hi = c->job.win_hi;
     const int K = c->job.K;
     const int R = d.choice_rows;
@@ -160,7 +160,10 @@ __device__ __forceinline__ bool sparse_score(const SparseVisit &sv, int t, doubl
 
 __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     Ctrl *c = d.ctrl;
-    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    // (the bucket sort's bins are free again: cleared here for the next pruned window)
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
     const long long win_base = c->job.win_base;
     const long long nrows = c->job.win_hi - win_base;
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;

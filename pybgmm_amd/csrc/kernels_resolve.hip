@@ -270,7 +270,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 const long long p = (long long)fm;
                 const double ema = 0.875 * c->ema_run + 0.125 * (double)(p - c->last_mover);
                 const bool dense = c->dense_mode == 2 || ema < 3.0 * (double)R;
-                if (dense && !j.prune && j.K + R + 2 <= Kcap) {
+                if (dense && !job_is_pruned(d, j.mode, j.prune) && j.K + R + 2 <= Kcap) {
                     S.active = 1;
                     S.sub_lo = p;
                     long long nr = j.win_hi - p;

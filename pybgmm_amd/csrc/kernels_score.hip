@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
                                                          int col_override, int skip_pruned_jobs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE || (skip_pruned_jobs && job.prune)) return;
+    if (job.mode == MODE_DONE || (skip_pruned_jobs && job_is_pruned(d, job.mode, job.prune))) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks) return;
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
                                                             double *__restrict__ q, long long qstride,
                                                             int col_override, int skip_pruned_jobs) {
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE || (skip_pruned_jobs && job.prune)) return;
+    if (job.mode == MODE_DONE || (skip_pruned_jobs && job_is_pruned(d, job.mode, job.prune))) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = 16 * RB;              // rows per wave
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                                                                   double *__restrict__ q, long long qstride) {
     extern __shared__ __attribute__((aligned(16))) double xs_all[];
     const JobView job = load_job(jobp);
-    if (job.mode != MODE_FRESH || !job.prune) return;
+    if (!job_is_pruned(d, job.mode, job.prune)) return;
     const int chunk = blockIdx.y;
     const int ngroups = (job.nlist + 15) >> 4;
     if (chunk >= job.chunks || chunk >= ngroups) return;

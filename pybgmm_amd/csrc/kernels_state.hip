@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     extern __shared__ int bins[];
     const Ctrl *c = d.ctrl;
-    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
@@ -265,10 +265,40 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
         if (bins[b]) atomicAdd(&d.bucket_bins[b], bins[b]);
 }
 
-__global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
+// block 0: exclusive prefix over the bins;  blocks 1..: the label-ordered tables of the pruning
+// kernel for the frozen state of this window (bgmm_device.h), one wave per group of 16 labels.
+__global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
     __shared__ int wsum_[16];
     const Ctrl *c = d.ctrl;
-    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    if (blockIdx.x > 0) {
+        const int K = c->job.K, G = ((int)blockIdx.x - 1) * 16 + (int)(threadIdx.x >> 6);
+        if (16 * G >= K) return;
+        const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+        const int t = 16 * G + lr;
+        const int s = t < K ? d.perm[t] : -1;
+        const int nkk = d.Dp / 4, D = d.D;
+        for (int kk = 0; kk < nkk; ++kk) {
+            const int l = 4 * kk + lk;
+            d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
+        }
+        if (lk == 0) {
+            const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
+            double *g = d.pr_const + (long long)G * 128 + lr;
+            g[0] = sc->logseat + sc->A;
+            g[16] = sc->half_vd;
+            g[32] = sc->inv_lam * sc->inv_cv;
+            g[48] = sc->mu2;
+            double m2p = 0.0;                        // |mu|^2 over the leading 32 dimensions (level-0 bound)
+            for (int l = 0; l < 32 && l < D; ++l) {
+                const double v = s >= 0 ? d.mu[(long long)s * D + l] : 0.0;
+                m2p += v * v;
+            }
+            g[64] = m2p;
+            d.pr_slot[G * 16 + lr] = s;
+        }
+        return;
+    }
     const int nb = d.nslots + 1;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
@@ -289,7 +319,7 @@ __global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     extern __shared__ int lds[];                  // [nb] local counts, then [nb] reserved bases
     const Ctrl *c = d.ctrl;
-    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
@@ -325,45 +355,14 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
         }
 }
 
-// Label-ordered tables of the pruning kernel for the frozen state of this window (bgmm_device.h).
-__global__ __launch_bounds__(64) void prune_tables_kernel(Dev d) {
-    const Ctrl *c = d.ctrl;
-    if (c->job.mode != MODE_FRESH || !c->job.prune) return;
-    const int K = c->job.K, G = blockIdx.x;
-    if (16 * G >= K) return;
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-    const int t = 16 * G + lr;
-    const int s = t < K ? d.perm[t] : -1;
-    const int nkk = d.Dp / 4, D = d.D;
-    for (int kk = 0; kk < nkk; ++kk) {
-        const int l = 4 * kk + lk;
-        d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
-    }
-    if (lk == 0) {
-        const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
-        double *g = d.pr_const + (long long)G * 128 + lr;
-        g[0] = sc->logseat + sc->A;
-        g[16] = sc->half_vd;
-        g[32] = sc->inv_lam * sc->inv_cv;
-        g[48] = sc->mu2;
-        double m2p = 0.0;                        // |mu|^2 over the leading 32 dimensions (level-0 bound)
-        for (int l = 0; l < 32 && l < D; ++l) {
-            const double v = s >= 0 ? d.mu[(long long)s * D + l] : 0.0;
-            m2p += v * v;
-        }
-        g[64] = m2p;
-        d.pr_slot[G * 16 + lr] = s;
-    }
-}
-
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
+    // (d.bucket_bins is zero on entry: cleared at create and by every choice_sparse_kernel)
     const int nb = d.nslots + 1;
     const unsigned g = (unsigned)((max_rows + BUCKET_ROWS - 1) / BUCKET_ROWS);
-    (void)hipMemsetAsync(d.bucket_bins, 0, sizeof(int) * (nb + 1), st);
+    const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
     hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), nb * (int)sizeof(int), st, d);
-    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(bucket_prefix_tables_kernel, dim3(1 + (ngrp + 15) / 16), dim3(1024), 0, st, d);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
-    hipLaunchKernelGGL(prune_tables_kernel, dim3((unsigned)((d.nslots + 15) / 16)), dim3(64), 0, st, d);
 }
 
 void launch_sweep_begin(const Dev &d, hipStream_t st) {
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     __shared__ MovePlan mp;
     __shared__ int do_move;
     Ctrl *c = d.ctrl;
-    if (c->job.mode == MODE_FRESH && c->job.prune && !c->skip_apply) {
+    if (job_is_pruned(d, c->job.mode, c->job.prune) && !c->skip_apply) {
         // fold (and clear) the pruning kernel's spread counters of this window
         __shared__ unsigned long long cnt_red[2 * TPB];
         cnt_red[threadIdx.x] = d.pr_counts[threadIdx.x];
@@ -533,6 +532,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             c->n_scored += (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
             const unsigned long long fm = c->first_mover;
             c->first_mover = kNoMover;
+            const bool was_pruned = job_is_pruned(d, j.mode, j.prune);
             if (fm == kNoMover) {
                 // every visit of the window keeps its component: the state is untouched
                 c->lik_evals += (j.win_hi - j.pos) * (long long)j.K;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     // (it is re-scored later as part of a fresh, smaller window) instead of
                     // re-evaluating all of it after every move
                     if (j.win_hi - (p + 1) > 2 * w) j.win_hi = p + 1 + w;
-                    if (p + 1 >= j.win_hi || j.prune) {      // (a pruned window ends at its first move)
+                    if (p + 1 >= j.win_hi || was_pruned) {   // (a pruned window ends at its first move)
                         start_window(d, c, p + 1);
                     } else {
                         j.pos = p + 1;

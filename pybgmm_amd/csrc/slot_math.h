@@ -280,7 +280,7 @@ __device__ inline void set_chunks(const Dev &d, Job &j) {
     long long ch = rb > 0 ? (d.target_blocks + rb - 1) / rb : 1;
     if (ch > kMaxChunks) ch = kMaxChunks;
     if (ch > nlist) ch = nlist;
-    if (j.prune) {
+    if (job_is_pruned(d, j.mode, j.prune)) {
         // the pruning kernel hands out GROUPS of 16 labels; a wave's fixed cost (its 32 rows of X,
         // the gathers behind Mlb) is paid once per chunk, so as few chunks as fill the chip
         const long long ngroups = (nlist + 15) / 16;
@@ -307,7 +307,7 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
         // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
         // score and promote a pruned component), so they are used while moves are sparse; the
         // mover-dense path (resolver) always works on complete scores.
-        j.prune = (d.prune_enabled && c->ema_run >= 256.0) ? 1 : 0;
+        j.prune = (d.prune_enabled == 2 || (d.prune_enabled == 1 && c->ema_run >= 256.0)) ? 1 : 0;
     }
     set_chunks(d, j);
 }
