@@ -143,11 +143,15 @@ int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
  *     that did work, [5] rows x components scored (incl. re-scores after moves; pruned pairs
  *     count: they are decided, just not by the full quadratic form), [6] (16-visit block,
  *     component) pairs the pruning kernel evaluated in full, [7] pairs it only bounded.
+ *   prune_stats: of the last sweep -- [0] = sweep_stats[6], [1] = sweep_stats[7], [2] the
+ *     v_mfma_f64_16x16x4_f64 instructions (2048 flop each) the pruning kernel issued for its
+ *     distance bounds and exact quadratic forms, [3] reserved (0).
  *   kernel timing: when enabled, every likelihood-kernel launch is bracketed by HIP events on
  *     the context's own stream; get returns the number of timed launches that did work and the
  *     sum of their durations in milliseconds since the last reset.
  */
 int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out8);
+int bgmm_get_prune_stats(bgmm_ctx *ctx, int64_t *out4);
 int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
 int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "bgmm_contingency": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, _vp]),
     "bgmm_cluster_dispersion": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_prune_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -246,6 +247,11 @@ class Context(object):
         keys = ("lik_evals", "moves", "windows", "steps", "score_launches", "scored", "kept_blocks",
                 "bound_blocks")
         return dict(zip(keys, (int(v) for v in out)))
+
+    def prune_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_prune_stats(self.h, _ptr(out)))
+        return {"kept_blocks": int(out[0]), "bound_blocks": int(out[1]), "mfma_instructions": int(out[2])}
 
     def set_kernel_timing(self, on):
         self._ck(self.L.bgmm_set_kernel_timing(self.h, 1 if on else 0))

@@ -63,6 +63,7 @@ struct bgmm_ctx {
     std::vector<hipEvent_t> ev0, ev1;
     long long timed_launches = 0;
     double timed_ms = 0.0;
+    long long prune_mfma = 0;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -222,9 +223,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_mufrag, ng * (size_t)(d.Dp / 4) * 64);
         DALLOC(c, d.pr_const, ng * 128);
         DALLOC(c, d.pr_slot, ng * 16);
+        DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
         DALLOC(c, d.wvisit, (size_t)rows);
-        DALLOC(c, d.pr_counts, 512);
-        CK(c, hipMemsetAsync(d.pr_counts, 0, 512 * sizeof(unsigned long long), c->stream));
+        DALLOC(c, d.pr_counts, 768);
+        CK(c, hipMemsetAsync(d.pr_counts, 0, 768 * sizeof(unsigned long long), c->stream));
     }
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
@@ -549,6 +551,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
     c->stats[6] = (long long)h.n_kept_blocks; c->stats[7] = (long long)h.n_bound_blocks;
+    c->prune_mfma = (long long)h.n_prune_mfma;
     return check_device_error(c);
 }
 
@@ -751,6 +754,12 @@ extern "C" int bgmm_debug_prof(bgmm_ctx *c, int64_t *out8) {
 extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out8) {
     if (!c || !out8) return BGMM_EINVAL;
     for (int t = 0; t < 8; ++t) out8[t] = c->stats[t];
+    return 0;
+}
+
+extern "C" int bgmm_get_prune_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    out4[0] = c->stats[6]; out4[1] = c->stats[7]; out4[2] = c->prune_mfma; out4[3] = 0;
     return 0;
 }
 

@@ -95,6 +95,8 @@ struct Ctrl {
     long long lik_evals, n_moves, n_windows, n_steps, n_score_launches, n_scored;
     unsigned long long n_kept_blocks;   // (16-visit block, slot) pairs the pruning kernel scored in full
     unsigned long long n_bound_blocks;  // (16-visit block, slot) pairs it bounded
+    int tables_valid;     // the pruned-window tables (pr_*) match the current means / labels / seating weights
+    unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
 };
 
@@ -137,9 +139,10 @@ struct Dev {
     // constants pr_const[G][4][16] = {logseat + A, half_vd, inv_lam * inv_cv, |mu|^2} and the slot
     // ids pr_slot[G][16] (-1 beyond the last label)
     double *pr_mufrag, *pr_const;
+    double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
     int *pr_slot;
     long long *wvisit;           // pruned windows: data index of the k-th row in evaluation order
-    unsigned long long *pr_counts;  // 2 x 256 spread counters (kept, bound) of the pruning kernel
+    unsigned long long *pr_counts;  // 3 x 256 spread counters (kept, bound, MFMA instructions) of the pruning kernel
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;
     const long long *order;      // may be null (identity)

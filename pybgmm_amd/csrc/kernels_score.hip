@@ -346,10 +346,13 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
     // (wave-private side arrays behind the staging area; accumulator element (R, r) of lane (lk, .)
     // is row 16 R + lk + 4 r).
-    double *__restrict__ sideM = xs_all + 4 * (ROWS_W * Ds) + w * 128;       // Mlb[32]
+    const int side_stride = 144 + d.keep_stride;
+    double *__restrict__ sideM = xs_all + 4 * (ROWS_W * Ds) + w * side_stride;   // Mlb[32]
     double *__restrict__ sideX2 = sideM + 32;                                 // |x|^2, all dimensions
     double *__restrict__ sideX2p = sideM + 64;                                // |x|^2, leading dimensions
     int *__restrict__ sideH = (int *)(sideM + 96);                            // home slot
+    double *__restrict__ sideRho = sideM + 112;                               // |x - mu_home|^2
+    unsigned long long *__restrict__ sideC = (unsigned long long *)(sideM + 144);   // coarse label mask
     const int hmine = imine >= 0 ? d.z[imine] : -2;                // home slot of row (lane & 31)
     if (lane < ROWS_W) {
         sideM[lane] = imine >= 0 ? d.log_alpha + d.log_prior[imine] : INFINITY;   // dead rows never keep a slot alive
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     // both blocks; the group loop skips them.  Up to 4 distinct homes; the rest is found by the loop.
     int done0 = -1, done1 = -1, done2 = -1, done3 = -1;
     int lab0 = 0, lab1 = 0, lab2 = 0, lab3 = 0, n_home = 0;
+    unsigned long long pending_homes;
     {
         unsigned long long pending = __ballot(lane < ROWS_W && hmine >= 0);
 #pragma unroll 1
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             else if (it == 2) { done2 = s; lab2 = lab; } else { done3 = s; lab3 = lab; }
             ++n_home;
         }
+        pending_homes = pending;                                   // homes beyond the first four
     }
     // the first ring of inverse-factor tiles of the first home travels together with the rows
     constexpr int PFK = pick_ring(NF, 20);
@@ -408,6 +413,47 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     }
     __syncthreads();
     if (kw >= nrows) return;
+    // Euclidean distance of every row to the mean of its own (home) component: the radius of the
+    // coarse triangle bound.  Lane = dimension; the 32 mean rows are in flight together; the 32 sums
+    // over 64 lanes are formed by a transposing butterfly (32 shuffles), row r ends up in lanes 2r, 2r+1.
+    {
+        static_assert(ROWS_W == 32, "the butterfly below reduces 32 rows");
+        constexpr int NP = (NJ * 16 + 63) / 64;
+        double mu_t[ROWS_W][NP];
+#pragma unroll
+        for (int row = 0; row < ROWS_W; ++row) {
+            const int h = __builtin_amdgcn_readlane(hmine, row);
+            const double *__restrict__ mrow = d.mu + (long long)(h >= 0 ? h : 0) * D;
+#pragma unroll
+            for (int pss = 0; pss < NP; ++pss) {
+                const int l = pss * 64 + lane;
+                mu_t[row][pss] = mrow[l < D ? l : 0];
+            }
+        }
+        double acc[ROWS_W];
+#pragma unroll
+        for (int row = 0; row < ROWS_W; ++row) {
+            double a = 0.0;
+#pragma unroll
+            for (int pss = 0; pss < NP; ++pss) {
+                const int l = pss * 64 + lane;
+                const double df = l < D ? xs[row * Ds + (l < NJ * 16 ? l : 0)] - mu_t[row][pss] : 0.0;
+                a = fma(df, df, a);
+            }
+            acc[row] = a;
+        }
+#pragma unroll
+        for (int half = 16; half >= 1; half >>= 1) {
+            const bool up = (lane & (2 * half)) != 0;                 // lane bit 5, 4, 3, 2, 1
+#pragma unroll
+            for (int r = 0; r < half; ++r) {
+                const double lo = acc[r], hi = acc[r + half];
+                acc[r] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 2 * half);
+            }
+        }
+        acc[0] += __shfl_xor(acc[0], 1);
+        if ((lane & 1) == 0) sideRho[lane >> 1] = acc[0];            // (rows without a home: unused)
+    }
     double xf[RB][NKK];
 #pragma unroll
     for (int R = 0; R < RB; ++R)
@@ -416,7 +462,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 
     if (probe) pr[1] = wall_clock64() + ((long long)(xf[0][0]) & 1);
     unsigned short *__restrict__ keep16 = (unsigned short *)d.keep64;
-    unsigned n_kept = 0, n_bound = 0;
+    unsigned n_kept = 0, n_bound = 0, n_mfma = 0;
 
     // Work list of the wave (reuses its staging area in LDS -- the rows live in registers now):
     // two ints per entry {slot, label | store0 << 30 | store1 << 31}.  The kernel alternates between
@@ -449,6 +495,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
                 for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
             }
+            n_mfma += RB * NF;
             const bool has_next = e + 1 < n_list;
             const int s_next = has_next ? __builtin_amdgcn_readfirstlane(wlist[2 * e + 2]) : s;
             const double *__restrict__ wf_next = d.Wfrag + (long long)s_next * nfrag64 + lane;
@@ -512,6 +559,53 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
         // ================= bounds, group by group, until the list is full =================
         if (!tables_ready) {
             tables_ready = true;
+            // ---- coarse bound, once per wave and label (triangle inequality through the home means):
+            // for the visits whose home is h,  |mu_t - x| >= |mu_t - mu_h| - max |x - mu_h|.  A label
+            // that this prunes for every home present in the wave is skipped for all 32 visits.
+            {
+                const bool all_homes = pending_homes == 0ull;
+                double rho[4], mmin[4];
+                const int hh = lane < ROWS_W ? sideH[lane] : -3;
+                const double r2 = lane < ROWS_W ? sideRho[lane] : 0.0;
+                const double ml = lane < ROWS_W ? sideM[lane] : INFINITY;
+                bool covered = hh == -2 || hh == -3;                   // dead rows / lanes
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dj = j == 0 ? done0 : (j == 1 ? done1 : (j == 2 ? done2 : done3));
+                    const bool sel = dj >= 0 && hh == dj;
+                    covered = covered || sel;
+                    double a = sel ? r2 : 0.0, b = sel ? ml : INFINITY;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        a = fmax(a, __shfl_xor(a, o));
+                        b = fmin(b, __shfl_xor(b, o));
+                    }
+                    rho[j] = sqrt(a) * (1.0 + 1e-9);
+                    mmin[j] = b;
+                }
+                const bool coarse_ok = all_homes && __ballot(!covered) == 0ull;
+                for (int t0 = 0; t0 < job.nlist; t0 += 64) {
+                    const int t = t0 + lane;
+                    bool need = t < job.nlist;
+                    if (coarse_ok && need) {
+                        const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
+                        const double base = g[0], hvd = g[16], tcoef = g[32];
+                        need = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int lj = j == 0 ? lab0 : (j == 1 ? lab1 : (j == 2 ? lab2 : lab3));
+                            if (j < n_home) {
+                                double dl = d.pr_dcc[(long long)lj * d.nslots + t] * (1.0 - 1e-9) - rho[j];
+                                dl = dl > 0.0 ? dl : 0.0;
+                                const double ub = base - hvd * log1p_lower(dl * dl * tcoef);
+                                need = need || (ub >= mmin[j] - kPruneMargin) || t == lj;
+                            }
+                        }
+                    }
+                    const unsigned long long m = __ballot(need);
+                    if (lane == 0) sideC[t0 >> 6] = m;
+                }
+            }
             // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes): all
             // dimensions and leading dimensions only
 #pragma unroll
@@ -542,18 +636,44 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             const double *__restrict__ g = d.pr_const + (long long)Gc * 128 + lr;
             gc_o.base = g[0]; gc_o.hvd = g[16]; gc_o.tcoef = g[32]; gc_o.mu2 = g[48]; gc_o.mu2p = g[64];
         };
+        // the 16 coarse bits of group Gq (wave-uniform), and the next group >= Gq of this chunk that
+        // has any
+        auto coarse16 = [&](int Gq) -> unsigned {
+            const unsigned long long wd = sideC[Gq >> 2];
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)((wd >> (16 * (Gq & 3))) & 0xFFFFull));
+        };
+        auto next_needed = [&](int Gq) -> int {
+            while (Gq < ngroups && coarse16(Gq) == 0u) Gq += job.chunks;
+            return Gq;
+        };
         int sg_next;
         double bm_next[NK0];
         GroupConst gc_next;
-        load_group(G, sg_next, bm_next, gc_next);
+        int G_next = next_needed(G);
+        load_group(G_next, sg_next, bm_next, gc_next);
 #pragma unroll 1
         for (; G < ngroups && n_list <= LIST_CAP; G += job.chunks) {
+            {
+                const int left = job.nlist - 16 * G;
+                n_bound += RB * (left < 16 ? left : 16);
+            }
+            if (G != G_next) {
+                // every label of the group is out for the whole wave
+                if (lane == 0) {
+#pragma unroll
+                    for (int R = 0; R < RB; ++R)
+                        if (kw + R * 16 < nrows) keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = 0;
+                }
+                continue;
+            }
+            const unsigned c16 = coarse16(G);
             const int sg = sg_next;
             const GroupConst gc = gc_next;
             double bm[NK0];
 #pragma unroll
             for (int kk = 0; kk < NK0; ++kk) bm[kk] = bm_next[kk];
-            load_group(G + job.chunks, sg_next, bm_next, gc_next);
+            G_next = next_needed(G + job.chunks);
+            load_group(G_next, sg_next, bm_next, gc_next);
             // distances to the 16 means: X . Mu'  (B fragment: mu_sg[4kk + lk]); leading dimensions
             v4d accG[RB];
 #pragma unroll
@@ -563,6 +683,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
                 for (int R = 0; R < RB; ++R)
                     accG[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bm[kk], accG[R], 0, 0, 0);
+            n_mfma += RB * NK0;
             bool need[RB];
             bool any0 = false;
 #pragma unroll
@@ -582,6 +703,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             }
             if (NKK > NK0 && __ballot(any0) != 0ull) {
                 // somebody survives the leading-dimension bound: the distance on all dimensions
+                n_mfma += RB * (NKK - NK0);
                 const double *__restrict__ mf = d.pr_mufrag + (long long)G * (NKK * 64) + lane;
                 double bmr[NKK > NK0 ? NKK - NK0 : 1];
 #pragma unroll
@@ -612,14 +734,10 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
             for (int R = 0; R < RB; ++R) {
                 const unsigned long long bl = __ballot(need[R]);
-                keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull);
+                keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull) & c16;
                 if (lane == 0 && kw + R * 16 < nrows)
                     keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = (unsigned short)keepmask[R];
                 n_kept += __popc(keepmask[R]);
-            }
-            {
-                const int left = job.nlist - 16 * G;
-                n_bound += RB * (left < 16 ? left : 16);
             }
             // the labels somebody needs go on the list (the homes scored up front are done already)
             unsigned todo = keepmask[0] | keepmask[RB - 1];
@@ -641,6 +759,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
         // (counters spread over 256 addresses; apply_kernel folds them)
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
         atomicAdd(&d.pr_counts[256 + (blockIdx.x & 255)], (unsigned long long)n_bound);
+        atomicAdd(&d.pr_counts[512 + (blockIdx.x & 255)], (unsigned long long)n_mfma);
     }
 }
 
@@ -648,12 +767,12 @@ template <int NJ>
 static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    constexpr int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * 128) * (int)sizeof(double);
+    const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (144 + d.keep_stride)) * (int)sizeof(double);
     auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    static int attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }

@@ -159,6 +159,7 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= n) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.ctrl->tables_valid = 0;
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->skip_apply = 0;
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
-        c->n_kept_blocks = 0; c->n_bound_blocks = 0;
+        c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0;
+        c->tables_valid = 0;             // (seating weights may have changed)
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
         if (c->win_size > c->win_cap) c->win_size = c->win_cap;
@@ -271,17 +273,41 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
     __shared__ int wsum_[16];
     const Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    const int n_tab_blocks = ((d.nslots + 15) / 16 + 15) / 16;
+    if ((int)blockIdx.x > n_tab_blocks) {
+        // centre-to-centre distances between labels (rebuilt only after the state changed)
+        __shared__ double mua[BGMM_MAX_D];
+        if (c->tables_valid) return;
+        const int K = c->job.K, a = (int)blockIdx.x - n_tab_blocks - 1, D = d.D;
+        if (a >= K) return;
+        const double *__restrict__ pa = d.mu + (long long)d.perm[a] * D;
+        for (int l = threadIdx.x; l < D; l += 1024) mua[l] = pa[l];
+        __syncthreads();
+        for (int b = threadIdx.x; b < K; b += 1024) {
+            const double *__restrict__ pb = d.mu + (long long)d.perm[b] * D;
+            double acc = 0.0;
+            for (int l = 0; l < D; ++l) { const double t = pb[l] - mua[l]; acc = fma(t, t, acc); }
+            d.pr_dcc[(long long)a * d.nslots + b] = sqrt(acc);
+        }
+        return;
+    }
     if (blockIdx.x > 0) {
+        if (c->tables_valid) return;
         const int K = c->job.K, G = ((int)blockIdx.x - 1) * 16 + (int)(threadIdx.x >> 6);
         if (16 * G >= K) return;
         const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
         const int t = 16 * G + lr;
         const int s = t < K ? d.perm[t] : -1;
         const int nkk = d.Dp / 4, D = d.D;
+        double m2p = 0.0;                            // |mu|^2 over the leading 32 dimensions (level-0 bound)
         for (int kk = 0; kk < nkk; ++kk) {
             const int l = 4 * kk + lk;
-            d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
+            const double v = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
+            d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = v;
+            if (kk < 8) m2p = fma(v, v, m2p);
         }
+        m2p += __shfl_xor(m2p, 16);
+        m2p += __shfl_xor(m2p, 32);
         if (lk == 0) {
             const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
             double *g = d.pr_const + (long long)G * 128 + lr;
@@ -289,11 +315,6 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
             g[16] = sc->half_vd;
             g[32] = sc->inv_lam * sc->inv_cv;
             g[48] = sc->mu2;
-            double m2p = 0.0;                        // |mu|^2 over the leading 32 dimensions (level-0 bound)
-            for (int l = 0; l < 32 && l < D; ++l) {
-                const double v = s >= 0 ? d.mu[(long long)s * D + l] : 0.0;
-                m2p += v * v;
-            }
             g[64] = m2p;
             d.pr_slot[G * 16 + lr] = s;
         }
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
     if (r0 >= nrows) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.ctrl->tables_valid = 1;    // (the tables kernel ran before us)
     const int nb = d.nslots + 1;
     int *cnt = lds, *res = lds + nb;
     for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
@@ -361,7 +383,7 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
     const unsigned g = (unsigned)((max_rows + BUCKET_ROWS - 1) / BUCKET_ROWS);
     const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
     hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), nb * (int)sizeof(int), st, d);
-    hipLaunchKernelGGL(bucket_prefix_tables_kernel, dim3(1 + (ngrp + 15) / 16), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(bucket_prefix_tables_kernel, dim3(1 + (ngrp + 15) / 16 + d.nslots), dim3(1024), 0, st, d);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
 }
 
@@ -505,20 +527,22 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (job_is_pruned(d, c->job.mode, c->job.prune) && !c->skip_apply) {
         // fold (and clear) the pruning kernel's spread counters of this window
-        __shared__ unsigned long long cnt_red[2 * TPB];
-        cnt_red[threadIdx.x] = d.pr_counts[threadIdx.x];
-        cnt_red[TPB + threadIdx.x] = d.pr_counts[256 + threadIdx.x];
-        d.pr_counts[threadIdx.x] = 0;
-        d.pr_counts[256 + threadIdx.x] = 0;
+        __shared__ unsigned long long cnt_red[3 * TPB];
+        for (int t = 0; t < 3; ++t) {
+            cnt_red[t * TPB + threadIdx.x] = d.pr_counts[t * 256 + threadIdx.x];
+            d.pr_counts[t * 256 + threadIdx.x] = 0;
+        }
         __syncthreads();
         for (int o = TPB / 2; o > 0; o >>= 1) {
-            if (threadIdx.x < o) {
-                cnt_red[threadIdx.x] += cnt_red[threadIdx.x + o];
-                cnt_red[TPB + threadIdx.x] += cnt_red[TPB + threadIdx.x + o];
-            }
+            if (threadIdx.x < o)
+                for (int t = 0; t < 3; ++t) cnt_red[t * TPB + threadIdx.x] += cnt_red[t * TPB + threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) { c->n_kept_blocks += cnt_red[0]; c->n_bound_blocks += cnt_red[TPB]; }
+        if (threadIdx.x == 0) {
+            c->n_kept_blocks += cnt_red[0];
+            c->n_bound_blocks += cnt_red[TPB];
+            c->n_prune_mfma += cnt_red[2 * TPB];
+        }
     }
     if (threadIdx.x == 0) {
         do_move = 0;
@@ -555,6 +579,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     j.mode = MODE_DONE;
                 } else {
                     do_move = 1;
+                    c->tables_valid = 0;
                     set_refresh(d, c, mp, true);
                     c->n_moves += 1;
                     // adaptive window: about half the running mean distance between movers
@@ -597,6 +622,7 @@ __global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, i
     if (threadIdx.x == 0) {
         mp.i = i; mp.sub_slot = -1; mp.add_slot = -1; mp.add_init = 0;
         ok = 1;
+        c->tables_valid = 0;
         if (op == 0) {
             mp.sub_slot = plan_unseat(d, c, i);
         } else {

@@ -20,6 +20,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C" -o pmc --output-format csv -- \
         python $REPO/bench.py --workload $WL --steps 2 --warmup 1 --cpu-visits 0 --no-kernel-timing \
         > "$OUT/pmc_$C.log" 2>&1
+    # the same with pruning off: every (visit, component) pair through the full-evaluation kernel
+    rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmcfull_$C" -o pmc --output-format csv -- \
+        python $REPO/bench.py --workload $WL --steps 2 --warmup 1 --cpu-visits 0 --no-kernel-timing --prune 1 \
+        > "$OUT/pmcfull_$C.log" 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace \
     -d "$OUT/pmc_SQ" -o pmc --output-format csv -- \

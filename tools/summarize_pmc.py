@@ -22,9 +22,10 @@ def main():
     if ks:
         shutil.copy(ks, os.path.join(out, "kernel_stats_%s.csv" % wl))
     summary = {}
-    for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    for d in sorted(glob.glob(os.path.join(out, "pmc*_*"))):
         if not os.path.isdir(d):
             continue
+        full = os.path.basename(d).startswith("pmcfull_")
         cc = find(d, "counter_collection.csv")
         if not cc:
             continue
@@ -36,7 +37,7 @@ def main():
         for k, cs in acc.items():
             for cname, vals in cs.items():
                 work = [v for v in vals if v[1] >= 20.0] or vals
-                summary.setdefault(k.split("(")[0], {})[cname] = {
+                summary.setdefault(k.split("(")[0] + (" [pruning off]" if full else ""), {})[cname] = {
                     "launches": len(vals), "working_launches": len(work),
                     "mean_working": sum(v[0] for v in work) / len(work),
                     "mean_working_us": sum(v[1] for v in work) / len(work)}
@@ -45,7 +46,12 @@ def main():
                        "gfx950 (MI355X_MICROARCH.md); mean over launches >= 20 us"}
     for k, cs in summary.items():
         if "score_mfma" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            key = "hbm_bytes_per_launch_pruned" if "prune" in k else "hbm_bytes_per_launch"
+            if "prune_kernel" in k and "[pruning off]" not in k:
+                key = "hbm_bytes_per_launch_pruned"
+            elif "prune_kernel" not in k and "[pruning off]" in k:
+                key = "hbm_bytes_per_launch"
+            else:
+                continue
             traffic[key] = int(1024 * (2 * cs["FETCH_SIZE"]["mean_working"] + cs["WRITE_SIZE"]["mean_working"]))
             traffic[key + "_kernel"] = k
             traffic[key + "_fetch_kb_raw"] = round(cs["FETCH_SIZE"]["mean_working"], 1)
