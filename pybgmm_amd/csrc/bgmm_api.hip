@@ -465,7 +465,6 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
-    { const char *e = getenv("BGMM_DEBUG_FLAGS"); d.debug_flags = e ? atoi(e) : 0; }
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
         launch_build_seat_table(d, c->tabSeat, st);
@@ -535,7 +534,6 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             for (long long t = 0; t < worked && t < T; ++t) {
                 float ms = 0.f;
                 CK(c, hipEventElapsedTime(&ms, c->ev0[(size_t)t], c->ev1[(size_t)t]));
-                if (d.debug_flags && c->timed_launches == 0) fprintf(stderr, "[bgmm debug] first launch %.4f ms\n", ms);
                 c->timed_ms += (double)ms;
                 c->timed_launches += 1;
             }

@@ -148,7 +148,6 @@ struct Dev {
     const long long *order;      // may be null (identity)
     int use_power;
     double power;
-    int debug_flags;             // (development probes; 0 in production)
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
                                  // queued steps: 0 never (only the dense kernels are launched), 1 the device
                                  // decides per window (job.prune; both kernel sets are launched), 2 every

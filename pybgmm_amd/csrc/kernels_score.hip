@@ -258,16 +258,24 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
 // a |d|^2 at every rank-1 addition; slot_math.h) the quadratic form is bounded from below by the
 // Euclidean distance:   q_s(x) = (mu-x)' S_N^-1 (mu-x) >= |mu - x|^2 / Lambda_s =: q_lb,   and
 //     lp_ub = logseat + A - half_vd * L(q_lb * inv_cv),     L(t) <= log(1 + t)  (cheap minorant)
-// is a rigorous upper bound of the component's log score for that visit.  |mu - x|^2 for 16
-// slots x 32 visits costs ONE v_mfma_f64_16x16x4 per slot and 16 visits (a [rows x D].[D x 16]
-// product against the means) -- 2.5 % of the full quadratic form at D = 64.
-// Every visit also has a lower bound M_lb of its maximum log score: the "new table" entry
-// log(alpha) + log_prior[i] (crpmm.py:74) to start with, raised by every exact score computed so
-// far.  A slot whose lp_ub < M_lb - kPruneMargin for all 32 visits of the wave, and that is
-// nobody's home, has weight exp(lp - max) < e^-80 ~ 2e-35 in each of those draws -- twenty orders
-// of magnitude below the rounding noise of the normaliser -- and is not scored: nothing is
-// written for it, which the draw kernel treats as an exact zero weight.  The bound holds against the
-// frozen state only, which is why a pruned window ends at its first move (slot_math.h).
+// is a rigorous upper bound of the component's log score for that visit; any lower bound of
+// |mu - x| can stand in for the distance.  Every visit also has a lower bound M_lb of its maximum
+// log score: the "new table" entry log(alpha) + log_prior[i] (crpmm.py:74) to start with, raised
+// by (a lower bound of) every exact score computed so far -- its own component first.  A slot whose
+// lp_ub < M_lb - kPruneMargin, and that is not the visit's home, has weight
+// exp(lp - max) < e^-80 ~ 2e-35 in that draw -- twenty orders of magnitude below the rounding
+// noise of the normaliser -- and is not scored: nothing is written for it, which the draw kernel
+// treats as an exact zero weight.  The bounds hold against the frozen state only, which is why a
+// pruned window ends at its first move (slot_math.h).
+//
+// Three levels, cheapest first, each only for what survived the one before:
+//   coarse   once per wave (32 visits) and label: |mu_t - x| >= |mu_t - mu_h| - max_v |x_v - mu_h|
+//            over the visits whose home is h (the visits are sorted by home, a wave has one or two),
+//            from the centre-to-centre table pr_dcc;  no matrix work at all
+//   level 0  per visit, distance on the leading 32 dimensions: 8 v_mfma_f64_16x16x4 per 16 visits
+//            and 16 labels
+//   level 1  per visit, all Dp dimensions (the remaining Dp/4 - 8 MFMAs)
+// and what survives those is scored exactly (2 nJ (nJ+1) MFMAs per 16 visits and label).
 // ------------------------------------------------------------------------------------------
 static constexpr double kPruneMargin = 80.0;
 
@@ -295,11 +303,7 @@ __device__ __forceinline__ double log1p_lower(double t) {
 // qb[(b * nslots + label) * 16 + v].  The draw kernel for pruned windows (choice_sparse_kernel)
 // reads nothing else.  Labels are handed out in groups of 16 (group G = labels 16G .. 16G+15,
 // one MFMA column each), group G to chunk G % chunks; everything a group needs comes from the
-// label-ordered tables prune_tables_kernel built for this window (coalesced 512-byte fragments).
-//
-// The bound is evaluated in two levels: first on the leading 32 dimensions only
-// (|mu - x|^2 >= sum_{l<32} (mu_l - x_l)^2: 8 MFMAs per block and group), and only for groups in
-// which some (visit, label) survives that on all Dp dimensions (the remaining Dp/4 - 4 MFMAs).
+// label-ordered tables bucket_prefix_tables_kernel keeps for the frozen state (coalesced 512-byte fragments).
 //
 // The 32 rows of a wave are staged through LDS (row-contiguous 512-byte global loads, then the
 // A fragments x[row lr][4kk + lk] are read back; row stride Ds = 4 mod 32 doubles).
@@ -322,14 +326,6 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
     const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
     if (kb >= nrows) return;
-    const bool probe = (d.debug_flags & 1024) && (threadIdx.x & 255) == 0 && (blockIdx.x == 0 || blockIdx.x == 600) && chunk == 0;
-    long long *pr = d.ctrl->prof + (blockIdx.x == 0 ? 0 : 8);
-    if (probe) { pr[0] = wall_clock64(); pr[5] = 0; pr[6] = 0; }
-    if ((d.debug_flags & 2048) && threadIdx.x == 0 && chunk == 0 && job.win_base == 0) {
-        const int bx = blockIdx.x;
-        const int slot = bx == 0 ? 0 : bx == 255 ? 1 : bx == 256 ? 2 : bx == 511 ? 3 : bx == 512 ? 4 : bx == 700 ? 5 : bx == 1023 ? 6 : -1;
-        if (slot >= 0) d.ctrl->prof[8 + slot] = wall_clock64();
-    }
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -460,7 +456,6 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) xf[R][kk] = xs[(R * 16 + lr) * Ds + 4 * kk + lk];
 
-    if (probe) pr[1] = wall_clock64() + ((long long)(xf[0][0]) & 1);
     unsigned short *__restrict__ keep16 = (unsigned short *)d.keep64;
     unsigned n_kept = 0, n_bound = 0, n_mfma = 0;
 
@@ -478,7 +473,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     bool ring_ready = n_home > 0;                                  // ringk holds the first tiles of entry 0
 
     int G = chunk;
-    bool tables_ready = false;
+    bool tables_ready = false, norms_ready = false;
 #pragma unroll 1
     for (;;) {
         // ================= exact quadratic forms of the listed (slot, label) entries =================
@@ -551,7 +546,6 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     q[((blk0 + R) * (long long)d.nslots + label) * 16 + lk + 4 * lr] = mine;
             }
         }
-        if (probe) { const long long t = wall_clock64() + ((long long)sideM[0] & 1); if (pr[5] == 0) pr[2] = t; pr[5] += n_list; }
         n_list = 0;
         ring_ready = false;                 // (already so: the last entry has no successor)
         if (G >= ngroups) break;
@@ -584,32 +578,53 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     mmin[j] = b;
                 }
                 const bool coarse_ok = all_homes && __ballot(!covered) == 0ull;
-                for (int t0 = 0; t0 < job.nlist; t0 += 64) {
-                    const int t = t0 + lane;
-                    bool need = t < job.nlist;
-                    if (coarse_ok && need) {
-                        const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
-                        const double base = g[0], hvd = g[16], tcoef = g[32];
-                        need = false;
+                // four batches of 64 labels per pass: all loads of a pass in flight together
+                for (int t00 = 0; t00 < job.nlist; t00 += 256) {
+                    double cb[4], ch[4], ct[4], cd[4][4];
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const int t = t00 + 64 * bq + lane;
+                        const int tc = t < job.nlist ? t : 0;
+                        const double *__restrict__ g = d.pr_const + (long long)(tc >> 4) * 128 + (tc & 15);
+                        cb[bq] = g[0]; ch[bq] = g[16]; ct[bq] = g[32];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int lj = j == 0 ? lab0 : (j == 1 ? lab1 : (j == 2 ? lab2 : lab3));
-                            if (j < n_home) {
-                                double dl = d.pr_dcc[(long long)lj * d.nslots + t] * (1.0 - 1e-9) - rho[j];
-                                dl = dl > 0.0 ? dl : 0.0;
-                                const double ub = base - hvd * log1p_lower(dl * dl * tcoef);
-                                need = need || (ub >= mmin[j] - kPruneMargin) || t == lj;
-                            }
+                            cd[bq][j] = d.pr_dcc[(long long)(j < n_home ? lj : 0) * d.nslots + tc];
                         }
                     }
-                    const unsigned long long m = __ballot(need);
-                    if (lane == 0) sideC[t0 >> 6] = m;
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const int t = t00 + 64 * bq + lane;
+                        if (t00 + 64 * bq < job.nlist) {               // (uniform)
+                            bool need = t < job.nlist;
+                            if (coarse_ok && need) {
+                                need = false;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int lj = j == 0 ? lab0 : (j == 1 ? lab1 : (j == 2 ? lab2 : lab3));
+                                    if (j < n_home) {
+                                        double dl = cd[bq][j] * (1.0 - 1e-9) - rho[j];
+                                        dl = dl > 0.0 ? dl : 0.0;
+                                        const double ub = cb[bq] - ch[bq] * log1p_lower(dl * dl * ct[bq]);
+                                        need = need || (ub >= mmin[j] - kPruneMargin) || t == lj;
+                                    }
+                                }
+                            }
+                            const unsigned long long m = __ballot(need);
+                            if (lane == 0) sideC[(t00 >> 6) + bq] = m;
+                        }
+                    }
                 }
             }
-            // |x|^2 of row lr from the A fragments (sum over kk, then over the 4 lk lanes): all
-            // dimensions and leading dimensions only
+        }
+        // |x|^2 of the rows (needed by the per-visit bounds only): computed when the first group that
+        // needs them comes up
+        auto rows_norms = [&]() {
 #pragma unroll
             for (int R = 0; R < RB; ++R) {
+                // from the A fragments (sum over kk, then over the 4 lk lanes): all dimensions and
+                // leading dimensions only
                 double part0 = 0.0, part = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < NK0; ++kk) part0 = fma(xf[R][kk], xf[R][kk], part0);
@@ -622,7 +637,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                 part0 += __shfl_xor(part0, 32);
                 if (lk == 0) { sideX2[R * 16 + lr] = part; sideX2p[R * 16 + lr] = part0; }
             }
-        }
+        };
         // Software pipeline over the groups: the level-0 fragments + constants of the next group are
         // in flight while this one is being bounded.
         struct GroupConst { double base, hvd, tcoef, mu2, mu2p; };
@@ -642,8 +657,18 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             const unsigned long long wd = sideC[Gq >> 2];
             return (unsigned)__builtin_amdgcn_readfirstlane((int)((wd >> (16 * (Gq & 3))) & 0xFFFFull));
         };
+        // the labels of the homes scored up front that fall into group Gq: kept without any test
+        auto home16 = [&](int Gq) -> unsigned {
+            unsigned hb = 0;
+            if (n_home > 0 && (lab0 >> 4) == Gq) hb |= 1u << (lab0 & 15);
+            if (n_home > 1 && (lab1 >> 4) == Gq) hb |= 1u << (lab1 & 15);
+            if (n_home > 2 && (lab2 >> 4) == Gq) hb |= 1u << (lab2 & 15);
+            if (n_home > 3 && (lab3 >> 4) == Gq) hb |= 1u << (lab3 & 15);
+            return hb;
+        };
+        // next group >= Gq of this chunk in which a label other than those homes survives
         auto next_needed = [&](int Gq) -> int {
-            while (Gq < ngroups && coarse16(Gq) == 0u) Gq += job.chunks;
+            while (Gq < ngroups && (coarse16(Gq) & ~home16(Gq)) == 0u) Gq += job.chunks;
             return Gq;
         };
         int sg_next;
@@ -658,14 +683,19 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                 n_bound += RB * (left < 16 ? left : 16);
             }
             if (G != G_next) {
-                // every label of the group is out for the whole wave
+                // every label of the group is out for the whole wave, except homes scored up front
+                // (their q lines exist for both blocks)
+                const unsigned hk = coarse16(G) & home16(G);
                 if (lane == 0) {
 #pragma unroll
                     for (int R = 0; R < RB; ++R)
-                        if (kw + R * 16 < nrows) keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = 0;
+                        if (kw + R * 16 < nrows)
+                            keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = (unsigned short)hk;
                 }
+                n_kept += RB * __popc(hk);
                 continue;
             }
+            if (!norms_ready) { norms_ready = true; rows_norms(); }
             const unsigned c16 = coarse16(G);
             const int sg = sg_next;
             const GroupConst gc = gc_next;
@@ -734,7 +764,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
 #pragma unroll
             for (int R = 0; R < RB; ++R) {
                 const unsigned long long bl = __ballot(need[R]);
-                keepmask[R] = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull) & c16;
+                keepmask[R] = ((unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xFFFFull) | home16(G)) & c16;
                 if (lane == 0 && kw + R * 16 < nrows)
                     keep16[(blk0 + R) * (4ll * d.keep_stride) + G] = (unsigned short)keepmask[R];
                 n_kept += __popc(keepmask[R]);
@@ -753,8 +783,6 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             }
         }
     }
-    if (probe) pr[4] = wall_clock64();
-    if ((d.debug_flags & 2048) && threadIdx.x == 0 && chunk == 0 && job.win_base == 0 && blockIdx.x == 1023) d.ctrl->prof[15] = wall_clock64();
     if (lane == 0) {
         // (counters spread over 256 addresses; apply_kernel folds them)
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
