@@ -170,6 +170,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
     d.tab_len = v_0 + N + 2;
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
+    d.batch_rows = 1 << 30;
     resolve_kind(c);
 
     const bool diag = cov_type != COV_FULL;                  // D-vector statistics (diag and fixed)
@@ -472,6 +473,16 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         c->seat_use_power = d.use_power;
         c->seat_power = d.power;
     }
+    // Launch grids follow the window scale: sized for twice the device's current window (at least
+    // 4096 rows, at most the allocation), never below the window that is already open.
+    auto rows_for = [&](long long win_now, long long open_rows) -> int {
+        long long r = 4096;
+        while (r < 2 * win_now && r < c->win_rows) r <<= 1;
+        while (r < open_rows && r < c->win_rows) r <<= 1;
+        if (r > c->win_rows) r = c->win_rows;
+        return (int)r;
+    };
+    d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
@@ -506,6 +517,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             const bool fresh = first_batch || hc.job.mode == MODE_FRESH;
             pmode = (hc.ema_run >= 2048.0 && fresh) ? 2 : (hc.ema_run < 64.0 ? 0 : 1);
         }
+        {
+            const Ctrl &hc = *c->ctrl_host;
+            const long long open_rows = first_batch ? (long long)d.batch_rows : hc.job.win_hi - hc.job.win_base;
+            d.batch_rows = rows_for(win, open_rows);
+        }
+        const long long grid_rows = d.batch_rows;
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
@@ -514,14 +531,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
-            if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 1, st);
-            if (pmode >= 1) launch_bucket_rows(d, c->win_rows, st);
+            if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
+            if (pmode >= 1) launch_bucket_rows(d, grid_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
-            if (pmode >= 1) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, c->win_rows, st);
-            else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, c->win_rows, 0, st);
+            if (pmode >= 1) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st);
+            else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
-            if (pmode <= 1) launch_choice(d, c->win_rows, st);
-            if (pmode >= 1) launch_choice_sparse(d, c->win_rows, st);
+            if (pmode <= 1) launch_choice(d, grid_rows, st);
+            if (pmode >= 1) launch_choice_sparse(d, grid_rows, st);
             if (use_resolver && pmode <= 1) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
             launch_refresh_ctrl(d, st);

@@ -148,6 +148,8 @@ struct Dev {
     const long long *order;      // may be null (identity)
     int use_power;
     double power;
+    int batch_rows;              // rows the launches of this batch of steps are sized for: no window
+                                 // opened during the batch is longer (the host raises it batch by batch)
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
                                  // queued steps: 0 never (only the dense kernels are launched), 1 the device
                                  // decides per window (job.prune; both kernel sets are launched), 2 every

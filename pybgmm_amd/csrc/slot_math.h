@@ -294,7 +294,7 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     Job &j = c->job;
     j.pos = pos;
     j.win_base = pos;
-    long long hi = pos + c->win_size;
+    long long hi = pos + (c->win_size < d.batch_rows ? c->win_size : d.batch_rows);
     if (hi > c->n_visits) hi = c->n_visits;
     j.win_hi = hi;
     j.n_dirty = 0;
