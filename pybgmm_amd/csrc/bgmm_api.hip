@@ -226,7 +226,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_const, ng * 128);
         DALLOC(c, d.pr_slot, ng * 16);
         DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
-        DALLOC(c, d.wvisit, (size_t)rows);
+        DALLOC(c, d.wrec, (size_t)rows);
         DALLOC(c, d.pr_counts, 768);
         CK(c, hipMemsetAsync(d.pr_counts, 0, 768 * sizeof(unsigned long long), c->stream));
     }

@@ -100,6 +100,16 @@ struct Ctrl {
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
 };
 
+// One row of a pruned window in evaluation order: everything the pruning kernel needs to start on
+// it comes with a single 32-byte load (instead of order -> label -> prior chains).
+struct WRec {
+    long long i;        // data index
+    int home;           // home slot (-1: unassigned)
+    int home_label;     // its label in this window's frozen state
+    double mlb0;        // log(alpha) + log_prior[i]: the "new table" score, first lower bound of the best score
+    double pad;
+};
+
 struct Dev {
     long long N;
     int cov_type;                // 0 full covariance, 1 diagonal (S and dw are D-vectors per slot),
@@ -141,7 +151,7 @@ struct Dev {
     double *pr_mufrag, *pr_const;
     double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
     int *pr_slot;
-    long long *wvisit;           // pruned windows: data index of the k-th row in evaluation order
+    struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
     unsigned long long *pr_counts;  // 3 x 256 spread counters (kept, bound, MFMA instructions) of the pruning kernel
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;

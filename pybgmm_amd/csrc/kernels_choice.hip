@@ -170,21 +170,21 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     if (k >= nrows) return;
     const int K = c->job.K;
     const long long p = win_base + d.wperm[k];
-    const long long i = d.order ? d.order[p] : p;
+    const WRec rec = d.wrec[k];                          // (index, home, its label, new-table score)
     SparseVisit sv;
     sv.d = &d;
     sv.K = K;
-    sv.h = d.z[i];
+    sv.h = rec.home;
     const int nh = sv.h >= 0 ? d.n[sv.h] : 0;
     sv.home_live = sv.h >= 0 && nh >= 2;
     sv.singleton = sv.h >= 0 && nh == 1;
-    sv.lab_h = sv.singleton ? d.label_of_slot[sv.h] : -1;
+    sv.lab_h = sv.singleton ? rec.home_label : -1;
     const long long b = k >> 4;
     sv.mask = d.keep64 + b * d.keep_stride;
     sv.qline = d.q + (b * (long long)d.nslots) * 16 + (k & 15);
     const int L = sv.singleton ? K - 1 : K;              // labels after the removal
     const int nw = (K + 63) >> 6;
-    const double vnew = d.log_alpha + d.log_prior[i];
+    const double vnew = rec.mlb0;
 
     // Post-removal label j is old label j, except that a deleted singleton's place lab_h is taken
     // by old label K-1 (swap with last).  Without a singleton the kept labels are walked by bit
@@ -192,37 +192,60 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     double mx = vnew, tot = 0.0, v;
     int pick = L;
     if (!sv.singleton) {
+        // the scores of the first four kept labels stay in registers: with at most four (the usual
+        // case: the home and a neighbour or two) the second and third pass need no memory at all
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int t0 = 0, t1 = 0, t2 = 0, t3 = 0, nc = 0;
         for (int wi = 0; wi < nw; ++wi) {
-            unsigned long long m = sv.mask[wi];
-            if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
-            while (m) {
-                const int t = wi * 64 + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (sparse_score(sv, t, v)) mx = fmax(mx, v);
-            }
-        }
-        for (int wi = 0; wi < nw; ++wi) {
-            unsigned long long m = sv.mask[wi];
-            if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
-            while (m) {
-                const int t = wi * 64 + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (sparse_score(sv, t, v)) tot += exp(v - mx);
-            }
-        }
-        tot += exp(vnew - mx);
-        const double lse = log(tot) + mx;
-        double uu = d.u[p];
-        bool done = false;
-        for (int wi = 0; wi < nw && !done; ++wi) {
             unsigned long long m = sv.mask[wi];
             if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
             while (m) {
                 const int t = wi * 64 + __ffsll((long long)m) - 1;
                 m &= m - 1;
                 if (sparse_score(sv, t, v)) {
-                    uu -= exp(v - lse);
-                    if (uu < 0.0) { pick = t; done = true; break; }
+                    mx = fmax(mx, v);
+                    if (nc == 0) { v0 = v; t0 = t; } else if (nc == 1) { v1 = v; t1 = t; }
+                    else if (nc == 2) { v2 = v; t2 = t; } else if (nc == 3) { v3 = v; t3 = t; }
+                    ++nc;
+                }
+            }
+        }
+        if (nc <= 4) {
+            if (nc > 0) tot += exp(v0 - mx);
+            if (nc > 1) tot += exp(v1 - mx);
+            if (nc > 2) tot += exp(v2 - mx);
+            if (nc > 3) tot += exp(v3 - mx);
+            tot += exp(vnew - mx);
+            const double lse = log(tot) + mx;
+            double uu = d.u[p];
+            if (nc > 0) { uu -= exp(v0 - lse); if (uu < 0.0) pick = t0; }
+            if (nc > 1 && pick == L) { uu -= exp(v1 - lse); if (uu < 0.0) pick = t1; }
+            if (nc > 2 && pick == L) { uu -= exp(v2 - lse); if (uu < 0.0) pick = t2; }
+            if (nc > 3 && pick == L) { uu -= exp(v3 - lse); if (uu < 0.0) pick = t3; }
+        } else {
+            for (int wi = 0; wi < nw; ++wi) {
+                unsigned long long m = sv.mask[wi];
+                if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+                while (m) {
+                    const int t = wi * 64 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (sparse_score(sv, t, v)) tot += exp(v - mx);
+                }
+            }
+            tot += exp(vnew - mx);
+            const double lse = log(tot) + mx;
+            double uu = d.u[p];
+            bool done = false;
+            for (int wi = 0; wi < nw && !done; ++wi) {
+                unsigned long long m = sv.mask[wi];
+                if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+                while (m) {
+                    const int t = wi * 64 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (sparse_score(sv, t, v)) {
+                        uu -= exp(v - lse);
+                        if (uu < 0.0) { pick = t; done = true; break; }
+                    }
                 }
             }
         }

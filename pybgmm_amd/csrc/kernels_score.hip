@@ -295,7 +295,7 @@ __device__ __forceinline__ double log1p_lower(double t) {
     return 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
 }
 
-// In a pruned window the visits are evaluated in the order of d.wvisit (grouped by home component,
+// In a pruned window the visits are evaluated in the order of d.wrec (grouped by home component,
 // kernels_state.hip: bucket_*_kernel), so that the visits of one wave mostly share a home and
 // need the same one or two components in full.  The output is block-sparse: for every 16-visit
 // evaluation block b a bitmask over labels (d.keep64) says which components were scored in full,
@@ -337,7 +337,10 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     // ---- stage the wave's rows: lane r < 32 owns the data index of row r
     double *__restrict__ xs = xs_all + w * (ROWS_W * Ds);
     const long long kmine = kw + (lane & (ROWS_W - 1));
-    const long long imine = kmine < nrows ? d.wvisit[kmine] : -1;
+    WRec rmine;
+    if (kmine < nrows) rmine = d.wrec[kmine];
+    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; }
+    const long long imine = rmine.i;
     // gathers behind the bound, one value per row of the wave: the lower bound of the visit's best log
     // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
     // (wave-private side arrays behind the staging area; accumulator element (R, r) of lane (lk, .)
@@ -349,9 +352,9 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     int *__restrict__ sideH = (int *)(sideM + 96);                            // home slot
     double *__restrict__ sideRho = sideM + 112;                               // |x - mu_home|^2
     unsigned long long *__restrict__ sideC = (unsigned long long *)(sideM + 144);   // coarse label mask
-    const int hmine = imine >= 0 ? d.z[imine] : -2;                // home slot of row (lane & 31)
+    const int hmine = rmine.home;                                  // home slot of row (lane & 31); dead rows -2
     if (lane < ROWS_W) {
-        sideM[lane] = imine >= 0 ? d.log_alpha + d.log_prior[imine] : INFINITY;   // dead rows never keep a slot alive
+        sideM[lane] = rmine.mlb0;                                  // dead rows: +inf, never keep a slot alive
         sideH[lane] = hmine;
     }
     // ---- the home components come first (the visits are grouped by home: mostly one or two per
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             const int first = __ffsll((long long)pending) - 1;
             const int s = __builtin_amdgcn_readfirstlane(__shfl(hmine, first));
             pending &= ~__ballot(lane < ROWS_W && hmine == s);
-            const int lab = d.label_of_slot[s];
+            const int lab = __builtin_amdgcn_readfirstlane(__shfl(rmine.home_label, first));
             if (it == 0) { done0 = s; lab0 = lab; } else if (it == 1) { done1 = s; lab1 = lab; }
             else if (it == 2) { done2 = s; lab2 = lab; } else { done3 = s; lab3 = lab; }
             ++n_home;

@@ -373,7 +373,13 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
             const int k = res[myb[t]] + myk[t];
             const long long p = base + r;
             d.wperm[k] = r;
-            d.wvisit[k] = d.order ? d.order[p] : p;
+            WRec rec;
+            rec.i = d.order ? d.order[p] : p;
+            rec.home = myb[t] - 1;
+            rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
+            rec.mlb0 = d.log_alpha + d.log_prior[rec.i];
+            rec.pad = 0.0;
+            d.wrec[k] = rec;
         }
 }
 
