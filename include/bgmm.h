@@ -158,7 +158,8 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
  * kernel (0 auto, 1 VALU, 2 MFMA); in-launch mover resolver (0 auto: when movers are dense,
  * 1 never, 2 whenever it fits); exact pruning of components whose weight in a draw is provably
- * below e^-80 (0 auto: on, 1 off).  None of them changes the sampled trajectory. */
+ * below e^-80 (0 auto: on while movers are sparse, 1 off, 2 in every window whatever the regime --
+ * slow when movers are dense, meant for tests).  None of them changes the sampled trajectory. */
 int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                     int32_t prune_mode);
 

@@ -54,7 +54,7 @@ struct bgmm_ctx {
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
     int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
-    int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off
+    int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off, 2 every window (tests)
     double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
     int seat_use_power = 0;
     double seat_power = 1.0;
@@ -516,6 +516,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             const Ctrl &hc = *c->ctrl_host;
             const bool fresh = first_batch || hc.job.mode == MODE_FRESH;
             pmode = (hc.ema_run >= 2048.0 && fresh) ? 2 : (hc.ema_run < 64.0 ? 0 : 1);
+            if (c->prune_mode == 2) pmode = 2;       // (every window pruned: exact whatever the regime, for tests)
         }
         {
             const Ctrl &hc = *c->ctrl_host;
@@ -526,7 +527,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
-        if (pmode == 2 && rate > 0.0 && T > lb + 64) T = (int)(lb + 64);
+        if (pmode == 2 && c->prune_mode != 2 && rate > 0.0 && T > lb + 64) T = (int)(lb + 64);
         for (int t = 0; t < T; ++t) {
             // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
             // only serves the re-scoring after a move; the events bracket the one that works in
@@ -800,7 +801,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
     if (resolver_mode < 0 || resolver_mode > 2) return fail(c, BGMM_EINVAL, "resolver_mode must be 0, 1 or 2");
-    if (prune_mode < 0 || prune_mode > 1) return fail(c, BGMM_EINVAL, "prune_mode must be 0 or 1");
+    if (prune_mode < 0 || prune_mode > 2) return fail(c, BGMM_EINVAL, "prune_mode must be 0, 1 or 2");
     c->kernel_kind = kernel_kind;
     c->resolver_mode = resolver_mode;
     c->prune_mode = prune_mode;

@@ -92,6 +92,58 @@ def test_pruning_does_not_change_trajectory(case, prune):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["crpmm_12d", "c3twin_pcrpmm_16d", "c3rand_pcrpmm_16d", "c4twin_crpmm_64d",
+                                  "c4rand_crpmm_64d"])
+def test_every_window_pruned(case):
+    """prune_mode 2: the pruned-window kernels (bucket sort, bounds, block-sparse scores, sparse draw)
+    evaluate EVERY window, also in the mover-dense sweeps of these fixtures -- singleton homes,
+    deletions and new components included."""
+    g = Golden(case)
+    ctx = make_ctx(g, kind=2, prune=2)
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        z = ctx.assignments()
+        bad = np.nonzero(z != g.z[it])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        assert abs(ctx.log_marg() - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
+        assert ctx.sweep_stats()["bound_blocks"] > 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,D,K,sep,label", [
+    (6000, 12, 1500, 4.0, "many tiny clusters: more than four homes per wave, K > 1024"),
+    (20000, 16, 40, 0.9, "overlapping clusters: survivors of every bound level, long work lists"),
+    (8000, 48, 300, 4.0, "K > 256: several coarse passes"),
+    (4000, 128, 20, 4.0, "D = 128"),
+])
+def test_every_window_pruned_against_c_oracle(N, D, K, sep, label):
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=900 + D, mu_scale=sep)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(K)
+    z0 = zt.copy()
+    z0[rs.rand(N) < 0.02] = -1                      # a few unassigned visits ("one-by-one")
+    us = rs.random_sample((2, N))
+    order = rs.permutation(N)
+    K_max = min(N, 2 * K + 64)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, tables=reference_tables(v_0, N))
+    ctx.set_tuning(kernel_kind=2, prune_mode=2)
+    ctx.set_assignments(z0)
+    for it in range(2):
+        power = 1.03 if it == 1 else None
+        o.sweep(us[it], order if it == 1 else None, power)
+        ctx.sweep(us[it], order if it == 1 else None, power)
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "%s: sweep %d: %d labels differ, first at i=%d" % (label, it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+    ctx.close()
+
+
 @pytest.mark.parametrize("window", [256, 1024])
 @pytest.mark.parametrize("case", ["c2twin_crpmm_2d", "c3rand_pcrpmm_16d", "each_in_own_50"])
 def test_window_size_does_not_change_trajectory(case, window):
