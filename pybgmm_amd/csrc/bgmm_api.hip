@@ -465,7 +465,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.u = c->cur_u;
     d.order = c->cur_order;
     resolve_kind(c);
-    const bool use_prune = c->prune_mode != 1 && c->kind == KERNEL_MFMA;
+    const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL);
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {

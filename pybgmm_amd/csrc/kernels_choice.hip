@@ -149,7 +149,10 @@ __device__ __forceinline__ bool sparse_score(const SparseVisit &sv, int t, doubl
     const int s = d.perm[t];
     const double qv = sv.qline[(long long)t * 16];
     const SlotConst *__restrict__ sc = d.sc + s;
-    if (sv.home_live && s == sv.h) {
+    if (d.cov_type != COV_FULL) {
+        // the diag / fixed likelihood kernels store log densities (home row: one-point-removed form)
+        v = ((sv.home_live && s == sv.h) ? sc->logseat1 : sc->logseat) + qv;
+    } else if (sv.home_live && s == sv.h) {
         const double a1 = sc->a1, den = 1.0 - a1 * qv;
         v = sc->logseat1 + sc->A1 - 0.5 * log(den) - sc->half_vd1 * log(1.0 + sc->coef1 * qv / den);
     } else {

@@ -808,10 +808,13 @@ static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long
     hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }
 
+static void launch_diag_prune(const Dev &d, const Job *job, double *q, long long max_rows, hipStream_t st);
+
 // Fresh-window scoring with pruning
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st) {
     if (max_rows <= 0) return true;
+    if (d.cov_type != COV_FULL) { launch_diag_prune(d, job, q, max_rows, st); return true; }
     switch (d.Dp / 16) {
         case 1: launch_mfma_prune<1>(d, job, q, qstride, max_rows, st); return true;
         case 2: launch_mfma_prune<2>(d, job, q, qstride, max_rows, st); return true;
@@ -835,12 +838,12 @@ static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstri
 }
 
 void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
-                       long long max_rows, hipStream_t st);
+                       long long max_rows, int skip_pruned_jobs, hipStream_t st);
 
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
                   long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
-    if (d.cov_type != COV_FULL) { launch_score_diag(d, job, q, qstride, col_override, max_rows, st); return; }
+    if (d.cov_type != COV_FULL) { launch_score_diag(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return; }
     if (kind == KERNEL_MFMA) {
         switch (d.Dp / 16) {
             case 1: launch_mfma<1>(d, job, q, qstride, col_override, max_rows, skip_pruned_jobs, st); return;
@@ -871,12 +874,17 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
 // one-point-removed form, rebuilt from (n-1, m-x, S-x^2) exactly as del_item does
 // (gaussian_components_diag.py:178-193).
 // ------------------------------------------------------------------------------------------
+// x tile in LDS: element (dimension l, visit r) at xs[l * kDiagLd + r]; the odd stride keeps the
+// transposing writes (consecutive l) off a single bank
+static constexpr int kDiagLd = kValuRows + 1;
+
 __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__restrict__ jobp,
                                                          double *__restrict__ q, long long qstride,
-                                                         int col_override, int home_correction) {
+                                                         int col_override, int home_correction,
+                                                         int skip_pruned_jobs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64]
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE) return;
+    if (job.mode == MODE_DONE || (skip_pruned_jobs && job_is_pruned(d, job.mode, job.prune))) return;
     const int chunk = blockIdx.y;
     if (chunk >= job.chunks) return;
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
@@ -890,7 +898,7 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
             const long long i = d.order ? d.order[p] : p;
             v = d.X[i * D + l];
         }
-        xs[l * kValuRows + r] = v;
+        xs[l * kDiagLd + r] = v;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -913,12 +921,12 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
         double acc = 0.0;
         if (fixed) {                // product of normals: sum (x - mu)^2 * predictive precision
             for (int l = 0; l < D; ++l) {
-                const double dl = xs[l * kValuRows + lane] - mu[l];
+                const double dl = xs[l * kDiagLd + lane] - mu[l];
                 acc += (dl * dl) * dw[l];
             }
         } else {
             for (int l = 0; l < D; ++l) {
-                const double dl = xs[l * kValuRows + lane] - mu[l];
+                const double dl = xs[l * kDiagLd + lane] - mu[l];
                 acc += log(1.0 + dl * dl * dw[l]);
             }
         }
@@ -930,7 +938,7 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
             const double *__restrict__ SS = d.S + (long long)s * 2 * D;
             double lpp = 0.0, a1 = 0.0;
             for (int l = 0; l < D; ++l) {
-                const double x = xs[l * kValuRows + lane];
+                const double x = xs[l * kDiagLd + lane];
                 const double p = d.prior_S[D + l];
                 const double mn = __dsub_rn(mS[l], __dmul_rn(p, x));
                 const double pN = __dsub_rn(SS[l], p);
@@ -949,7 +957,7 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
             const double scale1 = (k1 + 1.0) / (k1 * (double)v1), inv_v1 = 1.0 / (double)v1;
             double lpv = 0.0, a1 = 0.0;
             for (int l = 0; l < D; ++l) {
-                const double x = xs[l * kValuRows + lane];
+                const double x = xs[l * kDiagLd + lane];
                 const double m1 = __dsub_rn(mS[l], x);
                 const double S1 = __dsub_rn(SS[l], __dmul_rn(x, x));
                 const double mean = m1 / k1;
@@ -966,10 +974,255 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
 }
 
 void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
-                       long long max_rows, hipStream_t st) {
+                       long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
-    const int lds = d.D * kValuRows * (int)sizeof(double);
+    const int lds = d.D * kDiagLd * (int)sizeof(double);
     hipLaunchKernelGGL(score_diag_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
-                       col_override, job == &d.ctrl->job ? 1 : 0);
+                       col_override, job == &d.ctrl->job ? 1 : 0, skip_pruned_jobs);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pruned windows for diagonal / fixed-variance components.  Same contract as
+// score_mfma_prune_kernel (evaluation order d.wrec, block-sparse output: keep64 label masks + one
+// line of 16 values per kept (block, label); the values are log densities here).  Bound:
+//   diag   sum_d log(1 + a_d) >= log(1 + sum_d a_d) >= log(1 + w_min |x - mu|^2),   w_min = min_d dw_d
+//   fixed  sum_d (x_d - mu_d)^2 pp_d >= pp_min |x - mu|^2
+// with |x - mu_t| >= |mu_t - mu_home| - |x - mu_home| from the centre-to-centre table (no distance
+// work per pair at all).  A workgroup owns 64 consecutive visits (lane = visit, rows transposed in
+// LDS); its 4 waves split the label range by 64-bit mask words; what survives the bound is scored
+// exactly by the lanes (D logarithms / squares per pair).
+// ------------------------------------------------------------------------------------------
+// as-is log density of visit `lane` under slot s
+__device__ __forceinline__ double diag_pair_score(const Dev &d, const double *__restrict__ xs, int lane, int s) {
+    const int D = d.D;
+    const double *__restrict__ mu = d.mu + (long long)s * D;
+    const double *__restrict__ dw = d.dw + (long long)s * D;
+    double acc = 0.0;
+    if (d.cov_type == COV_FIXED) {
+        for (int l = 0; l < D; ++l) {
+            const double dl = xs[l * kDiagLd + lane] - mu[l];
+            acc += (dl * dl) * dw[l];
+        }
+    } else {
+        for (int l = 0; l < D; ++l) {
+            const double dl = xs[l * kDiagLd + lane] - mu[l];
+            acc += log(1.0 + dl * dl * dw[l]);
+        }
+    }
+    return d.sc[s].A - d.sc[s].half_vd * acc;
+}
+
+__global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job *__restrict__ jobp,
+                                                               double *__restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64], then the per-visit arrays
+    const JobView job = load_job(jobp);
+    if (!job_is_pruned(d, job.mode, job.prune)) return;
+    const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
+    const long long k0 = (long long)blockIdx.x * kValuRows;
+    if (k0 >= nrows) return;
+    const int D = d.D, K = job.nlist;
+    double *__restrict__ sM = xs + D * kDiagLd;                   // best-score lower bound per visit
+    double *__restrict__ sRho = sM + kValuRows;                   // |x - mu_home|
+    long long *__restrict__ sI = (long long *)(sRho + kValuRows); // data index (-1: dead row)
+    int *__restrict__ sH = (int *)(sI + kValuRows);               // home slot
+    int *__restrict__ sLab = sH + kValuRows;                      // its label
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kValuRows) {
+        const long long k = k0 + tid;
+        if (k < nrows) {
+            const WRec r = d.wrec[k];
+            sI[tid] = r.i; sH[tid] = r.home; sLab[tid] = r.home_label; sM[tid] = r.mlb0;
+        } else {
+            sI[tid] = -1; sH[tid] = -2; sLab[tid] = -1; sM[tid] = INFINITY;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < kValuRows * D; e += 256) {
+        const int r = e / D, l = e % D;
+        const long long i = sI[r];
+        xs[l * kDiagLd + r] = i >= 0 ? d.X[i * D + l] : 0.0;
+    }
+    __syncthreads();
+    // the home component of every visit: distance to its mean (the radius of the triangle bound)
+    // and its exact one-point-removed score (raises the visit's best-score bound, and is the value
+    // the label loop stores for the home).  The D dimensions are split over the 4 waves; partial
+    // sums meet in LDS.
+    double *__restrict__ sPart = (double *)(sLab + kValuRows);    // [4 waves][3][64]
+    double *__restrict__ sHomeLp = sPart + 12 * kValuRows;        // exact home score (no seating weight)
+    const int hv = sH[lane];
+    const bool live = sI[lane] >= 0;
+    const bool fixed = d.cov_type == COV_FIXED;
+    const int nhv = hv >= 0 ? d.n[hv] : 0;
+    {
+        double r2 = 0.0, t1 = 0.0, t2 = 0.0;                      // radius^2; the two sums of the home form
+        if (hv >= 0) {
+            const double *__restrict__ mh = d.mu + (long long)hv * D;
+            const double *__restrict__ mS = d.m + (long long)hv * D;
+            const double *__restrict__ SS = d.S + (long long)hv * (fixed ? 2 * D : D);
+            const double k1 = d.k0 + (double)(nhv - 1);
+            const long long v1 = d.v0 + nhv - 1;
+            const double scale1 = (k1 + 1.0) / (k1 * (double)v1), inv_v1 = 1.0 / (double)v1;
+            for (int l = w; l < D; l += 4) {
+                const double x = xs[l * kDiagLd + lane];
+                const double t = x - mh[l];
+                r2 = fma(t, t, r2);
+                if (nhv >= 2) {
+                    if (fixed) {        // gaussian_components_fixedvar.py:164-176: numerator -= p x, precision_N -= p
+                        const double p = d.prior_S[D + l];
+                        const double mn = __dsub_rn(mS[l], __dmul_rn(p, x));
+                        const double pN = __dsub_rn(SS[l], p);
+                        const double pp = pN * p / (pN + p);
+                        const double dl = x - mn / pN;
+                        t1 += log(pp);
+                        t2 += (dl * dl) * pp;
+                    } else {            // gaussian_components_diag.py:178-193
+                        const double m1 = __dsub_rn(mS[l], x);
+                        const double S1 = __dsub_rn(SS[l], __dmul_rn(x, x));
+                        const double mean = m1 / k1;
+                        const double var = scale1 * (S1 - k1 * (mean * mean));
+                        const double dl = x - mean;
+                        t1 += log(var);
+                        t2 += log(1.0 + inv_v1 * (dl * dl) * (1.0 / var));
+                    }
+                }
+            }
+        }
+        sPart[(w * 3 + 0) * kValuRows + lane] = r2;
+        sPart[(w * 3 + 1) * kValuRows + lane] = t1;
+        sPart[(w * 3 + 2) * kValuRows + lane] = t2;
+    }
+    __syncthreads();
+    if (w == 0) {
+        double r2 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int ww = 0; ww < 4; ++ww) {
+            r2 += sPart[(ww * 3 + 0) * kValuRows + lane];
+            t1 += sPart[(ww * 3 + 1) * kValuRows + lane];
+            t2 += sPart[(ww * 3 + 2) * kValuRows + lane];
+        }
+        sRho[lane] = sqrt(r2) * (1.0 + 1e-9);
+        if (hv >= 0 && nhv >= 2) {
+            const long long v1 = d.v0 + nhv - 1;
+            const double lp = fixed ? -0.5 * (double)D * log(2.0 * 3.14159265358979323846) + 0.5 * t1 - 0.5 * t2
+                                    : (double)D * (d.tab_lgam[v1 + 1] - d.tab_lgam[v1] - 0.5 * d.tab_log[v1] - 0.5 * BGMM_LOG_PI)
+                                          - 0.5 * t1 - 0.5 * (double)(v1 + 1) * t2;
+            sHomeLp[lane] = lp;
+            sM[lane] = fmax(sM[lane], d.sc[hv].logseat1 + lp);
+        }
+    }
+    __syncthreads();
+    const double rho = sRho[lane], thr = sM[lane] - kPruneMargin;
+    const int labv = sLab[lane];
+    const long long blk0 = k0 >> 4;
+    unsigned n_kept = 0, n_bound = 0;
+    const int nw = (K + 63) >> 6;
+    // Coarse pass, lane = LABEL: with at most four distinct homes among the 64 visits (they are
+    // sorted by home: usually one), a label is tested once per home against the largest radius and
+    // the weakest threshold of that home's visits; only the labels that survive are looked at per
+    // visit below.
+    int hs[4] = {-1, -1, -1, -1}, hl[4] = {0, 0, 0, 0}, nh = 0;
+    double hr[4] = {0.0, 0.0, 0.0, 0.0}, ht[4] = {0.0, 0.0, 0.0, 0.0};
+    bool coarse_ok;
+    {
+        unsigned long long pending = __ballot(live && hv >= 0);
+        const bool unassigned = __ballot(live && hv < 0) != 0ull;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (pending) {
+                const int first = __ffsll((long long)pending) - 1;
+                const int sh = __builtin_amdgcn_readfirstlane(__shfl(hv, first));
+                const bool sel = live && hv == sh;
+                pending &= ~__ballot(sel);
+                double a = sel ? rho : 0.0, bmin = sel ? thr : INFINITY;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    a = fmax(a, __shfl_xor(a, o));
+                    bmin = fmin(bmin, __shfl_xor(bmin, o));
+                }
+                hs[it] = sh; hl[it] = __builtin_amdgcn_readfirstlane(__shfl(labv, first));
+                hr[it] = a; ht[it] = bmin;
+                nh = it + 1;
+            }
+        }
+        coarse_ok = !unassigned && pending == 0ull;
+    }
+    for (int wi = w; wi < nw; wi += 4) {
+        unsigned long long mword0 = 0, mword1 = 0, mword2 = 0, mword3 = 0;
+        unsigned long long cmask;
+        {
+            const int t = wi * 64 + lane;
+            bool cand = t < K;
+            n_bound += 4 * __popcll(__ballot(cand));
+            if (coarse_ok && cand) {
+                const int st = d.perm[t];
+                const SlotConst *__restrict__ scp = d.sc + st;
+                const double base = scp->logseat + scp->A, hvd = scp->half_vd, tcoef = scp->inv_lam * scp->inv_cv;
+                cand = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nh) {
+                        double dl = d.pr_dcc[(long long)hl[j] * d.nslots + t] * (1.0 - 1e-9) - hr[j];
+                        dl = dl > 0.0 ? dl : 0.0;
+                        const double tt = dl * dl * tcoef;
+                        const double ub = base - hvd * (fixed ? tt : log1p_lower(tt));
+                        cand = cand || ub >= ht[j] || st == hs[j];
+                    }
+                }
+            }
+            cmask = __ballot(cand);
+        }
+        while (cmask) {
+            const int t = wi * 64 + __ffsll((long long)cmask) - 1;
+            cmask &= cmask - 1;
+            const int s = d.perm[t];
+            const SlotConst *__restrict__ scp = d.sc + s;
+            const double base = scp->logseat + scp->A, hvd = scp->half_vd, tcoef = scp->inv_lam * scp->inv_cv;
+            bool need = false;
+            if (live) {
+                if (hv == s) need = true;
+                else if (labv < 0) need = true;                 // unassigned visit: no centre to bound from
+                else {
+                    double dl = d.pr_dcc[(long long)labv * d.nslots + t] * (1.0 - 1e-9) - rho;
+                    dl = dl > 0.0 ? dl : 0.0;
+                    const double tt = dl * dl * tcoef;
+                    const double ub = base - hvd * (fixed ? tt : log1p_lower(tt));
+                    need = ub >= thr;
+                }
+            }
+            const unsigned long long bl = __ballot(need);
+            if (bl == 0ull) continue;
+            // somebody needs this label: exact scores for the 16-visit blocks that do
+            const unsigned long long bit = 1ull << (t & 63);
+            if (bl & 0xFFFFull) mword0 |= bit;
+            if (bl & 0xFFFF0000ull) mword1 |= bit;
+            if (bl & 0xFFFF00000000ull) mword2 |= bit;
+            if (bl & 0xFFFF000000000000ull) mword3 |= bit;
+            n_kept += ((bl & 0xFFFFull) != 0) + ((bl & 0xFFFF0000ull) != 0) + ((bl & 0xFFFF00000000ull) != 0)
+                      + ((bl & 0xFFFF000000000000ull) != 0);
+            const bool my_block = ((bl >> (lane & 48)) & 0xFFFFull) != 0ull;
+            if (my_block && live) {
+                const bool own = hv == s && nhv >= 2;
+                const double lp = own ? sHomeLp[lane] : diag_pair_score(d, xs, lane, s);
+                q[((blk0 + (lane >> 4)) * (long long)d.nslots + t) * 16 + (lane & 15)] = lp;
+            }
+        }
+        if (lane == 0) {
+            unsigned long long *__restrict__ kp = d.keep64 + blk0 * d.keep_stride + wi;
+            if (k0 < nrows) kp[0] = mword0;
+            if (k0 + 16 < nrows) kp[d.keep_stride] = mword1;
+            if (k0 + 32 < nrows) kp[2 * d.keep_stride] = mword2;
+            if (k0 + 48 < nrows) kp[3 * d.keep_stride] = mword3;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
+        atomicAdd(&d.pr_counts[256 + (blockIdx.x & 255)], (unsigned long long)n_bound);
+    }
+}
+
+static void launch_diag_prune(const Dev &d, const Job *job, double *q, long long max_rows, hipStream_t st) {
+    const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
+    const int lds = (d.D * kDiagLd + 17 * kValuRows) * (int)sizeof(double);   // tile + per-visit arrays + partial sums
+    hipLaunchKernelGGL(score_diag_prune_kernel, dim3(gx), dim3(256), lds, st, d, job, q);
 }

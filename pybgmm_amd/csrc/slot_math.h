@@ -333,7 +333,7 @@ __device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int t
     const long long v_N = d.v0 + n;
     const double scale = (k_N + 1.0) / (k_N * (double)v_N);
     const double inv_v = 1.0 / (double)v_N;
-    double lpv = 0.0, lsn = 0.0;
+    double lpv = 0.0, lsn = 0.0, wmin = INFINITY;
     bool bad = false;
     for (int l = tid; l < D; l += NT) {
         const double mean = d.m[(long long)s * D + l] / k_N;
@@ -341,7 +341,9 @@ __device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int t
         const double var = scale * sn;
         if (!(sn > 0.0)) bad = true;
         d.mu[(long long)s * D + l] = mean;
-        d.dw[(long long)s * D + l] = (1.0 / var) * inv_v;
+        const double wl = (1.0 / var) * inv_v;
+        d.dw[(long long)s * D + l] = wl;
+        wmin = fmin(wmin, wl);
         lpv += log(var);
         lsn += log(sn);
     }
@@ -349,19 +351,26 @@ __device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int t
     red[NT + tid] = lsn;
     if (bad) atomicCAS(&d.ctrl->error, 0, -4);
     __syncthreads();
-    if (tid == 0) {
-        double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0;
+    if (tid == 0)
         for (int t = 0; t < NT; ++t) { a += red[t]; b += red[NT + t]; }
+    __syncthreads();
+    red[tid] = wmin;
+    __syncthreads();
+    if (tid == 0) {
+        for (int t = 0; t < NT; ++t) wmin = fmin(wmin, red[t]);
         SlotConst c;
         c.A = (double)D * (d.tab_lgam[v_N + 1] - d.tab_lgam[v_N] - 0.5 * d.tab_log[v_N] - 0.5 * BGMM_LOG_PI) - 0.5 * a;
         c.half_vd = 0.5 * (double)(v_N + 1);
-        c.inv_cv = 0.0;
         c.A1 = a;                 // log prod of the predictive variances (reference log_prod_vars)
         c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
         c.logdetC = b;            // sum_d log S_N,d (log_marg_k)
         c.logseat = d.tabSeat[n];
         c.logseat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
-        c.inv_lam = 0.0; c.mu2 = 0.0;
+        // pruned windows: sum_d log(1 + a_d) >= log(1 + sum_d a_d) >= log(1 + min_d(w_d) |x - mu|^2)
+        c.inv_cv = 1.0;
+        c.inv_lam = (wmin > 0.0 && wmin < INFINITY) ? wmin * (1.0 - 1e-12) : 0.0;
+        c.mu2 = 0.0;
         d.sc[s] = c;
         d.nupd[s] = 0;
     }
@@ -377,30 +386,38 @@ template <int NT>
 __device__ inline void refresh_fixed_slot(const Dev &d, int s, double *red, int tid) {
     const int D = d.D;
     const int n = d.n[s];
-    double lpp = 0.0;
+    double lpp = 0.0, wmin = INFINITY;
     for (int l = tid; l < D; l += NT) {
         const double pN = d.S[(long long)s * 2 * D + l];
         const double p = d.prior_S[D + l];
         const double pp = s == d.K_max ? pN : pN * p / (pN + p);
         d.mu[(long long)s * D + l] = d.m[(long long)s * D + l] / pN;
         d.dw[(long long)s * D + l] = pp;
+        wmin = fmin(wmin, pp);
         lpp += log(pp);
     }
     red[tid] = lpp;
     __syncthreads();
-    if (tid == 0) {
-        double a = 0.0;
+    double a = 0.0;
+    if (tid == 0)
         for (int t = 0; t < NT; ++t) a += red[t];
+    __syncthreads();
+    red[tid] = wmin;
+    __syncthreads();
+    if (tid == 0) {
+        for (int t = 0; t < NT; ++t) wmin = fmin(wmin, red[t]);
         SlotConst c;
         c.A = -0.5 * (double)D * log(2.0 * 3.14159265358979323846) + 0.5 * a;
         c.half_vd = 0.5;
-        c.inv_cv = 0.0;
+        c.inv_cv = 1.0;
         c.A1 = a;                 // log prod of the predictive precisions
         c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
         c.logdetC = 0.0;
         c.logseat = d.tabSeat[n];
         c.logseat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
-        c.inv_lam = 0.0; c.mu2 = 0.0;
+        // pruned windows: sum_d (x_d - mu_d)^2 pp_d >= min_d(pp_d) |x - mu|^2
+        c.inv_lam = (wmin > 0.0 && wmin < INFINITY) ? wmin * (1.0 - 1e-12) : 0.0;
+        c.mu2 = 0.0;
         d.sc[s] = c;
         d.nupd[s] = 0;
     }

@@ -589,3 +589,59 @@ def test_fixed_against_c_oracle(N, D, K):
         lo = o.log_marg()
         assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
     ctx.close()
+
+
+# ---- pruned windows for diagonal / fixed-variance components --------------------------------
+@pytest.mark.parametrize("prune", [1, 2], ids=["unpruned", "every-window-pruned"])
+@pytest.mark.parametrize("case", DIAG_CASES + FIXED_CASES)
+def test_diag_fixed_pruning_does_not_change_trajectory(case, prune):
+    g = Golden(case)
+    ctx = make_ctx(g, prune=prune, tables=g.cov_type != "fixed")
+    for it in range(g.n_iter):
+        ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+        z = ctx.assignments()
+        bad = np.nonzero(z != g.z[it])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        assert abs(ctx.log_marg() - g.log_marg[it]) <= 1e-9 * abs(g.log_marg[it])
+        assert (ctx.sweep_stats()["bound_blocks"] > 0) == (prune == 2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cov", ["diag", "fixed"])
+@pytest.mark.parametrize("N,D,K,sep", [(20000, 16, 40, 4.0), (12000, 24, 300, 1.2), (6000, 8, 900, 4.0)])
+def test_diag_fixed_pruned_against_c_oracle(cov, N, D, K, sep):
+    """Steady-state start (labels at the truth, a few unassigned): the pruned-window kernels run by
+    the default policy and, second context, in every window."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=700 + D, mu_scale=sep)
+    rs = np.random.RandomState(K + D)
+    if cov == "diag":
+        m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+        S_0 = np.ascontiguousarray(np.diag(S_0))
+    else:
+        m_0, k_0, v_0 = np.zeros(D), 1.0, 1
+        S_0 = np.concatenate([0.4 + 0.2 * rs.rand(D), 15.0 + rs.rand(D)])      # [var ; var_0]
+    z0 = zt.copy()
+    z0[rs.rand(N) < 0.01] = -1
+    us = rs.random_sample((2, N))
+    order = rs.permutation(N)
+    K_max = min(N, 2 * K + 64)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max, cov_type=cov)
+    ref = []
+    for it in range(2):
+        o.sweep(us[it], order if it == 1 else None, 1.03 if it == 1 else None)
+        ref.append((o.z.copy(), o.log_marg()))
+    for prune in (0, 2):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, cov_type=cov,
+                           tables=reference_tables(v_0, N) if cov == "diag" else None)
+        ctx.set_tuning(prune_mode=prune)
+        ctx.set_assignments(z0)
+        for it in range(2):
+            ctx.sweep(us[it], order if it == 1 else None, 1.03 if it == 1 else None)
+            z = ctx.assignments()
+            bad = np.nonzero(z != ref[it][0])[0]
+            assert bad.size == 0, "prune %d sweep %d: %d labels differ, first at i=%d" % (prune, it, bad.size, bad[0])
+            assert abs(ctx.log_marg() - ref[it][1]) <= 1e-9 * abs(ref[it][1])
+        ctx.close()
