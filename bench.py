@@ -45,6 +45,18 @@ def flops_per_lik_eval(D):
     return 2.0 * D * D + 3.0 * D + 12.0
 
 
+def prior_for(cov, D):
+    """(m_0, k_0, v_0, S_0) of the demo scripts; fixed variance rides in the same slots."""
+    from pybgmm_amd.utils import gendata
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    if cov == "diag":
+        S_0 = np.ascontiguousarray(np.diag(S_0))
+    elif cov == "fixed":
+        m_0, k_0, v_0 = np.zeros(D), 1.0, 1
+        S_0 = np.concatenate([np.full(D, 0.49), np.full(D, 16.0)])          # [var ; var_0]
+    return m_0, k_0, v_0, S_0
+
+
 def cpu_baseline(D, K, seed, budget_visits, cov="full"):
     """C oracle (oracle/gibbs_oracle.c, scalar, 1 thread) on a down-sized twin of the
     workload: same D, K, prior, init-at-truth; per-visit cost does not depend on N."""
@@ -52,9 +64,7 @@ def cpu_baseline(D, K, seed, budget_visits, cov="full"):
     from pybgmm_amd.utils import gendata
     n_cpu = max(4 * K, budget_visits)
     X, z_true = gendata.synth_mixture(n_cpu, D, K, seed)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    if cov == "diag":
-        S_0 = np.ascontiguousarray(np.diag(S_0))
+    m_0, k_0, v_0, S_0 = prior_for(cov, D)
     t0 = time.time()
     o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z_true, 4 * K, scipy_tables=False, cov_type=cov)
     t_init = time.time() - t0
@@ -78,8 +88,8 @@ def main():
     ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 off, 2 always")
     ap.add_argument("--cpu-visits", type=int, default=20000,
                     help="visits of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cov", default="full", choices=["full", "diag"],
-                    help="covariance_type (diag: SURVEY 8f rank 1, not a BASELINE config)")
+    ap.add_argument("--cov", default="full", choices=["full", "diag", "fixed"],
+                    help="covariance_type (diag / fixed: SURVEY 8f rows, not BASELINE configs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -102,9 +112,7 @@ def main():
 
     N, D, K, model = WORKLOADS[args.workload]
     X, z_true = gendata.synth_mixture(N, D, K, seed=args.seed)          # replicated data set
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    if args.cov == "diag":
-        S_0 = np.ascontiguousarray(np.diag(S_0))
+    m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
     n_sweeps = args.warmup + args.steps
     # chain c: its own uniform (and permutation) streams, seeds seed + c
     rs = np.random.RandomState(1000 + args.seed + rank)
@@ -121,7 +129,7 @@ def main():
 
     t0 = time.time()
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, device=local_rank,
-                       tables=reference_tables(v_0, N), cov_type=args.cov)
+                       tables=reference_tables(v_0, N) if args.cov != "fixed" else None, cov_type=args.cov)
     ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
                    prune_mode=args.prune)
     ctx.set_assignments(z0)
@@ -179,7 +187,7 @@ def main():
         ctx.set_kernel_timing(False)
         if n_launch <= 0 or ms <= 0:
             return None
-        if args.cov == "diag":
+        if args.cov != "full" and st["bound_blocks"] == 0:
             # D logarithms per (visit, component): an FP64 VALU / transcendental kernel, no MFMA
             logs = st["scored"] * float(D)
             return {"kernel": "score_diag_kernel", "bound": "valu-transcendental",
@@ -187,7 +195,7 @@ def main():
                     "frac": None, "traffic": None, "launches": n_launch,
                     "avg_launch_ms": round(ms / n_launch, 4),
                     "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
-                    "note": "covariance_type=diag is a SURVEY 8f row, not a BASELINE config"}
+                    "note": "covariance_type=%s is a SURVEY 8f row, not a BASELINE config" % args.cov}
         flops = st["scored"] * flops_per_lik_eval(D)
         achieved = flops / (ms * 1e-3) / 1e12
         is_mfma = (args.kernel == 2 or (args.kernel == 0 and D >= 12)) and args.cov == "full"
@@ -215,7 +223,8 @@ def main():
             # what the same decisions would cost without pruning are reported next to it.
             ps = ctx.prune_stats()
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
-            out = {"kernel": "score_mfma_prune_kernel", "bound": "hbm",
+            out = {"kernel": "score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel",
+                   "bound": "hbm",
                    "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                    "frac": round(hbm / PEAK_HBM_GBPS, 4),
                    "algorithmic_bytes_per_visit": 8.0 * D + 24.0,
@@ -225,6 +234,11 @@ def main():
                    "mfma_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
                    "unpruned_equivalent_tflops": round(st["scored"] * flops_kernel_alg / (ms * 1e-3) / 1e12, 2)}
             out.update(common)
+            if args.cov != "full":          # no matrix work on this path; the PMC file is the full-covariance kernel's
+                for key in ("mfma_instructions_per_launch", "mfma_executed_tflops", "mfma_frac_of_spec_peak",
+                            "unpruned_equivalent_tflops"):
+                    out.pop(key)
+                out["traffic"] = None
             return out
         alg = st["scored"] * flops_kernel_alg / (ms * 1e-3) / 1e12
         executed = st["scored"] * exec_per_eval / (ms * 1e-3) / 1e12
@@ -244,7 +258,7 @@ def main():
     roofline = roofline_full = None
     if not args.no_kernel_timing:
         roofline = kernel_roofline(args.prune)
-        if roofline and roofline["kernel"] == "score_mfma_prune_kernel":
+        if roofline and roofline["kernel"].endswith("_prune_kernel"):
             # the same kernel family with pruning off: every (visit, component) pair through the
             # full quadratic form -- the MFMA-efficiency number
             roofline_full = kernel_roofline(1)
@@ -280,9 +294,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s D=%d N=%d K~%d%s, one independent chain per GPU, init=%s"
                                    % (args.workload, model, D, N, K,
-                                      " covariance_type=diag" if args.cov == "diag" else "", args.init),
+                                      " covariance_type=%s" % args.cov if args.cov != "full" else "", args.init),
                        "parallelism": "replica_chains_x%d" % n_gpus,
-                       "exact_pruning": bool(args.prune == 0 and args.kernel != 1 and (D >= 12 or args.kernel == 2))},
+                       "exact_pruning": bool(args.prune == 0 and (args.cov != "full" or (args.kernel != 1 and (D >= 12 or args.kernel == 2))))},
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
             "roofline": roofline,
