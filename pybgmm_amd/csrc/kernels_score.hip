@@ -890,15 +890,24 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
     if (p0 >= job.win_hi) return;
     const int D = d.D;
-    for (int e = threadIdx.x; e < kValuRows * D; e += 256) {
-        const int r = e / D, l = e % D;
-        const long long p = p0 + r;
-        double v = 0.0;
-        if (p < job.win_hi) {
-            const long long i = d.order ? d.order[p] : p;
-            v = d.X[i * D + l];
+    // (8 row-contiguous loads in flight per thread, then the transposing LDS writes)
+    for (int e0 = threadIdx.x; e0 < kValuRows * D; e0 += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + 256 * j;
+            const int r = e / D, l = e % D;
+            const long long p = p0 + r;
+            const bool ok = e < kValuRows * D && p < job.win_hi;
+            const long long i = ok ? (d.order ? d.order[p] : p) : 0;
+            v[j] = d.X[i * D + (ok ? l : 0)];
+            if (!ok) v[j] = 0.0;
         }
-        xs[l * kDiagLd + r] = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + 256 * j;
+            if (e < kValuRows * D) xs[(e % D) * kDiagLd + e / D] = v[j];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -1039,10 +1048,22 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
         }
     }
     __syncthreads();
-    for (int e = tid; e < kValuRows * D; e += 256) {
-        const int r = e / D, l = e % D;
-        const long long i = sI[r];
-        xs[l * kDiagLd + r] = i >= 0 ? d.X[i * D + l] : 0.0;
+    // (8 row-contiguous loads in flight per thread, then the transposing LDS writes)
+    for (int e0 = tid; e0 < kValuRows * D; e0 += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + 256 * j;
+            const bool in = e < kValuRows * D;
+            const long long i = in ? sI[e / D] : -1;
+            v[j] = d.X[(i >= 0 ? i : 0) * D + (in ? e % D : 0)];
+            if (i < 0) v[j] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + 256 * j;
+            if (e < kValuRows * D) xs[(e % D) * kDiagLd + e / D] = v[j];
+        }
     }
     __syncthreads();
     // the home component of every visit: distance to its mean (the radius of the triangle bound)
