@@ -64,6 +64,12 @@ struct bgmm_ctx {
     long long timed_launches = 0;
     double timed_ms = 0.0;
     long long prune_mfma = 0;
+    // A pruned component enters a draw with probability 0 instead of < 2e-35.  The reference's
+    // `u -= p` scan can tell the difference only for u == 0 exactly (it would return the first label
+    // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
+    // unpruned.
+    bool cur_zero_u = false;
+    std::vector<char> res_zero_u;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -417,6 +423,9 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     if (!c || !u) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     CK(c, hipMemcpyAsync(c->d_u, u, sizeof(double) * c->d.N, hipMemcpyHostToDevice, c->stream));
+    c->cur_zero_u = false;
+    for (long long i = 0; i < c->d.N; ++i)
+        if (u[i] == 0.0) { c->cur_zero_u = true; break; }
     c->have_order = order != nullptr;
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
@@ -440,6 +449,10 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
         CK(c, hipMemcpy(c->res_order, order_all, sizeof(long long) * N * n_sweeps, hipMemcpyHostToDevice));
     }
     c->res_n = n_sweeps;
+    c->res_zero_u.assign((size_t)n_sweeps, 0);
+    for (int32_t t = 0; t < n_sweeps; ++t)
+        for (size_t i = 0; i < N; ++i)
+            if (u_all[(size_t)t * N + i] == 0.0) { c->res_zero_u[(size_t)t] = 1; break; }
     return 0;
 }
 
@@ -465,7 +478,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.u = c->cur_u;
     d.order = c->cur_order;
     resolve_kind(c);
-    const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL);
+    const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
@@ -576,6 +589,7 @@ extern "C" int bgmm_sweep_resident(bgmm_ctx *c, int32_t index, int32_t use_power
     if (!c) return BGMM_EINVAL;
     if (index < 0 || index >= c->res_n) return fail(c, BGMM_EINVAL, "resident sweep index out of range");
     c->cur_u = c->res_u + (size_t)index * c->d.N;
+    c->cur_zero_u = c->res_zero_u[(size_t)index] != 0;
     c->cur_order = c->res_order ? c->res_order + (size_t)index * c->d.N : nullptr;
     return bgmm_sweep_staged(c, use_power, power);
 }

@@ -645,3 +645,25 @@ def test_diag_fixed_pruned_against_c_oracle(cov, N, D, K, sep):
             assert bad.size == 0, "prune %d sweep %d: %d labels differ, first at i=%d" % (prune, it, bad.size, bad[0])
             assert abs(ctx.log_marg() - ref[it][1]) <= 1e-9 * abs(ref[it][1])
         ctx.close()
+
+
+def test_uniform_exactly_zero_disables_pruning():
+    """u == 0.0 is the one uniform for which a pruned (probability 0 instead of < 2e-35) label is
+    visible to the reference's `u -= p` scan: it returns the FIRST label.  Such sweeps run unpruned."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 4000, 16, 12
+    X, zt = gendata.synth_mixture(N, D, K, seed=77)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    u = np.random.RandomState(5).random_sample(N)
+    u[[17, 2500]] = 0.0
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K)
+    o.sweep(u)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
+    ctx.set_tuning(kernel_kind=2)
+    ctx.set_assignments(zt)
+    ctx.sweep(u)
+    npt.assert_array_equal(ctx.assignments(), o.z)
+    assert ctx.assignments()[17] == 0 and ctx.sweep_stats()["bound_blocks"] == 0
+    ctx.close()
