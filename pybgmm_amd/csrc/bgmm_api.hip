@@ -68,6 +68,7 @@ struct bgmm_ctx {
     // `u -= p` scan can tell the difference only for u == 0 exactly (it would return the first label
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
+    bool rebuild_pending = false;    // slots changed by rank-1 steps since their last from-scratch rebuild
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -204,6 +205,13 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.n, ns);
     DALLOC(c, d.nupd, ns);
     DALLOC(c, d.sc, ns);
+    DALLOC(c, d.lam_lo, ns);
+    DALLOC(c, d.mu_ver, ns);
+    DALLOC(c, d.rho_cache, (size_t)N);
+    DALLOC(c, d.rho_tag, (size_t)N);
+    CK(c, hipMemsetAsync(d.lam_lo, 0, sizeof(double) * ns, c->stream));
+    CK(c, hipMemsetAsync(d.mu_ver, 0, sizeof(int) * ns, c->stream));
+    CK(c, hipMemsetAsync(d.rho_tag, 0xff, sizeof(long long) * (size_t)N, c->stream));
     DALLOC(c, d.perm, ns);
     DALLOC(c, d.label_of_slot, ns);
     DALLOC(c, d.ctrl, 1);
@@ -233,8 +241,11 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_slot, ng * 16);
         DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
         DALLOC(c, d.wrec, (size_t)rows);
-        DALLOC(c, d.pr_counts, 768);
-        CK(c, hipMemsetAsync(d.pr_counts, 0, 768 * sizeof(unsigned long long), c->stream));
+        DALLOC(c, d.pr_counts, 1024);
+        CK(c, hipMemsetAsync(d.pr_counts, 0, 1024 * sizeof(unsigned long long), c->stream));
+        DALLOC(c, d.pr_tiles, (size_t)rows / 32 + 8);
+        DALLOC(c, d.pr_ntiles, 4);
+        CK(c, hipMemsetAsync(d.pr_ntiles, 0, 4 * sizeof(int), c->stream));
     }
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
@@ -496,6 +507,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         return (int)r;
     };
     d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
+    if (c->rebuild_pending && d.cov_type == COV_FULL && use_prune) {
+        // certified stays need every live slot's eigenvalue bound, which only a from-scratch rebuild
+        // provides: rebuild all of them once after a sweep that moved points
+        launch_refresh_list(d, d.perm, c->ctrl_host->job.K, st);
+        c->rebuild_pending = false;
+    }
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
@@ -577,6 +594,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
     }
     c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
+    if (c->ctrl_host->n_moves > 0) c->rebuild_pending = true;
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
@@ -760,6 +778,7 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
     if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
     launch_item_op(c->d, op, i, k, c->stream);
     launch_refresh_ctrl(c->d, c->stream);
+    c->rebuild_pending = true;
     int rc = fetch_ctrl(c);
     if (rc) return rc;
     rc = check_device_error(c);

@@ -136,6 +136,15 @@ struct Dev {
     int *n;
     int *nupd;                   // rank-1 updates since the slot's last from-scratch refresh
     SlotConst *sc;
+    // certified stays (kernels_score.hip: certify_kernel): per slot a lower bound of lambda_min(S_N)
+    // (0 = none known) and a version of its derived state (mean, factor); per data point the cached
+    // squared distance to its home's mean, tagged (home slot << 32 | version)
+    double *lam_lo;
+    int *mu_ver;
+    double *rho_cache;
+    long long *rho_tag;
+    int *pr_tiles;               // pruned windows: 32-visit tiles the full pruning kernel still has to do
+    int *pr_ntiles;
     int *perm, *label_of_slot;
     Ctrl *ctrl;
     double *q;

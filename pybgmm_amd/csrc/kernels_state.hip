@@ -123,7 +123,9 @@ __device__ void refresh_slot(const Dev &d, int s, double *sm) {
     gershgorin_bound<TPB>(A, ld, D, row, &scal[2], tid, true);
     chol_inverse<TPB>(A, ld, D, row, &scal[0], (int *)&scal[1], tid, true);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
-    write_slot<TPB>(d, s, A, ld, mu, scal[0], scal[2], tid, nullptr, true);
+    factor_norm_bound<TPB>(A, ld, D, row, &scal[3], tid, true);
+    __syncthreads();
+    write_slot<TPB>(d, s, A, ld, mu, scal[0], scal[2], scal[3], tid, nullptr, true);
     if (tid == 0) d.nupd[s] = 0;
 }
 
@@ -152,6 +154,7 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     double d2 = 0.0;
     if (tid == 0) for (int l = 0; l < D; ++l) d2 = fma(dv[l], dv[l], d2);
     write_slot<TPB>(d, dst, W, ld, mu, logdet_src + log(1.0 + a * scal[0]), lam_after_rank1(inv_lam_src, a, d2),
+                    0.0 /* no lower bound after a rank-1 step: certified stays wait for the next rebuild */,
                     tid, nullptr, true);
     if (tid == 0) d.nupd[dst] += 1;
 }
