@@ -170,6 +170,7 @@ def main():
     else:
         lik_total, moves_total = float(lik), float(moves)
     last_stats = ctx.sweep_stats()
+    last_stats.update({"certified_visits": ctx.prune_stats()["certified_visits"]})
     log_marg = ctx.log_marg()
     K_final = ctx.K
 
@@ -203,7 +204,8 @@ def main():
         # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
         # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
         exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
-        pruning = bool(st["bound_blocks"] > 0)
+        ps = ctx.prune_stats()
+        pruning = bool(st["bound_blocks"] > 0 or ps["certified_visits"] > 0)
         # per (visit, component) in this library's formulation: y = cvec - Winv x through the lower
         # triangle (D (D + 1) flop), q = |y|^2 (2 D), the Student-t tail (~ D + 12)
         flops_kernel_alg = D * (D + 1.0) + 3.0 * D + 12.0
@@ -213,6 +215,7 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj.get("hbm_bytes_per_launch_pruned" if pruning else "hbm_bytes_per_launch")
+        n_visits_timed = st["scored"] / max(K_final, 1)
         common = {"traffic": traffic, "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                   "lik_evals_per_launch": round(st["scored"] / n_launch, 1)}
         if pruning:
@@ -221,13 +224,13 @@ def main():
             # floor is the HBM stream: algorithmic bytes = visits x (8 D + 24).  The matrix work it
             # still does (bounds + exact forms, counted in the kernel, 2048 flop per instruction) and
             # what the same decisions would cost without pruning are reported next to it.
-            ps = ctx.prune_stats()
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
-            out = {"kernel": "score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel",
+            out = {"kernel": "certify_kernel + score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel",
                    "bound": "hbm",
                    "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                    "frac": round(hbm / PEAK_HBM_GBPS, 4),
                    "algorithmic_bytes_per_visit": 8.0 * D + 24.0,
+                   "fraction_of_visits_certified_to_stay": round(ps["certified_visits"] / max(n_visits_timed, 1), 5),
                    "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 5),
                    "mfma_instructions_per_launch": round(ps["mfma_instructions"] / n_launch, 1),
                    "mfma_executed_tflops": round(executed, 3),

@@ -251,7 +251,8 @@ class Context(object):
     def prune_stats(self):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_prune_stats(self.h, _ptr(out)))
-        return {"kept_blocks": int(out[0]), "bound_blocks": int(out[1]), "mfma_instructions": int(out[2])}
+        return {"kept_blocks": int(out[0]), "bound_blocks": int(out[1]), "mfma_instructions": int(out[2]),
+                "certified_visits": int(out[3])}
 
     def set_kernel_timing(self, on):
         self._ck(self.L.bgmm_set_kernel_timing(self.h, 1 if on else 0))

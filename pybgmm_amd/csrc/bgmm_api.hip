@@ -63,12 +63,13 @@ struct bgmm_ctx {
     std::vector<hipEvent_t> ev0, ev1;
     long long timed_launches = 0;
     double timed_ms = 0.0;
-    long long prune_mfma = 0;
+    long long prune_mfma = 0, certified = 0;
     // A pruned component enters a draw with probability 0 instead of < 2e-35.  The reference's
     // `u -= p` scan can tell the difference only for u == 0 exactly (it would return the first label
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
-    bool rebuild_pending = false;    // slots changed by rank-1 steps since their last from-scratch rebuild
+    int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
+    int certify_fails = 0;           // consecutive sweeps in which it certified less than a tenth
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -177,6 +178,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
     d.tab_len = v_0 + N + 2;
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
+    d.use_tile_list = 0;
     d.batch_rows = 1 << 30;
     resolve_kind(c);
 
@@ -205,11 +207,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.n, ns);
     DALLOC(c, d.nupd, ns);
     DALLOC(c, d.sc, ns);
-    DALLOC(c, d.lam_lo, ns);
     DALLOC(c, d.mu_ver, ns);
     DALLOC(c, d.rho_cache, (size_t)N);
+    DALLOC(c, d.qhome_cache, (size_t)N);
     DALLOC(c, d.rho_tag, (size_t)N);
-    CK(c, hipMemsetAsync(d.lam_lo, 0, sizeof(double) * ns, c->stream));
     CK(c, hipMemsetAsync(d.mu_ver, 0, sizeof(int) * ns, c->stream));
     CK(c, hipMemsetAsync(d.rho_tag, 0xff, sizeof(long long) * (size_t)N, c->stream));
     DALLOC(c, d.perm, ns);
@@ -243,9 +244,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.wrec, (size_t)rows);
         DALLOC(c, d.pr_counts, 1024);
         CK(c, hipMemsetAsync(d.pr_counts, 0, 1024 * sizeof(unsigned long long), c->stream));
-        DALLOC(c, d.pr_tiles, (size_t)rows / 32 + 8);
-        DALLOC(c, d.pr_ntiles, 4);
-        CK(c, hipMemsetAsync(d.pr_ntiles, 0, 4 * sizeof(int), c->stream));
+        d.pr_tile_cap = (int)((rows / 32 + 63) / 64 + 1);
+        DALLOC(c, d.pr_tiles, (size_t)64 * d.pr_tile_cap);
+        DALLOC(c, d.pr_ntiles, 64);
+        CK(c, hipMemsetAsync(d.pr_ntiles, 0, 64 * sizeof(int), c->stream));
     }
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
@@ -491,6 +493,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
+    // certified stays pay off in converged chains only: after two consecutive sweeps (the first may
+    // just have been filling the per-point cache) in which less than a tenth of the visits could be
+    // certified the kernel is left out for the next 8 sweeps
+    const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0;
+    if (c->certify_skip > 0) c->certify_skip -= 1;
+    d.use_tile_list = use_certify ? 1 : 0;
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
         launch_build_seat_table(d, c->tabSeat, st);
@@ -507,12 +515,6 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         return (int)r;
     };
     d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
-    if (c->rebuild_pending && d.cov_type == COV_FULL && use_prune) {
-        // certified stays need every live slot's eigenvalue bound, which only a from-scratch rebuild
-        // provides: rebuild all of them once after a sweep that moved points
-        launch_refresh_list(d, d.perm, c->ctrl_host->job.K, st);
-        c->rebuild_pending = false;
-    }
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
@@ -565,6 +567,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
             if (pmode >= 1) launch_bucket_rows(d, grid_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
+            if (pmode >= 1 && use_certify) launch_certify(d, &d.ctrl->job, grid_rows, st);
             if (pmode >= 1) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st);
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
@@ -594,12 +597,16 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
     }
     c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
-    if (c->ctrl_host->n_moves > 0) c->rebuild_pending = true;
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;
     c->stats[3] = h.n_steps; c->stats[4] = h.n_score_launches; c->stats[5] = h.n_scored;
     c->stats[6] = (long long)h.n_kept_blocks; c->stats[7] = (long long)h.n_bound_blocks;
     c->prune_mfma = (long long)h.n_prune_mfma;
+    c->certified = (long long)h.n_certified;
+    if (use_certify && h.n_bound_blocks + h.n_certified > 0) {
+        c->certify_fails = h.n_certified * 10 < (unsigned long long)N ? c->certify_fails + 1 : 0;
+        if (c->certify_fails >= 2) { c->certify_skip = 8; c->certify_fails = 1; }
+    }
     return check_device_error(c);
 }
 
@@ -778,7 +785,6 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
     if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
     launch_item_op(c->d, op, i, k, c->stream);
     launch_refresh_ctrl(c->d, c->stream);
-    c->rebuild_pending = true;
     int rc = fetch_ctrl(c);
     if (rc) return rc;
     rc = check_device_error(c);
@@ -809,7 +815,7 @@ extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out8) {
 
 extern "C" int bgmm_get_prune_stats(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
-    out4[0] = c->stats[6]; out4[1] = c->stats[7]; out4[2] = c->prune_mfma; out4[3] = 0;
+    out4[0] = c->stats[6]; out4[1] = c->stats[7]; out4[2] = c->prune_mfma; out4[3] = c->certified;
     return 0;
 }
 

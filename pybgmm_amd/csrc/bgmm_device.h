@@ -97,6 +97,7 @@ struct Ctrl {
     unsigned long long n_bound_blocks;  // (16-visit block, slot) pairs it bounded
     int tables_valid;     // the pruned-window tables (pr_*) match the current means / labels / seating weights
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
+    unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
 };
 
@@ -107,7 +108,7 @@ struct WRec {
     int home;           // home slot (-1: unassigned)
     int home_label;     // its label in this window's frozen state
     double mlb0;        // log(alpha) + log_prior[i]: the "new table" score, first lower bound of the best score
-    double pad;
+    double certified;   // set by certify_kernel: the visit provably keeps its component
 };
 
 struct Dev {
@@ -136,15 +137,16 @@ struct Dev {
     int *n;
     int *nupd;                   // rank-1 updates since the slot's last from-scratch refresh
     SlotConst *sc;
-    // certified stays (kernels_score.hip: certify_kernel): per slot a lower bound of lambda_min(S_N)
-    // (0 = none known) and a version of its derived state (mean, factor); per data point the cached
-    // squared distance to its home's mean, tagged (home slot << 32 | version)
-    double *lam_lo;
+    // certified stays (kernels_score.hip: certify_kernel): per slot a version of its derived state
+    // (mean, factor); per data point the cached squared distance to its home's mean and its exact
+    // quadratic form under its home, tagged (home slot << 32 | version)
     int *mu_ver;
-    double *rho_cache;
+    double *rho_cache, *qhome_cache;
     long long *rho_tag;
-    int *pr_tiles;               // pruned windows: 32-visit tiles the full pruning kernel still has to do
-    int *pr_ntiles;
+    int *pr_tiles;               // pruned windows: 32-visit tiles the full pruning kernel still has to do,
+    int *pr_ntiles;              //   in 64 sub-lists (tile & 63) of capacity pr_tile_cap with their counts
+    int pr_tile_cap;
+    int use_tile_list;           // 1: certify_kernel ran before the pruning kernel (else it takes every tile)
     int *perm, *label_of_slot;
     Ctrl *ctrl;
     double *q;
@@ -161,7 +163,7 @@ struct Dev {
     double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
     int *pr_slot;
     struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
-    unsigned long long *pr_counts;  // 3 x 256 spread counters (kept, bound, MFMA instructions) of the pruning kernel
+    unsigned long long *pr_counts;  // 4 x 256 spread counters (kept, bound, MFMA instructions, certified visits) of the pruned-window kernels
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;
     const long long *order;      // may be null (identity)
@@ -201,6 +203,7 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
                   int col_override, long long max_rows, int skip_pruned_jobs, hipStream_t st);
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st);
+void launch_certify(const Dev &d, const Job *job, long long max_rows, hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   // pruned windows
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);

@@ -244,8 +244,7 @@ __device__ __forceinline__ void write_slot_team(const Dev &d, int s, const lds_f
     for (int l = ht; l < D; l += HT) d.mu[(long long)s * D + l] = mu[l];
     if (ht == 0) {
         d.sc[s] = sc_new;
-        d.lam_lo[s] = 0.0;                    // (slot_math.h write_slot: no lower bound, cached distances stale)
-        d.mu_ver[s] += 1;
+        d.mu_ver[s] += 1;                     // (as slot_math.h write_slot: per-point caches against this slot are stale)
         const double *src = (const double *)&sc_new;
 #pragma unroll
         for (int k = 0; k < 12; ++k) sc_lds[k] = src[k];

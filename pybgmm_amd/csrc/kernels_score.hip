@@ -295,6 +295,117 @@ __device__ __forceinline__ double log1p_lower(double t) {
     return 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
 }
 
+// ------------------------------------------------------------------------------------------
+// Certified stays.  In a converged chain almost every visit keeps its component with probability
+// 1 - epsilon, epsilon far below the resolution of the uniform.  certify_kernel proves that without
+// touching the data row.  score_mfma_prune_kernel leaves two numbers per point: its exact quadratic
+// form under its home component and its squared distance to that component's mean, tagged with the
+// home slot and the version of that slot's state (any change of a slot bumps its version).  While
+// the tag still matches, the home's score is known (slot_score_lower: within the dropped
+// -0.5 log(1 - a1 q) >= 0 and log(1+t) <= t), every other component is bounded from above exactly as
+// in the coarse level of the pruning kernel, and the new table's score is in the record.  If every
+// alternative lies more than
+// 38 + log(K + 1) nats below the home's lower bound, their total weight relative to the home is
+// < e^-38 = 3e-17 < 2^-53: the reference's normaliser rounds to the home's score, p_home = exp(0) = 1
+// exactly, everything before it in the scan subtracts < 3e-17 from a uniform that is at least 2^-53
+// (an exact zero disables pruning for the sweep, bgmm_api.hip), and `u - 1 < 0` returns the home.
+// One wave per 32-visit tile of the evaluation order; a tile is certified as a whole or handed to
+// score_mfma_prune_kernel through the list d.pr_tiles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restrict__ jobp) {
+    const JobView job = load_job(jobp);
+    if (!job_is_pruned(d, job.mode, job.prune)) return;
+    const long long nrows = job.win_hi - job.pos;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long tile = (long long)blockIdx.x * 4 + w;
+    const long long kw = tile * 32;
+    if (kw >= nrows) return;
+    const int K = job.nlist;
+    const double margin = 38.0 + log((double)K + 1.0);
+    const long long kmine = kw + (lane & 31);
+    const bool live = lane < 32 && kmine < nrows;
+    WRec rec;
+    rec.i = -1; rec.home = -2; rec.home_label = -1; rec.mlb0 = 0.0;
+    if (live) rec = d.wrec[kmine];
+    const int hv = rec.home;
+    bool ok = !live;
+    double hlb = INFINITY, rad = 0.0;
+    if (live && hv >= 0) {
+        const long long tag = ((long long)hv << 32) | (unsigned int)d.mu_ver[hv];
+        if (d.n[hv] >= 2 && d.rho_tag[rec.i] == tag) {
+            hlb = slot_score_lower(d.sc[hv], d.qhome_cache[rec.i], true);       // <= the exact home score
+            rad = sqrt(d.rho_cache[rec.i] * (1.0 + 1e-9)) * (1.0 + 1e-9);
+            ok = hlb - rec.mlb0 >= margin;                                      // the new table is negligible
+        }
+    }
+    bool all_ok = __ballot(!ok) == 0ull;
+    // the homes present in the tile (at most four, else hand over)
+    int hs[4] = {-1, -1, -1, -1}, hl[4] = {0, 0, 0, 0}, nh = 0;
+    double hr[4] = {0.0, 0.0, 0.0, 0.0}, ht[4] = {0.0, 0.0, 0.0, 0.0};
+    if (all_ok) {
+        unsigned long long pending = __ballot(live);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (pending) {
+                const int first = __ffsll((long long)pending) - 1;
+                const int sh = __builtin_amdgcn_readfirstlane(__shfl(hv, first));
+                const bool sel = live && hv == sh;
+                pending &= ~__ballot(sel);
+                double a = sel ? rad : 0.0, b = sel ? hlb : INFINITY;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    a = fmax(a, __shfl_xor(a, o));
+                    b = fmin(b, __shfl_xor(b, o));
+                }
+                hs[it] = sh;
+                hl[it] = __builtin_amdgcn_readfirstlane(__shfl(rec.home_label, first));
+                hr[it] = a;
+                ht[it] = b - margin;
+                nh = it + 1;
+            }
+        }
+        if (pending) all_ok = false;
+    }
+    if (all_ok) {
+        // every other label, lane = label: upper bound through the home means (pr_dcc), against the
+        // weakest home bound of each home's visits
+        bool viol = false;
+        for (int t0 = 0; t0 < K; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < K) {
+                const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
+                const double base = g[0], hvd = g[16], tcoef = g[32];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nh && t != hl[j]) {
+                        double dl = d.pr_dcc[(long long)hl[j] * d.nslots + t] * (1.0 - 1e-9) - hr[j];
+                        dl = dl > 0.0 ? dl : 0.0;
+                        const double ub = base - hvd * log1p_lower(dl * dl * tcoef);
+                        viol = viol || !(ub < ht[j]);
+                    }
+                }
+            }
+        }
+        all_ok = __ballot(viol) == 0ull;
+    }
+    if (all_ok) {
+        if (live) d.wrec[kmine].certified = 1.0;
+        if (lane == 0) {
+            const long long left = nrows - kw;
+            atomicAdd(&d.pr_counts[768 + (blockIdx.x & 255)], (unsigned long long)(left < 32 ? left : 32));
+        }
+    } else if (lane == 0) {
+        const int l = (int)(tile & 63);                    // 64 sub-lists keep the appends off one address
+        d.pr_tiles[l * d.pr_tile_cap + atomicAdd(&d.pr_ntiles[l], 1)] = (int)tile;
+    }
+}
+
+void launch_certify(const Dev &d, const Job *job, long long max_rows, hipStream_t st) {
+    if (max_rows <= 0) return;
+    hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((max_rows + 127) / 128)), dim3(256), 0, st, d, job);
+}
+
 // In a pruned window the visits are evaluated in the order of d.wrec (grouped by home component,
 // kernels_state.hip: bucket_*_kernel), so that the visits of one wave mostly share a home and
 // need the same one or two components in full.  The output is block-sparse: for every 16-visit
@@ -324,12 +435,26 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     constexpr int NK0 = NKK < 8 ? NKK : 8;                        // fragments of the level-0 bound (32 dimensions)
     constexpr int Ds = prune_row_stride(NJ * 16);
     const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
-    const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
-    if (kb >= nrows) return;
+    // the 32-visit tiles certify_kernel could not decide: 64 sub-lists; wave g takes the g-th entry of
+    // their concatenation
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long kw = kb + w * ROWS_W;                         // first evaluation position of the wave
+    int incl = d.use_tile_list ? d.pr_ntiles[lane] : 0;
+    const int mine = incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int ntiles = d.use_tile_list ? __shfl(incl, 63) : (int)((nrows + ROWS_W - 1) / ROWS_W);
+    if ((int)blockIdx.x * 4 >= ntiles) return;
+    const int g = (int)blockIdx.x * 4 + w;
+    const bool has_tile = g < ntiles;
+    long long kw = nrows;                                        // first evaluation position of the wave
+    if (has_tile && !d.use_tile_list) kw = (long long)g * ROWS_W;
+    else if (has_tile) {
+        const int l = __ffsll((long long)__ballot(incl > g)) - 1;
+        const int pos = g - (__shfl(incl, l) - __shfl(mine, l));
+        kw = (long long)d.pr_tiles[l * d.pr_tile_cap + pos] * ROWS_W;
+    }
     const int lr = lane & 15, lk = lane >> 4;
 
     const long long nfrag64 = (long long)NF * 64;
@@ -345,17 +470,19 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
     // (wave-private side arrays behind the staging area; accumulator element (R, r) of lane (lk, .)
     // is row 16 R + lk + 4 r).
-    const int side_stride = 144 + d.keep_stride;
+    const int side_stride = 176 + d.keep_stride;
     double *__restrict__ sideM = xs_all + 4 * (ROWS_W * Ds) + w * side_stride;   // Mlb[32]
     double *__restrict__ sideX2 = sideM + 32;                                 // |x|^2, all dimensions
     double *__restrict__ sideX2p = sideM + 64;                                // |x|^2, leading dimensions
     int *__restrict__ sideH = (int *)(sideM + 96);                            // home slot
     double *__restrict__ sideRho = sideM + 112;                               // |x - mu_home|^2
-    unsigned long long *__restrict__ sideC = (unsigned long long *)(sideM + 144);   // coarse label mask
+    long long *__restrict__ sideI = (long long *)(sideM + 144);                 // data index
+    unsigned long long *__restrict__ sideC = (unsigned long long *)(sideM + 176);   // coarse label mask
     const int hmine = rmine.home;                                  // home slot of row (lane & 31); dead rows -2
     if (lane < ROWS_W) {
         sideM[lane] = rmine.mlb0;                                  // dead rows: +inf, never keep a slot alive
         sideH[lane] = hmine;
+        sideI[lane] = imine;
     }
     // ---- the home components come first (the visits are grouped by home: mostly one or two per
     // wave), so that every bound below is taken against a tight Mlb.  Their q lines are stored for
@@ -451,7 +578,18 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             }
         }
         acc[0] += __shfl_xor(acc[0], 1);
-        if ((lane & 1) == 0) sideRho[lane >> 1] = acc[0];            // (rows without a home: unused)
+        {
+            // publish: the wave's side array, and the per-point cache certify_kernel reads next sweep
+            const long long irow = __shfl(imine, lane >> 1);
+            const int hrow = __shfl(hmine, lane >> 1);
+            if ((lane & 1) == 0) {
+                sideRho[lane >> 1] = acc[0];                                // (rows without a home: unused)
+                if (irow >= 0 && hrow >= 0) {
+                    d.rho_cache[irow] = acc[0];
+                    d.rho_tag[irow] = ((long long)hrow << 32) | (unsigned int)d.mu_ver[hrow];
+                }
+            }
+        }
     }
     double xf[RB][NKK];
 #pragma unroll
@@ -541,6 +679,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                         const int row = R * 16 + lk + 4 * r;
                         const bool own = sideH[row] == s;
                         if (!own || ns >= 2) sideM[row] = fmax(sideM[row], slot_score_lower(scs, v[r], own));
+                        if (own) d.qhome_cache[sideI[row]] = v[r];       // (tag written with the distance)
                     }
                 }
                 // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr
@@ -798,7 +937,7 @@ template <int NJ>
 static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (144 + d.keep_stride)) * (int)sizeof(double);
+    const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (176 + d.keep_stride)) * (int)sizeof(double);
     auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
     static int attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {

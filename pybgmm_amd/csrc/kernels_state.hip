@@ -123,9 +123,7 @@ __device__ void refresh_slot(const Dev &d, int s, double *sm) {
     gershgorin_bound<TPB>(A, ld, D, row, &scal[2], tid, true);
     chol_inverse<TPB>(A, ld, D, row, &scal[0], (int *)&scal[1], tid, true);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
-    factor_norm_bound<TPB>(A, ld, D, row, &scal[3], tid, true);
-    __syncthreads();
-    write_slot<TPB>(d, s, A, ld, mu, scal[0], scal[2], scal[3], tid, nullptr, true);
+    write_slot<TPB>(d, s, A, ld, mu, scal[0], scal[2], tid, nullptr, true);
     if (tid == 0) d.nupd[s] = 0;
 }
 
@@ -154,7 +152,6 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     double d2 = 0.0;
     if (tid == 0) for (int l = 0; l < D; ++l) d2 = fma(dv[l], dv[l], d2);
     write_slot<TPB>(d, dst, W, ld, mu, logdet_src + log(1.0 + a * scal[0]), lam_after_rank1(inv_lam_src, a, d2),
-                    0.0 /* no lower bound after a rank-1 step: certified stays wait for the next rebuild */,
                     tid, nullptr, true);
     if (tid == 0) d.nupd[dst] += 1;
 }
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->skip_apply = 0;
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
-        c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0;
+        c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
         c->tables_valid = 0;             // (seating weights may have changed)
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
@@ -323,6 +320,7 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
         }
         return;
     }
+    if (threadIdx.x < 64) d.pr_ntiles[threadIdx.x] = 0;   // (certify_kernel appends the tiles it could not decide)
     const int nb = d.nslots + 1;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
             rec.home = myb[t] - 1;
             rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
             rec.mlb0 = d.log_alpha + d.log_prior[rec.i];
-            rec.pad = 0.0;
+            rec.certified = 0.0;
             d.wrec[k] = rec;
         }
 }
@@ -536,21 +534,22 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (job_is_pruned(d, c->job.mode, c->job.prune) && !c->skip_apply) {
         // fold (and clear) the pruning kernel's spread counters of this window
-        __shared__ unsigned long long cnt_red[3 * TPB];
-        for (int t = 0; t < 3; ++t) {
+        __shared__ unsigned long long cnt_red[4 * TPB];
+        for (int t = 0; t < 4; ++t) {
             cnt_red[t * TPB + threadIdx.x] = d.pr_counts[t * 256 + threadIdx.x];
             d.pr_counts[t * 256 + threadIdx.x] = 0;
         }
         __syncthreads();
         for (int o = TPB / 2; o > 0; o >>= 1) {
             if (threadIdx.x < o)
-                for (int t = 0; t < 3; ++t) cnt_red[t * TPB + threadIdx.x] += cnt_red[t * TPB + threadIdx.x + o];
+                for (int t = 0; t < 4; ++t) cnt_red[t * TPB + threadIdx.x] += cnt_red[t * TPB + threadIdx.x + o];
             __syncthreads();
         }
         if (threadIdx.x == 0) {
             c->n_kept_blocks += cnt_red[0];
             c->n_bound_blocks += cnt_red[TPB];
             c->n_prune_mfma += cnt_red[2 * TPB];
+            c->n_certified += cnt_red[3 * TPB];
         }
     }
     if (threadIdx.x == 0) {

@@ -73,7 +73,7 @@ __device__ __forceinline__ double slot_log_score(const SlotConst &sc, double qv,
 // be complete (barrier before), and cv_lds is valid after the caller's next barrier.
 template <int NT>
 __device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, const double *mu,
-                                  double logdetC, double lam, double lam_lo, int tid, double *cv_lds, bool active) {
+                                  double logdetC, double lam, int tid, double *cv_lds, bool active) {
     if (!active) return;
     const int D = d.D, Dp = d.Dp;
     for (int j = tid; j < Dp; j += NT) {
@@ -101,31 +101,7 @@ __device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, 
         double mu2 = 0.0;
         for (int l = 0; l < D; ++l) mu2 = fma(mu[l], mu[l], mu2);
         d.sc[s] = make_consts(d, d.n[s], logdetC, lam, mu2);
-        d.lam_lo[s] = lam_lo;                 // lower bound of lambda_min(S_N), 0 = none
-        d.mu_ver[s] += 1;                     // cached distances to this slot's mean are stale now
-    }
-}
-
-// Lower bound of lambda_min(S_N) from the inverse Cholesky factor W (S_N^-1 = W'W):
-// lambda_max(S_N^-1) <= ||W'W||_inf <= ||W||_1 ||W||_inf.  W: LDS, lower triangle.  rowbuf: 2 D
-// doubles of LDS.  One barrier; result in *out for every thread after the caller's next barrier.
-template <int NT>
-__device__ inline void factor_norm_bound(const double *W, int ld, int D, double *rowbuf, double *out,
-                                         int tid, bool active) {
-    if (active)
-        for (int i = tid; i < D; i += NT) {
-            double r = 0.0, cs = 0.0;
-            for (int j = 0; j <= i; ++j) r += fabs(W[i * ld + j]);          // row i
-            for (int j = i; j < D; ++j) cs += fabs(W[j * ld + i]);          // column i
-            rowbuf[i] = r;
-            rowbuf[D + i] = cs;
-        }
-    __syncthreads();
-    if (active && tid == 0) {
-        double rmax = 0.0, cmax = 0.0;
-        for (int i = 0; i < D; ++i) { rmax = fmax(rmax, rowbuf[i]); cmax = fmax(cmax, rowbuf[D + i]); }
-        const double nrm = rmax * cmax;
-        *out = (nrm > 0.0 && nrm < 1e300) ? (1.0 - 1e-6) / nrm : 0.0;
+        d.mu_ver[s] += 1;                     // what is cached per point against this slot's state is stale now
     }
 }
 
