@@ -69,7 +69,7 @@ struct bgmm_ctx {
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
     int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
-    int certify_fails = 0;           // consecutive sweeps in which it certified less than a tenth
+    long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -428,7 +428,7 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
         rc = check_device_error(c);
     } while (0);
     (void)hipFree(dz); (void)hipFree(doff); (void)hipFree(dmem);
-    if (rc == 0) c->assigned = true;
+    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->certify_skip = 0; }
     return rc;
 }
 
@@ -493,9 +493,9 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
-    // certified stays pay off in converged chains only: after two consecutive sweeps (the first may
-    // just have been filling the per-point cache) in which less than a tenth of the visits could be
-    // certified the kernel is left out for the next 8 sweeps
+    // certified stays pay off in converged chains only: when the per-point cache was warm (hardly a
+    // move in this sweep and the one before) and still less than a tenth of the visits could be
+    // certified, the kernel is left out for the next 8 sweeps
     const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0;
     if (c->certify_skip > 0) c->certify_skip -= 1;
     d.use_tile_list = use_certify ? 1 : 0;
@@ -515,6 +515,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         return (int)r;
     };
     d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
+    if (c->moves_prev != 0 && d.cov_type == COV_FULL && use_prune)
+        launch_refresh_stale(d, c->ctrl_host->job.K, st);   // (tight bounds again after a sweep with moves)
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
@@ -604,9 +606,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
     if (use_certify && h.n_bound_blocks + h.n_certified > 0) {
-        c->certify_fails = h.n_certified * 10 < (unsigned long long)N ? c->certify_fails + 1 : 0;
-        if (c->certify_fails >= 2) { c->certify_skip = 8; c->certify_fails = 1; }
+        const bool warm = c->moves_prev >= 0 && (c->moves_prev + h.n_moves) * 1000 < N;
+        if (warm && h.n_certified * 10 < (unsigned long long)N) c->certify_skip = 8;
     }
+    c->moves_prev = h.n_moves;
     return check_device_error(c);
 }
 

@@ -189,6 +189,7 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
                        hipStream_t st);
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st);  // explicit slots
 void launch_refresh_ctrl(const Dev &d, hipStream_t st);                          // ctrl->refresh[]
+void launch_refresh_stale(const Dev &d, int K, hipStream_t st);                  // live slots with rank-1 steps
 void launch_sweep_begin(const Dev &d, hipStream_t st);
 void launch_build_tables(const Dev &d, double *tabG, double *tabLogC, hipStream_t st);
 void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st);

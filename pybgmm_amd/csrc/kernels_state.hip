@@ -166,6 +166,19 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
     else refresh_slot(d, s, sm);
 }
 
+// From-scratch rebuild of every live slot that has taken rank-1 steps since its last rebuild.  Run
+// once at the start of a sweep that follows a sweep with moves: the eigenvalue bound behind the
+// pruning only ever grows under rank-1 steps (slot_math.h: lam_after_rank1), so after a burn-in it
+// would stay loose until a slot's 64th update.
+__global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= d.ctrl->job.K) return;
+    const int s = d.perm[blockIdx.x];
+    if (d.nupd[s] == 0) return;
+    if (threadIdx.x == 0) d.ctrl->tables_valid = 0;
+    refresh_slot(d, s, sm);
+}
+
 __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = d.ctrl;
@@ -186,6 +199,13 @@ void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) 
     const int lds = refresh_lds_bytes(d.D);
     ensure_lds((const void *)refresh_list_kernel, lds);
     hipLaunchKernelGGL(refresh_list_kernel, dim3(n), dim3(TPB), lds, st, d, slots, n);
+}
+
+void launch_refresh_stale(const Dev &d, int K, hipStream_t st) {
+    if (K <= 0) return;
+    const int lds = refresh_lds_bytes(d.D);
+    ensure_lds((const void *)refresh_stale_kernel, lds);
+    hipLaunchKernelGGL(refresh_stale_kernel, dim3(K), dim3(TPB), lds, st, d);
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {

@@ -349,7 +349,7 @@ def test_full_size_properties(N, D, K):
     X, z_true = gendata.synth_mixture(N, D, K, seed=1)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     rs = np.random.RandomState(1)
-    u = rs.random_sample(N)
+    us = rs.random_sample((3, N))
     tabs = reference_tables(v_0, N)
     # perturb the true labelling so that the sweep has real moves to make
     z0 = z_true.copy()
@@ -360,12 +360,16 @@ def test_full_size_properties(N, D, K):
         ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
         ctx.set_tuning(max_window=window, kernel_kind=kind, prune_mode=prune)
         ctx.set_assignments(z0)
-        ctx.sweep(u)
+        moves = 0
+        for it in range(3):     # (sweeps 2 and 3 of the default configuration run on certified stays)
+            ctx.sweep(us[it])
+            moves += ctx.sweep_stats()["moves"]
         z = ctx.assignments()
         c = ctx.counts()
         lm = ctx.log_marg()
-        st = ctx.sweep_stats()
-        results.append((z, c, lm, st["moves"]))
+        results.append((z, c, lm, moves))
+        if kind == 0 and D >= 64:           # (C3's clusters are too close for certificates at the 2^-53 level)
+            assert ctx.prune_stats()["certified_visits"] > 0
         assert c.sum() == N and z.min() >= 0 and z.max() == len(c) - 1
         npt.assert_array_equal(np.bincount(z, minlength=len(c)), c)
         if kind == 0:
@@ -666,4 +670,35 @@ def test_uniform_exactly_zero_disables_pruning():
     ctx.sweep(u)
     npt.assert_array_equal(ctx.assignments(), o.z)
     assert ctx.assignments()[17] == 0 and ctx.sweep_stats()["bound_blocks"] == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,D,K,sep", [(30000, 32, 30, 4.0), (30000, 16, 40, 1.6), (20000, 64, 12, 2.2)])
+def test_certified_stays_against_c_oracle(N, D, K, sep):
+    """Several sweeps from the true labelling: from the second sweep on most visits are decided by
+    certify_kernel from the per-point cache (well separated data) or fall back to the pruning
+    kernel (overlapping data, after moves) -- the chain must not notice."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=31 + D, mu_scale=sep)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D)
+    us = rs.random_sample((5, N))
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
+    ctx.set_tuning(kernel_kind=2)
+    ctx.set_assignments(zt)
+    certified = 0
+    for it in range(5):
+        o.sweep(us[it])
+        ctx.sweep(us[it])
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        certified += ctx.prune_stats()["certified_visits"]
+    if sep >= 4.0:
+        assert certified > 3 * N          # sweeps 2..5 almost entirely certified
     ctx.close()
