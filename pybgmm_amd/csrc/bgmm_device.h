@@ -96,6 +96,10 @@ struct Ctrl {
     unsigned long long n_kept_blocks;   // (16-visit block, slot) pairs the pruning kernel scored in full
     unsigned long long n_bound_blocks;  // (16-visit block, slot) pairs it bounded
     int tables_valid;     // the pruned-window tables (pr_*) match the current means / labels / seating weights
+    // the evaluation order (wperm, wrec) of window [wsort_base, wsort_hi) is still the bucket sort of
+    // the current state (nothing moved since, same visiting order); skip_sort: the open window is that one
+    int wsort_valid, skip_sort;
+    long long wsort_base, wsort_hi;
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     const int K = c->job.K;
     const long long p = win_base + d.wperm[k];
     const WRec rec = d.wrec[k];                          // (index, home, its label, new-table score)
-    if (rec.certified != 0.0) {                          // certify_kernel: the visit provably stays
+    if (d.use_tile_list && rec.certified != 0.0) {       // certify_kernel (if it ran): the visit provably stays
         d.choice[p - win_base] = rec.home_label;
         return;
     }

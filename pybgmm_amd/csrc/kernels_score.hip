@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restri
         }
         all_ok = __ballot(viol) == 0ull;
     }
+    if (live) d.wrec[kmine].certified = all_ok ? 1.0 : 0.0;      // (records outlive a sweep: always rewritten)
     if (all_ok) {
-        if (live) d.wrec[kmine].certified = 1.0;
         if (lane == 0) {
             const long long left = nrows - kw;
             atomicAdd(&d.pr_counts[768 + (blockIdx.x & 255)], (unsigned long long)(left < 32 ? left : 32));

@@ -159,7 +159,7 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= n) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.ctrl->tables_valid = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->tables_valid = 0; d.ctrl->wsort_valid = 0; }
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
     if ((int)blockIdx.x >= d.ctrl->job.K) return;
     const int s = d.perm[blockIdx.x];
     if (d.nupd[s] == 0) return;
-    if (threadIdx.x == 0) d.ctrl->tables_valid = 0;
+    if (threadIdx.x == 0) d.ctrl->tables_valid = 0;      // (means and bounds change; the homes do not)
     refresh_slot(d, s, sm);
 }
 
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->n_score_launches = 0; c->n_scored = 0;
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
         c->tables_valid = 0;             // (seating weights may have changed)
+        if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
         if (c->win_size > c->win_cap) c->win_size = c->win_cap;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     extern __shared__ int bins[];
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
         return;
     }
     if (threadIdx.x < 64) d.pr_ntiles[threadIdx.x] = 0;   // (certify_kernel appends the tiles it could not decide)
+    if (c->skip_sort) return;
     const int nb = d.nslots + 1;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
@@ -361,12 +363,11 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     extern __shared__ int lds[];                  // [nb] local counts, then [nb] reserved bases
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
     if (r0 >= nrows) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.ctrl->tables_valid = 1;    // (the tables kernel ran before us)
     const int nb = d.nslots + 1;
     int *cnt = lds, *res = lds + nb;
     for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
@@ -585,6 +586,11 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             const unsigned long long fm = c->first_mover;
             c->first_mover = kNoMover;
             const bool was_pruned = job_is_pruned(d, j.mode, j.prune);
+            if (was_pruned) {
+                // this step's bucket / table kernels have run (or were skipped as still valid)
+                c->tables_valid = 1;
+                c->wsort_valid = 1; c->wsort_base = j.win_base; c->wsort_hi = j.win_hi;
+            }
             if (fm == kNoMover) {
                 // every visit of the window keeps its component: the state is untouched
                 c->lik_evals += (j.win_hi - j.pos) * (long long)j.K;
@@ -608,6 +614,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                 } else {
                     do_move = 1;
                     c->tables_valid = 0;
+                    c->wsort_valid = 0;
                     set_refresh(d, c, mp, true);
                     c->n_moves += 1;
                     // adaptive window: about half the running mean distance between movers
@@ -651,6 +658,7 @@ __global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, i
         mp.i = i; mp.sub_slot = -1; mp.add_slot = -1; mp.add_init = 0;
         ok = 1;
         c->tables_valid = 0;
+        c->wsort_valid = 0;
         if (op == 0) {
             mp.sub_slot = plan_unseat(d, c, i);
         } else {
