@@ -68,6 +68,7 @@ struct bgmm_ctx {
     // `u -= p` scan can tell the difference only for u == 0 exactly (it would return the first label
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
+    bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
     int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
     long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
     bool cur_zero_u = false;
@@ -178,7 +179,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
     d.tab_len = v_0 + N + 2;
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
-    d.use_tile_list = 0;
+    d.use_tile_list = 0; d.lean_step = 0;
     d.batch_rows = 1 << 30;
     resolve_kind(c);
 
@@ -428,7 +429,7 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
         rc = check_device_error(c);
     } while (0);
     (void)hipFree(dz); (void)hipFree(doff); (void)hipFree(dmem);
-    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->certify_skip = 0; }
+    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->certify_skip = 0; c->lean_ok = false; }
     return rc;
 }
 
@@ -499,6 +500,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0;
     if (c->certify_skip > 0) c->certify_skip -= 1;
     d.use_tile_list = use_certify ? 1 : 0;
+    bool lean = use_certify && c->lean_ok && c->prune_mode != 2;
     hipStream_t st = c->stream;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
         launch_build_seat_table(d, c->tabSeat, st);
@@ -558,6 +560,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             d.batch_rows = rows_for(win, open_rows);
         }
         const long long grid_rows = d.batch_rows;
+        if (pmode != 2) lean = false;
+        d.lean_step = lean ? 1 : 0;
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
@@ -570,11 +574,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (pmode >= 1) launch_bucket_rows(d, grid_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (pmode >= 1 && use_certify) launch_certify(d, &d.ctrl->job, grid_rows, st);
-            if (pmode >= 1) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st);
+            if (pmode >= 1) { if (!lean) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st); }
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
             if (pmode <= 1) launch_choice(d, grid_rows, st);
-            if (pmode >= 1) launch_choice_sparse(d, grid_rows, st);
+            if (pmode >= 1 && !lean) launch_choice_sparse(d, grid_rows, st);
             if (use_resolver && pmode <= 1) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
             launch_refresh_ctrl(d, st);
@@ -593,6 +597,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             }
         }
         steps_done = h.n_steps;
+        if (h.retry_full) {          // a lean step met something it could not certify: full steps from here on
+            lean = false;
+            c->ctrl_host->retry_full = 0;
+            CK(c, hipMemcpy(&d.ctrl->retry_full, &c->ctrl_host->retry_full, sizeof(int), hipMemcpyHostToDevice));
+        }
         if (h.error != 0 || h.job.mode == MODE_DONE) break;
         pos = h.job.pos;
         win = h.win_size > 0 ? h.win_size : win;
@@ -610,6 +619,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (warm && h.n_certified * 10 < (unsigned long long)N) c->certify_skip = 8;
     }
     c->moves_prev = h.n_moves;
+    c->lean_ok = use_certify && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
     return check_device_error(c);
 }
 

@@ -99,6 +99,7 @@ struct Ctrl {
     // the evaluation order (wperm, wrec) of window [wsort_base, wsort_hi) is still the bucket sort of
     // the current state (nothing moved since, same visiting order); skip_sort: the open window is that one
     int wsort_valid, skip_sort;
+    int retry_full;       // a lean step (certify only) met a tile it could not certify: queue full steps
     long long wsort_base, wsort_hi;
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
@@ -151,6 +152,8 @@ struct Dev {
     int *pr_ntiles;              //   in 64 sub-lists (tile & 63) of capacity pr_tile_cap with their counts
     int pr_tile_cap;
     int use_tile_list;           // 1: certify_kernel ran before the pruning kernel (else it takes every tile)
+    int lean_step;               // 1: this batch queues certify_kernel WITHOUT the pruning and draw kernels (the
+                                 // previous sweep certified every visit); apply_kernel refuses the step otherwise
     int *perm, *label_of_slot;
     Ctrl *ctrl;
     double *q;

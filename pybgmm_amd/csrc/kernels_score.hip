@@ -315,6 +315,10 @@ __device__ __forceinline__ double log1p_lower(double t) {
 __global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restrict__ jobp) {
     const JobView job = load_job(jobp);
     if (!job_is_pruned(d, job.mode, job.prune)) return;
+    // (the bucket sort's bins are free again: cleared for the next pruned window -- the sparse draw
+    // kernel, which also does this, is not part of a lean step)
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
     const long long nrows = job.win_hi - job.pos;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -553,6 +553,21 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     __shared__ MovePlan mp;
     __shared__ int do_move;
     Ctrl *c = d.ctrl;
+    if (d.lean_step && c->job.mode != MODE_DONE) {
+        // only certify_kernel ran: the step stands iff it certified every tile
+        __shared__ int left;
+        if (threadIdx.x == 0) {
+            int sum = 0;
+            for (int l = 0; l < 64; ++l) sum += d.pr_ntiles[l];
+            left = sum;
+            if (sum > 0) { c->retry_full = 1; c->n_refresh = 0; }
+        }
+        __syncthreads();
+        if (left > 0) {
+            for (int t = 0; t < 4; ++t) d.pr_counts[t * 256 + threadIdx.x] = 0;     // (its counts are discarded)
+            return;
+        }
+    }
     if (job_is_pruned(d, c->job.mode, c->job.prune) && !c->skip_apply) {
         // fold (and clear) the pruning kernel's spread counters of this window
         __shared__ unsigned long long cnt_red[4 * TPB];

@@ -702,3 +702,36 @@ def test_certified_stays_against_c_oracle(N, D, K, sep):
     if sep >= 4.0:
         assert certified > 3 * N          # sweeps 2..5 almost entirely certified
     ctx.close()
+
+
+def test_lean_steps_fall_back_when_certification_fails():
+    """After a sweep that certified every visit only certify_kernel is queued per step; when the state
+    was changed behind its back (add_item / del_item) the step is refused on the device and re-queued
+    with the full kernels."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 20000, 32, 10
+    X, zt = gendata.synth_mixture(N, D, K, seed=5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    us = np.random.RandomState(3).random_sample((5, N))
+    out = []
+    for prune in (0, 1):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
+        ctx.set_tuning(kernel_kind=2, prune_mode=prune)
+        ctx.set_assignments(zt)
+        traj = []
+        for it in range(5):
+            if it == 3:                      # move 40 points to a wrong component by hand
+                for i in range(100, 140):
+                    ctx.del_item(i)
+                    ctx.add_item(i, (int(zt[i]) + 1) % K)
+            ctx.sweep(us[it])
+            traj.append(ctx.assignments().copy())
+            if prune == 0 and it == 2:
+                assert ctx.prune_stats()["certified_visits"] == N
+        out.append((traj, ctx.log_marg()))
+        ctx.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        npt.assert_array_equal(a, b)
+    assert (out[0][0][3] != out[0][0][2]).sum() == 0      # the hand-moved points went back
+    assert abs(out[0][1] - out[1][1]) <= 1e-9 * abs(out[1][1])
