@@ -84,7 +84,8 @@ def main():
     ap.add_argument("--init", default="true", choices=["true", "rand"])
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 VALU, 2 MFMA")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--prune", type=int, default=0, help="0 auto (exact pruning on), 1 off")
+    ap.add_argument("--prune", type=int, default=0,
+                    help="0 auto (exact pruning + certified stays), 1 off, 3 pruning without certified stays")
     ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 off, 2 always")
     ap.add_argument("--cpu-visits", type=int, default=20000,
                     help="visits of the CPU baseline sample (0 = skip)")
@@ -219,27 +220,37 @@ def main():
         common = {"traffic": traffic, "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                   "lik_evals_per_launch": round(st["scored"] / n_launch, 1)}
         if pruning:
-            # The pruned-window kernel streams every visit's row once and decides almost all (visit,
-            # component) pairs from distance bounds; the few survivors get the full quadratic form.  Its
-            # floor is the HBM stream: algorithmic bytes = visits x (8 D + 24).  The matrix work it
-            # still does (bounds + exact forms, counted in the kernel, 2048 flop per instruction) and
-            # what the same decisions would cost without pruning are reported next to it.
+            # Pruned windows.  A visit that certify_kernel proves to keep its component
+            # costs 64 B (its 32-byte record, the cached distance / quadratic form / tag, the flag) and X is
+            # not read; any other visit is streamed once by the pruning kernel: its row and bookkeeping,
+            # 8 D + 24 B, on top.  `achieved` = those bytes / the launch time of the two kernels together;
+            # the same visits priced at SURVEY's 8 D + 24 B each are reported next to it.  The matrix work
+            # still issued (counted in the kernel, 2048 flop per instruction) and what the same decisions
+            # would cost without pruning are given as well.
+            n_cert = float(ps["certified_visits"])
+            need_bytes = n_cert * 64.0 + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 64.0)
+            need = need_bytes / (ms * 1e-3) / 1e9
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
-            out = {"kernel": "certify_kernel + score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel",
+            out = {"kernel": ("certify_kernel + score_mfma_prune_kernel" if n_cert > 0 else "score_mfma_prune_kernel")
+                             if args.cov == "full" else "score_diag_prune_kernel",
                    "bound": "hbm",
-                   "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                   "frac": round(hbm / PEAK_HBM_GBPS, 4),
-                   "algorithmic_bytes_per_visit": 8.0 * D + 24.0,
-                   "fraction_of_visits_certified_to_stay": round(ps["certified_visits"] / max(n_visits_timed, 1), 5),
+                   "achieved": round(need, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                   "frac": round(need / PEAK_HBM_GBPS, 4),
+                   "algorithmic_bytes_per_visit": round(need_bytes / max(n_visits_timed, 1), 1),
+                   "survey_bytes_per_visit": 8.0 * D + 24.0,
+                   "survey_equivalent_gbps": round(hbm, 2),
+                   "fraction_of_visits_certified_to_stay": round(n_cert / max(n_visits_timed, 1), 5),
                    "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 5),
                    "mfma_instructions_per_launch": round(ps["mfma_instructions"] / n_launch, 1),
                    "mfma_executed_tflops": round(executed, 3),
                    "mfma_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
                    "unpruned_equivalent_tflops": round(st["scored"] * flops_kernel_alg / (ms * 1e-3) / 1e12, 2)}
             out.update(common)
+            if n_cert > 0:
+                out["traffic"] = tj.get("hbm_bytes_per_launch_certified") if traffic is not None else None
             if args.cov != "full":          # no matrix work on this path; the PMC file is the full-covariance kernel's
                 for key in ("mfma_instructions_per_launch", "mfma_executed_tflops", "mfma_frac_of_spec_peak",
-                            "unpruned_equivalent_tflops"):
+                            "unpruned_equivalent_tflops", "fraction_of_visits_certified_to_stay"):
                     out.pop(key)
                 out["traffic"] = None
             return out
@@ -258,10 +269,13 @@ def main():
         out.update(common)
         return out
 
-    roofline = roofline_full = None
+    roofline = roofline_full = roofline_pruned = None
     if not args.no_kernel_timing:
         roofline = kernel_roofline(args.prune)
         if roofline and roofline["kernel"].endswith("_prune_kernel"):
+            if roofline.get("fraction_of_visits_certified_to_stay", 0) > 0:
+                # the same sweep without certified stays: every visit streamed by the pruning kernel
+                roofline_pruned = kernel_roofline(3)
             # the same kernel family with pruning off: every (visit, component) pair through the
             # full quadratic form -- the MFMA-efficiency number
             roofline_full = kernel_roofline(1)
@@ -303,6 +317,7 @@ def main():
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
             "roofline": roofline,
+            "roofline_pruned_evaluation": roofline_pruned,
             "roofline_full_evaluation": roofline_full,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),

@@ -145,7 +145,8 @@ int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
  *     component) pairs the pruning kernel evaluated in full, [7] pairs it only bounded.
  *   prune_stats: of the last sweep -- [0] = sweep_stats[6], [1] = sweep_stats[7], [2] the
  *     v_mfma_f64_16x16x4_f64 instructions (2048 flop each) the pruning kernel issued for its
- *     distance bounds and exact quadratic forms, [3] reserved (0).
+ *     distance bounds and exact quadratic forms, [3] visits decided by certify_kernel (they provably
+ *     keep their component: nothing scored, X not read).
  *   kernel timing: when enabled, every likelihood-kernel launch is bracketed by HIP events on
  *     the context's own stream; get returns the number of timed launches that did work and the
  *     sum of their durations in milliseconds since the last reset.
@@ -158,8 +159,9 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
  * kernel (0 auto, 1 VALU, 2 MFMA); in-launch mover resolver (0 auto: when movers are dense,
  * 1 never, 2 whenever it fits); exact pruning of components whose weight in a draw is provably
- * below e^-80 (0 auto: on while movers are sparse, 1 off, 2 in every window whatever the regime --
- * slow when movers are dense, meant for tests).  None of them changes the sampled trajectory. */
+ * below e^-80 (0 auto: on while movers are sparse, plus certified stays in converged chains; 1 off;
+ * 2 in every window whatever the regime -- slow when movers are dense, meant for tests; 3 as 0
+ * but without certified stays, for measurements).  None of them changes the sampled trajectory. */
 int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                     int32_t prune_mode);
 

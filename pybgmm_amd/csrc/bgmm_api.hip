@@ -54,7 +54,8 @@ struct bgmm_ctx {
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
     int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
-    int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off, 2 every window (tests)
+    int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off, 2 every window (tests),
+                                     // 3 auto without certified stays (measurement)
     double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
     int seat_use_power = 0;
     double seat_power = 1.0;
@@ -209,11 +210,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.nupd, ns);
     DALLOC(c, d.sc, ns);
     DALLOC(c, d.mu_ver, ns);
-    DALLOC(c, d.rho_cache, (size_t)N);
-    DALLOC(c, d.qhome_cache, (size_t)N);
-    DALLOC(c, d.rho_tag, (size_t)N);
+    DALLOC(c, d.pcache, (size_t)N);
     CK(c, hipMemsetAsync(d.mu_ver, 0, sizeof(int) * ns, c->stream));
-    CK(c, hipMemsetAsync(d.rho_tag, 0xff, sizeof(long long) * (size_t)N, c->stream));
+    CK(c, hipMemsetAsync(d.pcache, 0xff, sizeof(PCache) * (size_t)N, c->stream));       // (tags: no slot)
     DALLOC(c, d.perm, ns);
     DALLOC(c, d.label_of_slot, ns);
     DALLOC(c, d.ctrl, 1);
@@ -497,7 +496,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     // certified stays pay off in converged chains only: when the per-point cache was warm (hardly a
     // move in this sweep and the one before) and still less than a tenth of the visits could be
     // certified, the kernel is left out for the next 8 sweeps
-    const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0;
+    const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0 && c->prune_mode != 3;
     if (c->certify_skip > 0) c->certify_skip -= 1;
     d.use_tile_list = use_certify ? 1 : 0;
     bool lean = use_certify && c->lean_ok && c->prune_mode != 2;
@@ -853,7 +852,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
     if (resolver_mode < 0 || resolver_mode > 2) return fail(c, BGMM_EINVAL, "resolver_mode must be 0, 1 or 2");
-    if (prune_mode < 0 || prune_mode > 2) return fail(c, BGMM_EINVAL, "prune_mode must be 0, 1 or 2");
+    if (prune_mode < 0 || prune_mode > 3) return fail(c, BGMM_EINVAL, "prune_mode must be 0 .. 3");
     c->kernel_kind = kernel_kind;
     c->resolver_mode = resolver_mode;
     c->prune_mode = prune_mode;

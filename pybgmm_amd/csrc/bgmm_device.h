@@ -107,13 +107,24 @@ struct Ctrl {
 };
 
 // One row of a pruned window in evaluation order: everything the pruning kernel needs to start on
-// it comes with a single 32-byte load (instead of order -> label -> prior chains).
+// it comes with a single 64-byte load (instead of order -> label -> prior -> cache chains).
 struct WRec {
     long long i;        // data index
     int home;           // home slot (-1: unassigned)
     int home_label;     // its label in this window's frozen state
     double mlb0;        // log(alpha) + log_prior[i]: the "new table" score, first lower bound of the best score
     double certified;   // set by certify_kernel: the visit provably keeps its component
+    // the point's cache (PCache) as of the bucket sort / the last pruning-kernel pass over this row:
+    long long tag;      // home slot << 32 | version of that slot's state the two numbers belong to
+    double qhome;       // exact quadratic form under the home component
+    double rho2;        // |x - mu_home|^2
+    double pad;
+};
+
+// What score_mfma_prune_kernel leaves per DATA POINT for certify_kernel (survives re-sorting).
+struct PCache {
+    long long tag;
+    double qhome, rho2, pad;
 };
 
 struct Dev {
@@ -144,10 +155,10 @@ struct Dev {
     SlotConst *sc;
     // certified stays (kernels_score.hip: certify_kernel): per slot a version of its derived state
     // (mean, factor); per data point the cached squared distance to its home's mean and its exact
-    // quadratic form under its home, tagged (home slot << 32 | version)
+    // quadratic form under its home, tagged (home slot << 32 | version); copied into the window's
+    // records by the bucket sort so that certify_kernel reads contiguous memory only
     int *mu_ver;
-    double *rho_cache, *qhome_cache;
-    long long *rho_tag;
+    PCache *pcache;
     int *pr_tiles;               // pruned windows: 32-visit tiles the full pruning kernel still has to do,
     int *pr_ntiles;              //   in 64 sub-lists (tile & 63) of capacity pr_tile_cap with their counts
     int pr_tile_cap;
@@ -169,7 +180,7 @@ struct Dev {
     double *pr_mufrag, *pr_const;
     double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
     int *pr_slot;
-    struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
+    struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 64-byte record)
     unsigned long long *pr_counts;  // 4 x 256 spread counters (kept, bound, MFMA instructions, certified visits) of the pruned-window kernels
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;

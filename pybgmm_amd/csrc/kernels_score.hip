@@ -330,16 +330,17 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restri
     const long long kmine = kw + (lane & 31);
     const bool live = lane < 32 && kmine < nrows;
     WRec rec;
-    rec.i = -1; rec.home = -2; rec.home_label = -1; rec.mlb0 = 0.0;
+    rec.i = -1; rec.home = -2; rec.home_label = -1; rec.mlb0 = 0.0; rec.certified = 0.0; rec.tag = -1;
+    rec.qhome = 0.0; rec.rho2 = 0.0;
     if (live) rec = d.wrec[kmine];
     const int hv = rec.home;
     bool ok = !live;
     double hlb = INFINITY, rad = 0.0;
     if (live && hv >= 0) {
         const long long tag = ((long long)hv << 32) | (unsigned int)d.mu_ver[hv];
-        if (d.n[hv] >= 2 && d.rho_tag[rec.i] == tag) {
-            hlb = slot_score_lower(d.sc[hv], d.qhome_cache[rec.i], true);       // <= the exact home score
-            rad = sqrt(d.rho_cache[rec.i] * (1.0 + 1e-9)) * (1.0 + 1e-9);
+        if (d.n[hv] >= 2 && rec.tag == tag) {
+            hlb = slot_score_lower(d.sc[hv], rec.qhome, true);                  // <= the exact home score
+            rad = sqrt(rec.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
             ok = hlb - rec.mlb0 >= margin;                                      // the new table is negligible
         }
     }
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restri
         }
         all_ok = __ballot(viol) == 0ull;
     }
-    if (live) d.wrec[kmine].certified = all_ok ? 1.0 : 0.0;      // (records outlive a sweep: always rewritten)
+    // (records outlive a sweep; rewritten only when the verdict changes: no write traffic at rest)
+    if (live && rec.certified != (all_ok ? 1.0 : 0.0)) d.wrec[kmine].certified = all_ok ? 1.0 : 0.0;
     if (all_ok) {
         if (lane == 0) {
             const long long left = nrows - kw;
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     const long long kmine = kw + (lane & (ROWS_W - 1));
     WRec rmine;
     if (kmine < nrows) rmine = d.wrec[kmine];
-    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; }
+    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; rmine.tag = -1; }
     const long long imine = rmine.i;
     // gathers behind the bound, one value per row of the wave: the lower bound of the visit's best log
     // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
@@ -589,8 +591,12 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
             if ((lane & 1) == 0) {
                 sideRho[lane >> 1] = acc[0];                                // (rows without a home: unused)
                 if (irow >= 0 && hrow >= 0) {
-                    d.rho_cache[irow] = acc[0];
-                    d.rho_tag[irow] = ((long long)hrow << 32) | (unsigned int)d.mu_ver[hrow];
+                    const long long tg = ((long long)hrow << 32) | (unsigned int)d.mu_ver[hrow];
+                    d.pcache[irow].tag = tg;
+                    d.pcache[irow].rho2 = acc[0];
+                    WRec *wr = d.wrec + kw + (lane >> 1);
+                    wr->tag = tg;
+                    wr->rho2 = acc[0];
                 }
             }
         }
@@ -683,7 +689,10 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                         const int row = R * 16 + lk + 4 * r;
                         const bool own = sideH[row] == s;
                         if (!own || ns >= 2) sideM[row] = fmax(sideM[row], slot_score_lower(scs, v[r], own));
-                        if (own) d.qhome_cache[sideI[row]] = v[r];       // (tag written with the distance)
+                        if (own) {                                       // (tag written with the distance)
+                            d.pcache[sideI[row]].qhome = v[r];
+                            d.wrec[kw + row].qhome = v[r];
+                        }
                     }
                 }
                 // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr

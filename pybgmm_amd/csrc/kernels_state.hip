@@ -401,6 +401,8 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
             rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
             rec.mlb0 = d.log_alpha + d.log_prior[rec.i];
             rec.certified = 0.0;
+            const PCache pc = d.pcache[rec.i];
+            rec.tag = pc.tag; rec.qhome = pc.qhome; rec.rho2 = pc.rho2; rec.pad = 0.0;
             d.wrec[k] = rec;
         }
 }

@@ -20,6 +20,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C" -o pmc --output-format csv -- \
         python $REPO/bench.py --workload $WL --steps 2 --warmup 1 --cpu-visits 0 --no-kernel-timing \
         > "$OUT/pmc_$C.log" 2>&1
+    # pruning without certified stays: every visit streamed by the pruning kernel
+    rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmcprune_$C" -o pmc --output-format csv -- \
+        python $REPO/bench.py --workload $WL --steps 2 --warmup 1 --cpu-visits 0 --no-kernel-timing --prune 3 \
+        > "$OUT/pmcprune_$C.log" 2>&1
     # the same with pruning off: every (visit, component) pair through the full-evaluation kernel
     rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmcfull_$C" -o pmc --output-format csv -- \
         python $REPO/bench.py --workload $WL --steps 2 --warmup 1 --cpu-visits 0 --no-kernel-timing --prune 1 \

@@ -26,6 +26,7 @@ def main():
         if not os.path.isdir(d):
             continue
         full = os.path.basename(d).startswith("pmcfull_")
+        pruneonly = os.path.basename(d).startswith("pmcprune_")
         cc = find(d, "counter_collection.csv")
         if not cc:
             continue
@@ -37,7 +38,7 @@ def main():
         for k, cs in acc.items():
             for cname, vals in cs.items():
                 work = [v for v in vals if v[1] >= 20.0] or vals
-                summary.setdefault(k.split("(")[0] + (" [pruning off]" if full else ""), {})[cname] = {
+                summary.setdefault(k.split("(")[0] + (" [pruning off]" if full else " [no certified stays]" if pruneonly else ""), {})[cname] = {
                     "launches": len(vals), "working_launches": len(work),
                     "mean_working": sum(v[0] for v in work) / len(work),
                     "mean_working_us": sum(v[1] for v in work) / len(work)}
@@ -46,7 +47,7 @@ def main():
                        "gfx950 (MI355X_MICROARCH.md); mean over launches >= 20 us"}
     for k, cs in summary.items():
         if "score_mfma" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            if "prune_kernel" in k and "[pruning off]" not in k:
+            if "prune_kernel" in k and "[no certified stays]" in k:
                 key = "hbm_bytes_per_launch_pruned"
             elif "prune_kernel" not in k and "[pruning off]" in k:
                 key = "hbm_bytes_per_launch"
@@ -56,6 +57,12 @@ def main():
             traffic[key + "_kernel"] = k
             traffic[key + "_fetch_kb_raw"] = round(cs["FETCH_SIZE"]["mean_working"], 1)
             traffic[key + "_write_kb"] = round(cs["WRITE_SIZE"]["mean_working"], 1)
+    for k, cs in summary.items():
+        if k.startswith("certify_kernel") and "[" not in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic["hbm_bytes_per_launch_certified"] = int(1024 * (2 * cs["FETCH_SIZE"]["mean_working"]
+                                                                    + cs["WRITE_SIZE"]["mean_working"]))
+            traffic["hbm_bytes_per_launch_certified_fetch_kb_raw"] = round(cs["FETCH_SIZE"]["mean_working"], 1)
+            traffic["hbm_bytes_per_launch_certified_write_kb"] = round(cs["WRITE_SIZE"]["mean_working"], 1)
     json.dump(traffic, open(os.path.join(out, "traffic_%s.json" % wl), "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
 
