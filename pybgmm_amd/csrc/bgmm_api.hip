@@ -180,7 +180,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.v0 = v_0; d.k0 = k_0; d.alpha = alpha; d.log_alpha = std::log(alpha);
     d.tab_len = v_0 + N + 2;
     d.use_power = 0; d.power = 1.0; d.order = nullptr; d.u = nullptr; d.prune_enabled = 0;
-    d.use_tile_list = 0; d.lean_step = 0;
+    d.use_certify = 0; d.lean_step = 0; d.seat_dirty = 0;
     d.batch_rows = 1 << 30;
     resolve_kind(c);
 
@@ -244,10 +244,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.wrec, (size_t)rows);
         DALLOC(c, d.pr_counts, 1024);
         CK(c, hipMemsetAsync(d.pr_counts, 0, 1024 * sizeof(unsigned long long), c->stream));
-        d.pr_tile_cap = (int)((rows / 32 + 63) / 64 + 1);
-        DALLOC(c, d.pr_tiles, (size_t)64 * d.pr_tile_cap);
-        DALLOC(c, d.pr_ntiles, 64);
-        CK(c, hipMemsetAsync(d.pr_ntiles, 0, 64 * sizeof(int), c->stream));
+        DALLOC(c, d.cert, (size_t)rows);
+        DALLOC(c, d.ftab, (size_t)d.nslots * 64);
+        DALLOC(c, d.finv, (size_t)d.nslots);
     }
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
@@ -498,10 +497,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     // certified, the kernel is left out for the next 8 sweeps
     const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0 && c->prune_mode != 3;
     if (c->certify_skip > 0) c->certify_skip -= 1;
-    d.use_tile_list = use_certify ? 1 : 0;
+    d.use_certify = use_certify ? 1 : 0;
     bool lean = use_certify && c->lean_ok && c->prune_mode != 2;
     hipStream_t st = c->stream;
+    d.seat_dirty = 0;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
+        d.seat_dirty = 1;
         launch_build_seat_table(d, c->tabSeat, st);
         c->seat_use_power = d.use_power;
         c->seat_power = d.power;
@@ -570,9 +571,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
             if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
-            if (pmode >= 1) launch_bucket_rows(d, grid_rows, st);
+            if (pmode >= 1) launch_prune_tables(d, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
-            if (pmode >= 1 && use_certify) launch_certify(d, &d.ctrl->job, grid_rows, st);
+            if (pmode >= 1 && use_certify) launch_certify(d, grid_rows, st);
+            if (pmode >= 1 && !lean) launch_bucket_rows(d, grid_rows, st);
             if (pmode >= 1) { if (!lean) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st); }
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));

@@ -99,7 +99,8 @@ struct Ctrl {
     // the evaluation order (wperm, wrec) of window [wsort_base, wsort_hi) is still the bucket sort of
     // the current state (nothing moved since, same visiting order); skip_sort: the open window is that one
     int wsort_valid, skip_sort;
-    int retry_full;       // a lean step (certify only) met a tile it could not certify: queue full steps
+    int retry_full;       // a lean step (certify only) met a visit it could not certify: queue full steps
+    int n_sorted;         // rows of the open pruned window that went through the bucket sort (the uncertified ones)
     long long wsort_base, wsort_hi;
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
@@ -107,21 +108,18 @@ struct Ctrl {
 };
 
 // One row of a pruned window in evaluation order: everything the pruning kernel needs to start on
-// it comes with a single 64-byte load (instead of order -> label -> prior -> cache chains).
+// it comes with a single 32-byte load (instead of order -> label -> prior chains).
 struct WRec {
     long long i;        // data index
     int home;           // home slot (-1: unassigned)
     int home_label;     // its label in this window's frozen state
     double mlb0;        // log(alpha) + log_prior[i]: the "new table" score, first lower bound of the best score
-    double certified;   // set by certify_kernel: the visit provably keeps its component
-    // the point's cache (PCache) as of the bucket sort / the last pruning-kernel pass over this row:
-    long long tag;      // home slot << 32 | version of that slot's state the two numbers belong to
-    double qhome;       // exact quadratic form under the home component
-    double rho2;        // |x - mu_home|^2
     double pad;
 };
 
-// What score_mfma_prune_kernel leaves per DATA POINT for certify_kernel (survives re-sorting).
+// What score_mfma_prune_kernel leaves per DATA POINT for certify_kernel: its exact quadratic form
+// under its home component and its squared distance to that component's mean, tagged with
+// (home slot << 32 | version of that slot's state).
 struct PCache {
     long long tag;
     double qhome, rho2, pad;
@@ -155,14 +153,14 @@ struct Dev {
     SlotConst *sc;
     // certified stays (kernels_score.hip: certify_kernel): per slot a version of its derived state
     // (mean, factor); per data point the cached squared distance to its home's mean and its exact
-    // quadratic form under its home, tagged (home slot << 32 | version); copied into the window's
-    // records by the bucket sort so that certify_kernel reads contiguous memory only
+    // quadratic form under its home, tagged (home slot << 32 | version)
     int *mu_ver;
     PCache *pcache;
-    int *pr_tiles;               // pruned windows: 32-visit tiles the full pruning kernel still has to do,
-    int *pr_ntiles;              //   in 64 sub-lists (tile & 63) of capacity pr_tile_cap with their counts
-    int pr_tile_cap;
-    int use_tile_list;           // 1: certify_kernel ran before the pruning kernel (else it takes every tile)
+    unsigned char *cert;         // pruned windows, per window row: 1 = certify_kernel proved that the visit stays
+    double *ftab, *finv;         // per home label a: ftab[a][j] = upper bound of every other component's score for
+                                 // a visit of a at distance <= j / finv[a] from a's mean, j = 0 .. 63
+    int seat_dirty;              // this sweep's seating weights differ from the last sweep's (exponent changed)
+    int use_certify;             // 1: certify_kernel runs in front of the bucket sort (which then skips its rows)
     int lean_step;               // 1: this batch queues certify_kernel WITHOUT the pruning and draw kernels (the
                                  // previous sweep certified every visit); apply_kernel refuses the step otherwise
     int *perm, *label_of_slot;
@@ -180,7 +178,7 @@ struct Dev {
     double *pr_mufrag, *pr_const;
     double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
     int *pr_slot;
-    struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 64-byte record)
+    struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
     unsigned long long *pr_counts;  // 4 x 256 spread counters (kept, bound, MFMA instructions, certified visits) of the pruned-window kernels
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
     const double *u;
@@ -222,7 +220,8 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
                   int col_override, long long max_rows, int skip_pruned_jobs, hipStream_t st);
 bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                          hipStream_t st);
-void launch_certify(const Dev &d, const Job *job, long long max_rows, hipStream_t st);
+void launch_certify(const Dev &d, long long max_rows, hipStream_t st);
+void launch_prune_tables(const Dev &d, hipStream_t st);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   // pruned windows
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);

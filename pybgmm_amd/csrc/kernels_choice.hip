@@ -168,16 +168,12 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     if (blockIdx.x == 0)
         for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
     const long long win_base = c->job.win_base;
-    const long long nrows = c->job.win_hi - win_base;
+    const long long nrows = c->n_sorted;                 // (rows certify_kernel proved to stay are not here)
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nrows) return;
     const int K = c->job.K;
     const long long p = win_base + d.wperm[k];
     const WRec rec = d.wrec[k];                          // (index, home, its label, new-table score)
-    if (d.use_tile_list && rec.certified != 0.0) {       // certify_kernel (if it ran): the visit provably stays
-        d.choice[p - win_base] = rec.home_label;
-        return;
-    }
     SparseVisit sv;
     sv.d = &d;
     sv.K = K;

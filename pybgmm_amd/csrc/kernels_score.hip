@@ -297,119 +297,62 @@ __device__ __forceinline__ double log1p_lower(double t) {
 
 // ------------------------------------------------------------------------------------------
 // Certified stays.  In a converged chain almost every visit keeps its component with probability
-// 1 - epsilon, epsilon far below the resolution of the uniform.  certify_kernel proves that without
-// touching the data row.  score_mfma_prune_kernel leaves two numbers per point: its exact quadratic
-// form under its home component and its squared distance to that component's mean, tagged with the
-// home slot and the version of that slot's state (any change of a slot bumps its version).  While
-// the tag still matches, the home's score is known (slot_score_lower: within the dropped
-// -0.5 log(1 - a1 q) >= 0 and log(1+t) <= t), every other component is bounded from above exactly as
-// in the coarse level of the pruning kernel, and the new table's score is in the record.  If every
-// alternative lies more than
-// 38 + log(K + 1) nats below the home's lower bound, their total weight relative to the home is
-// < e^-38 = 3e-17 < 2^-53: the reference's normaliser rounds to the home's score, p_home = exp(0) = 1
-// exactly, everything before it in the scan subtracts < 3e-17 from a uniform that is at least 2^-53
-// (an exact zero disables pruning for the sweep, bgmm_api.hip), and `u - 1 < 0` returns the home.
-// One wave per 32-visit tile of the evaluation order; a tile is certified as a whole or handed to
-// score_mfma_prune_kernel through the list d.pr_tiles.
+// 1 - epsilon, epsilon far below the resolution of the uniform.  certify_kernel proves that per
+// visit without touching the data row.  score_mfma_prune_kernel leaves two numbers per point
+// (PCache): its exact quadratic form under its home component and its squared distance to that
+// component's mean, tagged with the home slot and the version of that slot's state (any change of a
+// slot bumps its version).  While the tag still matches, the home's score is known
+// (slot_score_lower: within the dropped -0.5 log(1 - a1 q) >= 0 and log(1+t) <= t), the new
+// table's score is log(alpha) + log_prior[i], and every other component is bounded from above by
+// ftab[home label][radius bin] (kernels_state.hip: prune_ftable_kernel -- the coarse triangle
+// bound of the pruning kernel, maximised over the other labels, tabulated over the distance to
+// the home's mean).  If every alternative lies more than 38 + log(K + 1) nats below the home's
+// lower bound, their total weight relative to the home is < e^-38 = 3e-17 < 2^-53: the reference's
+// normaliser rounds to the home's score, p_home = exp(0) = 1 exactly, everything before it in the
+// scan subtracts < 3e-17 from a uniform that is at least 2^-53 (an exact zero disables pruning for
+// the sweep, bgmm_api.hip), and `u - 1 < 0` returns the home.
+// One thread per window row, in visiting order; the rows it certifies are left out of the bucket
+// sort and of everything behind it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void certify_kernel(Dev d, const Job *__restrict__ jobp) {
-    const JobView job = load_job(jobp);
-    if (!job_is_pruned(d, job.mode, job.prune)) return;
+__global__ __launch_bounds__(256) void certify_kernel(Dev d) {
+    const Ctrl *c = d.ctrl;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
     // (the bucket sort's bins are free again: cleared for the next pruned window -- the sparse draw
     // kernel, which also does this, is not part of a lean step)
     if (blockIdx.x == 0)
         for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
-    const long long nrows = job.win_hi - job.pos;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long tile = (long long)blockIdx.x * 4 + w;
-    const long long kw = tile * 32;
-    if (kw >= nrows) return;
-    const int K = job.nlist;
-    const double margin = 38.0 + log((double)K + 1.0);
-    const long long kmine = kw + (lane & 31);
-    const bool live = lane < 32 && kmine < nrows;
-    WRec rec;
-    rec.i = -1; rec.home = -2; rec.home_label = -1; rec.mlb0 = 0.0; rec.certified = 0.0; rec.tag = -1;
-    rec.qhome = 0.0; rec.rho2 = 0.0;
-    if (live) rec = d.wrec[kmine];
-    const int hv = rec.home;
-    bool ok = !live;
-    double hlb = INFINITY, rad = 0.0;
-    if (live && hv >= 0) {
-        const long long tag = ((long long)hv << 32) | (unsigned int)d.mu_ver[hv];
-        if (d.n[hv] >= 2 && rec.tag == tag) {
-            hlb = slot_score_lower(d.sc[hv], rec.qhome, true);                  // <= the exact home score
-            rad = sqrt(rec.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
-            ok = hlb - rec.mlb0 >= margin;                                      // the new table is negligible
-        }
-    }
-    bool all_ok = __ballot(!ok) == 0ull;
-    // the homes present in the tile (at most four, else hand over)
-    int hs[4] = {-1, -1, -1, -1}, hl[4] = {0, 0, 0, 0}, nh = 0;
-    double hr[4] = {0.0, 0.0, 0.0, 0.0}, ht[4] = {0.0, 0.0, 0.0, 0.0};
-    if (all_ok) {
-        unsigned long long pending = __ballot(live);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            if (pending) {
-                const int first = __ffsll((long long)pending) - 1;
-                const int sh = __builtin_amdgcn_readfirstlane(__shfl(hv, first));
-                const bool sel = live && hv == sh;
-                pending &= ~__ballot(sel);
-                double a = sel ? rad : 0.0, b = sel ? hlb : INFINITY;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    a = fmax(a, __shfl_xor(a, o));
-                    b = fmin(b, __shfl_xor(b, o));
-                }
-                hs[it] = sh;
-                hl[it] = __builtin_amdgcn_readfirstlane(__shfl(rec.home_label, first));
-                hr[it] = a;
-                ht[it] = b - margin;
-                nh = it + 1;
-            }
-        }
-        if (pending) all_ok = false;
-    }
-    if (all_ok) {
-        // every other label, lane = label: upper bound through the home means (pr_dcc), against the
-        // weakest home bound of each home's visits
-        bool viol = false;
-        for (int t0 = 0; t0 < K; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < K) {
-                const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
-                const double base = g[0], hvd = g[16], tcoef = g[32];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < nh && t != hl[j]) {
-                        double dl = d.pr_dcc[(long long)hl[j] * d.nslots + t] * (1.0 - 1e-9) - hr[j];
-                        dl = dl > 0.0 ? dl : 0.0;
-                        const double ub = base - hvd * log1p_lower(dl * dl * tcoef);
-                        viol = viol || !(ub < ht[j]);
-                    }
+    const long long base = c->job.win_base;
+    const long long nrows = c->job.win_hi - base;
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    if (r < nrows) {
+        const long long p = base + r;
+        const long long i = d.order ? d.order[p] : p;
+        const int h = d.z[i];
+        if (h >= 0 && d.n[h] >= 2) {
+            const PCache pc = d.pcache[i];
+            if (pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
+                const double margin = 38.0 + log((double)c->job.K + 1.0);
+                const double hlb = slot_score_lower(d.sc[h], pc.qhome, true);       // <= the exact home score
+                const double thr = hlb - margin;
+                if (d.log_alpha + d.log_prior[i] < thr) {                            // the new table is negligible
+                    const int a = d.label_of_slot[h];
+                    const double rad = sqrt(pc.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
+                    const double jf = rad * d.finv[a];
+                    if (jf < 62.0) ok = d.ftab[(long long)a * 64 + (int)jf + 1] < thr;   // (radius rounded up)
                 }
             }
         }
-        all_ok = __ballot(viol) == 0ull;
+        d.cert[r] = ok ? 1 : 0;
     }
-    // (records outlive a sweep; rewritten only when the verdict changes: no write traffic at rest)
-    if (live && rec.certified != (all_ok ? 1.0 : 0.0)) d.wrec[kmine].certified = all_ok ? 1.0 : 0.0;
-    if (all_ok) {
-        if (lane == 0) {
-            const long long left = nrows - kw;
-            atomicAdd(&d.pr_counts[768 + (blockIdx.x & 255)], (unsigned long long)(left < 32 ? left : 32));
-        }
-    } else if (lane == 0) {
-        const int l = (int)(tile & 63);                    // 64 sub-lists keep the appends off one address
-        d.pr_tiles[l * d.pr_tile_cap + atomicAdd(&d.pr_ntiles[l], 1)] = (int)tile;
-    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(&d.pr_counts[768 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255)], (unsigned long long)__popcll(m));
 }
 
-void launch_certify(const Dev &d, const Job *job, long long max_rows, hipStream_t st) {
+void launch_certify(const Dev &d, long long max_rows, hipStream_t st) {
     if (max_rows <= 0) return;
-    hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((max_rows + 127) / 128)), dim3(256), 0, st, d, job);
+    hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((max_rows + 255) / 256)), dim3(256), 0, st, d);
 }
 
 // In a pruned window the visits are evaluated in the order of d.wrec (grouped by home component,
@@ -440,27 +383,13 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     constexpr int NKK = NJ * 4;
     constexpr int NK0 = NKK < 8 ? NKK : 8;                        // fragments of the level-0 bound (32 dimensions)
     constexpr int Ds = prune_row_stride(NJ * 16);
-    const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
-    // the 32-visit tiles certify_kernel could not decide: 64 sub-lists; wave g takes the g-th entry of
-    // their concatenation
+    const long long nrows = d.ctrl->n_sorted;                     // the rows the bucket sort kept (not certified)
+    const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
+    if (kb >= nrows) return;
     const int D = d.D;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int incl = d.use_tile_list ? d.pr_ntiles[lane] : 0;
-    const int mine = incl;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    const int ntiles = d.use_tile_list ? __shfl(incl, 63) : (int)((nrows + ROWS_W - 1) / ROWS_W);
-    if ((int)blockIdx.x * 4 >= ntiles) return;
-    const int g = (int)blockIdx.x * 4 + w;
-    const bool has_tile = g < ntiles;
-    long long kw = nrows;                                        // first evaluation position of the wave
-    if (has_tile && !d.use_tile_list) kw = (long long)g * ROWS_W;
-    else if (has_tile) {
-        const int l = __ffsll((long long)__ballot(incl > g)) - 1;
-        const int pos = g - (__shfl(incl, l) - __shfl(mine, l));
-        kw = (long long)d.pr_tiles[l * d.pr_tile_cap + pos] * ROWS_W;
-    }
+    const long long kw = kb + w * ROWS_W;                         // first evaluation position of the wave
     const int lr = lane & 15, lk = lane >> 4;
 
     const long long nfrag64 = (long long)NF * 64;
@@ -470,7 +399,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     const long long kmine = kw + (lane & (ROWS_W - 1));
     WRec rmine;
     if (kmine < nrows) rmine = d.wrec[kmine];
-    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; rmine.tag = -1; }
+    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; }
     const long long imine = rmine.i;
     // gathers behind the bound, one value per row of the wave: the lower bound of the visit's best log
     // score (starts at the "new table" entry) and its home slot.  They live in LDS next to |x|^2
@@ -594,9 +523,6 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                     const long long tg = ((long long)hrow << 32) | (unsigned int)d.mu_ver[hrow];
                     d.pcache[irow].tag = tg;
                     d.pcache[irow].rho2 = acc[0];
-                    WRec *wr = d.wrec + kw + (lane >> 1);
-                    wr->tag = tg;
-                    wr->rho2 = acc[0];
                 }
             }
         }
@@ -689,10 +615,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                         const int row = R * 16 + lk + 4 * r;
                         const bool own = sideH[row] == s;
                         if (!own || ns >= 2) sideM[row] = fmax(sideM[row], slot_score_lower(scs, v[r], own));
-                        if (own) {                                       // (tag written with the distance)
-                            d.pcache[sideI[row]].qhome = v[r];
-                            d.wrec[kw + row].qhome = v[r];
-                        }
+                        if (own) d.pcache[sideI[row]].qhome = v[r];     // (tag written with the distance)
                     }
                 }
                 // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr
@@ -1179,7 +1102,7 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
     extern __shared__ __attribute__((aligned(16))) double xs[];   // [D][64], then the per-visit arrays
     const JobView job = load_job(jobp);
     if (!job_is_pruned(d, job.mode, job.prune)) return;
-    const long long nrows = job.win_hi - job.pos;                 // (a pruned window starts at win_base)
+    const long long nrows = d.ctrl->n_sorted;                     // rows of the bucket sort (all of the window here)
     const long long k0 = (long long)blockIdx.x * kValuRows;
     if (k0 >= nrows) return;
     const int D = d.D, K = job.nlist;

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
-        c->tables_valid = 0;             // (seating weights may have changed)
+        if (d.seat_dirty) c->tables_valid = 0;   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0;
     __syncthreads();
     for (int r = r0 + threadIdx.x; r < r0 + BUCKET_ROWS && r < nrows; r += 256) {
+        if (d.use_certify && d.cert[r]) continue;          // (proved to stay: not part of the sort)
         const long long p = base + r;
         const long long i = d.order ? d.order[p] : p;
         atomicAdd(&bins[d.z[i] + 1], 1);
@@ -288,18 +289,17 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
         if (bins[b]) atomicAdd(&d.bucket_bins[b], bins[b]);
 }
 
-// block 0: exclusive prefix over the bins;  blocks 1..: the label-ordered tables of the pruning
-// kernel for the frozen state of this window (bgmm_device.h), one wave per group of 16 labels.
-__global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
-    __shared__ int wsum_[16];
+// The label-ordered tables of the pruned-window kernels for the frozen state of this window
+// (bgmm_device.h); rebuilt only after the state changed (Ctrl::tables_valid).
+// blocks 0 .. n_tab_blocks-1: fragments / constants / slots, one wave per group of 16 labels;
+// the rest: one label a each, its centre-to-centre distances.
+__global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid) return;
     const int n_tab_blocks = ((d.nslots + 15) / 16 + 15) / 16;
-    if ((int)blockIdx.x > n_tab_blocks) {
-        // centre-to-centre distances between labels (rebuilt only after the state changed)
+    if ((int)blockIdx.x >= n_tab_blocks) {
         __shared__ double mua[BGMM_MAX_D];
-        if (c->tables_valid) return;
-        const int K = c->job.K, a = (int)blockIdx.x - n_tab_blocks - 1, D = d.D;
+        const int K = c->job.K, a = (int)blockIdx.x - n_tab_blocks, D = d.D;
         if (a >= K) return;
         const double *__restrict__ pa = d.mu + (long long)d.perm[a] * D;
         for (int l = threadIdx.x; l < D; l += 1024) mua[l] = pa[l];
@@ -312,37 +312,73 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
         }
         return;
     }
-    if (blockIdx.x > 0) {
-        if (c->tables_valid) return;
-        const int K = c->job.K, G = ((int)blockIdx.x - 1) * 16 + (int)(threadIdx.x >> 6);
-        if (16 * G >= K) return;
-        const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-        const int t = 16 * G + lr;
-        const int s = t < K ? d.perm[t] : -1;
-        const int nkk = d.Dp / 4, D = d.D;
-        double m2p = 0.0;                            // |mu|^2 over the leading 32 dimensions (level-0 bound)
-        for (int kk = 0; kk < nkk; ++kk) {
-            const int l = 4 * kk + lk;
-            const double v = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
-            d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = v;
-            if (kk < 8) m2p = fma(v, v, m2p);
-        }
-        m2p += __shfl_xor(m2p, 16);
-        m2p += __shfl_xor(m2p, 32);
-        if (lk == 0) {
-            const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
-            double *g = d.pr_const + (long long)G * 128 + lr;
-            g[0] = sc->logseat + sc->A;
-            g[16] = sc->half_vd;
-            g[32] = sc->inv_lam * sc->inv_cv;
-            g[48] = sc->mu2;
-            g[64] = m2p;
-            d.pr_slot[G * 16 + lr] = s;
-        }
-        return;
+    const int K = c->job.K, G = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
+    if (16 * G >= K) return;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int t = 16 * G + lr;
+    const int s = t < K ? d.perm[t] : -1;
+    const int nkk = d.Dp / 4, D = d.D;
+    double m2p = 0.0;                            // |mu|^2 over the leading 32 dimensions (level-0 bound)
+    for (int kk = 0; kk < nkk; ++kk) {
+        const int l = 4 * kk + lk;
+        const double v = (s >= 0 && l < D) ? d.mu[(long long)s * D + l] : 0.0;
+        d.pr_mufrag[((long long)G * nkk + kk) * 64 + lane] = v;
+        if (kk < 8) m2p = fma(v, v, m2p);
     }
-    if (threadIdx.x < 64) d.pr_ntiles[threadIdx.x] = 0;   // (certify_kernel appends the tiles it could not decide)
-    if (c->skip_sort) return;
+    m2p += __shfl_xor(m2p, 16);
+    m2p += __shfl_xor(m2p, 32);
+    if (lk == 0) {
+        const SlotConst *sc = d.sc + (s >= 0 ? s : 0);
+        double *g = d.pr_const + (long long)G * 128 + lr;
+        g[0] = sc->logseat + sc->A;
+        g[16] = sc->half_vd;
+        g[32] = sc->inv_lam * sc->inv_cv;
+        g[48] = sc->mu2;
+        g[64] = m2p;
+        d.pr_slot[G * 16 + lr] = s;
+    }
+}
+
+// For every home label a (one block, 64 threads = 64 radii): ftab[a][j] = max over the other labels t
+// of the upper bound of t's log score for a visit whose home is a and whose distance to a's mean is at
+// most r_j = j / finv[a]  (triangle inequality through the centre distances, as in the coarse level of
+// score_mfma_prune_kernel); the grid reaches half the distance to a's nearest neighbour.  Increasing
+// in j.  Runs after prune_tables_kernel (same validity flag, set by apply_kernel afterwards).
+__global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
+    const Ctrl *c = d.ctrl;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid) return;
+    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
+    if (a >= K) return;
+    const double *__restrict__ dc = d.pr_dcc + (long long)a * d.nslots;
+    double dmin = INFINITY;
+    for (int t = 0; t < K; ++t)
+        if (t != a) dmin = fmin(dmin, dc[t]);
+    const bool fixed = d.cov_type == COV_FIXED;
+    const double step = K > 1 ? 0.5 * dmin / 63.0 : 1.0;
+    const double rj = (double)j * step * (1.0 + 1e-9);
+    double f = -INFINITY;
+    for (int t = 0; t < K; ++t) {
+        if (t == a) continue;
+        const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
+        double dl = dc[t] * (1.0 - 1e-9) - rj;
+        dl = dl > 0.0 ? dl : 0.0;
+        const double tt = dl * dl * g[32];
+        // (log1p_lower of kernels_score.hip, restated: frexp + chord)
+        const double y = 1.0 + tt;
+        const double m = __builtin_amdgcn_frexp_mant(y);
+        const int e = __builtin_amdgcn_frexp_exp(y);
+        const double L = 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
+        f = fmax(f, g[0] - g[16] * (fixed ? tt : L));
+    }
+    d.ftab[(long long)a * 64 + j] = f;
+    if (j == 0) d.finv[a] = (step > 0.0 && step < INFINITY) ? 1.0 / step : 0.0;
+}
+
+// exclusive prefix over the bins of the bucket sort (one block)
+__global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
+    __shared__ int wsum_[16];
+    const Ctrl *c = d.ctrl;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
     const int nb = d.nslots + 1;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
@@ -358,6 +394,7 @@ __global__ __launch_bounds__(1024) void bucket_prefix_tables_kernel(Dev d) {
     for (int k = 0; k < w; ++k) woff += wsum_[k];
     int run = woff + incl - local;
     for (int b = lo; b < hi; ++b) { const int v = d.bucket_bins[b]; d.bucket_bins[b] = run; run += v; }
+    if (threadIdx.x == 1023) d.ctrl->n_sorted = run;          // rows that take part (all but the certified ones)
 }
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
         const int r = r0 + threadIdx.x + t * 256;
         myb[t] = -1;
-        if (r < nrows) {
+        if (r < nrows && !(d.use_certify && d.cert[r])) {
             const long long p = base + r;
             const long long i = d.order ? d.order[p] : p;
             myb[t] = d.z[i] + 1;
@@ -400,20 +437,24 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
             rec.home = myb[t] - 1;
             rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
             rec.mlb0 = d.log_alpha + d.log_prior[rec.i];
-            rec.certified = 0.0;
-            const PCache pc = d.pcache[rec.i];
-            rec.tag = pc.tag; rec.qhome = pc.qhome; rec.rho2 = pc.rho2; rec.pad = 0.0;
+            rec.pad = 0.0;
             d.wrec[k] = rec;
         }
 }
 
+void launch_prune_tables(const Dev &d, hipStream_t st) {
+    const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
+    hipLaunchKernelGGL(prune_tables_kernel, dim3((ngrp + 15) / 16 + d.nslots), dim3(1024), 0, st, d);
+    // (always together with the tables, also in sweeps that do not certify: one validity flag)
+    if (d.cov_type == COV_FULL) hipLaunchKernelGGL(prune_ftable_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+}
+
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
-    // (d.bucket_bins is zero on entry: cleared at create and by every choice_sparse_kernel)
+    // (d.bucket_bins is zero on entry: cleared at create and by certify_kernel / choice_sparse_kernel)
     const int nb = d.nslots + 1;
     const unsigned g = (unsigned)((max_rows + BUCKET_ROWS - 1) / BUCKET_ROWS);
-    const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
     hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), nb * (int)sizeof(int), st, d);
-    hipLaunchKernelGGL(bucket_prefix_tables_kernel, dim3(1 + (ngrp + 15) / 16 + d.nslots), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(1024), 0, st, d);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
 }
 
@@ -556,16 +597,21 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     __shared__ int do_move;
     Ctrl *c = d.ctrl;
     if (d.lean_step && c->job.mode != MODE_DONE) {
-        // only certify_kernel ran: the step stands iff it certified every tile
+        // only certify_kernel ran: the step stands iff it certified every visit of the window
+        __shared__ unsigned long long csum[TPB];
         __shared__ int left;
+        csum[threadIdx.x] = d.pr_counts[768 + threadIdx.x];
+        __syncthreads();
+        for (int o = TPB / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) csum[threadIdx.x] += csum[threadIdx.x + o];
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
-            int sum = 0;
-            for (int l = 0; l < 64; ++l) sum += d.pr_ntiles[l];
-            left = sum;
-            if (sum > 0) { c->retry_full = 1; c->n_refresh = 0; }
+            left = (long long)csum[0] < c->job.win_hi - c->job.pos ? 1 : 0;
+            if (left) { c->retry_full = 1; c->n_refresh = 0; }
         }
         __syncthreads();
-        if (left > 0) {
+        if (left) {
             for (int t = 0; t < 4; ++t) d.pr_counts[t * 256 + threadIdx.x] = 0;     // (its counts are discarded)
             return;
         }
