@@ -221,14 +221,14 @@ def main():
                   "lik_evals_per_launch": round(st["scored"] / n_launch, 1)}
         if pruning:
             # Pruned windows.  A visit that certify_kernel proves to keep its component
-            # costs 64 B (its 32-byte record, the cached distance / quadratic form / tag, the flag) and X is
-            # not read; any other visit is streamed once by the pruning kernel: its row and bookkeeping,
-            # 8 D + 24 B, on top.  `achieved` = those bytes / the launch time of the two kernels together;
+            # costs 45 B (its label, the 32-byte per-point cache, its prior score, the flag) and X is not
+            # read; any other visit is also sorted (32-byte record) and streamed once by the pruning kernel:
+            # its row and bookkeeping, 8 D + 24 B, on top.  `achieved` = those bytes / the launch time of the two kernels together;
             # the same visits priced at SURVEY's 8 D + 24 B each are reported next to it.  The matrix work
             # still issued (counted in the kernel, 2048 flop per instruction) and what the same decisions
             # would cost without pruning are given as well.
             n_cert = float(ps["certified_visits"])
-            need_bytes = n_cert * 64.0 + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 64.0)
+            need_bytes = n_cert * 45.0 + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 77.0)
             need = need_bytes / (ms * 1e-3) / 1e9
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
             out = {"kernel": ("certify_kernel + score_mfma_prune_kernel" if n_cert > 0 else "score_mfma_prune_kernel")

@@ -652,7 +652,8 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             if (was_pruned) {
                 // this step's bucket / table kernels have run (or were skipped as still valid)
                 c->tables_valid = 1;
-                c->wsort_valid = 1; c->wsort_base = j.win_base; c->wsort_hi = j.win_hi;
+                // (the sort of a certifying sweep holds only the rows certify_kernel left: not reusable)
+                c->wsort_valid = d.use_certify ? 0 : 1; c->wsort_base = j.win_base; c->wsort_hi = j.win_hi;
             }
             if (fm == kNoMover) {
                 // every visit of the window keeps its component: the state is untouched

@@ -715,12 +715,14 @@ def test_lean_steps_fall_back_when_certification_fails():
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     us = np.random.RandomState(3).random_sample((5, N))
     out = []
-    for prune in (0, 1):
+    for prune in (0, 1, 30):                 # 30: certified stays for three sweeps, then switched off
         ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
-        ctx.set_tuning(kernel_kind=2, prune_mode=prune)
+        ctx.set_tuning(kernel_kind=2, prune_mode=prune % 10)
         ctx.set_assignments(zt)
         traj = []
         for it in range(5):
+            if it == 3 and prune == 30:
+                ctx.set_tuning(kernel_kind=2, prune_mode=3)
             if it == 3:                      # move 40 points to a wrong component by hand
                 for i in range(100, 140):
                     ctx.del_item(i)
@@ -731,7 +733,8 @@ def test_lean_steps_fall_back_when_certification_fails():
                 assert ctx.prune_stats()["certified_visits"] == N
         out.append((traj, ctx.log_marg()))
         ctx.close()
-    for a, b in zip(out[0][0], out[1][0]):
+    for a, b, c3 in zip(out[0][0], out[1][0], out[2][0]):
         npt.assert_array_equal(a, b)
+        npt.assert_array_equal(c3, b)
     assert (out[0][0][3] != out[0][0][2]).sum() == 0      # the hand-moved points went back
     assert abs(out[0][1] - out[1][1]) <= 1e-9 * abs(out[1][1])
