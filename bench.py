@@ -189,7 +189,7 @@ def main():
         ctx.set_kernel_timing(False)
         if n_launch <= 0 or ms <= 0:
             return None
-        if args.cov != "full" and st["bound_blocks"] == 0:
+        if args.cov != "full" and st["bound_blocks"] == 0 and ctx.prune_stats()["certified_visits"] == 0:
             # D logarithms per (visit, component): an FP64 VALU / transcendental kernel, no MFMA
             logs = st["scored"] * float(D)
             return {"kernel": "score_diag_kernel", "bound": "valu-transcendental",
@@ -231,8 +231,8 @@ def main():
             need_bytes = n_cert * 45.0 + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 77.0)
             need = need_bytes / (ms * 1e-3) / 1e9
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
-            out = {"kernel": ("certify_kernel + score_mfma_prune_kernel" if n_cert > 0 else "score_mfma_prune_kernel")
-                             if args.cov == "full" else "score_diag_prune_kernel",
+            heavy = "score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel"
+            out = {"kernel": ("certify_kernel + " + heavy) if n_cert > 0 else heavy,
                    "bound": "hbm",
                    "achieved": round(need, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                    "frac": round(need / PEAK_HBM_GBPS, 4),
@@ -250,7 +250,7 @@ def main():
                 out["traffic"] = tj.get("hbm_bytes_per_launch_certified") if traffic is not None else None
             if args.cov != "full":          # no matrix work on this path; the PMC file is the full-covariance kernel's
                 for key in ("mfma_instructions_per_launch", "mfma_executed_tflops", "mfma_frac_of_spec_peak",
-                            "unpruned_equivalent_tflops", "fraction_of_visits_certified_to_stay"):
+                            "unpruned_equivalent_tflops"):
                     out.pop(key)
                 out["traffic"] = None
             return out

@@ -495,7 +495,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     // certified stays pay off in converged chains only: when the per-point cache was warm (hardly a
     // move in this sweep and the one before) and still less than a tenth of the visits could be
     // certified, the kernel is left out for the next 8 sweeps
-    const bool use_certify = use_prune && d.cov_type == COV_FULL && c->certify_skip == 0 && c->prune_mode != 3;
+    const bool use_certify = use_prune && c->certify_skip == 0 && c->prune_mode != 3;
     if (c->certify_skip > 0) c->certify_skip -= 1;
     d.use_certify = use_certify ? 1 : 0;
     bool lean = use_certify && c->lean_ok && c->prune_mode != 2;

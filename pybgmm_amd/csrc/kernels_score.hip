@@ -333,7 +333,9 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
             const PCache pc = d.pcache[i];
             if (pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
                 const double margin = 38.0 + log((double)c->job.K + 1.0);
-                const double hlb = slot_score_lower(d.sc[h], pc.qhome, true);       // <= the exact home score
+                // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
+                const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
+                                                          : d.sc[h].logseat1 + pc.qhome;
                 const double thr = hlb - margin;
                 if (d.log_alpha + d.log_prior[i] < thr) {                            // the new table is negligible
                     const int a = d.label_of_slot[h];
@@ -1205,6 +1207,14 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
                                           - 0.5 * t1 - 0.5 * (double)(v1 + 1) * t2;
             sHomeLp[lane] = lp;
             sM[lane] = fmax(sM[lane], d.sc[hv].logseat1 + lp);
+            if (live) {                 // what certify_kernel reads next sweep (bgmm_device.h: PCache)
+                PCache pc;
+                pc.tag = ((long long)hv << 32) | (unsigned int)d.mu_ver[hv];
+                pc.qhome = lp;
+                pc.rho2 = r2;
+                pc.pad = 0.0;
+                d.pcache[sI[lane]] = pc;
+            }
         }
     }
     __syncthreads();

@@ -446,7 +446,7 @@ void launch_prune_tables(const Dev &d, hipStream_t st) {
     const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
     hipLaunchKernelGGL(prune_tables_kernel, dim3((ngrp + 15) / 16 + d.nslots), dim3(1024), 0, st, d);
     // (always together with the tables, also in sweeps that do not certify: one validity flag)
-    if (d.cov_type == COV_FULL) hipLaunchKernelGGL(prune_ftable_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(prune_ftable_kernel, dim3(d.nslots), dim3(64), 0, st, d);
 }
 
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {

@@ -375,6 +375,7 @@ __device__ inline void refresh_diag_slot(const Dev &d, int s, double *red, int t
         c.inv_lam = (wmin > 0.0 && wmin < INFINITY) ? wmin * (1.0 - 1e-12) : 0.0;
         c.mu2 = 0.0;
         d.sc[s] = c;
+        d.mu_ver[s] += 1;                     // (per-point caches against this slot's state are stale now)
         d.nupd[s] = 0;
     }
     __syncthreads();
@@ -422,6 +423,7 @@ __device__ inline void refresh_fixed_slot(const Dev &d, int s, double *red, int 
         c.inv_lam = (wmin > 0.0 && wmin < INFINITY) ? wmin * (1.0 - 1e-12) : 0.0;
         c.mu2 = 0.0;
         d.sc[s] = c;
+        d.mu_ver[s] += 1;                     // (per-point caches against this slot's state are stale now)
         d.nupd[s] = 0;
     }
     __syncthreads();

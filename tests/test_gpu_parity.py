@@ -738,3 +738,39 @@ def test_lean_steps_fall_back_when_certification_fails():
         npt.assert_array_equal(c3, b)
     assert (out[0][0][3] != out[0][0][2]).sum() == 0      # the hand-moved points went back
     assert abs(out[0][1] - out[1][1]) <= 1e-9 * abs(out[1][1])
+
+
+@pytest.mark.parametrize("cov", ["diag", "fixed"])
+def test_certified_stays_diag_fixed_against_c_oracle(cov):
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 30000, 24, 30
+    X, zt = gendata.synth_mixture(N, D, K, seed=88)
+    rs = np.random.RandomState(4)
+    if cov == "diag":
+        m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+        S_0 = np.ascontiguousarray(np.diag(S_0))
+    else:
+        m_0, k_0, v_0 = np.zeros(D), 1.0, 1
+        S_0 = np.concatenate([np.full(D, 0.49), np.full(D, 16.0)])
+    z0 = zt.copy()
+    flip = rs.choice(N, size=60, replace=False)
+    z0[flip] = rs.randint(0, K, size=flip.size)          # sweep 1 has moves to make; 2.. run on certificates
+    us = rs.random_sample((5, N))
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, cov_type=cov)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, cov_type=cov,
+                       tables=reference_tables(v_0, N) if cov == "diag" else None)
+    ctx.set_assignments(z0)
+    certified = 0
+    for it in range(5):
+        o.sweep(us[it])
+        ctx.sweep(us[it])
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        certified += ctx.prune_stats()["certified_visits"]
+    assert certified > 2 * N
+    ctx.close()
