@@ -365,7 +365,7 @@ void launch_certify(const Dev &d, long long max_rows, hipStream_t st) {
 // qb[(b * nslots + label) * 16 + v].  The draw kernel for pruned windows (choice_sparse_kernel)
 // reads nothing else.  Labels are handed out in groups of 16 (group G = labels 16G .. 16G+15,
 // one MFMA column each), group G to chunk G % chunks; everything a group needs comes from the
-// label-ordered tables bucket_prefix_tables_kernel keeps for the frozen state (coalesced 512-byte fragments).
+// label-ordered tables prune_tables_kernel keeps for the frozen state (coalesced 512-byte fragments).
 //
 // The 32 rows of a wave are staged through LDS (row-contiguous 512-byte global loads, then the
 // A fragments x[row lr][4kk + lk] are read back; row stride Ds = 4 mod 32 doubles).
