@@ -211,8 +211,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.sc, ns);
     DALLOC(c, d.mu_ver, ns);
     DALLOC(c, d.pcache, (size_t)N);
+    DALLOC(c, d.pcache2, (size_t)N);
     CK(c, hipMemsetAsync(d.mu_ver, 0, sizeof(int) * ns, c->stream));
     CK(c, hipMemsetAsync(d.pcache, 0xff, sizeof(PCache) * (size_t)N, c->stream));       // (tags: no slot)
+    CK(c, hipMemsetAsync(d.pcache2, 0xff, sizeof(PCacheExact) * (size_t)N, c->stream)); // (epochs: none)
     DALLOC(c, d.perm, ns);
     DALLOC(c, d.label_of_slot, ns);
     DALLOC(c, d.ctrl, 1);

@@ -100,6 +100,7 @@ struct Ctrl {
     // the current state (nothing moved since, same visiting order); skip_sort: the open window is that one
     int wsort_valid, skip_sort;
     int retry_full;       // a lean step (certify only) met a visit it could not certify: queue full steps
+    long long state_epoch;  // bumped by every change of the sampler's state (move, rebuild, new seating weights)
     int n_sorted;         // rows of the open pruned window that went through the bucket sort (the uncertified ones)
     long long wsort_base, wsort_hi;
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
@@ -123,6 +124,14 @@ struct WRec {
 struct PCache {
     long long tag;
     double qhome, rho2, pad;
+};
+
+// What choice_sparse_kernel leaves per data point: vhome - other_ub = -log of the total weight of all
+// alternatives relative to the home component's (the labels it scored exactly, each pruned one below
+// e^-80 of the best score) as of state epoch `epoch` -- valid as long as NOTHING has changed since.
+struct PCacheExact {
+    long long epoch;
+    double vhome, other_ub, pad;
 };
 
 struct Dev {
@@ -156,6 +165,7 @@ struct Dev {
     // quadratic form under its home, tagged (home slot << 32 | version)
     int *mu_ver;
     PCache *pcache;
+    PCacheExact *pcache2;
     unsigned char *cert;         // pruned windows, per window row: 1 = certify_kernel proved that the visit stays
     double *ftab, *finv;         // per home label a: ftab[a][j] = upper bound of every other component's score for
                                  // a visit of a at distance <= j / finv[a] from a's mean, j = 0 .. 63

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     // by old label K-1 (swap with last).  Without a singleton the kept labels are walked by bit
     // scan; the singleton case (rare) walks all L labels.
     double mx = vnew, tot = 0.0, v;
+    double vh = -INFINITY, toth = 0.0;          // exact score of the home label; sum of exp(v - mx) over the alternatives
     int pick = L;
     if (!sv.singleton) {
         // the scores of the first four kept labels stay in registers: with at most four (the usual
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
                 m &= m - 1;
                 if (sparse_score(sv, t, v)) {
                     mx = fmax(mx, v);
+                    if (t == rec.home_label) vh = v;
                     if (nc == 0) { v0 = v; t0 = t; } else if (nc == 1) { v1 = v; t1 = t; }
                     else if (nc == 2) { v2 = v; t2 = t; } else if (nc == 3) { v3 = v; t3 = t; }
                     ++nc;
@@ -214,11 +216,12 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
             }
         }
         if (nc <= 4) {
-            if (nc > 0) tot += exp(v0 - mx);
-            if (nc > 1) tot += exp(v1 - mx);
-            if (nc > 2) tot += exp(v2 - mx);
-            if (nc > 3) tot += exp(v3 - mx);
-            tot += exp(vnew - mx);
+            double e;
+            if (nc > 0) { e = exp(v0 - mx); tot += e; if (t0 != rec.home_label) toth += e; }
+            if (nc > 1) { e = exp(v1 - mx); tot += e; if (t1 != rec.home_label) toth += e; }
+            if (nc > 2) { e = exp(v2 - mx); tot += e; if (t2 != rec.home_label) toth += e; }
+            if (nc > 3) { e = exp(v3 - mx); tot += e; if (t3 != rec.home_label) toth += e; }
+            e = exp(vnew - mx); tot += e; toth += e;
             const double lse = log(tot) + mx;
             double uu = d.u[p];
             if (nc > 0) { uu -= exp(v0 - lse); if (uu < 0.0) pick = t0; }
@@ -232,10 +235,14 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
                 while (m) {
                     const int t = wi * 64 + __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    if (sparse_score(sv, t, v)) tot += exp(v - mx);
+                    if (sparse_score(sv, t, v)) {
+                        const double e = exp(v - mx);
+                        tot += e;
+                        if (t != rec.home_label) toth += e;
+                    }
                 }
             }
-            tot += exp(vnew - mx);
+            { const double e = exp(vnew - mx); tot += e; toth += e; }
             const double lse = log(tot) + mx;
             double uu = d.u[p];
             bool done = false;
@@ -268,6 +275,16 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
             }
     }
     d.choice[p - win_base] = pick;
+    if (sv.home_live) {
+        // for certify_kernel, while nothing changes: log of the total weight of all alternatives relative
+        // to the home's -- the scored ones exactly, every pruned label below e^-80 of the best score
+        PCacheExact pe;
+        pe.epoch = c->state_epoch;
+        pe.vhome = 0.0;
+        pe.other_ub = log(toth * exp(mx - vh) + (double)K * exp(mx - 80.0 - vh));
+        pe.pad = 0.0;
+        d.pcache2[rec.i] = pe;
+    }
     const bool stay = sv.home_live && pick < L && d.perm[pick] == sv.h;
     if (!stay) atomicMin(&c->first_mover, (unsigned long long)p);
 }

@@ -246,6 +246,7 @@ __device__ __forceinline__ void write_slot_team(const Dev &d, int s, const lds_f
         d.sc[s] = sc_new;
         d.mu_ver[s] += 1;                     // (as slot_math.h write_slot: per-point caches against this slot are stale)
         d.ctrl->tables_valid = 0;             // a move: the pruned-window tables and the cached bucket sort are stale
+        d.ctrl->state_epoch += 1;
         d.ctrl->wsort_valid = 0;
         const double *src = (const double *)&sc_new;
 #pragma unroll
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
         c->prof[7] += 1;
         c->lik_evals += S.lik;
         c->n_moves += S.moves;
-        if (S.moves > 0) { c->tables_valid = 0; c->wsort_valid = 0; }
+        if (S.moves > 0) { c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; }
         c->first_mover = kNoMover;
         c->n_refresh = 0;
         c->skip_apply = 1;

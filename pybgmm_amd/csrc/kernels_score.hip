@@ -330,18 +330,27 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
         const long long i = d.order ? d.order[p] : p;
         const int h = d.z[i];
         if (h >= 0 && d.n[h] >= 2) {
-            const PCache pc = d.pcache[i];
-            if (pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
-                const double margin = 38.0 + log((double)c->job.K + 1.0);
-                // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
-                const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
-                                                          : d.sc[h].logseat1 + pc.qhome;
-                const double thr = hlb - margin;
-                if (d.log_alpha + d.log_prior[i] < thr) {                            // the new table is negligible
-                    const int a = d.label_of_slot[h];
-                    const double rad = sqrt(pc.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
-                    const double jf = rad * d.finv[a];
-                    if (jf < 62.0) ok = d.ftab[(long long)a * 64 + (int)jf + 1] < thr;   // (radius rounded up)
+            const double margin = 38.0 + log((double)c->job.K + 1.0);
+            // tier 1: nothing at all has changed since the draw kernel last scored this visit -- the
+            // total weight of its alternatives relative to the home is still the one it stored
+            const PCacheExact pe = d.pcache2[i];
+            if (pe.epoch == c->state_epoch) {
+                ok = pe.vhome - pe.other_ub >= 37.75;     // total alternative weight < e^-37.75 < 2^-53 (36.74), 1 nat to spare
+            } else {
+                // tier 2: only the home component's state must be unchanged; the others are bounded
+                // through the per-home table
+                const PCache pc = d.pcache[i];
+                if (pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
+                    // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
+                    const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
+                                                              : d.sc[h].logseat1 + pc.qhome;
+                    const double thr = hlb - margin;
+                    if (d.log_alpha + d.log_prior[i] < thr) {                            // the new table is negligible
+                        const int a = d.label_of_slot[h];
+                        const double rad = sqrt(pc.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
+                        const double jf = rad * d.finv[a];
+                        if (jf < 62.0) ok = d.ftab[(long long)a * 64 + (int)jf + 1] < thr;   // (radius rounded up)
+                    }
                 }
             }
         }

@@ -159,7 +159,7 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= n) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->tables_valid = 0; d.ctrl->wsort_valid = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->tables_valid = 0; d.ctrl->wsort_valid = 0; d.ctrl->state_epoch += 1; }
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
     if ((int)blockIdx.x >= d.ctrl->job.K) return;
     const int s = d.perm[blockIdx.x];
     if (d.nupd[s] == 0) return;
-    if (threadIdx.x == 0) d.ctrl->tables_valid = 0;      // (means and bounds change; the homes do not)
+    if (threadIdx.x == 0) { d.ctrl->tables_valid = 0; atomicAdd((unsigned long long *)&d.ctrl->state_epoch, 1ull); }   // (means and bounds change; the homes do not)
     refresh_slot(d, s, sm);
 }
 
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
-        if (d.seat_dirty) c->tables_valid = 0;   // (the tables carry log seating weights)
+        if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
         if (c->win_size < 64) c->win_size = 64;
@@ -679,6 +679,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     do_move = 1;
                     c->tables_valid = 0;
                     c->wsort_valid = 0;
+                    c->state_epoch += 1;
                     set_refresh(d, c, mp, true);
                     c->n_moves += 1;
                     // adaptive window: about half the running mean distance between movers
@@ -723,6 +724,7 @@ __global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, i
         ok = 1;
         c->tables_valid = 0;
         c->wsort_valid = 0;
+        c->state_epoch += 1;
         if (op == 0) {
             mp.sub_slot = plan_unseat(d, c, i);
         } else {
