@@ -18,7 +18,7 @@
 //     sc[s]            scalar constants of the Student-t predictive (SlotConst)
 //   q[nslots][Wmax]    quadratic forms (mu_s - x)^T C_s^{-1} (mu_s - x) of the current window,
 //                      slot major so that both kernels touch it in full 64/128-byte segments
-//                      A PRUNED window (kernels_score.hip) reuses the same buffer block-sparse:
+//                      A PRUNED window (kernels_prune.hip) reuses the same buffer block-sparse:
 //                      qb[(block * nslots + label) * 16 + v] for the 16 visits of an evaluation
 //                      block, only the (block, label) lines the pruning kernel kept are written,
 //   keep64[Wmax/16][keep_stride]  bit `label` of a block's mask = "that line holds exact scores"
@@ -160,7 +160,7 @@ struct Dev {
     int *n;
     int *nupd;                   // rank-1 updates since the slot's last from-scratch refresh
     SlotConst *sc;
-    // certified stays (kernels_score.hip: certify_kernel): per slot a version of its derived state
+    // certified stays (kernels_prune.hip: certify_kernel): per slot a version of its derived state
     // (mean, factor); per data point the cached squared distance to its home's mean and its exact
     // quadratic form under its home, tagged (home slot << 32 | version)
     int *mu_ver;

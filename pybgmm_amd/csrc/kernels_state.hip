@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
         double dl = dc[t] * (1.0 - 1e-9) - rj;
         dl = dl > 0.0 ? dl : 0.0;
         const double tt = dl * dl * g[32];
-        // (log1p_lower of kernels_score.hip, restated: frexp + chord)
+        // (log1p_lower of kernels_prune.hip, restated: frexp + chord)
         const double y = 1.0 + tt;
         const double m = __builtin_amdgcn_frexp_mant(y);
         const int e = __builtin_amdgcn_frexp_exp(y);
