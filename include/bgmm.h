@@ -92,6 +92,18 @@ int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, int32_t use
 int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
 int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
 
+/*
+ * The sweep's uniforms continued ON THE DEVICE from the caller's Mersenne Twister: replaces the
+ * N calls of random.random() (utils/utils.py:13-16) plus the upload.  key624 / pos are the 624 state
+ * words and the position of random.getstate()[1]; on return they hold the state N calls of
+ * random.random() leave behind (feed them to random.setstate()).  The doubles are bit-identical to
+ * CPython's genrand_res53.  `order` as in bgmm_stage_sweep_inputs (NULL = identity).  Follow with
+ * bgmm_sweep_staged.
+ */
+int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *key624, int32_t *pos);
+/* The N uniforms currently staged for the next sweep (whichever way they got there). */
+int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
+
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
  * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no
  * host-to-device traffic inside the call. */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "bgmm_set_assignments": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
+    "bgmm_stage_mt19937": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
     "bgmm_sweep_resident": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
@@ -157,6 +159,23 @@ class Context(object):
         if order is not None:
             order = np.ascontiguousarray(order, dtype=np.int64)
         self._ck(self.L.bgmm_stage_sweep_inputs(self.h, _ptr(order), _ptr(u)))
+
+    def stage_mt19937(self, key624, pos, order=None):
+        """Uniforms of the next sweep generated on the device from an MT19937 state (624 uint32 words +
+        position, as in ``random.getstate()[1]``).  Returns the advanced ``(key624, pos)``."""
+        key = np.ascontiguousarray(key624, dtype=np.uint32).copy()
+        assert key.shape == (624,)
+        p = ctypes.c_int32(int(pos))
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int64)
+            assert order.shape == (self.N,)
+        self._ck(self.L.bgmm_stage_mt19937(self.h, _ptr(order), _ptr(key), ctypes.byref(p)))
+        return key, int(p.value)
+
+    def staged_uniforms(self):
+        u = np.empty(self.N, dtype=np.float64)
+        self._ck(self.L.bgmm_get_staged_uniforms(self.h, _ptr(u)))
+        return u
 
     def sweep_staged(self, power=None):
         self._ck(self.L.bgmm_sweep_staged(self.h, 0 if power is None else 1,

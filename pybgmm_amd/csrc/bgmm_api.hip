@@ -72,6 +72,7 @@ struct bgmm_ctx {
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
     int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
     long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
+    unsigned *mt_words = nullptr;    // device scratch of bgmm_stage_mt19937: 624 state words, position, flag, 2N outputs
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -159,6 +160,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->mt_words) (void)hipFree(c->mt_words);
     if (c->res_u) (void)hipFree(c->res_u);
     if (c->res_order) (void)hipFree(c->res_order);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
@@ -446,6 +448,39 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     CK(c, hipStreamSynchronize(c->stream));
     c->cur_u = c->d_u;
     c->cur_order = order ? c->d_order : nullptr;
+    return 0;
+}
+
+extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *key624, int32_t *pos) {
+    if (!c || !key624 || !pos) return BGMM_EINVAL;
+    if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
+    CK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->d.N;
+    if (!c->mt_words) CK(c, hipMalloc((void **)&c->mt_words, sizeof(unsigned) * (640 + 2 * N)));
+    unsigned *dkey = c->mt_words, *dwords = c->mt_words + 640;
+    int *dpos = (int *)(c->mt_words + 624), *dflag = (int *)(c->mt_words + 625);
+    int host_tail[2] = {*pos, 0};
+    CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
+    c->have_order = order != nullptr;
+    if (order)
+        CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
+    launch_mt19937(dkey, dpos, dwords, c->d_u, (long long)N, dflag, c->stream);
+    CK(c, hipMemcpyAsync(key624, dkey, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(host_tail, dpos, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    *pos = host_tail[0];
+    c->cur_zero_u = host_tail[1] != 0;
+    c->cur_u = c->d_u;
+    c->cur_order = order ? c->d_order : nullptr;
+    return 0;
+}
+
+extern "C" int bgmm_get_staged_uniforms(bgmm_ctx *c, double *u_out) {
+    if (!c || !u_out) return BGMM_EINVAL;
+    if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpy(u_out, c->cur_u, sizeof(double) * c->d.N, hipMemcpyDeviceToHost));
     return 0;
 }
 

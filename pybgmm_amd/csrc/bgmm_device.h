@@ -238,3 +238,5 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
 int refresh_lds_bytes(int D);
+void launch_mt19937(unsigned *key_io, int *pos_io, unsigned *words, double *u, long long n, int *zero_flag,
+                    hipStream_t st);

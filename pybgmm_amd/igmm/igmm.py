@@ -129,5 +129,8 @@ class IGMM(GMM):
     # ------------------------------------------------------------------ #
     def _sweep(self, order=None, power=None):
         """One device sweep fed from the caller's random streams."""
-        u = _rng.take_uniforms(self.N, self._rng)
-        self.components._ctx.sweep(u, order, power)
+        ctx = self.components._ctx
+        if _rng.stage_uniforms_on_device(ctx, order, self._rng):     # the caller's stream, continued on the GPU
+            ctx.sweep_staged(power)
+        else:
+            ctx.sweep(_rng.take_uniforms(self.N, self._rng), order, power)

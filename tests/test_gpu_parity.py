@@ -774,3 +774,27 @@ def test_certified_stays_diag_fixed_against_c_oracle(cov):
         certified += ctx.prune_stats()["certified_visits"]
     assert certified > 2 * N
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,burn", [(0, 0), (12345, 1), (7, 311), (99, 623), (2014, 1247)])
+def test_device_mt19937_continues_the_callers_stream(seed, burn):
+    """bgmm_stage_mt19937: the device produces exactly the doubles random.random() would, from any
+    position inside a block, and leaves the generator where N host calls would."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    N, D, K = 5000, 2, 3
+    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(zt)
+    host, dev = random.Random(seed), random.Random(seed)
+    for _ in range(burn):                       # (an odd count leaves the position odd: a double then straddles)
+        host.getrandbits(32); dev.getrandbits(32)
+    for it in range(3):
+        expect = np.array([host.random() for _ in range(N)])
+        assert _rng.stage_uniforms_on_device(ctx, None, dev)
+        npt.assert_array_equal(ctx.staged_uniforms(), expect)
+        assert dev.getstate() == host.getstate()
+        ctx.sweep_staged(None)
+    ctx.close()
