@@ -140,7 +140,8 @@ int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
  * Per-sweep clustering metrics of the record dict (gmm/gmm.py:85-104), SURVEY.md 8f rank 2.
  *   bgmm_contingency: table[t * K + k] = #{i : true_idx[i] == t and label(i) == k}, the K_true x K
  *     contingency table from which mutual_information / normalized_mutual_information /
- *     information_variation (infopy/infopy.py:31-119) follow; true_idx holds 0..K_true-1.
+ *     information_variation (infopy/infopy.py:31-119) follow; true_idx holds 0..K_true-1 and is kept
+ *     on the device: NULL means "the labelling of the previous call".
  *   bgmm_cluster_dispersion: out[k] = sum_{i in k} |x_i - mean_k|^2 from the component's sufficient
  *     statistics -- what utils.cluster_loss_inertia (utils/utils.py:31-88) takes the square root of.
  */

@@ -246,9 +246,11 @@ class Context(object):
 
     # -- record-dict metrics --------------------------------------------------
     def contingency(self, true_idx, K_true):
-        """K_true x K table of (true class, current label) counts."""
-        true_idx = np.ascontiguousarray(true_idx, dtype=np.int64)
-        assert true_idx.shape == (self.N,)
+        """K_true x K table of (true class, current label) counts.  ``true_idx=None``: the labelling
+        uploaded by the previous call (it stays on the device)."""
+        if true_idx is not None:
+            true_idx = np.ascontiguousarray(true_idx, dtype=np.int64)
+            assert true_idx.shape == (self.N,)
         K = self.K
         table = np.zeros((int(K_true), max(K, 1)), dtype=np.int64)
         self._ck(self.L.bgmm_contingency(self.h, _ptr(true_idx), int(K_true), _ptr(table)))

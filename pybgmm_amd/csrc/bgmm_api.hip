@@ -72,6 +72,9 @@ struct bgmm_ctx {
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
     int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
     long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
+    long long *true_dev = nullptr;   // bgmm_contingency: the reference labelling, kept between calls
+    unsigned long long *table_dev = nullptr;
+    size_t table_cells = 0;
     unsigned *mt_words = nullptr;    // device scratch of bgmm_stage_mt19937: 624 state words, position, flag, 2N outputs
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
@@ -161,6 +164,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->mt_words) (void)hipFree(c->mt_words);
+    if (c->true_dev) (void)hipFree(c->true_dev);
+    if (c->table_dev) (void)hipFree(c->table_dev);
     if (c->res_u) (void)hipFree(c->res_u);
     if (c->res_order) (void)hipFree(c->res_order);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
@@ -771,26 +776,28 @@ extern "C" int bgmm_log_marg_k(bgmm_ctx *c, int32_t k, double *out) {
 }
 
 extern "C" int bgmm_contingency(bgmm_ctx *c, const int64_t *true_idx, int32_t K_true, int64_t *table_out) {
-    if (!c || !true_idx || !table_out || K_true < 1) return BGMM_EINVAL;
+    if (!c || !table_out || K_true < 1) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
+    if (!true_idx && !c->true_dev) return fail(c, BGMM_EINVAL, "no reference labelling uploaded yet");
     int rc = fetch_ctrl(c);
     if (rc) return rc;
     const int K = c->ctrl_host->job.K;
     if (K == 0) return 0;
-    long long *dt = nullptr;
-    unsigned long long *dtab = nullptr;
     const size_t cells = (size_t)K_true * K;
-    hipError_t e = hipMalloc((void **)&dt, sizeof(long long) * c->d.N);
-    if (e == hipSuccess) e = hipMalloc((void **)&dtab, sizeof(unsigned long long) * cells);
-    if (e == hipSuccess) e = hipMemcpyAsync(dt, true_idx, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dtab, 0, sizeof(unsigned long long) * cells, c->stream);
-    if (e == hipSuccess) {
-        launch_contingency(c->d, dt, K_true, dtab, c->stream);
-        e = hipMemcpyAsync(table_out, dtab, sizeof(long long) * cells, hipMemcpyDeviceToHost, c->stream);
+    // the reference labelling stays on the device between calls (true_idx == NULL: the same as last time)
+    if (!c->true_dev) CK(c, hipMalloc((void **)&c->true_dev, sizeof(long long) * c->d.N));
+    if (true_idx)
+        CK(c, hipMemcpyAsync(c->true_dev, true_idx, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
+    if (cells > c->table_cells) {
+        if (c->table_dev) (void)hipFree(c->table_dev);
+        c->table_dev = nullptr; c->table_cells = 0;
+        CK(c, hipMalloc((void **)&c->table_dev, sizeof(unsigned long long) * cells));
+        c->table_cells = cells;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dt); (void)hipFree(dtab);
-    CK(c, e);
+    CK(c, hipMemsetAsync(c->table_dev, 0, sizeof(unsigned long long) * cells, c->stream));
+    launch_contingency(c->d, c->true_dev, K_true, c->table_dev, c->stream);
+    CK(c, hipMemcpyAsync(table_out, c->table_dev, sizeof(long long) * cells, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

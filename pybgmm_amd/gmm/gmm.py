@@ -50,9 +50,12 @@ class GMM(object):
         if cache is None or cache[0] is not true_assignments:
             _metrics._check(t, t)
             uniq, idx = np.unique(t, return_inverse=True)
-            cache = (true_assignments, idx.astype(np.int64), len(uniq))
+            cache = [true_assignments, idx.astype(np.int64), len(uniq), None]
             self._true_idx_cache = cache
-        table = ctx.contingency(cache[1], cache[2])
+        # the class indices go to the device once per (labelling, context)
+        first = cache[3] is not ctx
+        table = ctx.contingency(cache[1] if first else None, cache[2])
+        cache[3] = ctx
         nmi, mi, vi = _metrics.table_metrics(table)
         loss = _metrics.loss_from_dispersion(ctx.cluster_dispersion())
         return nmi, mi, vi, loss
