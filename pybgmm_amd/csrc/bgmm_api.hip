@@ -613,7 +613,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
             if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
-            if (pmode >= 1) launch_prune_tables(d, st);
+            if (pmode >= 1 && !lean) launch_prune_tables(d, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (pmode >= 1 && use_certify) launch_certify(d, grid_rows, st);
             if (pmode >= 1 && !lean) launch_bucket_rows(d, grid_rows, st);
@@ -624,7 +624,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (pmode >= 1 && !lean) launch_choice_sparse(d, grid_rows, st);
             if (use_resolver && pmode <= 1) launch_resolve(d, res_R, res_Kcap, res_lds, st);
             launch_apply(d, st);
-            launch_refresh_ctrl(d, st);
+            if (!lean) launch_refresh_ctrl(d, st);        // (a lean step moves nothing: apply refuses it otherwise)
         }
         CK(c, hipGetLastError());
         int rc = fetch_ctrl(c);

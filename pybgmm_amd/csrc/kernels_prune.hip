@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
                 // tier 2: only the home component's state must be unchanged; the others are bounded
                 // through the per-home table
                 const PCache pc = d.pcache[i];
-                if (pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
+                // (the per-home table must belong to the current state: a full step has just rebuilt it
+                // if need be, a lean step has not)
+                if ((!d.lean_step || c->tables_valid) && pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
                     // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
                     const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
                                                               : d.sc[h].logseat1 + pc.qhome;

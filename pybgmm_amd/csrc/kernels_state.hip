@@ -661,8 +661,9 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             c->first_mover = kNoMover;
             const bool was_pruned = job_is_pruned(d, j.mode, j.prune);
             if (was_pruned) {
-                // this step's bucket / table kernels have run (or were skipped as still valid)
-                c->tables_valid = 1;
+                // this step's bucket / table kernels have run (or were skipped as still valid);
+                // a lean step queues neither
+                if (!d.lean_step) c->tables_valid = 1;
                 // (the sort of a certifying sweep holds only the rows certify_kernel left: not reusable)
                 c->wsort_valid = d.use_certify ? 0 : 1; c->wsort_base = j.win_base; c->wsort_hi = j.win_hi;
             }
