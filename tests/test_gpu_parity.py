@@ -10,6 +10,8 @@ Parity of the HIP path (through the C-ABI) with the reference.
 Tolerances: integer trajectory bit-exact; log marginal 1e-6 relative (north_star), observed
 ~1e-12; m / S bit-exact; logdet / inverse 1e-8.
 """
+import os
+
 import numpy as np
 import numpy.testing as npt
 import pytest
@@ -798,3 +800,15 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
         assert dev.getstate() == host.getstate()
         ctx.sweep_staged(None)
     ctx.close()
+
+
+def test_soak_default_against_full_evaluation():
+    """tools/soak.py: 24 random configurations (shape, separation, covariance type, visiting order,
+    seating exponent, flipped / unassigned labels, add_item / del_item between sweeps), 10 sweeps each:
+    the default configuration and the plain full evaluation walk the same chain."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "24", "11"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
