@@ -126,12 +126,12 @@ struct PCache {
     double qhome, rho2, pad;
 };
 
-// What choice_sparse_kernel leaves per data point: vhome - other_ub = -log of the total weight of all
-// alternatives relative to the home component's (the labels it scored exactly, each pruned one below
-// e^-80 of the best score) as of state epoch `epoch` -- valid as long as NOTHING has changed since.
+// What choice_sparse_kernel leaves per data point: the log of the total weight of all alternatives
+// relative to the home component's (the labels it scored exactly, each pruned one below e^-80 of the
+// best score) as of state epoch `epoch` -- valid as long as NOTHING has changed since.
 struct PCacheExact {
     long long epoch;
-    double vhome, other_ub, pad;
+    double log_alt;
 };
 
 struct Dev {

@@ -280,9 +280,7 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
         // to the home's -- the scored ones exactly, every pruned label below e^-80 of the best score
         PCacheExact pe;
         pe.epoch = c->state_epoch;
-        pe.vhome = 0.0;
-        pe.other_ub = log(toth * exp(mx - vh) + (double)K * exp(mx - 80.0 - vh));
-        pe.pad = 0.0;
+        pe.log_alt = log(toth * exp(mx - vh) + (double)K * exp(mx - 80.0 - vh));
         d.pcache2[rec.i] = pe;
     }
     const bool stay = sv.home_live && pick < L && d.perm[pick] == sv.h;

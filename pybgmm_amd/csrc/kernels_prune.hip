@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
             // total weight of its alternatives relative to the home is still the one it stored
             const PCacheExact pe = d.pcache2[i];
             if (pe.epoch == c->state_epoch) {
-                ok = pe.vhome - pe.other_ub >= 37.75;     // total alternative weight < e^-37.75 < 2^-53 (36.74), 1 nat to spare
+                ok = pe.log_alt <= -37.75;     // total alternative weight < e^-37.75 < 2^-53 (e^-36.74), 1 nat to spare
             } else {
                 // tier 2: only the home component's state must be unchanged; the others are bounded
                 // through the per-home table
