@@ -282,6 +282,24 @@ def main():
         ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
                        prune_mode=args.prune)
 
+    # --- the same chain with the exact shortcuts switched off, whole sweeps timed the same way ---
+    # (the trajectory is identical in all modes; tests/test_gpu_parity.py, tools/soak.py)
+    by_mode = None
+    if rank == 0 and n_gpus == 1 and not args.no_kernel_timing and args.prune == 0:
+        by_mode = {"as_benchmarked": round(args.steps / elapsed, 2)}
+        for name, mode, reps in (("certified_stays_off", 3, 5), ("pruning_off_every_pair_evaluated", 1, 3)):
+            ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                           prune_mode=mode)
+            ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+            barrier()
+            t0 = time.time()
+            for _ in range(reps):
+                ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+            barrier()
+            by_mode[name] = round(reps / (time.time() - t0), 2)
+        ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                       prune_mode=args.prune)
+
     # --- the one collective: final label gather (RCCL over xGMI), outside the timed region ---
     t0 = time.time()
     z_all, lm_all = gather_chains(ctx.assignments(), np.array([log_marg]),
@@ -313,6 +331,7 @@ def main():
                                    % (args.workload, model, D, N, K,
                                       " covariance_type=%s" % args.cov if args.cov != "full" else "", args.init),
                        "parallelism": "replica_chains_x%d" % n_gpus,
+                       "certified_stays": bool(args.prune == 0),
                        "exact_pruning": bool(args.prune == 0 and (args.cov != "full" or (args.kernel != 1 and (D >= 12 or args.kernel == 2))))},
             "lik_evals_per_sec": round(lik_total / elapsed, 1),
             "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
@@ -326,6 +345,7 @@ def main():
                       "h2d_streams_s": round(t_h2d, 4),
                       "pcie_inclusive_sweeps_per_s": round(
                           sweeps_total / (elapsed + t_h2d * args.steps / n_sweeps), 4),
+                      "sweeps_per_s_by_mode": by_mode,
                       "label_gather_s": round(t_gather, 4),
                       "gathered_shape": list(z_all.shape)},
         }
