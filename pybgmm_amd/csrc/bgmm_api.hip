@@ -54,6 +54,7 @@ struct bgmm_ctx {
     int win_rows = 0;                // allocated q / choice rows
     double last_move_rate = 0.0;     // movers per visit of the previous sweep
     int resolver_mode = 0;           // 0 auto, 1 off, 2 always when it fits
+    bool order_is_perm = true;       // the staged visiting order visits every point exactly once (or is absent)
     int prune_mode = 0;              // 0 auto (on with the MFMA kernel), 1 off, 2 every window (tests),
                                      // 3 auto without certified stays (measurement)
     double *tabSeat = nullptr;       // seating-weight table (rebuilt when the exponent changes)
@@ -78,6 +79,7 @@ struct bgmm_ctx {
     unsigned *mt_words = nullptr;    // device scratch of bgmm_stage_mt19937: 624 state words, position, flag, 2N outputs
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
+    std::vector<char> res_perm;      // per resident sweep: its order is a permutation (or absent)
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -440,6 +442,19 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
     return rc;
 }
 
+// The sequential small-D sweep fetches z[i] ahead of the visit of i: sound only when no index
+// comes twice.  Checked on the host for the shapes that can take that path.
+static bool seq_shape(const bgmm_ctx *c) { return c->d.cov_type == COV_FULL && c->d.D <= 4; }
+static bool order_is_permutation(const int64_t *order, long long N) {
+    std::vector<unsigned char> seen((size_t)N, 0);
+    for (long long p = 0; p < N; ++p) {
+        const int64_t i = order[p];
+        if (i < 0 || i >= N || seen[(size_t)i]) return false;
+        seen[(size_t)i] = 1;
+    }
+    return true;
+}
+
 extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const double *u) {
     if (!c || !u) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
@@ -448,6 +463,7 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     for (long long i = 0; i < c->d.N; ++i)
         if (u[i] == 0.0) { c->cur_zero_u = true; break; }
     c->have_order = order != nullptr;
+    c->order_is_perm = !order || (seq_shape(c) && order_is_permutation(order, c->d.N));
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
@@ -468,6 +484,7 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
     c->have_order = order != nullptr;
+    c->order_is_perm = !order || (seq_shape(c) && order_is_permutation(order, (long long)N));
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
     launch_mt19937(dkey, dpos, dwords, c->d_u, (long long)N, dflag, c->stream);
@@ -507,6 +524,10 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
     for (int32_t t = 0; t < n_sweeps; ++t)
         for (size_t i = 0; i < N; ++i)
             if (u_all[(size_t)t * N + i] == 0.0) { c->res_zero_u[(size_t)t] = 1; break; }
+    c->res_perm.assign((size_t)n_sweeps, 1);
+    if (order_all)
+        for (int32_t t = 0; t < n_sweeps; ++t)
+            c->res_perm[(size_t)t] = seq_shape(c) && order_is_permutation(order_all + (size_t)t * N, (long long)N);
     return 0;
 }
 
@@ -563,6 +584,28 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         launch_refresh_stale(d, c->ctrl_host->job.K, st);   // (tight bounds again after a sweep with moves)
     launch_sweep_begin(d, st);
     long long steps_done = 0;
+    // Tiny dimensions: one wavefront walks the visits in order with the labels' state in LDS
+    // (kernels_state.hip: sweep_seq_kernel).  It leaves the sweep DONE, or -- when the labels outgrow
+    // its LDS plan -- a window open at the visit it stopped at, and the loop below carries on.
+    bool seq_ran = false;
+    if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
+        c->order_is_perm) {
+        const int per = sweep_seq_bytes_per_label(d.D);
+        int cap = (150 * 1024) / per;
+        if (const char *e = getenv("BGMM_SEQ_CAP")) {      // (tests: a small plan, to exercise the hand-over)
+            const int v = atoi(e);
+            if (v >= 2 && v < cap) cap = v;
+        }
+        if (cap > d.K_max + 1) cap = d.K_max + 1;
+        if (c->ctrl_host->job.K + 1 <= cap) {
+            if (!launch_sweep_seq(d, cap, st)) return fail(c, BGMM_EDEVICE, "sequential sweep kernel launch failed");
+            CK(c, hipGetLastError());
+            int rc = fetch_ctrl(c);
+            if (rc) return rc;
+            seq_ran = true;
+            steps_done = c->ctrl_host->n_steps;
+        }
+    }
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
     // Lower bound on the steps still needed: one per remaining window.  On top of that,
     // one step per expected mover, estimated from the rate observed so far in this sweep
@@ -572,7 +615,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     int win = c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows;
     double rate = c->last_move_rate;
     bool first_batch = true;               // (sweep_begin has just opened a fresh window at visit 0)
+    if (seq_ran) {
+        first_batch = false;
+        pos = c->ctrl_host->job.pos;
+    }
     for (;;) {
+        if (seq_ran && (c->ctrl_host->error != 0 || c->ctrl_host->job.mode == MODE_DONE)) break;
         const long long remaining = N - pos;
         long long lb = (remaining + win - 1) / win;
         long long extra = (long long)std::ceil(rate * (double)remaining * 1.1);
@@ -671,6 +719,7 @@ extern "C" int bgmm_sweep_resident(bgmm_ctx *c, int32_t index, int32_t use_power
     if (index < 0 || index >= c->res_n) return fail(c, BGMM_EINVAL, "resident sweep index out of range");
     c->cur_u = c->res_u + (size_t)index * c->d.N;
     c->cur_zero_u = c->res_zero_u[(size_t)index] != 0;
+    c->order_is_perm = c->res_perm[(size_t)index] != 0;
     c->cur_order = c->res_order ? c->res_order + (size_t)index * c->d.N : nullptr;
     return bgmm_sweep_staged(c, use_power, power);
 }

@@ -27,15 +27,28 @@ __device__ __forceinline__ double cov_scale(const Dev &d, int n) {
 // constants of the predictive for a slot with count n and logdet(S_N) = logdetC.  Everything
 // that depends on n alone comes from the device-built tables (no transcendental on this path:
 // it sits on the critical chain of every move).
-__device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC, double lam, double mu2) {
+struct SlotTab { double g, lc, seat, g1, lc1, seat1; };
+
+__device__ __forceinline__ SlotTab load_slot_tab(const Dev &d, int n) {
+    SlotTab t;
+    const long long v = d.v0 + n - d.D + 1;
+    t.g = d.tabG[v]; t.lc = d.tabLogC[n]; t.seat = d.tabSeat[n];
+    t.g1 = n >= 2 ? d.tabG[v - 1] : 0.0;
+    t.lc1 = n >= 1 ? d.tabLogC[n - 1] : 0.0;
+    t.seat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
+    return t;
+}
+
+__device__ inline SlotConst make_consts_from(const Dev &d, int n, const SlotTab &t, double logdetC, double lam,
+                                             double mu2) {
     SlotConst c;
     const int D = d.D;
     const double Dd = (double)D;
     const double k_N = d.k0 + (double)n;
     const long long v = d.v0 + n - D + 1;
-    const double g = d.tabG[v], lc = d.tabLogC[n], seat = d.tabSeat[n];
-    const double g1 = n >= 2 ? d.tabG[v - 1] : 0.0, lc1 = n >= 1 ? d.tabLogC[n - 1] : 0.0;
-    const double seat1 = n >= 1 ? d.tabSeat[n - 1] : 0.0;
+    const double g = t.g, lc = t.lc, seat = t.seat;
+    const double g1 = t.g1, lc1 = t.lc1;
+    const double seat1 = t.seat1;
     const double cs = (k_N + 1.0) / (k_N * (double)v);
     c.logdetC = logdetC;
     c.A = g - 0.5 * (Dd * lc + logdetC);
@@ -57,6 +70,10 @@ __device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC, dou
     c.inv_lam = (lam > 0.0 && lam < 1e300) ? 1.0 / lam : 0.0;
     c.mu2 = mu2;
     return c;
+}
+
+__device__ inline SlotConst make_consts(const Dev &d, int n, double logdetC, double lam, double mu2) {
+    return make_consts_from(d, n, load_slot_tab(d, n), logdetC, lam, mu2);
 }
 
 // log score of one (visit, slot) pair from its quadratic form (seating weight included)

@@ -33,9 +33,11 @@ def make_ctx(g, kind=0, window=0, tables=True, resolver=0, prune=0):
     return ctx
 
 
-@pytest.mark.parametrize("kind", [1, 2], ids=["valu", "mfma"])
+@pytest.mark.parametrize("kind", [0, 1, 2], ids=["auto", "valu", "mfma"])
 @pytest.mark.parametrize("case", ALL_CASES)
 def test_golden_trajectory(case, kind):
+    # ("auto": D <= 4 full-covariance cases take the sequential one-wavefront sweep, the rest the
+    # windowed kernels the host would pick by itself)
     g = Golden(case)
     ctx = make_ctx(g, kind)
     npt.assert_allclose(ctx.log_prior()[:4096], g.d["cached_log_prior"], rtol=1e-11, atol=1e-11)
@@ -150,7 +152,7 @@ def test_every_window_pruned_against_c_oracle(N, D, K, sep, label):
 @pytest.mark.parametrize("case", ["c2twin_crpmm_2d", "c3rand_pcrpmm_16d", "each_in_own_50"])
 def test_window_size_does_not_change_trajectory(case, window):
     g = Golden(case)
-    ctx = make_ctx(g, 0, window)
+    ctx = make_ctx(g, 1 if g.D <= 4 else 0, window)      # (kind 0 would take the window-less sequential sweep)
     for it in range(g.n_iter):
         ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
         npt.assert_array_equal(ctx.assignments(), g.z[it])
@@ -800,6 +802,17 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
         assert dev.getstate() == host.getstate()
         ctx.sweep_staged(None)
     ctx.close()
+
+
+def test_soak_sequential_small_d_against_windowed():
+    """tools/soak_seq.py: 24 random D <= 4 configurations, the sequential one-wavefront sweep (with a
+    small LDS plan in a third of them, so that it hands over to the windowed kernels mid-sweep) against
+    the windowed VALU path; any difference in the trajectory fails."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_seq.py"), "24", "5"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_soak_default_against_full_evaluation():
