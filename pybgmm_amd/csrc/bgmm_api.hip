@@ -590,8 +590,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     bool seq_ran = false;
     if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
         c->order_is_perm) {
-        const int per = sweep_seq_bytes_per_label(d.D);
-        int cap = (150 * 1024) / per;
+        int cap = 2;
+        while (sweep_seq_lds_bytes(d.D, cap + 16) <= 150 * 1024) cap += 16;
         if (const char *e = getenv("BGMM_SEQ_CAP")) {      // (tests: a small plan, to exercise the hand-over)
             const int v = atoi(e);
             if (v >= 2 && v < cap) cap = v;

@@ -727,22 +727,24 @@ void launch_apply(const Dev &d, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sequential sweep for tiny dimensions (D <= 4, full covariance): ONE wavefront walks the N visits
-// in order, exactly as the reference's loop does (igmm/crpmm.py:57-88, igmm/pcrpmm.py:93-131).
+// Sequential sweep for tiny dimensions (D <= 4, full covariance): ONE workgroup walks the N visits
+// in order, as the reference's loop does (igmm/crpmm.py:57-88, igmm/pcrpmm.py:93-131).
 // With D(D+1)/2 + D multiply-adds per (visit, component) there is nothing to tile; what a visit
-// costs is latency, so everything it touches is kept where latency is short:
+// costs is the latency of one dependent chain (~400 instructions: a logarithm, an exponential, two
+// divisions, three wave reductions), so everything it touches is kept where latency is short:
 //   * the state of every ACTIVE LABEL lives in LDS for the whole sweep (statistics m, S; inverse
 //     factor, Winv mu, predictive constants; slot id, count), struct-of-arrays with lane = label;
-//     global memory is written through on every move and never read back;
-//   * the per-visit inputs (index, row of X, home slot, log prior, uniform) are fetched 64 visits
-//     at a time, one visit per lane, a batch ahead of their use, and handed to the visit with
-//     v_readlane (scalar registers).  z[i] may be fetched ahead because only the visit of i itself
-//     writes it: the host takes this path only when the visiting order is a permutation.
-// A stay costs the scores (frozen-factor home form as in choice_kernel), three wave reductions and
-// the scan; a move adds the two statistics updates (same roundings as apply_rank1) and the two
-// rebuilds from scratch (Cholesky of S_N, its inverse, constants), one lane per touched label.
-// No speculation, no windows: the mover-dense regime the windowed path pays ~20 us per move for
-// (overlapping clusters in 2-D: a quarter of the visits move at equilibrium) costs ~1 us here.
+//     global memory gets z[i] at every move and the labels' state once, at the end;
+//   * the per-visit inputs (index, row of X, home slot, log prior, uniform) sit in an LDS ring that
+//     wave 0 refills 64 visits at a time, a batch ahead of their use.  z[i] may be fetched ahead
+//     because only the visit of i itself writes it: the host takes this path only when the visiting
+//     order is a permutation;
+//   * kSeqWaves wavefronts evaluate kSeqWaves consecutive visits side by side against the same
+//     state; the visits in front of the first one that does not stay are exact as they are (a stay
+//     changes nothing), that one is applied by its own wavefront -- statistics with the roundings of
+//     apply_rank1, the two touched labels rebuilt from scratch (Cholesky of S_N, its inverse, the
+//     constants), one lane each -- and the round restarts behind it.  The windowed path's
+//     speculation at the scale of a workgroup: no launches, no global round trips.
 // When the labels outgrow the LDS plan (K + 1 > cap) the kernel opens a window at the next visit
 // and returns; the host carries on with the windowed kernels (the global state is complete).
 // ------------------------------------------------------------------------------------------
@@ -754,10 +756,6 @@ struct SeqLayout {   // SoA fields, in units of `cap` doubles
     //            9 logdetC, 10 inv_lam, 11 mu2 (carried for the write-back)
 };
 
-int sweep_seq_bytes_per_label(int D) {
-    const int T = D * (D + 1) / 2;
-    return (2 * D + 2 * T + 12 + 1) * (int)sizeof(double) + 4 * (int)sizeof(int);
-}
 
 __device__ __forceinline__ double readlane_f64(double v, int t) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), t);
@@ -890,22 +888,39 @@ __device__ __forceinline__ void seq_rebuild_label(const Dev &d, double *F, int c
 #define PF(k)
 #endif
 
+constexpr int kSeqWaves = 8;      // visits evaluated side by side (one wavefront each)
+constexpr int kSeqRing = 256;     // visits whose inputs sit in LDS (a power of two)
+
+// LDS of the plan for `cap` labels
+int sweep_seq_lds_bytes(int D, int cap) {
+    const int T = D * (D + 1) / 2, NF = 2 * D + 2 * T + 12;
+    return cap * ((NF + kSeqWaves) * (int)sizeof(double) + 4 * (int)sizeof(int)) +
+           kSeqRing * ((3 + D) * (int)sizeof(double) + (int)sizeof(int));
+}
+
 template <int DD>
-__global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
+__global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int cap) {
     using Ly = SeqLayout<DD>;
     constexpr int T = Ly::T, NS = DD + T;               // NS: statistics per label (m, packed S)
+    constexpr int NW = kSeqWaves, RING = kSeqRing, NT = 64 * NW;
     extern __shared__ double F[];
-    double *eb = F + Ly::NF * cap;                     // weights of one visit (K + 2 > 64 only)
-    int *Lslot = (int *)(eb + cap);                    // slot of label j; entries K .. K_hi: free slots (perm[j])
-    int *Ln = Lslot + cap, *Lver = Ln + cap, *Lnupd = Lver + cap;
+    double *eb_all = F + Ly::NF * cap;                 // weights of one visit per wave (K + 2 > 64 only)
+    double *ring_u = eb_all + NW * cap, *ring_lp = ring_u + RING, *ring_x = ring_lp + RING;   // ring_x[DD][RING]
+    long long *ring_i = (long long *)(ring_x + DD * RING);
+    int *Lslot = (int *)(ring_i + RING);               // slot of label j; entries K .. K_hi: free slots (perm[j])
+    int *Ln = Lslot + cap, *Lver = Ln + cap, *Lnupd = Lver + cap, *ring_z = Lnupd + cap;
+    __shared__ int sh_res[2][NW];
+    __shared__ int sh_K, sh_Khi, sh_stop, sh_moved;
+    __shared__ long long sh_stop_at;
     Ctrl *c = d.ctrl;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *eb = eb_all + w * cap;
     if (c->error != 0 || c->job.mode == MODE_DONE) return;        // (sweep_begin has opened the sweep)
     int K = c->job.K;
     if (K + 1 > cap) return;                           // the open window goes to the windowed kernels
     int K_hi = K < d.K_max ? K : K - 1;                // Lslot / Lver are valid for indices <= K_hi
     const long long N = d.N;
-    for (int j = lane; j <= K_hi; j += 64) {
+    for (int j = tid; j <= K_hi; j += NT) {
         const int s = d.perm[j];
         Lslot[j] = s;
         Lver[j] = d.mu_ver[s];
@@ -935,8 +950,11 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
 #pragma unroll
         for (int b = 0; b <= a; ++b) pri[DD + seq_pk(a, b)] = d.prior_S[a * DD + b];
     }
-    // per-visit inputs, one visit per lane, a batch ahead
+    // Per-visit inputs: a ring of RING visits in LDS, filled 64 visits at a time by wave 0, whose
+    // registers hold the next batch while its loads are in flight.
     long long n_i = 0; double n_x[DD], n_lp = 0.0, n_u = 0.0; int n_z = -1;
+#pragma unroll
+    for (int a = 0; a < DD; ++a) n_x[a] = 0.0;
 #define SEQ_FETCH(PB)                                                              \
     {                                                                              \
         const long long p_ = (PB) + lane;                                          \
@@ -948,24 +966,46 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
             _Pragma("unroll") for (int a = 0; a < DD; ++a) n_x[a] = d.X[n_i * DD + a]; \
         }                                                                          \
     }
-    SEQ_FETCH(0)
-    long long lik = 0, moves = 0, stop_at = -1;
+#define SEQ_COMMIT(PB)                                                             \
+    {                                                                              \
+        const int sl_ = (int)(((PB) + lane) & (RING - 1));                         \
+        ring_i[sl_] = n_i; ring_u[sl_] = n_u; ring_lp[sl_] = n_lp; ring_z[sl_] = n_z; \
+        _Pragma("unroll") for (int a = 0; a < DD; ++a) ring_x[a * RING + sl_] = n_x[a]; \
+    }
+    long long filled = 0;                              // (wave 0) visits [0, filled) have been in the ring
+    if (w < 2) {
+        SEQ_FETCH(64 * w)
+        SEQ_COMMIT(64 * w)
+    }
+    if (w == 0) {
+        filled = 128;
+        SEQ_FETCH(filled)
+    }
+    if (tid == 0) { sh_K = K; sh_Khi = K_hi; sh_stop = 0; sh_stop_at = -1; sh_moved = 0; }
+    __syncthreads();
+    long long lik = 0, moves = 0;
+    long long p = 0;
+    int stop = 0, round = 0;
 #ifdef BGMM_SEQ_PROF
     long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk0 = clock64(), tk1;
 #endif
-    for (long long pb = 0; pb < N && stop_at < 0; pb += 64) {
-        const long long c_i = n_i; const double c_lp = n_lp, c_u = n_u; const int c_z = n_z;
-        double c_x[DD];
+    while (p < N) {
+        if (w == 0 && filled < N && filled < p + 128) {
+            SEQ_COMMIT(filled)
+            filled += 64;
+            SEQ_FETCH(filled)
+        }
+        const long long pv = p + w;
+        int res = -1;                                  // -1: stays (or no visit); >= 0: moves to this label; -2: error
+        int h = -1, lab_h = -1, nh = 0, L = K, pick = K;
+        bool home_live = false, singleton = false;
+        double x[DD];
+        if (pv < N) {
+            const int sl = (int)(pv & (RING - 1));
+            h = __builtin_amdgcn_readfirstlane(ring_z[sl]);
+            const double u = ring_u[sl], lp = ring_lp[sl];
 #pragma unroll
-        for (int a = 0; a < DD; ++a) c_x[a] = n_x[a];
-        SEQ_FETCH(pb + 64)
-        const int nb = N - pb < 64 ? (int)(N - pb) : 64;
-        for (int t = 0; t < nb; ++t) {
-            const int h = __builtin_amdgcn_readlane(c_z, t);
-            const double u = readlane_f64(c_u, t), lp = readlane_f64(c_lp, t);
-            double x[DD];
-#pragma unroll
-            for (int a = 0; a < DD; ++a) x[a] = readlane_f64(c_x[a], t);
+            for (int a = 0; a < DD; ++a) x[a] = ring_x[a * RING + sl];
             PF(0)
             // the quadratic form of the lane's own label (does not wait for the home's label)
             double q_own = 0.0;
@@ -979,201 +1019,225 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
                     q_own = fma(acc, acc, q_own);
                 }
             }
-            int lab_h = -1;
             if (h >= 0) {
                 for (int j0 = 0; j0 < K; j0 += 64) {
                     const unsigned long long mm = __ballot(j0 + lane < K && Lslot[j0 + lane] == h);
                     if (mm) { lab_h = j0 + __ffsll((long long)mm) - 1; break; }
                 }
-                if (lab_h < 0) { if (lane == 0) atomicCAS(&c->error, 0, -5); stop_at = N; break; }
             }
-            const int nh = h >= 0 ? Ln[lab_h] : 0;
-            const bool home_live = h >= 0 && nh >= 2;          // removal keeps the component
-            const bool singleton = h >= 0 && nh == 1;          // removal deletes it (swap with last)
-            const int L = singleton ? K - 1 : K;               // labels after the removal
-            PF(1)
-            int pick = L;
-            if (K + 2 <= 64) {
-                // Everything of the visit in registers, one label per lane: lane L is the new table and,
-                // for a live home, lane L + 1 evaluates the second logarithm of the home form (the
-                // frozen-factor downdate, choice_kernel), so that every lane runs ONE log.
-                const bool is_lab = lane < L, is_aux = home_live && lane == L + 1;
-                const int jj = is_aux ? lab_h : ((singleton && lane == lab_h) ? K - 1 : (is_lab ? lane : 0));
-                const double q_home = readlane_f64(q_own, lab_h >= 0 ? lab_h : 0);
-                const double q_last = readlane_f64(q_own, K >= 1 ? K - 1 : 0);
-                const double qv = is_aux ? q_home : ((singleton && lane == lab_h) ? q_last : q_own);
-                const double *C = F + Ly::OC * cap + jj;
-                const bool homeform = home_live && jj == lab_h && (is_lab || is_aux);
-                const double den = homeform ? 1.0 - C[8 * cap] * qv : 1.0;
-                const double num = homeform ? C[7 * cap] * qv : qv * C[3 * cap];
-                double arg = 1.0 + num / den;
-                double hv = homeform ? C[6 * cap] : C[2 * cap];
-                double base = homeform ? C[4 * cap] + C[5 * cap] : C[0] + C[cap];
-                if (is_aux) arg = den;
-                if (!is_lab) { hv = 0.0; base = lane == L ? d.log_alpha + lp : -INFINITY; if (!is_aux) arg = 1.0; }
-                const double lg = log(arg);
-                const double lg_aux = readlane_f64(lg, L + 1);
-                if (homeform && is_lab) base = base - 0.5 * lg_aux;
-                const double v = base - hv * lg;
-                const double mx = seq_wave_max(v);
-                const double e = exp(v - mx);
-                const double tot = seq_wave_sum(e);
-                const double cum = seq_wave_scan(e / tot, lane);
-                const unsigned long long mhit = __ballot(lane <= L && (u - cum) < 0.0);
-                if (mhit) pick = __ffsll((long long)mhit) - 1;
+            if (h >= 0 && lab_h < 0) {
+                res = -2;                              // the label maps are broken
             } else {
-                // pass 1: log scores (as choice_kernel)
-                double mx = -INFINITY;
-                for (int j0 = 0; j0 <= L; j0 += 64) {
-                    const int j = j0 + lane;
-                    double v = -INFINITY;
-                    if (j == L) {
-                        v = d.log_alpha + lp;
-                    } else if (j < L) {
-                        const int jj = (singleton && j == lab_h) ? K - 1 : j;
-                        double qv = 0.0;
+                nh = h >= 0 ? __builtin_amdgcn_readfirstlane(Ln[lab_h]) : 0;
+                home_live = h >= 0 && nh >= 2;         // removal keeps the component
+                singleton = h >= 0 && nh == 1;         // removal deletes it (swap with last)
+                L = singleton ? K - 1 : K;             // labels after the removal
+                PF(1)
+                pick = L;
+                if (K + 2 <= 64) {
+                    // Everything of the visit in registers, one label per lane: lane L is the new table and,
+                    // for a live home, lane L + 1 evaluates the second logarithm of the home form (the
+                    // frozen-factor downdate, choice_kernel), so that every lane runs ONE log.
+                    const bool is_lab = lane < L, is_aux = home_live && lane == L + 1;
+                    const int jj = is_aux ? lab_h : ((singleton && lane == lab_h) ? K - 1 : (is_lab ? lane : 0));
+                    const double q_home = readlane_f64(q_own, lab_h >= 0 ? lab_h : 0);
+                    const double q_last = readlane_f64(q_own, K >= 1 ? K - 1 : 0);
+                    const double qv = is_aux ? q_home : ((singleton && lane == lab_h) ? q_last : q_own);
+                    const double *C = F + Ly::OC * cap + jj;
+                    const bool homeform = home_live && jj == lab_h && (is_lab || is_aux);
+                    const double den = homeform ? 1.0 - C[8 * cap] * qv : 1.0;
+                    const double num = homeform ? C[7 * cap] * qv : qv * C[3 * cap];
+                    double arg = 1.0 + num / den;
+                    double hv = homeform ? C[6 * cap] : C[2 * cap];
+                    double base = homeform ? C[4 * cap] + C[5 * cap] : C[0] + C[cap];
+                    if (is_aux) arg = den;
+                    if (!is_lab) { hv = 0.0; base = lane == L ? d.log_alpha + lp : -INFINITY; if (!is_aux) arg = 1.0; }
+                    const double lg = log(arg);
+                    const double lg_aux = readlane_f64(lg, L + 1);
+                    if (homeform && is_lab) base = base - 0.5 * lg_aux;
+                    const double v = base - hv * lg;
+                    const double mx = seq_wave_max(v);
+                    const double e = exp(v - mx);
+                    const double tot = seq_wave_sum(e);
+                    const double cum = seq_wave_scan(e / tot, lane);
+                    const unsigned long long mhit = __ballot(lane <= L && (u - cum) < 0.0);
+                    if (mhit) pick = __ffsll((long long)mhit) - 1;
+                } else {
+                    // pass 1: log scores (as choice_kernel)
+                    double mx = -INFINITY;
+                    for (int j0 = 0; j0 <= L; j0 += 64) {
+                        const int j = j0 + lane;
+                        double v = -INFINITY;
+                        if (j == L) {
+                            v = d.log_alpha + lp;
+                        } else if (j < L) {
+                            const int jj = (singleton && j == lab_h) ? K - 1 : j;
+                            double qv = 0.0;
 #pragma unroll
-                        for (int r = 0; r < DD; ++r) {
-                            double acc = F[(Ly::OCV + r) * cap + jj];
+                            for (int r = 0; r < DD; ++r) {
+                                double acc = F[(Ly::OCV + r) * cap + jj];
 #pragma unroll
-                            for (int l = 0; l <= r; ++l) acc = fma(-F[(Ly::OW + seq_pk(r, l)) * cap + jj], x[l], acc);
-                            qv = fma(acc, acc, qv);
+                                for (int l = 0; l <= r; ++l) acc = fma(-F[(Ly::OW + seq_pk(r, l)) * cap + jj], x[l], acc);
+                                qv = fma(acc, acc, qv);
+                            }
+                            const double *C = F + Ly::OC * cap + jj;
+                            if (home_live && jj == lab_h) {
+                                const double den = 1.0 - C[8 * cap] * qv;
+                                v = C[4 * cap] + C[5 * cap] - 0.5 * log(den) - C[6 * cap] * log(1.0 + C[7 * cap] * qv / den);
+                            } else {
+                                v = C[0] + C[cap] - C[2 * cap] * log(1.0 + qv * C[3 * cap]);
+                            }
                         }
-                        const double *C = F + Ly::OC * cap + jj;
-                        if (home_live && jj == lab_h) {
-                            const double den = 1.0 - C[8 * cap] * qv;
-                            v = C[4 * cap] + C[5 * cap] - 0.5 * log(den) - C[6 * cap] * log(1.0 + C[7 * cap] * qv / den);
-                        } else {
-                            v = C[0] + C[cap] - C[2 * cap] * log(1.0 + qv * C[3 * cap]);
+                        if (j <= L) eb[j] = v;
+                        mx = fmax(mx, v);
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+                    // pass 2: exp and total
+                    double tot = 0.0;
+                    for (int j = lane; j <= L; j += 64) {
+                        const double e = exp(eb[j] - mx);
+                        eb[j] = e;
+                        tot += e;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                    // pass 3: sequential-subtract scan in label order, 64 labels at a time (utils.py:15-20)
+                    double carry = 0.0;
+                    for (int j0 = 0; j0 <= L; j0 += 64) {
+                        const int j = j0 + lane;
+                        double cum = j <= L ? eb[j] / tot : 0.0;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const double tt = __shfl_up(cum, o);
+                            if (lane >= o) cum += tt;
                         }
-                    }
-                    if (j <= L) eb[j] = v;
-                    mx = fmax(mx, v);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-                // pass 2: exp and total
-                double tot = 0.0;
-                for (int j = lane; j <= L; j += 64) {
-                    const double e = exp(eb[j] - mx);
-                    eb[j] = e;
-                    tot += e;
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-                // pass 3: sequential-subtract scan in label order, 64 labels at a time (utils.py:15-20)
-                double carry = 0.0;
-                for (int j0 = 0; j0 <= L; j0 += 64) {
-                    const int j = j0 + lane;
-                    double cum = j <= L ? eb[j] / tot : 0.0;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const double tt = __shfl_up(cum, o);
-                        if (lane >= o) cum += tt;
-                    }
-                    cum = carry + cum;
-                    const unsigned long long mhit = __ballot(j <= L && (u - cum) < 0.0);
-                    if (mhit) { pick = j0 + __ffsll((long long)mhit) - 1; break; }
-                    carry = __shfl(cum, 63);
-                }
-            }
-            lik += L;
-            PF(2)
-            if (home_live && pick == lab_h) continue;          // stays: nothing changes
-            // ---- the visit moves (del_item / add_item, gaussian_components.py:168-205).  All of it in
-            // LDS and registers; global memory sees z[i] now and the labels' state at the end.
-            const bool add_init = pick >= L;                   // a new component
-            const int pre = add_init ? 0 : ((singleton && pick == lab_h) ? K - 1 : pick);   // destination, old numbering
-            if (add_init && L >= d.K_max) {
-                if (lane == 0) atomicCAS(&c->error, 0, -3);
-                stop_at = N;
-                break;
-            }
-            // the rebuild lanes (0: destination, 1: home) ask for their count's table entries first
-            const int n_dst = add_init ? 1 : Ln[pre] + 1;
-            const int n_mine = lane == 0 ? n_dst : ((lane == 1 && home_live) ? nh - 1 : 0);
-            SlotTab tab = {};
-            if (n_mine > 0) tab = load_slot_tab(d, n_mine);
-            // statistics with the roundings of apply_rank1
-            double hs[NS], ds[NS];
-            const int hl = home_live ? lab_h : 0;
-#pragma unroll
-            for (int e = 0; e < NS; ++e) { hs[e] = F[(Ly::OM + e) * cap + hl]; ds[e] = F[(Ly::OM + e) * cap + pre]; }
-            const int tslot = add_init ? (singleton ? h : Lslot[K]) : Lslot[pre];
-#pragma unroll
-            for (int e = 0; e < NS; ++e) ds[e] = add_init ? pri[e] : ds[e];
-#pragma unroll
-            for (int a = 0; a < DD; ++a) {
-                hs[a] = __dsub_rn(hs[a], x[a]);
-                ds[a] = __dadd_rn(ds[a], x[a]);
-#pragma unroll
-                for (int b = 0; b <= a; ++b) {
-                    const double xx = __dmul_rn(x[a], x[b]);
-                    hs[DD + seq_pk(a, b)] = __dsub_rn(hs[DD + seq_pk(a, b)], xx);
-                    ds[DD + seq_pk(a, b)] = __dadd_rn(ds[DD + seq_pk(a, b)], xx);
-                }
-            }
-            PF(3)
-            int sub_lab = -1;
-            if (home_live) {
-                sub_lab = lab_h;
-                if (lane == 0) {
-                    Ln[lab_h] = nh - 1;
-#pragma unroll
-                    for (int e = 0; e < NS; ++e) F[(Ly::OM + e) * cap + lab_h] = hs[e];
-                }
-            } else if (singleton) {
-                // swap-with-last delete; the freed slot (and its version) stays at index `last`
-                const int last = K - 1;
-                if (lab_h != last) {
-                    const int s_last = Lslot[last], v_last = Lver[last], v_h = Lver[lab_h];
-                    const int n_last = Ln[last], u_last = Lnupd[last];
-                    for (int f = lane; f < Ly::NF; f += 64) F[f * cap + lab_h] = F[f * cap + last];
-                    if (lane == 0) {
-                        Lslot[lab_h] = s_last; Ln[lab_h] = n_last; Lver[lab_h] = v_last; Lnupd[lab_h] = u_last;
-                        Lslot[last] = h; Lver[last] = v_h;
+                        cum = carry + cum;
+                        const unsigned long long mhit = __ballot(j <= L && (u - cum) < 0.0);
+                        if (mhit) { pick = j0 + __ffsll((long long)mhit) - 1; break; }
+                        carry = __shfl(cum, 63);
                     }
                 }
-                K = last;
+                res = (home_live && pick == lab_h) ? -1 : pick;
+                PF(2)
             }
-            int add_lab = pick;
-            if (add_init) {
-                add_lab = K;
-                K += 1;
-                if (K > K_hi && K < d.K_max && K < cap) {      // the next free slot comes from global memory,
-                    if (lane == 0) {                           // untouched there beyond K_hi
-                        const int s2 = d.perm[K];
-                        Lslot[K] = s2;
-                        Lver[K] = d.mu_ver[s2];
-                    }
-                    K_hi = K;
-                }
-            }
-            if (lane == 0) {
-                Ln[add_lab] = n_dst;
-#pragma unroll
-                for (int e = 0; e < NS; ++e) F[(Ly::OM + e) * cap + add_lab] = ds[e];
-                const long long i = ((long long)__builtin_amdgcn_readlane((int)(c_i >> 32), t) << 32) |
-                                    (unsigned)__builtin_amdgcn_readlane((int)c_i, t);
-                d.z[i] = tslot;
-            }
-            PF(4)
-            // derived state of the touched labels, one lane each
-            const int rl = lane == 0 ? add_lab : (lane == 1 ? sub_lab : -1);
-            if (rl >= 0) {
-                double st[NS];
-#pragma unroll
-                for (int e = 0; e < NS; ++e) st[e] = lane == 0 ? ds[e] : hs[e];
-                seq_rebuild_label<DD>(d, F, cap, Lver, Lnupd, rl, n_mine, st, tab);
-            }
-            PF(5)
-            moves += 1;
-            if (K + 1 > cap) { stop_at = pb + t + 1; break; }  // the labels outgrew the LDS plan
         }
+        // ---- which of the NW visits is the first that does not stay?  Everything behind it was
+        // evaluated against a state that is about to change and is evaluated again.
+        if (lane == 0) sh_res[round & 1][w] = res;
+        __syncthreads();
+        const int r_l = lane < NW ? sh_res[round & 1][lane] : -1;
+        const unsigned long long mmov = __ballot(r_l != -1);
+        const int f = mmov ? __ffsll((long long)mmov) - 1 : NW;
+        round += 1;
+        if (pv < N && w <= f) lik += L;
+        if (f == NW) { p += NW; continue; }
+        if (w == f) {
+            // ---- this wave's visit moves (del_item / add_item, gaussian_components.py:168-205).  All of
+            // it in LDS and registers; global memory sees z[i] now and the labels' state at the end.
+            const bool add_init = pick >= L;                   // a new component
+            if (res == -2) {
+                if (lane == 0) { atomicCAS(&c->error, 0, -5); sh_stop = 1; }
+            } else if (add_init && L >= d.K_max) {
+                if (lane == 0) { atomicCAS(&c->error, 0, -3); sh_stop = 1; }
+            } else {
+                const int pre = add_init ? 0 : ((singleton && pick == lab_h) ? K - 1 : pick);   // destination, old numbering
+                // the rebuild lanes (0: destination, 1: home) ask for their count's table entries first
+                const int n_dst = add_init ? 1 : __builtin_amdgcn_readfirstlane(Ln[pre]) + 1;
+                const int n_mine = lane == 0 ? n_dst : ((lane == 1 && home_live) ? nh - 1 : 0);
+                SlotTab tab = {};
+                if (n_mine > 0) tab = load_slot_tab(d, n_mine);
+                // statistics with the roundings of apply_rank1
+                double hs[NS], ds[NS];
+                const int hl = home_live ? lab_h : 0;
+#pragma unroll
+                for (int e = 0; e < NS; ++e) { hs[e] = F[(Ly::OM + e) * cap + hl]; ds[e] = F[(Ly::OM + e) * cap + pre]; }
+                const int tslot = __builtin_amdgcn_readfirstlane(add_init ? (singleton ? h : Lslot[K]) : Lslot[pre]);
+                const long long i = ring_i[(int)(pv & (RING - 1))];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) ds[e] = add_init ? pri[e] : ds[e];
+#pragma unroll
+                for (int a = 0; a < DD; ++a) {
+                    hs[a] = __dsub_rn(hs[a], x[a]);
+                    ds[a] = __dadd_rn(ds[a], x[a]);
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        const double xx = __dmul_rn(x[a], x[b]);
+                        hs[DD + seq_pk(a, b)] = __dsub_rn(hs[DD + seq_pk(a, b)], xx);
+                        ds[DD + seq_pk(a, b)] = __dadd_rn(ds[DD + seq_pk(a, b)], xx);
+                    }
+                }
+                PF(3)
+                int sub_lab = -1;
+                if (home_live) {
+                    sub_lab = lab_h;
+                    if (lane == 0) {
+                        Ln[lab_h] = nh - 1;
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) F[(Ly::OM + e) * cap + lab_h] = hs[e];
+                    }
+                } else if (singleton) {
+                    // swap-with-last delete; the freed slot (and its version) stays at index `last`
+                    const int last = K - 1;
+                    if (lab_h != last) {
+                        const int s_last = Lslot[last], v_last = Lver[last], v_h = Lver[lab_h];
+                        const int n_last = Ln[last], u_last = Lnupd[last];
+                        for (int fi = lane; fi < Ly::NF; fi += 64) F[fi * cap + lab_h] = F[fi * cap + last];
+                        if (lane == 0) {
+                            Lslot[lab_h] = s_last; Ln[lab_h] = n_last; Lver[lab_h] = v_last; Lnupd[lab_h] = u_last;
+                            Lslot[last] = h; Lver[last] = v_h;
+                        }
+                    }
+                    K = last;
+                }
+                int add_lab = pick;
+                if (add_init) {
+                    add_lab = K;
+                    K += 1;
+                    if (K > K_hi && K < d.K_max && K < cap) {  // the next free slot comes from global memory,
+                        if (lane == 0) {                       // untouched there beyond K_hi
+                            const int s2 = d.perm[K];
+                            Lslot[K] = s2;
+                            Lver[K] = d.mu_ver[s2];
+                        }
+                        K_hi = K;
+                    }
+                }
+                if (lane == 0) {
+                    Ln[add_lab] = n_dst;
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) F[(Ly::OM + e) * cap + add_lab] = ds[e];
+                    d.z[i] = tslot;
+                }
+                PF(4)
+                // derived state of the touched labels, one lane each
+                const int rl = lane == 0 ? add_lab : (lane == 1 ? sub_lab : -1);
+                if (rl >= 0) {
+                    double st[NS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) st[e] = lane == 0 ? ds[e] : hs[e];
+                    seq_rebuild_label<DD>(d, F, cap, Lver, Lnupd, rl, n_mine, st, tab);
+                }
+                PF(5)
+                moves += 1;
+                if (lane == 0) {
+                    sh_K = K; sh_Khi = K_hi; sh_moved = 1;
+                    if (K + 1 > cap) { sh_stop = 2; sh_stop_at = pv + 1; }   // the labels outgrew the LDS plan
+                }
+            }
+        }
+        __syncthreads();
+        K = __builtin_amdgcn_readfirstlane(sh_K);
+        K_hi = __builtin_amdgcn_readfirstlane(sh_Khi);
+        stop = __builtin_amdgcn_readfirstlane(sh_stop);
+        p += f + 1;
+        if (stop) break;
     }
 #undef SEQ_FETCH
+#undef SEQ_COMMIT
+    __syncthreads();
     // ---- write the labels' state back (slot order of the windowed kernels: bgmm_device.h)
-    for (int j = lane; j <= K_hi; j += 64) {
+    for (int j = tid; j <= K_hi; j += NT) {
         const int s = Lslot[j];
         d.perm[j] = s;
         d.label_of_slot[s] = j;
@@ -1204,7 +1268,7 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
         }
     }
     // the MFMA fragments of the factors (only a forced MFMA kernel reads them at this D)
-    for (int j = 0; j < K; ++j) {
+    for (int j = w; j < K; j += NW) {
         double *wf = d.Wfrag + (long long)Lslot[j] * d.nfrag * 64;
         const int jr = lane & 15, lc = lane >> 4;
         double v0 = 0.0;
@@ -1214,23 +1278,25 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(Dev d, int cap) {
             for (int b = 0; b <= a; ++b)
                 if (jr == a && lc == b) v0 = -F[(Ly::OW + seq_pk(a, b)) * cap + j];
         wf[lane] = v0;
-        for (int f = 1; f < d.nfrag; ++f) wf[f * 64 + lane] = 0.0;
+        for (int fi = 1; fi < d.nfrag; ++fi) wf[fi * 64 + lane] = 0.0;
     }
     if (lane == 0) {
+        atomicAdd((unsigned long long *)&c->lik_evals, (unsigned long long)lik);
+        atomicAdd((unsigned long long *)&c->n_scored, (unsigned long long)lik);
+        atomicAdd((unsigned long long *)&c->n_moves, (unsigned long long)moves);
 #ifdef BGMM_SEQ_PROF
-        for (int k = 0; k < 8; ++k) c->prof[k] = pf[k];
+        for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&c->prof[k], (unsigned long long)pf[k]);
 #endif
-        c->job.K = K;
-        c->lik_evals += lik;
-        c->n_moves += moves;
-        c->n_steps += 1;
-        c->n_score_launches += 1;
-        c->n_scored += lik;
-        if (moves > 0) { c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; }
     }
     __threadfence();
-    if (lane == 0) {
-        if (stop_at >= 0 && stop_at < N) {
+    __syncthreads();
+    if (tid == 0) {
+        const long long stop_at = sh_stop_at;
+        c->job.K = K;
+        c->n_steps += 1;
+        c->n_score_launches += 1;
+        if (sh_moved) { c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; }
+        if (stop == 2 && stop_at >= 0 && stop_at < N) {
             start_window(d, c, stop_at);               // the windowed kernels take it from here
         } else {
             Job &j = c->job;
@@ -1244,13 +1310,13 @@ template <int DD>
 static hipError_t launch_seq_t(const Dev &d, int cap, int lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void *)sweep_seq_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sweep_seq_kernel<DD>, dim3(1), dim3(64), lds, st, d, cap);
+    hipLaunchKernelGGL(sweep_seq_kernel<DD>, dim3(1), dim3(64 * kSeqWaves), lds, st, d, cap);
     return hipSuccess;
 }
 
 // cap: labels (plus the next free slot) the LDS plan holds.  Returns false when D is out of range.
 bool launch_sweep_seq(const Dev &d, int cap, hipStream_t st) {
-    const int lds = cap * sweep_seq_bytes_per_label(d.D);
+    const int lds = sweep_seq_lds_bytes(d.D, cap);
     switch (d.D) {
         case 1: return launch_seq_t<1>(d, cap, lds, st) == hipSuccess;
         case 2: return launch_seq_t<2>(d, cap, lds, st) == hipSuccess;

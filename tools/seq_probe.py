@@ -1,22 +1,19 @@
-import sys, os, time, ctypes
-sys.path.insert(0, "/root/repo")
+"""Timing probe of the small-D sequential sweep: C2-like (movers dense) and a well-separated twin (hardly a move)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pybgmm_amd import _lib
 from pybgmm_amd.utils import gendata
-N, D, K = 100000, 2, 20
-X, zt = gendata.synth_mixture(N, D, K, seed=1)
-m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 256)
-c.set_assignments(zt)
-rs = np.random.RandomState(0)
-for it in range(4):
-    u = rs.random_sample(N)
-    t0 = time.time(); c.sweep(u); dt = time.time() - t0
-    st = c.sweep_stats()
-    out = (ctypes.c_int64 * 16)()
-    c.L.bgmm_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    c.L.bgmm_debug_prof(c.h, out)
-    v = list(out)[:8]
-    mv = max(st["moves"], 1)
-    print("sweep %d: %.1f ms, moves %d K %d | ticks/visit: fetch %.0f find %.0f score %.0f | per mover: book %.0f stats %.0f rebuild %.0f wfrag %.0f | total ticks %d" % (
-        it, dt * 1e3, st["moves"], c.K, v[0] / N, v[1] / N, v[2] / N, v[3] / mv, v[4] / mv, v[5] / mv, v[6] / mv, sum(v)))
+for (N, D, K, sep) in ((100000, 2, 20, 1.0), (100000, 2, 20, 8.0), (100000, 4, 40, 3.0)):
+    X, zt = gendata.synth_mixture(N, D, K, seed=1, mu_scale=sep)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 256)
+    c.set_assignments(zt)
+    rs = np.random.RandomState(0)
+    for it in range(4):
+        u = rs.random_sample(N)
+        t0 = time.time(); c.sweep(u); dt = time.time() - t0
+        st = c.sweep_stats()
+    print("N=%d D=%d K=%d sep=%.1f: %.1f ms/sweep, %.3f us/visit, moves %d, K_end %d" % (
+        N, D, K, sep, dt * 1e3, dt * 1e6 / N, st["moves"], c.K))
+    c.close()
