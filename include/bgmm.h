@@ -174,7 +174,11 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
  * 1 never, 2 whenever it fits); exact pruning of components whose weight in a draw is provably
  * below e^-80 (0 auto: on while movers are sparse, plus certified stays in converged chains; 1 off;
  * 2 in every window whatever the regime -- slow when movers are dense, meant for tests; 3 as 0
- * but without certified stays, for measurements).  None of them changes the sampled trajectory. */
+ * but without certified stays, for measurements).  None of them changes the sampled trajectory.
+ * With everything on auto, full-covariance problems of D <= 4 whose staged visiting order is a
+ * permutation (or absent) are swept by one workgroup that keeps the labels' state in LDS
+ * (sweep_seq_kernel); forcing a kernel or a resolver mode, or prune_mode 2, selects the windowed
+ * kernels instead.  In that path sweep_stats [2], [3] and [4] are 1. */
 int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                     int32_t prune_mode);
 

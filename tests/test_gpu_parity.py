@@ -804,6 +804,40 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
     ctx.close()
 
 
+def test_sequential_sweep_refuses_an_order_with_repeats():
+    """The small-D sweep fetches a visit's home slot ahead of time, which is sound only when no index
+    comes twice: a visiting order with repeats must take the windowed kernels (same trajectory as the
+    forced VALU path), a permutation the sequential kernel (one 'window', one step)."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 6000, 2, 6
+    X, zt = gendata.synth_mixture(N, D, K, seed=77, mu_scale=1.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(3)
+    ctxs = []
+    for kind in (0, 1):
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 64)
+        c.set_tuning(kernel_kind=kind, resolver_mode=0 if kind == 0 else 1)
+        c.set_assignments(zt)
+        ctxs.append(c)
+    for it in range(4):
+        u = rs.random_sample(N)
+        order = rs.permutation(N)
+        if it % 2 == 1:
+            order[rs.randint(0, N, size=200)] = order[rs.randint(0, N, size=200)]     # repeats (and gaps)
+        for c in ctxs:
+            c.sweep(u, order, None)
+        npt.assert_array_equal(ctxs[0].assignments(), ctxs[1].assignments())
+        st = ctxs[0].sweep_stats()
+        if it % 2 == 0:
+            assert st["steps"] == 1 and st["windows"] == 1          # the sequential kernel did the sweep
+        else:
+            assert st["steps"] > 1                                  # the windowed kernels did
+        assert st["lik_evals"] == ctxs[1].sweep_stats()["lik_evals"]
+    for c in ctxs:
+        c.close()
+
+
 def test_soak_sequential_small_d_against_windowed():
     """tools/soak_seq.py: 24 random D <= 4 configurations, the sequential one-wavefront sweep (with a
     small LDS plan in a third of them, so that it hands over to the windowed kernels mid-sweep) against
