@@ -344,6 +344,42 @@ def test_against_c_oracle(N, D, K, init):
     ctx.close()
 
 
+@pytest.mark.parametrize("init", ["true", "rand", "one"])
+def test_c2_full_size_against_c_oracle(init):
+    """BASELINE config C2 at its full size (CRPMM, N=1e5, D=2, K~20; a quarter of the visits move per
+    sweep), seed-locked against the C port of the reference: identical labels after every sweep."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 100000, 2, 20
+    X, z_true = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(42)
+    if init == "true":
+        z0 = z_true
+    elif init == "rand":
+        z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    else:
+        z0 = np.zeros(N, dtype=np.int64)
+    Kmax = 8 * K
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, Kmax)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, Kmax, tables=reference_tables(v_0, N))
+    ctx.set_assignments(z0)
+    for it in range(3):
+        u = rs.random_sample(N)
+        o.sweep(u, None, None)
+        ctx.sweep(u, None, None)
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        st = ctx.sweep_stats()
+        assert st["steps"] == 1                                # (the one-workgroup sweep)
+        assert st["moves"] > 1000 or init == "one"             # (the chain really moves)
+    ctx.close()
+
+
 # ---- BASELINE sizes: size-independent properties -------------------------------------------
 @pytest.mark.parametrize("N,D,K", [(100000, 2, 20), (1000000, 16, 100), (1000000, 64, 200)],
                          ids=["C2", "C3", "C4"])
