@@ -68,6 +68,27 @@ __device__ __forceinline__ double log1p_lower(double t) {
 // One thread per window row, in visiting order; the rows it certifies are left out of the bucket
 // sort and of everything behind it.
 // ------------------------------------------------------------------------------------------
+// tier 2 of certify_kernel for one visit (its home slot h is live)
+__device__ __forceinline__ bool certify_tier2(const Dev &d, const Ctrl *c, long long i, int h, double margin) {
+    const PCache pc = d.pcache[i];
+    // (the per-home table must belong to the current state: a full step has just rebuilt it
+    // if need be, a lean step has not)
+    if ((d.lean_step && !c->tables_valid) || pc.tag != (((long long)h << 32) | (unsigned int)d.mu_ver[h])) return false;
+    // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
+    const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
+                                              : d.sc[h].logseat1 + pc.qhome;
+    const double thr = hlb - margin;
+    if (!(d.log_alpha + d.log_prior[i] < thr)) return false;                // the new table is not negligible
+    const int a = d.label_of_slot[h];
+    const double rad = sqrt(pc.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
+    const double jf = rad * d.finv[a];
+    return jf < 62.0 && d.ftab[(long long)a * 64 + (int)jf + 1] < thr;      // (radius rounded up)
+}
+
+// kCertVisits visits per thread (rows r0 + 256 k: every load instruction of a wave stays contiguous):
+// their loads (index, home slot, tier-1 record, then the homes' counts) are issued side by side --
+// the kernel is a chain of dependent loads per visit, so what it costs is round trips, not bytes.
+constexpr int kCertVisits = 4;
 __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
@@ -77,49 +98,52 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
         for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
     const long long base = c->job.win_base;
     const long long nrows = c->job.win_hi - base;
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    bool ok = false;
-    if (r < nrows) {
-        const long long p = base + r;
-        const long long i = d.order ? d.order[p] : p;
-        const int h = d.z[i];
-        if (h >= 0 && d.n[h] >= 2) {
-            const double margin = 38.0 + log((double)c->job.K + 1.0);
-            // tier 1: nothing at all has changed since the draw kernel last scored this visit -- the
-            // total weight of its alternatives relative to the home is still the one it stored
-            const PCacheExact pe = d.pcache2[i];
-            if (pe.epoch == c->state_epoch) {
-                ok = pe.log_alt <= -37.75;     // total alternative weight < e^-37.75 < 2^-53 (e^-36.74), 1 nat to spare
+    const long long epoch = c->state_epoch;
+    const double margin = 38.0 + log((double)c->job.K + 1.0);
+    const long long r0 = (long long)blockIdx.x * 256 * kCertVisits + threadIdx.x;
+    long long iv[kCertVisits];
+    int hv[kCertVisits], nv[kCertVisits];
+    PCacheExact pe[kCertVisits];
+#pragma unroll
+    for (int k = 0; k < kCertVisits; ++k) {
+        const long long r = r0 + 256 * k;
+        iv[k] = r < nrows ? (d.order ? d.order[base + r] : base + r) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kCertVisits; ++k) {
+        hv[k] = iv[k] >= 0 ? d.z[iv[k]] : -1;
+        // tier 1: nothing at all has changed since the draw kernel last scored this visit -- the
+        // total weight of its alternatives relative to the home is still the one it stored
+        pe[k] = d.pcache2[iv[k] >= 0 ? iv[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < kCertVisits; ++k) nv[k] = hv[k] >= 0 ? d.n[hv[k]] : 0;
+    int n_ok = 0;
+#pragma unroll
+    for (int k = 0; k < kCertVisits; ++k) {
+        bool ok = false;
+        if (nv[k] >= 2) {
+            if (pe[k].epoch == epoch) {
+                ok = pe[k].log_alt <= -37.75;  // total alternative weight < e^-37.75 < 2^-53 (e^-36.74), 1 nat to spare
             } else {
                 // tier 2: only the home component's state must be unchanged; the others are bounded
                 // through the per-home table
-                const PCache pc = d.pcache[i];
-                // (the per-home table must belong to the current state: a full step has just rebuilt it
-                // if need be, a lean step has not)
-                if ((!d.lean_step || c->tables_valid) && pc.tag == (((long long)h << 32) | (unsigned int)d.mu_ver[h])) {
-                    // <= the exact home score (diag / fixed: the cache holds the one-point-removed log density)
-                    const double hlb = d.cov_type == COV_FULL ? slot_score_lower(d.sc[h], pc.qhome, true)
-                                                              : d.sc[h].logseat1 + pc.qhome;
-                    const double thr = hlb - margin;
-                    if (d.log_alpha + d.log_prior[i] < thr) {                            // the new table is negligible
-                        const int a = d.label_of_slot[h];
-                        const double rad = sqrt(pc.rho2 * (1.0 + 1e-9)) * (1.0 + 1e-9);
-                        const double jf = rad * d.finv[a];
-                        if (jf < 62.0) ok = d.ftab[(long long)a * 64 + (int)jf + 1] < thr;   // (radius rounded up)
-                    }
-                }
+                ok = certify_tier2(d, c, iv[k], hv[k], margin);
             }
         }
-        d.cert[r] = ok ? 1 : 0;
+        if (r0 + 256 * k < nrows) d.cert[r0 + 256 * k] = ok ? 1 : 0;
+        n_ok += ok ? 1 : 0;
     }
-    const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m)
-        atomicAdd(&d.pr_counts[768 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255)], (unsigned long long)__popcll(m));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_ok += __shfl_xor(n_ok, o);
+    if ((threadIdx.x & 63) == 0 && n_ok)
+        atomicAdd(&d.pr_counts[768 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255)], (unsigned long long)n_ok);
 }
 
 void launch_certify(const Dev &d, long long max_rows, hipStream_t st) {
     if (max_rows <= 0) return;
-    hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((max_rows + 255) / 256)), dim3(256), 0, st, d);
+    const long long per_block = 256ll * kCertVisits;
+    hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((max_rows + per_block - 1) / per_block)), dim3(256), 0, st, d);
 }
 
 // In a pruned window the visits are evaluated in the order of d.wrec (grouped by home component,
