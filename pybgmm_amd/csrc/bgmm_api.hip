@@ -232,10 +232,11 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, c->util_out, ns + 8);
     DALLOC(c, c->d_u, (size_t)N);
     DALLOC(c, c->d_order, (size_t)N);
-    // speculative window: up to 2^20 visits, q bounded by 16 GiB (288 GB of HBM per GPU).  Large
+    // speculative window: 2^20 visits (up to 2^22 for larger N), q bounded by 16 GiB (288 GB of HBM per GPU).  Large
     // windows matter in the sparse-mover regime: the fixed cost of a step is paid once per window and
     // the pruned-window kernel overlaps its latency-bound phases over more workgroup rounds.
     long long rows = 1ll << 20;
+    while (rows < N && rows < (1ll << 22)) rows <<= 1;       // (one window per sweep up to 4 Mi visits, memory permitting)
     if (const char *e = getenv("BGMM_WIN_ROWS")) { long long v = atoll(e); if (v >= 1024) rows = v; }
     while (rows > 1024 && (size_t)rows * d.nslots * sizeof(double) > ((size_t)16 << 30)) rows >>= 1;
     long long n_up = (N + kMfmaRows - 1) / kMfmaRows * kMfmaRows;

@@ -744,6 +744,51 @@ def test_certified_stays_against_c_oracle(N, D, K, sep):
     ctx.close()
 
 
+def test_lean_steps_with_a_fresh_permutation_every_sweep():
+    """pCRP order: a new permutation per sweep.  A lean step examines the points in storage order (the
+    window is the whole sweep and only the count of certified visits matters); a changed labelling makes
+    it fail and fall back.  Same chain as the plain evaluation, and as the C port of the reference."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 20000, 32, 10
+    X, zt = gendata.synth_mixture(N, D, K, seed=5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(8)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K)
+    ctxs = []
+    for prune in (0, 1):
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
+        c.set_tuning(kernel_kind=2, prune_mode=prune)
+        c.set_assignments(zt)
+        ctxs.append(c)
+    lean_sweeps = 0
+    for it in range(8):
+        u = rs.random_sample(N)
+        order = rs.permutation(N)
+        power = 1.02 if it >= 1 else None
+        if it == 4:                          # restart all three from a labelling with 30 wrong points
+            z1 = np.array(o.z, dtype=np.int64)
+            assert z1.max() == K - 1
+            z1[500:530] = (z1[500:530] + 1) % K
+            o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z1, 4 * K)
+            for c in ctxs:
+                c.set_assignments(z1)
+        o.sweep(u, order, power)
+        for c in ctxs:
+            c.sweep(u, order, power)
+        npt.assert_array_equal(ctxs[0].assignments(), o.z)
+        npt.assert_array_equal(ctxs[1].assignments(), o.z)
+        st, ps = ctxs[0].sweep_stats(), ctxs[0].prune_stats()
+        if ps["certified_visits"] == N and st["moves"] == 0:
+            lean_sweeps += 1
+    assert lean_sweeps >= 3                   # (the steady sweeps before and after the disturbance)
+    lo = o.log_marg()
+    assert abs(ctxs[0].log_marg() - lo) <= 1e-9 * abs(lo)
+    for c in ctxs:
+        c.close()
+
+
 def test_lean_steps_fall_back_when_certification_fails():
     """After a sweep that certified every visit only certify_kernel is queued per step; when the state
     was changed behind its back (add_item / del_item) the step is refused on the device and re-queued
