@@ -78,8 +78,8 @@ def cpu_baseline(D, K, seed, budget_visits, cov="full"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--init", default="true", choices=["true", "rand"])
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 VALU, 2 MFMA")
