@@ -885,6 +885,46 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
     ctx.close()
 
 
+@pytest.mark.parametrize("N", [1, 2, 9, 63, 64, 65, 130, 513])
+def test_sequential_sweep_tiny_inputs(N):
+    """Edge sizes of the one-workgroup sweep (fewer visits than wavefronts, ring and batch boundaries,
+    everything unassigned at the start, K_max reached) against the windowed VALU path."""
+    from pybgmm_amd import _lib
+    rs = np.random.RandomState(N)
+    for D in (1, 3):
+        X = np.ascontiguousarray(rs.randn(N, D) * 3.0)
+        m_0, k_0, v_0, S_0 = np.zeros(D), 0.05, D + 3, np.eye(D)
+        for init in ("unassigned", "one"):
+            z0 = -np.ones(N, dtype=np.int64) if init == "unassigned" else np.zeros(N, dtype=np.int64)
+            K_max = max(2, min(N, 12))
+            ctxs = []
+            for kind in (0, 1):
+                c = _lib.Context(X, m_0, k_0, v_0, S_0, 2.0, K_max)
+                c.set_tuning(kernel_kind=kind, resolver_mode=0 if kind == 0 else 1)
+                c.set_assignments(z0)
+                ctxs.append(c)
+            for it in range(4):
+                u = rs.random_sample(N)
+                order = rs.permutation(N) if it % 2 else None
+                errs = []
+                for c in ctxs:
+                    try:
+                        c.sweep(u, order, None)
+                        errs.append(None)
+                    except Exception as e:            # K_max reached: both paths must refuse alike
+                        errs.append(type(e).__name__ + str(e)[:40])
+                assert (errs[0] is None) == (errs[1] is None), errs
+                if errs[0] is not None:
+                    break
+                npt.assert_array_equal(ctxs[0].assignments(), ctxs[1].assignments())
+                assert ctxs[0].K == ctxs[1].K
+                la, lb = ctxs[0].log_marg(), ctxs[1].log_marg()
+                assert abs(la - lb) <= 1e-9 * max(abs(lb), 1.0)
+                assert ctxs[0].sweep_stats()["lik_evals"] == ctxs[1].sweep_stats()["lik_evals"]
+            for c in ctxs:
+                c.close()
+
+
 def test_sequential_sweep_refuses_an_order_with_repeats():
     """The small-D sweep fetches a visit's home slot ahead of time, which is sound only when no index
     comes twice: a visiting order with repeats must take the windowed kernels (same trajectory as the
