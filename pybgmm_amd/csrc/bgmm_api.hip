@@ -37,6 +37,7 @@ struct bgmm_ctx {
     std::string err;
     std::vector<void *> allocs;
     Ctrl *ctrl_host = nullptr;       // pinned mirror
+    Ctrl *ctrl_pub = nullptr;        // pinned and device-mapped: apply_kernel publishes the control block here (lean batches)
     Job *util_job = nullptr;         // device
     double *util_q = nullptr;        // device [ldq]
     double *util_out = nullptr;      // device [nslots + 8]
@@ -171,6 +172,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (c->res_u) (void)hipFree(c->res_u);
     if (c->res_order) (void)hipFree(c->res_order);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
+    if (c->ctrl_pub) (void)hipHostFree(c->ctrl_pub);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -265,6 +267,9 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.bucket_bins, ns + 4);
     CK(c, hipMemsetAsync(d.bucket_bins, 0, sizeof(int) * (ns + 4), c->stream));
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
+    CK(c, hipHostMalloc((void **)&c->ctrl_pub, sizeof(Ctrl), hipHostMallocMapped));
+    CK(c, hipHostGetDevicePointer((void **)&d.ctrl_pub, c->ctrl_pub, 0));
+    d.publish = 0;
 
     d.X = dX; d.tab_lgam = dtl; d.tab_log = dtg; d.prior_m = dpm; d.prior_S = dpS;
     d.tabG = dtG; d.tabLogC = dtC; d.tabSeat = dtS;
@@ -653,6 +658,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         const long long grid_rows = d.batch_rows;
         if (pmode != 2) lean = false;
         d.lean_step = lean ? 1 : 0;
+        d.publish = lean ? 1 : 0;
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
@@ -676,8 +682,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (!lean) launch_refresh_ctrl(d, st);        // (a lean step moves nothing: apply refuses it otherwise)
         }
         CK(c, hipGetLastError());
-        int rc = fetch_ctrl(c);
-        if (rc) return rc;
+        if (lean) {
+            // (apply_kernel has left the control block in host memory: no copy in the queue)
+            CK(c, hipStreamSynchronize(st));
+            memcpy(c->ctrl_host, c->ctrl_pub, sizeof(Ctrl));
+        } else {
+            int rc = fetch_ctrl(c);
+            if (rc) return rc;
+        }
         const Ctrl &h = *c->ctrl_host;
         if (c->timing) {
             const long long worked = h.n_steps - steps_done;   // the first `worked` steps did work

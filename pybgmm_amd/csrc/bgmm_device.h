@@ -173,6 +173,9 @@ struct Dev {
     int use_certify;             // 1: certify_kernel runs in front of the bucket sort (which then skips its rows)
     int lean_step;               // 1: this batch queues certify_kernel WITHOUT the pruning and draw kernels (the
                                  // previous sweep certified every visit); apply_kernel refuses the step otherwise
+    int publish;                 // 1: apply_kernel leaves a copy of the control block in host memory (ctrl_pub), so that
+                                 // the host reads the outcome of a lean batch without a device-to-host copy in the queue
+    Ctrl *ctrl_pub;              // host-pinned, device-mapped
     int *perm, *label_of_slot;
     Ctrl *ctrl;
     double *q;

@@ -603,6 +603,20 @@ __device__ void set_refresh(const Dev &d, Ctrl *c, const MovePlan &mp, bool rank
     c->n_refresh = nr;
 }
 
+// The control block as thread 0 has just left it (and fenced), copied to the host-mapped mirror by
+// the first lanes of the block: one 8-byte word each, read past the L1 -- contiguous stores that
+// leave the GPU as a few bus writes instead of one per word.  Called by ALL threads of the block.
+__device__ __forceinline__ void publish_ctrl_block(const Dev &d) {
+    static_assert(sizeof(Ctrl) % sizeof(long long) == 0 && sizeof(Ctrl) / sizeof(long long) <= TPB,
+                  "Ctrl is copied in 8-byte words, one per thread");
+    __syncthreads();
+    if (threadIdx.x < (int)(sizeof(Ctrl) / sizeof(long long))) {
+        const long long v = __hip_atomic_load((const long long *)d.ctrl + threadIdx.x, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        ((long long *)d.ctrl_pub)[threadIdx.x] = v;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     __shared__ MovePlan mp;
     __shared__ int do_move;
@@ -619,11 +633,12 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
         }
         if (threadIdx.x == 0) {
             left = (long long)csum[0] < c->job.win_hi - c->job.pos ? 1 : 0;
-            if (left) { c->retry_full = 1; c->n_refresh = 0; }
+            if (left) { c->retry_full = 1; c->n_refresh = 0; __threadfence(); }
         }
         __syncthreads();
         if (left) {
             for (int t = 0; t < 4; ++t) d.pr_counts[t * 256 + threadIdx.x] = 0;     // (its counts are discarded)
+            if (d.publish) publish_ctrl_block(d);
             return;
         }
     }
@@ -717,6 +732,10 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                 }
             }
         }
+    }
+    if (d.publish) {
+        if (threadIdx.x == 0) __threadfence();
+        publish_ctrl_block(d);
     }
     __syncthreads();
     if (do_move) apply_rank1(d, mp);
