@@ -8,12 +8,14 @@
 // calls of random.random() would return, and hands back the state those calls would leave behind
 // (random.setstate()).  Bit-identical by construction; tests/test_gpu_parity.py compares with the host.
 //
-// The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) yields 227 new words from the previous
-// 624 independently of each other: one workgroup slides over the sequence, 227 words and one barrier
-// per step, tempering and storing them as it goes; a second kernel pairs the words into doubles.
+// The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) is a chain through k -> k + 227: word k of
+// the next block needs word k - 227 of the SAME block when k >= 227.  One workgroup regenerates a
+// whole 624-word block per barrier: lane l < 227 computes the words l, l + 227 and l + 454 of the new
+// block one after the other -- each is the (k - 227) term of the next, a register -- from the old
+// block in LDS (double buffered); the last word also needs the new word 0, which its lane (169)
+// recomputes from the old block instead of waiting for lane 0.  Tempered words go straight to global
+// memory; a second kernel pairs them into doubles.
 #include "bgmm_device.h"
-
-static constexpr int kMtRing = 2048;
 
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     y ^= y >> 11;
@@ -23,52 +25,59 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     return y;
 }
 
-// key_io: 624 state words in / out;  pos_io: position in / out;  words: 2 n tempered outputs.
-// Thread t of a step computes x[P + t], P = words known so far.  Its x[.-227] term is its own output
-// of the previous step (a register); the two x[.-624], x[.-623] terms were written at least two steps
-// ago, so they are fetched from LDS one step ahead, and the only thing on the critical path of a step
-// is the barrier that publishes its 227 new words.
+__device__ __forceinline__ unsigned mt_twist(unsigned y0, unsigned y1) {
+    const unsigned y = (y0 & 0x80000000u) | (y1 & 0x7fffffffu);
+    return (y >> 1) ^ ((y1 & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// key_io: 624 state words in / out;  pos_io: position in / out;  words: n_words tempered outputs.
 __global__ __launch_bounds__(256) void mt19937_words_kernel(unsigned *__restrict__ key_io, int *__restrict__ pos_io,
                                                             unsigned *__restrict__ words, long long n_words) {
-    __shared__ unsigned ring[kMtRing];
+    __shared__ unsigned blk[2][624];
     const int tid = threadIdx.x;
-    for (int k = tid; k < 624; k += 256) ring[k] = key_io[k];
+    for (int k = tid; k < 624; k += 256) blk[0][k] = key_io[k];
     const long long pos = pos_io[0];
     __syncthreads();
     const long long E = pos + n_words;                        // one past the last consumed index of x
     // what is left of the current block
-    for (long long k = pos + tid; k < 624 && k < E; k += 256) words[k - pos] = mt_temper(ring[k]);
+    for (long long k = pos + tid; k < 624 && k < E; k += 256) words[k - pos] = mt_temper(blk[0][k]);
     if (E <= 624) {
         if (tid == 0) pos_io[0] = (int)E;
         return;
     }
-    const long long b = (E - 1) / 624;                        // block the generator ends in
-    const long long target = 624 * (b + 1);
-    const int t = tid < 227 ? tid : 0;
-    unsigned prev = ring[397 + t];                            // x[P - 227 + t] at P = 624
-    unsigned o0 = ring[t], o1 = ring[t + 1];                  // x[P - 624 + t], x[P - 623 + t]
-    for (long long produced = 624; produced < target; produced += 227) {
-        const long long left = target - produced;
-        const int n = left < 227 ? (int)left : 227;
-        const unsigned y = (o0 & 0x80000000u) | (o1 & 0x7fffffffu);
-        const unsigned xn = prev ^ (y >> 1) ^ ((o1 & 1u) ? 0x9908b0dfu : 0u);
-        // the old terms of the NEXT step: indices < produced - 169, published by earlier barriers
-        const long long kn = produced + 227 - 624 + t;
-        o0 = ring[kn & (kMtRing - 1)];
-        o1 = ring[(kn + 1) & (kMtRing - 1)];
-        if (tid < n) {
-            const long long idx = produced + tid;
-            ring[idx & (kMtRing - 1)] = xn;
-            if (idx < E) words[idx - pos] = mt_temper(xn);
+    const long long nblocks = (E - 1) / 624;                  // blocks to generate; the generator ends in the last
+    const int l = tid < 227 ? tid : 0;
+    const bool has_c = l <= 169;                              // word l + 454 exists
+    int cur = 0;
+    for (long long b = 1; b <= nblocks; ++b) {
+        const unsigned *__restrict__ old = blk[cur];
+        unsigned *__restrict__ nw = blk[cur ^ 1];
+        const unsigned a0 = old[l], a1 = old[l + 1], a397 = old[l + 397];
+        const unsigned b0 = old[l + 227], b1 = old[l + 228];
+        const unsigned c0 = old[has_c ? l + 454 : 623];
+        const unsigned z0 = old[0], z1 = old[1], z397 = old[397];
+        const unsigned c1_old = old[(has_c && l < 169) ? l + 455 : 623];
+        const unsigned nA = a397 ^ mt_twist(a0, a1);
+        const unsigned nB = nA ^ mt_twist(b0, b1);
+        const unsigned n0 = z397 ^ mt_twist(z0, z1);          // the new word 0 (lane 169: the x[k+1] term of k = 623)
+        const unsigned nC = nB ^ mt_twist(c0, l == 169 ? n0 : c1_old);
+        if (tid < 227) {
+            nw[l] = nA;
+            nw[l + 227] = nB;
+            if (has_c) nw[l + 454] = nC;
+            const long long base = 624 * b - pos;             // stream index of word 0 of this block
+            if (base + l < n_words) words[base + l] = mt_temper(nA);
+            if (base + l + 227 < n_words) words[base + l + 227] = mt_temper(nB);
+            if (has_c && base + l + 454 < n_words) words[base + l + 454] = mt_temper(nC);
         }
-        prev = xn;
+        cur ^= 1;
         // publish the LDS words only: the global stores above need not have landed (a plain
-        // __syncthreads() would also wait for them, every step)
+        // __syncthreads() would also wait for them, every block)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __syncthreads();
-    for (int k = tid; k < 624; k += 256) key_io[k] = ring[(624 * b + k) & (kMtRing - 1)];
-    if (tid == 0) pos_io[0] = (int)(E - 624 * b);
+    for (int k = tid; k < 624; k += 256) key_io[k] = blk[cur][k];
+    if (tid == 0) pos_io[0] = (int)(E - 624 * nblocks);
 }
 
 __global__ void mt19937_doubles_kernel(const unsigned *__restrict__ words, double *__restrict__ u, long long n,
