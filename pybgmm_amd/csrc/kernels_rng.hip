@@ -48,33 +48,39 @@ __global__ __launch_bounds__(256) void mt19937_words_kernel(unsigned *__restrict
     const long long nblocks = (E - 1) / 624;                  // blocks to generate; the generator ends in the last
     const int l = tid < 227 ? tid : 0;
     const bool has_c = l <= 169;                              // word l + 454 exists
+    const int ic0 = has_c ? l + 454 : 623, ic1 = (has_c && l < 169) ? l + 455 : 623;
     int cur = 0;
-    for (long long b = 1; b <= nblocks; ++b) {
-        const unsigned *__restrict__ old = blk[cur];
-        unsigned *__restrict__ nw = blk[cur ^ 1];
-        const unsigned a0 = old[l], a1 = old[l + 1], a397 = old[l + 397];
-        const unsigned b0 = old[l + 227], b1 = old[l + 228];
-        const unsigned c0 = old[has_c ? l + 454 : 623];
-        const unsigned z0 = old[0], z1 = old[1], z397 = old[397];
-        const unsigned c1_old = old[(has_c && l < 169) ? l + 455 : 623];
-        const unsigned nA = a397 ^ mt_twist(a0, a1);
-        const unsigned nB = nA ^ mt_twist(b0, b1);
-        const unsigned n0 = z397 ^ mt_twist(z0, z1);          // the new word 0 (lane 169: the x[k+1] term of k = 623)
-        const unsigned nC = nB ^ mt_twist(c0, l == 169 ? n0 : c1_old);
-        if (tid < 227) {
-            nw[l] = nA;
-            nw[l + 227] = nB;
-            if (has_c) nw[l + 454] = nC;
-            const long long base = 624 * b - pos;             // stream index of word 0 of this block
-            if (base + l < n_words) words[base + l] = mt_temper(nA);
-            if (base + l + 227 < n_words) words[base + l + 227] = mt_temper(nB);
-            if (has_c && base + l + 454 < n_words) words[base + l + 454] = mt_temper(nC);
-        }
-        cur ^= 1;
-        // publish the LDS words only: the global stores above need not have landed (a plain
-        // __syncthreads() would also wait for them, every block)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    unsigned *wp = words + (624 - pos) + l;                   // word l of block 1 in the output stream
+    // every block but the last lies entirely inside the requested range: no bounds checks there
+#define MT_BLOCK(CHECKED)                                                                          \
+    {                                                                                              \
+        const unsigned *__restrict__ old = blk[cur];                                               \
+        unsigned *__restrict__ nw = blk[cur ^ 1];                                                  \
+        const unsigned a0 = old[l], a1 = old[l + 1], a397 = old[l + 397];                          \
+        const unsigned b0 = old[l + 227], b1 = old[l + 228];                                       \
+        const unsigned c0 = old[ic0], c1_old = old[ic1];                                           \
+        const unsigned z0 = old[0], z1 = old[1], z397 = old[397];                                  \
+        const unsigned nA = a397 ^ mt_twist(a0, a1);                                               \
+        const unsigned nB = nA ^ mt_twist(b0, b1);                                                 \
+        const unsigned n0 = z397 ^ mt_twist(z0, z1); /* new word 0: lane 169's x[k+1] at k = 623 */ \
+        const unsigned nC = nB ^ mt_twist(c0, l == 169 ? n0 : c1_old);                             \
+        if (tid < 227) {                                                                           \
+            nw[l] = nA;                                                                            \
+            nw[l + 227] = nB;                                                                      \
+            if (has_c) nw[l + 454] = nC;                                                           \
+            if (!(CHECKED) || wp < wend) wp[0] = mt_temper(nA);                                    \
+            if (!(CHECKED) || wp + 227 < wend) wp[227] = mt_temper(nB);                            \
+            if (has_c && (!(CHECKED) || wp + 454 < wend)) wp[454] = mt_temper(nC);                 \
+        }                                                                                          \
+        wp += 624;                                                                                 \
+        cur ^= 1;                                                                                  \
+        /* publish the LDS words only: the global stores need not have landed */                   \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                            \
     }
+    const unsigned *wend = words + n_words;
+    for (long long b = 1; b < nblocks; ++b) MT_BLOCK(false)
+    MT_BLOCK(true)
+#undef MT_BLOCK
     __syncthreads();
     for (int k = tid; k < 624; k += 256) key_io[k] = blk[cur][k];
     if (tid == 0) pos_io[0] = (int)(E - 624 * nblocks);
