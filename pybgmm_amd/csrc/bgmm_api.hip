@@ -719,7 +719,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
     if (use_certify && h.n_bound_blocks + h.n_certified > 0) {
-        const bool warm = c->moves_prev >= 0 && (c->moves_prev + h.n_moves) * 1000 < N;
+        // (warm: the caches this sweep read were written in a sweep without moves and nothing has moved
+        // since -- after a sweep with moves every touched slot has a new version and the epoch is new,
+        // so a low yield says nothing about the data)
+        const bool warm = c->moves_prev == 0 && h.n_moves == 0;
         if (warm && h.n_certified * 10 < (unsigned long long)N) c->certify_skip = 8;
     }
     c->moves_prev = h.n_moves;
@@ -913,6 +916,7 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
         (void)hipMemcpy(&c->d.ctrl->error, &c->ctrl_host->error, sizeof(int), hipMemcpyHostToDevice);
     }
     c->assigned = true;
+    c->moves_prev = -1;          // (the state changed behind the sweeps' back: the next sweep's caches are cold)
     return rc;
 }
 

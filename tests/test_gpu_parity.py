@@ -381,8 +381,8 @@ def test_c2_full_size_against_c_oracle(init):
 
 
 # ---- BASELINE sizes: size-independent properties -------------------------------------------
-@pytest.mark.parametrize("N,D,K", [(100000, 2, 20), (1000000, 16, 100), (1000000, 64, 200)],
-                         ids=["C2", "C3", "C4"])
+@pytest.mark.parametrize("N,D,K", [(100000, 2, 20), (1000000, 16, 100), (1000000, 64, 200), (2000000, 128, 200)],
+                         ids=["C2", "C3", "C4", "C5"])
 def test_full_size_properties(N, D, K):
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
