@@ -221,16 +221,16 @@ def main():
                   "lik_evals_per_launch": round(st["scored"] / n_launch, 1)}
         if pruning:
             # Pruned windows.  A visit that certify_kernel proves to keep its component
-            # costs 21 B while nothing at all has moved (tier 1: its label 4, the 16-byte record of the draw
-            # kernel's exact alternative weight, the flag 1) or 61 B after a move somewhere (tier 2: the
-            # 32-byte per-point cache and its prior score on top), and X is not read; any other visit is also
+            # costs 17 B while nothing at all has moved (tier 1: the 16-byte record of the draw kernel's exact
+            # alternative weight, the flag 1) or 61 B after a move somewhere (tier 2: its label, the 32-byte
+            # per-point cache and its prior score on top), and X is not read; any other visit is also
             # sorted (32-byte record) and streamed once by the pruning kernel: 45 + 32 B and its row and
             # bookkeeping, 8 D + 24 B, on top.  `achieved` = those bytes / the launch time of the two kernels together;
             # the same visits priced at SURVEY's 8 D + 24 B each are reported next to it.  The matrix work
             # still issued (counted in the kernel, 2048 flop per instruction) and what the same decisions
             # would cost without pruning are given as well.
             n_cert = float(ps["certified_visits"])
-            cert_bytes = 21.0 if st["moves"] == 0 else 61.0
+            cert_bytes = 17.0 if st["moves"] == 0 else 61.0
             need_bytes = n_cert * cert_bytes + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 77.0)
             need = need_bytes / (ms * 1e-3) / 1e9
             executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12

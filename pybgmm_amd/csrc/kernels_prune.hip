@@ -86,8 +86,8 @@ __device__ __forceinline__ bool certify_tier2(const Dev &d, const Ctrl *c, long 
 }
 
 // kCertVisits visits per thread (rows r0 + 256 k: every load instruction of a wave stays contiguous):
-// their loads (index, home slot, tier-1 record, then the homes' counts) are issued side by side --
-// the kernel is a chain of dependent loads per visit, so what it costs is round trips, not bytes.
+// their loads (index, then the tier-1 record) are issued side by side -- the kernel is a chain of
+// dependent loads per visit, so what it costs is round trips, not bytes.
 constexpr int kCertVisits = 4;
 __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
@@ -108,33 +108,30 @@ __global__ __launch_bounds__(256) void certify_kernel(Dev d) {
     // for an order with repeats.)
     const bool data_order = d.lean_step && base == 0 && nrows == d.N;
     long long iv[kCertVisits];
-    int hv[kCertVisits], nv[kCertVisits];
     PCacheExact pe[kCertVisits];
 #pragma unroll
     for (int k = 0; k < kCertVisits; ++k) {
         const long long r = r0 + 256 * k;
         iv[k] = r < nrows ? ((d.order && !data_order) ? d.order[base + r] : base + r) : -1;
     }
+    // tier 1: nothing at all has changed since the draw kernel last scored this visit -- the total
+    // weight of its alternatives relative to the home is still the one it stored.  The record is only
+    // written for a visit whose home is live (choice_sparse_kernel), and every change of any label,
+    // count or component bumps the epoch: a matching epoch needs neither the label nor the count.
 #pragma unroll
-    for (int k = 0; k < kCertVisits; ++k) {
-        hv[k] = iv[k] >= 0 ? d.z[iv[k]] : -1;
-        // tier 1: nothing at all has changed since the draw kernel last scored this visit -- the
-        // total weight of its alternatives relative to the home is still the one it stored
-        pe[k] = d.pcache2[iv[k] >= 0 ? iv[k] : 0];
-    }
-#pragma unroll
-    for (int k = 0; k < kCertVisits; ++k) nv[k] = hv[k] >= 0 ? d.n[hv[k]] : 0;
+    for (int k = 0; k < kCertVisits; ++k) pe[k] = d.pcache2[iv[k] >= 0 ? iv[k] : 0];
     int n_ok = 0;
 #pragma unroll
     for (int k = 0; k < kCertVisits; ++k) {
         bool ok = false;
-        if (nv[k] >= 2) {
+        if (iv[k] >= 0) {
             if (pe[k].epoch == epoch) {
                 ok = pe[k].log_alt <= -37.75;  // total alternative weight < e^-37.75 < 2^-53 (e^-36.74), 1 nat to spare
             } else {
                 // tier 2: only the home component's state must be unchanged; the others are bounded
                 // through the per-home table
-                ok = certify_tier2(d, c, iv[k], hv[k], margin);
+                const int h = d.z[iv[k]];
+                if (h >= 0 && d.n[h] >= 2) ok = certify_tier2(d, c, iv[k], h, margin);
             }
         }
         if (r0 + 256 * k < nrows) d.cert[r0 + 256 * k] = ok ? 1 : 0;
