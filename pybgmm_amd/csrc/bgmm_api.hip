@@ -72,7 +72,6 @@ struct bgmm_ctx {
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
-    int certify_skip = 0;            // sweeps left during which certify_kernel is not launched (it found nothing)
     long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
     long long *true_dev = nullptr;   // bgmm_contingency: the reference labelling, kept between calls
     unsigned long long *table_dev = nullptr;
@@ -444,7 +443,7 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
         rc = check_device_error(c);
     } while (0);
     (void)hipFree(dz); (void)hipFree(doff); (void)hipFree(dmem);
-    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->certify_skip = 0; c->lean_ok = false; }
+    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->lean_ok = false; }
     return rc;
 }
 
@@ -561,11 +560,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
-    // certified stays pay off in converged chains only: when the per-point cache was warm (hardly a
-    // move in this sweep and the one before) and still less than a tenth of the visits could be
-    // certified, the kernel is left out for the next 8 sweeps
-    const bool use_certify = use_prune && c->certify_skip == 0 && c->prune_mode != 3;
-    if (c->certify_skip > 0) c->certify_skip -= 1;
+    // (certify_kernel runs in front of every pruned window: on data it can do nothing for it costs
+    // a tenth of the pruning kernel behind it; a rule that left it out after a poor yield misjudged
+    // cold caches for hopeless data twice and was dropped)
+    const bool use_certify = use_prune && c->prune_mode != 3;
     d.use_certify = use_certify ? 1 : 0;
     bool lean = use_certify && c->lean_ok && c->prune_mode != 2;
     hipStream_t st = c->stream;
@@ -578,9 +576,9 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     }
     // Launch grids follow the window scale: sized for twice the device's current window (at least
     // 4096 rows, at most the allocation), never below the window that is already open.
-    auto rows_for = [&](long long win_now, long long open_rows) -> int {
+    auto rows_for = [&](long long win_now, long long open_rows, long long grow = 2) -> int {
         long long r = 4096;
-        while (r < 2 * win_now && r < c->win_rows) r <<= 1;
+        while (r < grow * win_now && r < c->win_rows) r <<= 1;
         while (r < open_rows && r < c->win_rows) r <<= 1;
         if (r > c->win_rows) r = c->win_rows;
         return (int)r;
@@ -631,9 +629,16 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         long long lb = (remaining + win - 1) / win;
         long long extra = (long long)std::ceil(rate * (double)remaining * 1.1);
         if (extra > 2048) extra = 2048;
+        // (a clean window doubles the device's window, but the launch grids of this batch were sized for
+        // the current one: while nothing moves a few steps per batch are all that can be used)
+        if (rate == 0.0 && lb > 8) lb = 8;
         long long Tl = lb + extra;
         if (Tl < 1) Tl = 1;
         if (Tl > 4096) Tl = 4096;
+        // (the first batch of a sweep runs on the previous sweep's mover rate: keep it short, the next
+        // one is planned on what this sweep has shown -- a step queued behind the end of the sweep is a
+        // dozen empty launches)
+        if (first_batch && Tl > 64) Tl = 64;
         int T = (int)Tl;
         // the resolver's LDS plan depends on the number of labels: re-planned every chunk
         int res_R = 0, res_Kcap = 0, res_lds = 0;
@@ -647,13 +652,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (use_prune) {
             const Ctrl &hc = *c->ctrl_host;
             const bool fresh = first_batch || hc.job.mode == MODE_FRESH;
-            pmode = (hc.ema_run >= 2048.0 && fresh) ? 2 : (hc.ema_run < 64.0 ? 0 : 1);
+            pmode = (hc.ema_run >= 4.0 * kPruneMinRun && fresh) ? 2 : (hc.ema_run < 0.5 * kPruneMinRun ? 0 : 1);
             if (c->prune_mode == 2) pmode = 2;       // (every window pruned: exact whatever the regime, for tests)
         }
         {
             const Ctrl &hc = *c->ctrl_host;
             const long long open_rows = first_batch ? (long long)d.batch_rows : hc.job.win_hi - hc.job.win_base;
-            d.batch_rows = rows_for(win, open_rows);
+            // (while nothing moves every clean window doubles the next: room for four doublings per batch)
+            d.batch_rows = rows_for(win, open_rows, rate == 0.0 ? 16 : 2);
         }
         const long long grid_rows = d.batch_rows;
         if (pmode != 2) lean = false;
@@ -718,13 +724,6 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->stats[6] = (long long)h.n_kept_blocks; c->stats[7] = (long long)h.n_bound_blocks;
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
-    if (use_certify && h.n_bound_blocks + h.n_certified > 0) {
-        // (warm: the caches this sweep read were written in a sweep without moves and nothing has moved
-        // since -- after a sweep with moves every touched slot has a new version and the epoch is new,
-        // so a low yield says nothing about the data)
-        const bool warm = c->moves_prev == 0 && h.n_moves == 0;
-        if (warm && h.n_certified * 10 < (unsigned long long)N) c->certify_skip = 8;
-    }
     c->moves_prev = h.n_moves;
     c->lean_ok = use_certify && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
     return check_device_error(c);

@@ -76,6 +76,13 @@ struct Job {
     int prune;            // fresh window scored by the pruning kernel (valid only while nothing moves)
 };
 
+// A pruned window is thrown away at its first mover and pays ~13 launches per step, a dense one is
+// re-scored for the two changed components only (~5 launches): pruning pays when the windows are
+// mostly mover-free AND long (dense evaluation costs ~17 ns per row at K = 200, D = 64, the pruned one
+// ~1 ns but 100-300 us more per step).  Mean distance between movers from which fresh windows are
+// pruned (windows are about half of it):
+constexpr double kPruneMinRun = 16384.0;
+
 struct Ctrl {
     Job job;
     long long n_visits;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
             const unsigned long long fm = c->first_mover;
             if (fm != kNoMover) {
                 const long long p = (long long)fm;
-                const double ema = 0.875 * c->ema_run + 0.125 * (double)(p - c->last_mover);
+                const double ema = ema_after_mover(c->ema_run, (double)(p - c->last_mover));
                 const bool dense = c->dense_mode == 2 || ema < 3.0 * (double)R;
                 if (dense && !job_is_pruned(d, j.mode, j.prune) && j.K + R + 2 <= Kcap) {
                     S.active = 1;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 S.inv_lam_src[hf] = d.sc[S.src[hf]].inv_lam;
             }
             const long long p = sub_lo + cur;
-            c->ema_run = 0.875 * c->ema_run + 0.125 * (double)(p - c->last_mover);
+            c->ema_run = ema_after_mover(c->ema_run, (double)(p - c->last_mover));
             c->last_mover = p;
         }
         if (tid >= 64 && tid < 64 + D) xm[tid - 64] = d.X[L.rowi[cur] * D + (tid - 64)];

@@ -244,6 +244,10 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         d.sc[s].logseat1 = d.n[s] >= 1 ? d.tabSeat[d.n[s] - 1] : 0.0;
     }
     if (threadIdx.x == 0) {
+        // (a whole sweep without a move: the chain is at rest, back to the optimistic window plan it
+        // started with -- the mover-free stretch inside one sweep cannot say more than N)
+        if (c->n_visits > 0 && c->n_moves == 0 && c->ema_run < 4.0 * (double)c->win_cap)
+            c->ema_run = 4.0 * (double)c->win_cap;
         c->n_visits = d.N;
         c->first_mover = kNoMover;
         c->n_refresh = 0;
@@ -685,6 +689,10 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             if (fm == kNoMover) {
                 // every visit of the window keeps its component: the state is untouched
                 c->lik_evals += (j.win_hi - j.pos) * (long long)j.K;
+                // (the mover-free stretch seen so far is a lower bound of the next distance between
+                // movers: a chain that has come to rest finds its way back to the long windows)
+                const double since = (double)(j.win_hi - c->last_mover);
+                if (since > c->ema_run) c->ema_run = since;
                 if (j.pos == j.win_base) {           // a clean window: be more optimistic
                     long long w = 2ll * c->win_size;
                     c->win_size = (int)(w > c->win_cap ? c->win_cap : w);
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                     // adaptive window: about half the running mean distance between movers
                     const double run = (double)(p - c->last_mover);
                     c->last_mover = p;
-                    c->ema_run = 0.875 * c->ema_run + 0.125 * run;
+                    c->ema_run = ema_after_mover(c->ema_run, run);
                     const long long w = window_for_rate(c);
                     c->win_size = (int)w;
                     // movers are dense relative to what is left of this window: give up its tail

@@ -327,11 +327,18 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
         // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
         // score and promote a pruned component), so they are used while moves are sparse; the
         // mover-dense path (resolver) always works on complete scores.
-        j.prune = (d.prune_enabled == 2 || (d.prune_enabled == 1 && c->ema_run >= 256.0)) ? 1 : 0;
+        j.prune = (d.prune_enabled == 2 || (d.prune_enabled == 1 && c->ema_run >= kPruneMinRun)) ? 1 : 0;
     }
     set_chunks(d, j);
 }
 
+
+// Running mean distance between movers.  A run far below the mean (the chain has just been
+// disturbed: the mean still remembers the quiet stretch before) pulls it down fast -- every mover
+// that arrives while the windows are still sized for the old mean throws a whole window away.
+__device__ __forceinline__ double ema_after_mover(double ema, double run) {
+    return run < 0.25 * ema ? 0.5 * ema + 0.5 * run : 0.875 * ema + 0.125 * run;
+}
 
 // window size from the running mean distance between movers: about half of it, a power of two
 __device__ inline long long window_for_rate(const Ctrl *c) {
