@@ -38,7 +38,9 @@ for case in range(n_cases):
     ctxs = []
     for mode in (0, 1):
         c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, cov_type=cov)
-        c.set_tuning(prune_mode=mode, resolver_mode=1 if mode == 1 else 0)
+        # (the default configuration keeps pruned windows for long mover-free stretches; every third
+        # case forces them in every regime so that the pruning / certification kernels see moving chains)
+        c.set_tuning(prune_mode=(2 if case % 3 == 0 else 0) if mode == 0 else 1, resolver_mode=1 if mode == 1 else 0)
         c.set_assignments(z0)
         ctxs.append(c)
     n_sweeps = 10
