@@ -581,17 +581,11 @@ __device__ void set_refresh(const Dev &d, Ctrl *c, const MovePlan &mp, bool rank
     c->refresh_i = mp.i;
     if (d.cov_type != COV_FULL) rank1 = false;      // the diag / fixed refresh is O(D) anyway
     if (mp.sub_slot >= 0) {
-        bool scratch = !(rank1 && d.nupd[mp.sub_slot] < kRefreshEvery);
-        if (!scratch) {
-            // A point far from the rest of its component inflates the eigenvalue bound behind the
-            // pruning, and a rank-1 removal cannot shrink it again (slot_math.h: lam_after_rank1).
-            // When the leaving point accounts for a good part of the bound, rebuild from scratch.
-            const int D = d.D;
-            const double *x = d.X + mp.i * D, *mu = d.mu + (long long)mp.sub_slot * D;
-            double d2 = 0.0;
-            for (int l = 0; l < D; ++l) { const double t = x[l] - mu[l]; d2 = fma(t, t, d2); }
-            scratch = d2 * d.sc[mp.sub_slot].inv_lam > 0.05;
-        }
+        // (A point far from the rest of its component inflates the eigenvalue bound behind the
+        // pruning, and a rank-1 removal cannot shrink it again -- slot_math.h: lam_after_rank1.  The
+        // slots that took rank-1 steps are rebuilt before the next sweep, refresh_stale_kernel; a
+        // rebuild here, on the movers' chain, cost a disturbed chain 125 us per departing outlier.)
+        const bool scratch = !(rank1 && d.nupd[mp.sub_slot] < kRefreshEvery);
         c->refresh_kind[nr] = scratch ? REFRESH_SCRATCH : REFRESH_SUB;
         c->refresh[nr++] = mp.sub_slot;
     }
