@@ -659,7 +659,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             const Ctrl &hc = *c->ctrl_host;
             const long long open_rows = first_batch ? (long long)d.batch_rows : hc.job.win_hi - hc.job.win_base;
             // (while nothing moves every clean window doubles the next: room for four doublings per batch)
-            d.batch_rows = rows_for(win, open_rows, rate == 0.0 ? 16 : 2);
+            d.batch_rows = rows_for(win, open_rows, rate == 0.0 ? 16 : 8);
         }
         const long long grid_rows = d.batch_rows;
         if (pmode != 2) lean = false;

@@ -293,6 +293,30 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
     }
     __syncthreads();
     if (!S.active) return;
+    // A visiting order that names a point twice inside this sub-window: the second visit's home is
+    // whatever the first left, but the rows' homes (and their tiles) are set up once, here.  Such a
+    // stretch is left to the per-mover kernels, which read the labels live.  (The reference's orders
+    // are permutations; the C-ABI takes any index array.)
+    if (d.order) {
+        const int nr = S.nrows;
+        const long long mine = tid < nr ? d.order[S.sub_lo + tid] : -1;
+        if (tid == 0) S.pad0 = 0;
+        if (tid < nr) L.rowi[tid] = mine;
+        __syncthreads();
+        bool dup = false;
+        for (int r2 = 0; r2 < tid && tid < nr; ++r2) dup |= L.rowi[r2] == mine;
+        if (dup) S.pad0 = 1;
+        __syncthreads();
+        if (S.pad0) {
+            if (tid == 0) {     // (undo the step this launch has just booked: apply_kernel books it again)
+                const Job &j = c->job;
+                c->n_steps -= 1;
+                c->n_score_launches -= 1;
+                c->n_scored -= (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
+            }
+            return;
+        }
+    }
     // phase clocks (build with -DBGMM_PROFILE; every probe costs a global read-modify-write)
 #ifdef BGMM_PROFILE
     long long tk = clock64(), tk2;

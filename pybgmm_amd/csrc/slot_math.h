@@ -312,7 +312,16 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     Job &j = c->job;
     j.pos = pos;
     j.win_base = pos;
-    long long hi = pos + (c->win_size < d.batch_rows ? c->win_size : d.batch_rows);
+    // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
+    // score and promote a pruned component), so they are used while moves are sparse; the
+    // mover-dense path (resolver) always works on complete scores.
+    const bool prune = d.prune_enabled == 2 || (d.prune_enabled == 1 && c->ema_run >= kPruneMinRun);
+    // (win_size is about half the mean distance between movers: right for a pruned window, which
+    // ends at its first mover; a dense window is only re-scored for two components behind a mover,
+    // so it may as well reach a few movers ahead and save the steps of the clean windows in between)
+    long long w = prune ? (long long)c->win_size : 4ll * c->win_size;
+    if (w > d.batch_rows) w = d.batch_rows;
+    long long hi = pos + w;
     if (hi > c->n_visits) hi = c->n_visits;
     j.win_hi = hi;
     j.n_dirty = 0;
@@ -324,10 +333,7 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     } else {
         j.mode = MODE_FRESH;
         c->n_windows += 1;
-        // Pruned scores are valid against the FROZEN state only (a move can lower a visit's best
-        // score and promote a pruned component), so they are used while moves are sparse; the
-        // mover-dense path (resolver) always works on complete scores.
-        j.prune = (d.prune_enabled == 2 || (d.prune_enabled == 1 && c->ema_run >= kPruneMinRun)) ? 1 : 0;
+        j.prune = prune ? 1 : 0;
     }
     set_chunks(d, j);
 }

@@ -934,13 +934,15 @@ def test_sequential_sweep_refuses_an_order_with_repeats():
     N, D, K = 6000, 2, 6
     X, zt = gendata.synth_mixture(N, D, K, seed=77, mu_scale=1.5)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    from oracle import c_oracle
     rs = np.random.RandomState(3)
     ctxs = []
     for kind in (0, 1):
-        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 64)
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 64, tables=reference_tables(v_0, N))
         c.set_tuning(kernel_kind=kind, resolver_mode=0 if kind == 0 else 1)
         c.set_assignments(zt)
         ctxs.append(c)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 64)
     for it in range(4):
         u = rs.random_sample(N)
         order = rs.permutation(N)
@@ -948,7 +950,9 @@ def test_sequential_sweep_refuses_an_order_with_repeats():
             order[rs.randint(0, N, size=200)] = order[rs.randint(0, N, size=200)]     # repeats (and gaps)
         for c in ctxs:
             c.sweep(u, order, None)
+        o.sweep(u, order, None)
         npt.assert_array_equal(ctxs[0].assignments(), ctxs[1].assignments())
+        npt.assert_array_equal(ctxs[0].assignments(), o.z)     # (the in-launch resolver leaves such stretches alone)
         st = ctxs[0].sweep_stats()
         if it % 2 == 0:
             assert st["steps"] == 1 and st["windows"] == 1          # the sequential kernel did the sweep
