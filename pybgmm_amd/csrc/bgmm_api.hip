@@ -638,7 +638,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         // (the first batch of a sweep runs on the previous sweep's mover rate: keep it short, the next
         // one is planned on what this sweep has shown -- a step queued behind the end of the sweep is a
         // dozen empty launches)
-        if (first_batch && Tl > 64) Tl = 64;
+        if (first_batch && Tl > 8) Tl = 8;
         int T = (int)Tl;
         // the resolver's LDS plan depends on the number of labels: re-planned every chunk
         int res_R = 0, res_Kcap = 0, res_lds = 0;
