@@ -589,7 +589,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     launch_sweep_begin(d, st);
     long long steps_done = 0;
     // Tiny dimensions: one wavefront walks the visits in order with the labels' state in LDS
-    // (kernels_state.hip: sweep_seq_kernel).  It leaves the sweep DONE, or -- when the labels outgrow
+    // (kernels_seq.hip: sweep_seq_kernel).  It leaves the sweep DONE, or -- when the labels outgrow
     // its LDS plan -- a window open at the visit it stopped at, and the loop below carries on.
     bool seq_ran = false;
     if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&

@@ -1,4 +1,4 @@
-"""Soak test of the sequential small-D sweep (kernels_state.hip: sweep_seq_kernel): default tuning (which
+"""Soak test of the sequential small-D sweep (kernels_seq.hip: sweep_seq_kernel): default tuning (which
 takes it for D <= 4, full covariance) against the windowed VALU path with the resolver off, over random
 shapes, separations, visiting orders, seating exponents, unassigned points and hand-made state changes.
 A third of the cases run with a small LDS plan (BGMM_SEQ_CAP) so that the kernel hands over to the
