@@ -925,6 +925,39 @@ def test_sequential_sweep_tiny_inputs(N):
                 c.close()
 
 
+@pytest.mark.parametrize("prune", [0, 2], ids=["default", "every-window-pruned"])
+def test_order_with_repeats_through_the_pruned_kernels(prune):
+    """An index array with repeats and gaps as visiting order (the C-ABI takes any), D = 16: certify,
+    bucket sort, pruning kernel, sparse draw and the resolver against the C port of the reference."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 9000, 16, 8
+    X, zt = gendata.synth_mixture(N, D, K, seed=21, mu_scale=2.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(12)
+    z0 = zt.copy()
+    z0[rs.choice(N, size=300, replace=False)] = rs.randint(0, K, size=300)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=reference_tables(v_0, N))
+    ctx.set_tuning(prune_mode=prune)
+    ctx.set_assignments(z0)
+    for it in range(4):
+        u = rs.random_sample(N)
+        order = rs.permutation(N)
+        order[rs.randint(0, N, size=400)] = order[rs.randint(0, N, size=400)]
+        if it == 2:
+            order[100:140] = order[100]                  # the same point forty times in a row
+        o.sweep(u, order, None)
+        ctx.sweep(u, order, None)
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+    ctx.close()
+
+
 def test_sequential_sweep_refuses_an_order_with_repeats():
     """The small-D sweep fetches a visit's home slot ahead of time, which is sound only when no index
     comes twice: a visiting order with repeats must take the windowed kernels (same trajectory as the
