@@ -885,6 +885,43 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
     ctx.close()
 
 
+@pytest.mark.parametrize("N", [1, 2, 5, 17, 64, 65, 300])
+@pytest.mark.parametrize("D", [12, 33])
+def test_tiny_inputs_windowed_kernels(N, D):
+    """Edge sizes of the windowed path (MFMA kernels at D >= 12, one visit to a few tiles): default
+    configuration against the C port of the reference, started from one table."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    rs = np.random.RandomState(1000 * D + N)
+    X = np.ascontiguousarray(rs.randn(N, D) * 2.0 + (rs.randint(0, 3, size=(N, 1)) * 6.0))
+    m_0, k_0, v_0, S_0 = np.zeros(D), 0.05, D + 3, np.eye(D)
+    z0 = np.zeros(N, dtype=np.int64)
+    K_max = max(2, min(N, 10))
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 2.0, z0, K_max)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 2.0, K_max, tables=reference_tables(v_0, N))
+    ctx.set_assignments(z0)
+    for it in range(4):
+        u = rs.random_sample(N)
+        order = rs.permutation(N) if it % 2 else None
+        try:
+            o.sweep(u, order, None)
+            o_err = None
+        except Exception as e:
+            o_err = e
+        try:
+            ctx.sweep(u, order, None)
+            c_err = None
+        except Exception as e:
+            c_err = e
+        assert (o_err is None) == (c_err is None), (o_err, c_err)
+        if o_err is not None:
+            break
+        npt.assert_array_equal(ctx.assignments(), o.z)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * max(abs(lo), 1.0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("N", [1, 2, 9, 63, 64, 65, 130, 513])
 def test_sequential_sweep_tiny_inputs(N):
     """Edge sizes of the one-workgroup sweep (fewer visits than wavefronts, ring and batch boundaries,
