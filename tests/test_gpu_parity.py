@@ -885,6 +885,50 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
     ctx.close()
 
 
+@pytest.mark.parametrize("cov", ["diag", "fixed"])
+@pytest.mark.parametrize("N", [1, 3, 64, 65, 700])
+def test_diag_fixed_edge_sizes_and_repeated_orders(cov, N):
+    """Diagonal / fixed-variance components at edge sizes, with an index array that repeats and skips
+    points as visiting order in every other sweep, against the C port of the reference."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    D = 6
+    rs = np.random.RandomState(77 + N)
+    X = np.ascontiguousarray(rs.randn(N, D) + (rs.randint(0, 3, size=(N, 1)) * 5.0))
+    if cov == "diag":
+        m_0, k_0, v_0, S_0 = np.zeros(D), 0.05, D + 3, np.ones(D)
+    else:
+        m_0, k_0, v_0 = np.zeros(D), 1.0, 1
+        S_0 = np.concatenate([np.full(D, 0.8), np.full(D, 25.0)])
+    z0 = np.zeros(N, dtype=np.int64)
+    K_max = max(2, min(N, 12))
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.5, z0, K_max, cov_type=cov)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.5, K_max, cov_type=cov,
+                       tables=reference_tables(v_0, N) if cov == "diag" else None)
+    ctx.set_assignments(z0)
+    for it in range(5):
+        u = rs.random_sample(N)
+        order = None
+        if it % 2:
+            order = rs.permutation(N)
+            if N > 2:
+                order[rs.randint(0, N, size=max(N // 10, 1))] = order[rs.randint(0, N, size=max(N // 10, 1))]
+        errs = []
+        for obj in (o, ctx):
+            try:
+                obj.sweep(u, order, None)
+                errs.append(None)
+            except Exception as e:
+                errs.append(e)
+        assert (errs[0] is None) == (errs[1] is None), errs
+        if errs[0] is not None:
+            break
+        npt.assert_array_equal(ctx.assignments(), o.z)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * max(abs(lo), 1.0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("N", [1, 2, 5, 17, 64, 65, 300])
 @pytest.mark.parametrize("D", [12, 33])
 def test_tiny_inputs_windowed_kernels(N, D):
