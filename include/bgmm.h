@@ -166,12 +166,23 @@ int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
  */
 int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out8);
 int bgmm_get_prune_stats(bgmm_ctx *ctx, int64_t *out4);
+/*   path_stats: of the last sweep -- [0] (visit, component) pairs whose quadratic form was EXECUTED (dense
+ *     windows: every pair; pruned windows: the pairs scored in full; frozen-factor windows: rows x
+ *     (components + the prior); certified visits contribute nothing), [1] frozen-factor windows
+ *     (the mover-dense path), [2] visits they consumed, [3] reserved. */
+int bgmm_get_path_stats(bgmm_ctx *ctx, int64_t *out4);
+/*   phase clocks: shader-clock ticks the one-workgroup kernels of the mover-dense path spent per phase,
+ *     accumulated since bgmm_create -- all zero unless the library was built with -DBGMM_PROFILE
+ *     (a development aid: every probe costs the kernel a global read-modify-write). */
+int bgmm_get_phase_clocks(bgmm_ctx *ctx, int64_t *out16);
 int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
 int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
- * kernel (0 auto, 1 VALU, 2 MFMA); in-launch mover resolver (0 auto: when movers are dense,
- * 1 never, 2 whenever it fits); exact pruning of components whose weight in a draw is provably
+ * kernel (0 auto, 1 VALU, 2 MFMA); mover-dense path (0 auto: frozen-factor windows while the mean
+ * distance between movers is short, 1 never: the per-mover kernel chain, 2 the one-workgroup resolver
+ * that updates both factors in LDS whenever it fits (D <= 64), 3 frozen-factor windows in every
+ * regime); exact pruning of components whose weight in a draw is provably
  * below e^-80 (0 auto: on while movers are sparse, plus certified stays in converged chains; 1 off;
  * 2 in every window whatever the regime -- slow when movers are dense, meant for tests; 3 as 0
  * but without certified stays, for measurements).  None of them changes the sampled trajectory.
@@ -181,6 +192,11 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
  * kernels instead.  In that path sweep_stats [2], [3] and [4] are 1. */
 int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                     int32_t prune_mode);
+
+/* Labels (components + 1) the one-workgroup small-D sweep keeps in LDS before it hands the sweep over to
+ * the windowed kernels; 0 = as many as fit (the default).  A smaller plan changes where the hand-over
+ * happens, never the trajectory (the tests use it to exercise the hand-over). */
+int bgmm_set_seq_plan(bgmm_ctx *ctx, int32_t max_labels);
 
 /* Blocks until all work queued on the context's stream has finished. */
 int bgmm_synchronize(bgmm_ctx *ctx);

@@ -50,9 +50,12 @@ SIGNATURES = {
     "bgmm_cluster_dispersion": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_prune_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_path_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_phase_clocks": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "bgmm_set_seq_plan": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_synchronize": (ctypes.c_int, [_vp]),
 }
 
@@ -275,6 +278,16 @@ class Context(object):
         return {"kept_blocks": int(out[0]), "bound_blocks": int(out[1]), "mfma_instructions": int(out[2]),
                 "certified_visits": int(out[3])}
 
+    def path_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_path_stats(self.h, _ptr(out)))
+        return {"pairs_executed": int(out[0]), "frozen_windows": int(out[1]), "frozen_window_visits": int(out[2])}
+
+    def phase_clocks(self):
+        out = np.zeros(16, dtype=np.int64)
+        self._ck(self.L.bgmm_get_phase_clocks(self.h, _ptr(out)))
+        return [int(v) for v in out]
+
     def set_kernel_timing(self, on):
         self._ck(self.L.bgmm_set_kernel_timing(self.h, 1 if on else 0))
 
@@ -287,6 +300,9 @@ class Context(object):
     def set_tuning(self, max_window=0, kernel_kind=0, resolver_mode=0, prune_mode=0):
         self._ck(self.L.bgmm_set_tuning(self.h, int(max_window), int(kernel_kind), int(resolver_mode),
                                         int(prune_mode)))
+
+    def set_seq_plan(self, max_labels=0):
+        self._ck(self.L.bgmm_set_seq_plan(self.h, int(max_labels)))
 
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))

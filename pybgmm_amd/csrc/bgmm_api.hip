@@ -81,7 +81,17 @@ struct bgmm_ctx {
     std::vector<char> res_zero_u;
     std::vector<char> res_perm;      // per resident sweep: its order is a permutation (or absent)
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stats2[4] = {0, 0, 0, 0};   // pairs whose quadratic form was executed, frozen-factor windows, their rows, spare
+    // frozen-factor windows (kernels_gram.hip): buffers sized for `gcols` columns, re-allocated when the labels outgrow them
+    void *gram_mem[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int gram_lds = 0;
+    bool gram_off = false;           // this context cannot use them (too many labels for the LDS plan)
+    int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
 };
+
+// Mean distance between movers below which the frozen-factor windows take over from the per-mover
+// kernel chain: a window costs ~60 us plus ~1.5 us per mover and covers 64 visits, the chain ~190 us per mover.
+constexpr double kGramRun = 192.0;
 
 #define CK(ctx, call)                                                                       \
     do {                                                                                    \
@@ -166,6 +176,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->mt_words) (void)hipFree(c->mt_words);
+    for (void *p : c->gram_mem) if (p) (void)hipFree(p);
     if (c->true_dev) (void)hipFree(c->true_dev);
     if (c->table_dev) (void)hipFree(c->table_dev);
     if (c->res_u) (void)hipFree(c->res_u);
@@ -238,7 +249,6 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     // the pruned-window kernel overlaps its latency-bound phases over more workgroup rounds.
     long long rows = 1ll << 20;
     while (rows < N && rows < (1ll << 22)) rows <<= 1;       // (one window per sweep up to 4 Mi visits, memory permitting)
-    if (const char *e = getenv("BGMM_WIN_ROWS")) { long long v = atoll(e); if (v >= 1024) rows = v; }
     while (rows > 1024 && (size_t)rows * d.nslots * sizeof(double) > ((size_t)16 << 30)) rows >>= 1;
     long long n_up = (N + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
     if (rows > n_up) rows = n_up;
@@ -450,14 +460,18 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
 // The sequential small-D sweep fetches z[i] ahead of the visit of i: sound only when no index
 // comes twice.  Checked on the host for the shapes that can take that path.
 static bool seq_shape(const bgmm_ctx *c) { return c->d.cov_type == COV_FULL && c->d.D <= 4; }
-static bool order_is_permutation(const int64_t *order, long long N) {
+// 1: a permutation of 0 .. N-1; 0: in range but with repeats (the C-ABI takes any index array: the
+// kernels that fetch a visit's home ahead of time are not used); -1: an index out of range.
+static int classify_order(const int64_t *order, long long N) {
     std::vector<unsigned char> seen((size_t)N, 0);
+    int kind = 1;
     for (long long p = 0; p < N; ++p) {
         const int64_t i = order[p];
-        if (i < 0 || i >= N || seen[(size_t)i]) return false;
+        if (i < 0 || i >= N) return -1;
+        if (seen[(size_t)i]) kind = 0;
         seen[(size_t)i] = 1;
     }
-    return true;
+    return kind;
 }
 
 extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const double *u) {
@@ -468,7 +482,9 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     for (long long i = 0; i < c->d.N; ++i)
         if (u[i] == 0.0) { c->cur_zero_u = true; break; }
     c->have_order = order != nullptr;
-    c->order_is_perm = !order || (seq_shape(c) && order_is_permutation(order, c->d.N));
+    const int okind = order ? classify_order(order, c->d.N) : 1;
+    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
+    c->order_is_perm = okind == 1;
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
@@ -489,7 +505,9 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
     c->have_order = order != nullptr;
-    c->order_is_perm = !order || (seq_shape(c) && order_is_permutation(order, (long long)N));
+    const int okind = order ? classify_order(order, (long long)N) : 1;
+    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
+    c->order_is_perm = okind == 1;
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
     launch_mt19937(dkey, dpos, dwords, c->d_u, (long long)N, dflag, c->stream);
@@ -515,6 +533,13 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
     if (!c || !u_all || n_sweeps < 1) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->d.N;
+    std::vector<char> perm_kind((size_t)n_sweeps, 1);
+    if (order_all)
+        for (int32_t t = 0; t < n_sweeps; ++t) {
+            const int k = classify_order(order_all + (size_t)t * N, (long long)N);
+            if (k < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
+            perm_kind[(size_t)t] = (char)k;
+        }
     if (c->res_u) { (void)hipFree(c->res_u); c->res_u = nullptr; }
     if (c->res_order) { (void)hipFree(c->res_order); c->res_order = nullptr; }
     c->res_n = 0;
@@ -529,11 +554,47 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
     for (int32_t t = 0; t < n_sweeps; ++t)
         for (size_t i = 0; i < N; ++i)
             if (u_all[(size_t)t * N + i] == 0.0) { c->res_zero_u[(size_t)t] = 1; break; }
-    c->res_perm.assign((size_t)n_sweeps, 1);
-    if (order_all)
-        for (int32_t t = 0; t < n_sweeps; ++t)
-            c->res_perm[(size_t)t] = seq_shape(c) && order_is_permutation(order_all + (size_t)t * N, (long long)N);
+    c->res_perm = perm_kind;
     return 0;
+}
+
+// Buffers and LDS plan of the frozen-factor windows for K labels now (room for the labels a batch of
+// windows may open).  Returns false when the plan does not fit (the classic kernels carry on).
+static bool ensure_gram(bgmm_ctx *c, int K) {
+    Dev &d = c->d;
+    if (c->gram_off) return false;
+    const int need = K + kGramColSlack;
+    if (d.gcols < need || !c->gram_mem[0]) {
+        int cols = (need + 128 + 7) & ~7;
+        if (cols > d.nslots + kGramColSlack) cols = (d.nslots + kGramColSlack + 7) & ~7;
+        if (cols < need) { c->gram_off = true; return false; }
+        (void)hipStreamSynchronize(c->stream);
+        for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
+        const size_t sz[7] = {sizeof(double) * (size_t)cols * kGramRows * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
+                              sizeof(double) * (size_t)cols * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
+                              sizeof(GramMove) * (size_t)kGramMaxTerms, sizeof(int) * (size_t)kGramMaxTerms,
+                              sizeof(double) * 2 * kGramRows};
+        for (int t = 0; t < 7; ++t)
+            if (hipMalloc(&c->gram_mem[t], sz[t] + 64) != hipSuccess) {
+                for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
+                d.gcols = 0;
+                c->gram_off = true;
+                return false;
+            }
+        d.gC = (double *)c->gram_mem[0]; d.gq0 = (double *)c->gram_mem[1];
+        d.glp0 = (double *)c->gram_mem[2]; d.ge0 = (double *)c->gram_mem[3];
+        d.gmoves = (GramMove *)c->gram_mem[4]; d.gtouched = (int *)c->gram_mem[5];
+        d.gM = (double *)c->gram_mem[6];
+        d.gcols = cols;
+        // terms the resolver's LDS holds next to the per-column bookkeeping (160 KiB per workgroup)
+        int T = kGramMaxTerms;
+        while (T >= 32 && gram_resolve_lds_bytes(cols, T) > 160 * 1024) T -= 8;
+        if (T < 32) { c->gram_off = true; return false; }
+        d.gram_terms = T;
+        c->gram_lds = gram_resolve_lds_bytes(cols, T);
+        gram_configure(d, c->gram_lds);
+    }
+    return K + d.gram_terms / 2 + 2 <= 512;
 }
 
 static int ensure_events(bgmm_ctx *c, size_t n) {
@@ -596,10 +657,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         c->order_is_perm) {
         int cap = 2;
         while (sweep_seq_lds_bytes(d.D, cap + 16) <= 150 * 1024) cap += 16;
-        if (const char *e = getenv("BGMM_SEQ_CAP")) {      // (tests: a small plan, to exercise the hand-over)
-            const int v = atoi(e);
-            if (v >= 2 && v < cap) cap = v;
-        }
+        if (c->seq_cap >= 2 && c->seq_cap < cap) cap = c->seq_cap;     // (bgmm_set_seq_plan)
         if (cap > d.K_max + 1) cap = d.K_max + 1;
         if (c->ctrl_host->job.K + 1 <= cap) {
             if (!launch_sweep_seq(d, cap, st)) return fail(c, BGMM_EDEVICE, "sequential sweep kernel launch failed");
@@ -640,9 +698,60 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         // dozen empty launches)
         if (first_batch && Tl > 8) Tl = 8;
         int T = (int)Tl;
+        // Mover-dense stretches (burn-in, overlapping clusters): frozen-factor windows (kernels_gram.hip).
+        // Three launches per window of 64 visits, no per-mover kernel chain.  resolver_mode 3 forces them.
+        bool use_gram = false;
+        if (d.cov_type == COV_FULL && (c->resolver_mode == 0 || c->resolver_mode == 3) && c->order_is_perm &&
+            c->prune_mode != 2 && d.Dp / 16 <= 8 && true) {
+            const Ctrl &hc = *c->ctrl_host;
+            const bool dense = c->resolver_mode == 3 || (c->kernel_kind != KERNEL_VALU && hc.ema_run < kGramRun);
+            if (dense) use_gram = ensure_gram(c, hc.job.K);
+        }
+        if (use_gram) {
+            const Ctrl &hc = *c->ctrl_host;
+            // windows still needed: from the rows a window has consumed on average so far in this sweep
+            double rpw = hc.gram_windows > 0 ? (double)hc.gram_rows_total / (double)hc.gram_windows : 32.0;
+            if (rpw < 8.0) rpw = 8.0;
+            long long Tg = (long long)std::ceil((double)remaining / rpw) + 1;
+            if (first_batch && Tg > 16) Tg = 16;
+            if (Tg > 512) Tg = 512;
+            if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
+            d.lean_step = 0; d.publish = 0; d.prune_enabled = 0;
+            d.gram_K = hc.job.K;
+            lean = false;
+            first_batch = false;
+            for (int t = 0; t < (int)Tg; ++t)
+                if (!launch_gram_step(d, c->gram_lds, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
+                    return fail(c, BGMM_EDEVICE, "frozen-factor window launch failed");
+            CK(c, hipGetLastError());
+            int rc = fetch_ctrl(c);
+            if (rc) return rc;
+            const Ctrl &h = *c->ctrl_host;
+            if (c->timing) {
+                const long long worked = h.n_steps - steps_done;
+                for (long long t = 0; t < worked && t < Tg; ++t) {
+                    float ms = 0.f;
+                    CK(c, hipEventElapsedTime(&ms, c->ev0[(size_t)t], c->ev1[(size_t)t]));
+                    c->timed_ms += (double)ms;
+                    c->timed_launches += 1;
+                }
+            }
+            steps_done = h.n_steps;
+            if (h.gram_stall) {            // the labels outgrew the columns: larger buffers, or the classic kernels
+                c->ctrl_host->gram_stall = 0;
+                CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
+                if (h.job.K + kGramColSlack > d.gcols) d.gcols = 0;          // (else: only the draw wave's width, re-picked per batch)
+                if (h.job.K + d.gram_terms / 2 + 2 > 512) c->gram_off = true;
+            }
+            if (h.error != 0 || h.job.mode == MODE_DONE) break;
+            pos = h.job.pos;
+            win = h.win_size > 0 ? h.win_size : win;
+            rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
+            continue;
+        }
         // the resolver's LDS plan depends on the number of labels: re-planned every chunk
         int res_R = 0, res_Kcap = 0, res_lds = 0;
-        const bool use_resolver = c->resolver_mode != 1 &&
+        const bool use_resolver = c->resolver_mode == 2 &&
                                   resolve_plan(d, c->ctrl_host->job.K, &res_R, &res_Kcap, &res_lds);
         if (c->timing) { int rc = ensure_events(c, (size_t)T); if (rc) return rc; }
         // Which kernel set this batch of steps needs (bgmm_device.h: Dev::prune_enabled).  Far inside
@@ -724,6 +833,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->stats[6] = (long long)h.n_kept_blocks; c->stats[7] = (long long)h.n_bound_blocks;
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
+    c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
     c->moves_prev = h.n_moves;
     c->lean_ok = use_certify && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
     return check_device_error(c);
@@ -922,11 +1032,12 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
 extern "C" int bgmm_add_item(bgmm_ctx *c, int64_t i, int32_t k) { return item_op(c, 1, i, k); }
 extern "C" int bgmm_del_item(bgmm_ctx *c, int64_t i) { return item_op(c, 0, i, 0); }
 
-extern "C" int bgmm_debug_prof(bgmm_ctx *c, int64_t *out8) {
-    if (!c || !out8) return BGMM_EINVAL;
+extern "C" int bgmm_get_phase_clocks(bgmm_ctx *c, int64_t *out16) {
+    if (!c || !out16) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
-    for (int t = 0; t < 16; ++t) out8[t] = c->ctrl_host->prof[t];
+    for (int t = 0; t < 16; ++t) out16[t] = c->ctrl_host->prof[t];
     return 0;
 }
 
@@ -939,6 +1050,12 @@ extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out8) {
 extern "C" int bgmm_get_prune_stats(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
     out4[0] = c->stats[6]; out4[1] = c->stats[7]; out4[2] = c->prune_mfma; out4[3] = c->certified;
+    return 0;
+}
+
+extern "C" int bgmm_get_path_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    for (int t = 0; t < 4; ++t) out4[t] = c->stats2[t];
     return 0;
 }
 
@@ -962,7 +1079,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
     if (!c) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
-    if (resolver_mode < 0 || resolver_mode > 2) return fail(c, BGMM_EINVAL, "resolver_mode must be 0, 1 or 2");
+    if (resolver_mode < 0 || resolver_mode > 3) return fail(c, BGMM_EINVAL, "resolver_mode must be 0 .. 3");
     if (prune_mode < 0 || prune_mode > 3) return fail(c, BGMM_EINVAL, "prune_mode must be 0 .. 3");
     c->kernel_kind = kernel_kind;
     c->resolver_mode = resolver_mode;
@@ -979,6 +1096,12 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
         CK(c, hipMemcpy(&c->d.ctrl->win_cap, &c->ctrl_host->win_cap, sizeof(int), hipMemcpyHostToDevice));
         CK(c, hipMemcpy(&c->d.ctrl->win_size, &c->ctrl_host->win_size, sizeof(int), hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+extern "C" int bgmm_set_seq_plan(bgmm_ctx *c, int32_t max_labels) {
+    if (!c || max_labels < 0) return BGMM_EINVAL;
+    c->seq_cap = max_labels;
     return 0;
 }
 

@@ -45,6 +45,11 @@ static constexpr int kMaxChunks = 8;       // grid.y of the likelihood kernels
 static constexpr int kValuRows = 64;       // rows (visits) per block, VALU likelihood kernel
 static constexpr int kMfmaRows = 128;      // rows per block, MFMA likelihood kernel (4 waves x 2 x 16)
 static constexpr int kChoiceRowsMax = 8;   // rows per block of the draw kernel (one wave per row)
+// frozen-factor windows (kernels_gram.hip): rows per window, and the most terms (rank-1 changes of a
+// component: one per removal, one per addition) a window can carry
+static constexpr int kGramRows = 64;
+static constexpr int kGramMaxTerms = 128;
+static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a window may open (new components + the prior)
 
 // Per-slot scalar constants.  (Diagonal covariance uses A = D*(lgamma terms) - 0.5 log prod var,
 // half_vd = (v_N+1)/2, logdetC = sum log S_N,d, A1 = log prod var, the seating weights; rest 0.)
@@ -113,6 +118,23 @@ struct Ctrl {
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
     long long prof[16];    // resolver phase clocks (setup, A, B, C, D1, D2, tail, calls), clock64 ticks
+    // frozen-factor windows (kernels_gram.hip)
+    int gram_nmoves;       // moves the last window logged (GramMove records)
+    int gram_ntouched;     // live slots whose statistics / factor the finish kernel has to bring up to date
+    int gram_stall;        // 1: the window needs more columns than are allocated (host reallocates)
+    int gram_pad;
+    unsigned long long n_pairs_exact;   // (visit, component) pairs whose quadratic form was executed this sweep
+    long long gram_rows_total, gram_windows;   // rows consumed by / number of frozen-factor windows this sweep
+};
+
+// One reassignment logged by a frozen-factor window, in visiting order: the finish kernel replays
+// them slot by slot (bit-identical m, S: the same roundings in the same order as apply_rank1).
+struct GramMove {
+    long long i;          // data index
+    int sub_slot;         // slot x_i leaves (-1: none, or the component was deleted with it)
+    int add_slot;         // slot x_i joins (-1: none -- K_max exceeded)
+    int add_init;         // 1: add_slot is a component opened by this move (starts from the prior)
+    int pad;
 };
 
 // One row of a pruned window in evaluation order: everything the pruning kernel needs to start on
@@ -207,6 +229,16 @@ struct Dev {
     double power;
     int batch_rows;              // rows the launches of this batch of steps are sized for: no window
                                  // opened during the batch is longer (the host raises it batch by batch)
+    // frozen-factor windows (kernels_gram.hip): per column c (label c of the window's frozen state; column K
+    // = the bare prior) gC[c][r][r'] = a_c(x_r) . a_c(x_r') with a_c(x) = Winv_c (x - mu_c), r' >= r by
+    // 16 x 16 tiles; gq0[c][r] = |a_c(x_r)|^2; glp0[r][c] / ge0[r][c] = frozen log score / exp(lp0 - M_r)
+    double *gC, *gq0, *glp0, *ge0;
+    double *gM;                  // [2][64]: the rows' reference points M_r, their new-table weights exp(lp_new - M_r)
+    int gcols;                   // columns allocated (also the leading dimension of glp0 / ge0)
+    GramMove *gmoves;            // [kGramMaxTerms]
+    int *gtouched;               // [kGramMaxTerms]
+    int gram_terms;              // terms the resolver's LDS plan holds (<= kGramMaxTerms)
+    int gram_K;                  // labels when the current batch of windows was queued (host side: picks the draw wave's width)
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
                                  // queued steps: 0 never (only the dense kernels are launched), 1 the device
                                  // decides per window (job.prune; both kernel sets are launched), 2 every
@@ -250,5 +282,9 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
 int refresh_lds_bytes(int D);
+int gram_resolve_lds_bytes(int gcols, int terms);
+bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
+void gram_configure(const Dev &d, int resolve_lds);      // per-device kernel attributes (once per context and plan)
+void launch_gram_finish(const Dev &d, hipStream_t st);
 void launch_mt19937(unsigned *key_io, int *pos_io, unsigned *words, double *u, long long n, int *zero_flag,
                     hipStream_t st);

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                     c->n_steps += 1;
                     c->n_score_launches += 1;
                     c->n_scored += (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
+                    c->n_pairs_exact += (unsigned long long)((j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty));
                 }
             }
         }
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(RT) void resolve_kernel(Dev d, int R, int Kcap) {
                 c->n_steps -= 1;
                 c->n_score_launches -= 1;
                 c->n_scored -= (j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty);
+                c->n_pairs_exact -= (unsigned long long)((j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty));
             }
             return;
         }

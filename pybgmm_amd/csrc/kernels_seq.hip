@@ -564,6 +564,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
     if (lane == 0) {
         atomicAdd((unsigned long long *)&c->lik_evals, (unsigned long long)lik);
         atomicAdd((unsigned long long *)&c->n_scored, (unsigned long long)lik);
+        atomicAdd(&c->n_pairs_exact, (unsigned long long)lik);
         atomicAdd((unsigned long long *)&c->n_moves, (unsigned long long)moves);
 #ifdef BGMM_SEQ_PROF
         for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&c->prof[k], (unsigned long long)pf[k]);

@@ -194,6 +194,43 @@ static void ensure_lds(const void *fn, int bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// Frozen-factor windows (kernels_gram.hip), last kernel of a step: block b brings slot gtouched[b] up to
+// date -- the window's logged moves replayed on (m, S) in visiting order with the roundings of
+// apply_rank1 (bit-identical statistics), then the derived state rebuilt from scratch.
+__global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const Ctrl *c = d.ctrl;
+    if ((int)blockIdx.x >= c->gram_ntouched) return;
+    const int s = d.gtouched[blockIdx.x];
+    const int D = d.D, nm = c->gram_nmoves;
+    double *m = d.m + (long long)s * D;
+    double *S = d.S + (long long)s * D * D;
+    for (int k = 0; k < nm; ++k) {
+        const GramMove mv = d.gmoves[k];
+        const bool sub = mv.sub_slot == s, add = mv.add_slot == s;
+        if (!sub && !add) continue;                          // (block uniform)
+        const double *__restrict__ x = d.X + mv.i * D;
+        for (int a = threadIdx.x; a < D; a += TPB) {
+            if (sub) m[a] = __dsub_rn(m[a], x[a]);
+            else m[a] = __dadd_rn(mv.add_init ? d.prior_m[a] : m[a], x[a]);
+        }
+        for (int e = threadIdx.x; e < D * D; e += TPB) {
+            const double xx = __dmul_rn(x[e / D], x[e % D]);
+            if (sub) S[e] = __dsub_rn(S[e], xx);
+            else S[e] = __dadd_rn(mv.add_init ? d.prior_S[e] : S[e], xx);
+        }
+    }
+    __syncthreads();
+    refresh_slot(d, s, sm);
+}
+
+void launch_gram_finish(const Dev &d, hipStream_t st) {
+    const int lds = refresh_lds_bytes(d.D);
+    (void)hipFuncSetAttribute((const void *)gram_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(kGramMaxTerms), dim3(TPB), lds, st, d);
+}
+
+
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) {
     if (n <= 0) return;
     const int lds = refresh_lds_bytes(d.D);
@@ -255,6 +292,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
+        c->n_pairs_exact = 0; c->gram_rows_total = 0; c->gram_windows = 0; c->gram_ntouched = 0; c->gram_nmoves = 0;
         if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
@@ -655,6 +693,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
         }
         if (threadIdx.x == 0) {
             c->n_kept_blocks += cnt_red[0];
+            c->n_pairs_exact += 16ull * cnt_red[0];         // (16-visit blocks scored in full)
             c->n_bound_blocks += cnt_red[TPB];
             c->n_prune_mfma += cnt_red[2 * TPB];
             c->n_certified += cnt_red[3 * TPB];
@@ -673,6 +712,8 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             const unsigned long long fm = c->first_mover;
             c->first_mover = kNoMover;
             const bool was_pruned = job_is_pruned(d, j.mode, j.prune);
+            if (!was_pruned && !d.lean_step)
+                c->n_pairs_exact += (unsigned long long)((j.win_hi - j.pos) * (long long)(j.mode == MODE_FRESH ? j.K : j.n_dirty));
             if (was_pruned) {
                 // this step's bucket / table kernels have run (or were skipped as still valid);
                 // a lean step queues neither

@@ -60,10 +60,11 @@ def test_golden_trajectory(case, kind):
     ctx.close()
 
 
-@pytest.mark.parametrize("resolver", [1, 2], ids=["per-mover-kernels", "in-launch-resolver"])
+@pytest.mark.parametrize("resolver", [1, 2, 3], ids=["per-mover-kernels", "in-launch-resolver", "frozen-factor-windows"])
 @pytest.mark.parametrize("case", ALL_CASES)
 def test_golden_trajectory_both_mover_paths(case, resolver):
-    """Force the per-mover kernel chain (1) and the in-launch resolver (2): same chain."""
+    """Force the per-mover kernel chain (1), the in-launch resolver (2) and the frozen-factor windows
+    (3: every visit of every sweep goes through gram_kernel / gram_resolve_kernel): same chain."""
     g = Golden(case)
     ctx = make_ctx(g, 0, 0, resolver=resolver)
     for it in range(g.n_iter):

@@ -18,15 +18,4 @@ for it in range(int(sys.argv[4]) if len(sys.argv) > 4 else 1):
     print("sweep %d: %.3f s  %.2f us/visit  moves=%d steps=%d windows=%d K=%d  us/step=%.1f" % (
         it, dt, dt / N * 1e6, st["moves"], st["steps"], st["windows"], ctx.K, dt / max(st["steps"], 1) * 1e6))
 
-import ctypes
-out = (ctypes.c_int64 * 16)()
-ctx.L.bgmm_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-ctx.L.bgmm_debug_prof(ctx.h, out)
-v = list(out)
-tot = (sum(v[:7]) + sum(v[8:12])) or 1
-print("resolver ticks: setup %.1f%% A %.1f%% B %.1f%% C %.1f%% D1 %.1f%% D2 %.1f%% | total ticks %d calls %d ticks/call %.0f" % (
-    *(100.0 * x / tot for x in v[:6]), tot, v[7], tot / max(v[7], 1)))
-
-mv = max(st["moves"], 1)
-print("ticks per mover: A %.0f | B: load+stats %.0f, p %.0f, scan %.0f, columns %.0f, outputs %.0f | C %.0f D1 %.0f pick %.0f" % (
-    v[1] / mv, v[8] / mv, v[9] / mv, v[10] / mv, v[11] / mv, v[2] / mv, v[3] / mv, v[4] / mv, v[5] / mv))
+print("path:", ctx.path_stats())

@@ -1,7 +1,7 @@
 """Soak test of the sequential small-D sweep (kernels_seq.hip: sweep_seq_kernel): default tuning (which
 takes it for D <= 4, full covariance) against the windowed VALU path with the resolver off, over random
 shapes, separations, visiting orders, seating exponents, unassigned points and hand-made state changes.
-A third of the cases run with a small LDS plan (BGMM_SEQ_CAP) so that the kernel hands over to the
+A third of the cases run with a small LDS plan (Context.set_seq_plan) so that the kernel hands over to the
 windowed kernels mid-sweep.  Any difference in the label trajectory is a bug.
     python tools/soak_seq.py [n_cases [seed]]"""
 import os, sys, time
@@ -60,9 +60,8 @@ for case in range(n_cases):
                     c.del_item(i)
                     c.add_item(i, min(lab, c.K))
             if k == 0 and cap:
-                os.environ["BGMM_SEQ_CAP"] = str(cap)
+                c.set_seq_plan(cap)
             c.sweep(u, order, power)
-            os.environ.pop("BGMM_SEQ_CAP", None)
         za, zb = ctxs[0].assignments(), ctxs[1].assignments()
         if not np.array_equal(za, zb):
             dd = np.nonzero(za != zb)[0]
