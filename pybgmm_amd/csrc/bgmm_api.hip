@@ -83,7 +83,7 @@ struct bgmm_ctx {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats2[4] = {0, 0, 0, 0};   // pairs whose quadratic form was executed, frozen-factor windows, their rows, spare
     // frozen-factor windows (kernels_gram.hip): buffers sized for `gcols` columns, re-allocated when the labels outgrow them
-    void *gram_mem[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *gram_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gram_lds = 0;
     bool gram_off = false;           // this context cannot use them (too many labels for the LDS plan)
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
@@ -559,22 +559,20 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
 }
 
 // Buffers and LDS plan of the frozen-factor windows for K labels now (room for the labels a batch of
-// windows may open).  Returns false when the plan does not fit (the classic kernels carry on).
+// windows may open).  Returns false when no plan fits (the classic kernels carry on).
 static bool ensure_gram(bgmm_ctx *c, int K) {
     Dev &d = c->d;
     if (c->gram_off) return false;
-    const int need = K + kGramColSlack;
-    if (d.gcols < need || !c->gram_mem[0]) {
-        int cols = (need + 128 + 7) & ~7;
-        if (cols > d.nslots + kGramColSlack) cols = (d.nslots + kGramColSlack + 7) & ~7;
-        if (cols < need) { c->gram_off = true; return false; }
+    int cols = 0, T = 0, lds = 0;
+    if (!gram_plan_for(K, &cols, &T, &lds)) { c->gram_off = true; return false; }
+    if (d.gcols != cols || !c->gram_mem[0]) {
         (void)hipStreamSynchronize(c->stream);
         for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
-        const size_t sz[7] = {sizeof(double) * (size_t)cols * kGramRows * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
+        const size_t sz[8] = {sizeof(double) * (size_t)cols * kGramRows * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
                               sizeof(double) * (size_t)cols * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
                               sizeof(GramMove) * (size_t)kGramMaxTerms, sizeof(int) * (size_t)kGramMaxTerms,
-                              sizeof(double) * 2 * kGramRows};
-        for (int t = 0; t < 7; ++t)
+                              sizeof(double) * 2 * kGramRows, sizeof(double) * (size_t)cols * 40};
+        for (int t = 0; t < 8; ++t)
             if (hipMalloc(&c->gram_mem[t], sz[t] + 64) != hipSuccess) {
                 for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
                 d.gcols = 0;
@@ -585,16 +583,13 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
         d.glp0 = (double *)c->gram_mem[2]; d.ge0 = (double *)c->gram_mem[3];
         d.gmoves = (GramMove *)c->gram_mem[4]; d.gtouched = (int *)c->gram_mem[5];
         d.gM = (double *)c->gram_mem[6];
+        d.gcc = (double *)c->gram_mem[7];
         d.gcols = cols;
-        // terms the resolver's LDS holds next to the per-column bookkeeping (160 KiB per workgroup)
-        int T = kGramMaxTerms;
-        while (T >= 32 && gram_resolve_lds_bytes(cols, T) > 160 * 1024) T -= 8;
-        if (T < 32) { c->gram_off = true; return false; }
         d.gram_terms = T;
-        c->gram_lds = gram_resolve_lds_bytes(cols, T);
-        gram_configure(d, c->gram_lds);
+        c->gram_lds = lds;
+        gram_configure(d, lds);
     }
-    return K + d.gram_terms / 2 + 2 <= 512;
+    return true;
 }
 
 static int ensure_events(bgmm_ctx *c, size_t n) {
@@ -676,6 +671,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     long long pos = 0;
     int win = c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows;
     double rate = c->last_move_rate;
+    // movers per visit over the last batch of steps (first batch: over the previous sweep): what decides
+    // between the per-mover kernel chain and the frozen-factor windows while the device's running mean
+    // is still catching up with a change of regime
+    double recent_rate = c->last_move_rate;
+    long long batch_pos0 = 0, batch_moves0 = 0;
     bool first_batch = true;               // (sweep_begin has just opened a fresh window at visit 0)
     if (seq_ran) {
         first_batch = false;
@@ -697,16 +697,19 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         // one is planned on what this sweep has shown -- a step queued behind the end of the sweep is a
         // dozen empty launches)
         if (first_batch && Tl > 8) Tl = 8;
-        int T = (int)Tl;
         // Mover-dense stretches (burn-in, overlapping clusters): frozen-factor windows (kernels_gram.hip).
-        // Three launches per window of 64 visits, no per-mover kernel chain.  resolver_mode 3 forces them.
-        bool use_gram = false;
+        // Four launches per window of 64 visits, no per-mover kernel chain.  resolver_mode 3 forces them.
+        bool use_gram = false, gram_possible = false;
         if (d.cov_type == COV_FULL && (c->resolver_mode == 0 || c->resolver_mode == 3) && c->order_is_perm &&
-            c->prune_mode != 2 && d.Dp / 16 <= 8 && true) {
+            c->prune_mode != 2 && d.Dp / 16 <= 8 && (c->resolver_mode == 3 || c->kernel_kind != KERNEL_VALU)) {
             const Ctrl &hc = *c->ctrl_host;
-            const bool dense = c->resolver_mode == 3 || (c->kernel_kind != KERNEL_VALU && hc.ema_run < kGramRun);
+            const bool dense = c->resolver_mode == 3 || hc.ema_run < kGramRun || recent_rate * kGramRun > 1.0;
             if (dense) use_gram = ensure_gram(c, hc.job.K);
+            gram_possible = !c->gram_off;
         }
+        // (the frozen-factor windows take over once the movers prove dense: look again soon)
+        if (gram_possible && rate > 0.0 && Tl > 24) Tl = 24;
+        int T = (int)Tl;
         if (use_gram) {
             const Ctrl &hc = *c->ctrl_host;
             // windows still needed: from the rows a window has consumed on average so far in this sweep
@@ -740,13 +743,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (h.gram_stall) {            // the labels outgrew the columns: larger buffers, or the classic kernels
                 c->ctrl_host->gram_stall = 0;
                 CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
-                if (h.job.K + kGramColSlack > d.gcols) d.gcols = 0;          // (else: only the draw wave's width, re-picked per batch)
-                if (h.job.K + d.gram_terms / 2 + 2 > 512) c->gram_off = true;
+                // (the plan -- columns, terms, the draw wave's width -- is re-picked for the labels there are now)
             }
             if (h.error != 0 || h.job.mode == MODE_DONE) break;
             pos = h.job.pos;
             win = h.win_size > 0 ? h.win_size : win;
             rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
+            if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
+            batch_pos0 = pos; batch_moves0 = h.n_moves;
             continue;
         }
         // the resolver's LDS plan depends on the number of labels: re-planned every chunk
@@ -825,6 +829,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         pos = h.job.pos;
         win = h.win_size > 0 ? h.win_size : win;
         rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
+        if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
+        batch_pos0 = pos; batch_moves0 = h.n_moves;
     }
     c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
     const Ctrl &h = *c->ctrl_host;

@@ -234,6 +234,9 @@ struct Dev {
     // 16 x 16 tiles; gq0[c][r] = |a_c(x_r)|^2; glp0[r][c] / ge0[r][c] = frozen log score / exp(lp0 - M_r)
     double *gC, *gq0, *glp0, *ge0;
     double *gM;                  // [2][64]: the rows' reference points M_r, their new-table weights exp(lp_new - M_r)
+    double *gcc;                 // [gcols][5][8]: per column, for the counts n0-2 .. n0+2 it can reach with up to two terms:
+                                 // {1/k_N0, 1/k_N, k_N/(k_N+1), (v+D)/2, seat + Student-t constant - logdet0/2 - log(k_N0/k_N)/2,
+                                 //  the count, logdet0, -} (kernels_gram.hip: what an update needs besides its loads)
     int gcols;                   // columns allocated (also the leading dimension of glp0 / ge0)
     GramMove *gmoves;            // [kGramMaxTerms]
     int *gtouched;               // [kGramMaxTerms]
@@ -282,7 +285,7 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
 int refresh_lds_bytes(int D);
-int gram_resolve_lds_bytes(int gcols, int terms);
+bool gram_plan_for(int K, int *gcols, int *terms, int *lds);   // LDS plan of the window resolver for K labels
 bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
 void gram_configure(const Dev &d, int resolve_lds);      // per-device kernel attributes (once per context and plan)
 void launch_gram_finish(const Dev &d, hipStream_t st);

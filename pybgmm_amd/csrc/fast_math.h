@@ -58,6 +58,33 @@ FM_HD double fm_log(double x) {
     return dk * ln2_hi - ((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
+// log(1 + f) for -0.28 < f < 0.28 (1 + f inside [sqrt(1/2), sqrt(2)]: the k = 0 branch of the same
+// algorithm, without forming 1 + f -- what the Student-t predictive of a point near a large component asks for)
+FM_HD double fm_log1p_small(double f) {
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double s = fm_div(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return f - (hfsq - s * (hfsq + R));
+}
+
+// 1 / sqrt(x), x positive and normal: hardware estimate + two Newton steps
+FM_HD double fm_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(y, 0.5 * __builtin_fma(-(x * y), y, 1.0), y);
+    y = __builtin_fma(y, 0.5 * __builtin_fma(-(x * y), y, 1.0), y);
+    return y;
+#else
+    return 1.0 / std::sqrt(x);
+#endif
+}
+
 FM_HD double fm_exp(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;

@@ -118,6 +118,23 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
             }
         }
     }
+    // what an update of this column needs besides its loads, for every count two terms can take it to
+    if (threadIdx.x < 5) {
+        const int n0 = col < K ? d.n[s] : 0, nn = n0 + (int)threadIdx.x - 2;
+        const double kN0 = d.k0 + (double)n0, logdet0 = d.sc[s].logdetC;
+        double *g = d.gcc + ((long long)col * 5 + threadIdx.x) * 8;
+        g[0] = 1.0 / kN0; g[6] = logdet0; g[5] = -1.0;
+        if (nn >= 1) {
+            const SlotTab tab = load_slot_tab(d, nn);
+            const double kN = d.k0 + (double)nn;
+            const long long v = d.v0 + nn - d.D + 1;
+            g[1] = 1.0 / kN;
+            g[2] = kN / (kN + 1.0);
+            g[3] = 0.5 * (double)(v + d.D);
+            g[4] = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet0)) - 0.5 * log(kN0 / kN);
+            g[5] = (double)nn;
+        }
+    }
     __syncthreads();
     // Gram tiles (ti, tj), tj >= ti: G[16 ti + i][16 tj + j] = y_{16 ti + i} . y_{16 tj + j}
     double *__restrict__ Cc = d.gC + (long long)col * GR * GR;
@@ -195,65 +212,71 @@ __global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) {
 // LDS plan: etT[T][64] weights of touched columns, wv[T][64] the terms' w vectors; per column / label /
 // term bookkeeping.
 // ------------------------------------------------------------------------------------------
-// One touched column of a move, everything waves 1 / 2 need (one LDS round trip)
+// What wave 0 publishes about a move (one LDS round trip for the update waves).  mode 0: the usual move,
+// the update waves read and write their column's bookkeeping themselves; mode 1: a component was
+// deleted / opened, wave 0 has done the bookkeeping and filled upd[].
 struct GramUpd {
-    int col, sigma, term, tix, base, slot, n_new, prev;
-    double ik, logdet0, logf, pad;
+    int col, sigma, term, base, slot, n_new, prev, eidx;
+    double rcf;                    // prod |D_t|^-1/2 over the column's terms so far
 };
 
 struct GramShared {
     int active, nrows, K0, ncols, cprior, err, event, cur;
-    int upd_n, K, nmoves, pad0;
+    int pub_mode, pub_hcol, pub_pcol, pub_has0, pub_term, upd_n, K, nmoves;
     GramUpd upd[2];
     long long pos0, lik, last_mover;
     double ema_run;
     long long prof[8];
 };
 
-struct GramLds {
-    LDS_AS GramShared *S;
-    lds_f64 etT, wv, rowM, termInvD, colLogdet, colIk, colLogF;
-    lds_i64 mvI;                 // the window's move log (GramMove fields)
-    lds_i32 rowhome, rowhcol, termPrev, colSlot, colN, colTix, colBase, colLab, colLast, labCol, permL;
-    lds_i32 mvSub, mvAdd, mvInit;
+// LDS plan, all offsets compile-time (KC columns, T terms): byte offsets from the start of dynamic LDS
+template <int KC, int T>
+struct GramPlan {
+    static constexpr unsigned oS = 0;
+    static constexpr unsigned oEt = 512;                          // etT[T][64]: weights of a column's current term, per row
+    static constexpr unsigned oWv = oEt + T * GR * 8;             // wv[T][64]: the terms' w vectors
+    static constexpr unsigned oRowM = oWv + T * GR * 8;           // rowM[64]
+    static constexpr unsigned oInvD = oRowM + GR * 8;             // termInvD[T]
+    static constexpr unsigned oRcf = oInvD + T * 8;               // colRCF[KC]
+    static constexpr unsigned oMvI = oRcf + KC * 8;               // move log: data index [64]
+    static constexpr unsigned oRowHome = oMvI + GR * 8;           // [64]
+    static constexpr unsigned oRowHcol = oRowHome + GR * 4;       // [64]
+    static constexpr unsigned oMv = oRowHcol + GR * 4;            // move log: sub slot, add slot, init flag [3][64]
+    static constexpr unsigned oTermPrev = oMv + 3 * GR * 4;       // [T]
+    static constexpr unsigned oColSlot = oTermPrev + T * 4;       // per column [KC] ints from here on
+    static constexpr unsigned oColN = oColSlot + KC * 4;
+    static constexpr unsigned oColN0 = oColN + KC * 4;
+    static constexpr unsigned oColBase = oColN0 + KC * 4;
+    static constexpr unsigned oColLab = oColBase + KC * 4;
+    static constexpr unsigned oColLast = oColLab + KC * 4;
+    static constexpr unsigned oLabCol = oColLast + KC * 4;
+    static constexpr unsigned oPermL = oLabCol + KC * 4;
+    static constexpr unsigned bytes = oPermL + KC * 4;
 };
 
-__host__ __device__ inline size_t gram_carve(int Kc, int T, unsigned *o /* 21 offsets or null */) {
-    size_t off = 512;                                   // GramShared
-    unsigned dummy[21];
-    if (!o) o = dummy;
-    int k = 0;
-    auto take = [&](size_t bytes) { o[k++] = (unsigned)off; off += (bytes + 15) & ~(size_t)15; };
-    take(sizeof(double) * (size_t)T * GR);      // 0 etT
-    take(sizeof(double) * (size_t)T * GR);      // 1 wv
-    take(sizeof(double) * GR);                  // 2 rowM
-    take(sizeof(double) * T);                   // 3 termInvD
-    take(sizeof(double) * Kc);                  // 4 colLogdet (of the frozen state)
-    take(sizeof(double) * Kc);                  // 5 colIk
-    take(sizeof(long long) * GR);               // 6 move log: data index
-    take(sizeof(int) * GR);                     // 7 rowhome
-    take(sizeof(int) * GR);                     // 8 rowhcol
-    take(sizeof(int) * T);                      // 9 termPrev
-    take(sizeof(int) * Kc);                     // 10 colSlot
-    take(sizeof(int) * Kc);                     // 11 colN
-    take(sizeof(int) * Kc);                     // 12 colTix
-    take(sizeof(int) * Kc);                     // 13 colBase
-    take(sizeof(int) * Kc);                     // 14 colLab
-    take(sizeof(int) * Kc);                     // 15 colLast
-    take(sizeof(int) * Kc);                     // 16 labCol
-    take(sizeof(int) * Kc);                     // 17 permL
-    take(sizeof(int) * 3 * GR);                 // 18 move log: sub slot, add slot, init flag
-    take(sizeof(double) * Kc);                  // 19 colLogF: log(det S_N now / det S_N frozen) of the column
-    return off;
-}
+// the two plans the host chooses between (columns, terms)
+static constexpr int kPlanA_KC = 448, kPlanA_T = 128;      // up to ~250 labels
+static constexpr int kPlanB_KC = 1024, kPlanB_T = 64;      // up to ~440 labels
+static_assert(GramPlan<kPlanA_KC, kPlanA_T>::bytes <= 160 * 1024, "plan A exceeds the LDS of a CU");
+static_assert(GramPlan<kPlanB_KC, kPlanB_T>::bytes <= 160 * 1024, "plan B exceeds the LDS of a CU");
 
-int gram_resolve_lds_bytes(int gcols, int terms) { return (int)gram_carve(gcols, terms, nullptr); }
+bool gram_plan_for(int K, int *gcols, int *terms, int *lds) {
+    if (K + kPlanA_T / 2 + 2 + 128 <= kPlanA_KC) { *gcols = kPlanA_KC; *terms = kPlanA_T; *lds = (int)GramPlan<kPlanA_KC, kPlanA_T>::bytes; return true; }
+    if (K + kPlanB_T / 2 + 2 + 32 <= 512) { *gcols = kPlanB_KC; *terms = kPlanB_T; *lds = (int)GramPlan<kPlanB_KC, kPlanB_T>::bytes; return true; }
+    return false;
+}
 
 __device__ __forceinline__ void gram_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 enum { GEV_DONE = 0, GEV_MOVE = 1, GEV_CUT = 2 };
+
+// base[idx] with a 32-bit element index (the buffers of a window hold far fewer than 2^29 doubles):
+// one scalar base + 32-bit vector offset instead of 64-bit address arithmetic on the chain
+__device__ __forceinline__ double gram_ld(const double *base, unsigned idx) {
+    return *(const double *)((const char *)base + (size_t)(idx << 3));
+}
 
 #define GRT 256
 
@@ -269,33 +292,27 @@ __device__ __forceinline__ long long wv_readlane_i64(long long v, int t) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// LPL: labels per lane of the draw wave (label j = lane * LPL + t); 64 LPL - 1 bounds the labels a
-// window can reach.
-template <int LPL>
-__global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
+// LPL: labels per lane of the draw wave (label j = lane * LPL + t): 64 LPL - 1 bounds the labels a window can
+// reach.  KC / T: the LDS plan (columns, terms; a term's index is also its line of weights).
+template <int LPL, int KC, int T>
+__global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     static_assert(sizeof(GramShared) <= 512, "GramShared has 512 bytes of LDS");
-    GramLds L;
-    const int Kc = d.gcols;
-    {
-        unsigned o[21];
-        gram_carve(Kc, T, o);
-        LDS_AS unsigned char *b = (LDS_AS unsigned char *)lds_raw;
-        L.S = (LDS_AS GramShared *)b;
-        L.etT = (lds_f64)(b + o[0]); L.wv = (lds_f64)(b + o[1]); L.rowM = (lds_f64)(b + o[2]);
-        L.termInvD = (lds_f64)(b + o[3]); L.colLogdet = (lds_f64)(b + o[4]); L.colIk = (lds_f64)(b + o[5]);
-        L.mvI = (lds_i64)(b + o[6]);
-        L.rowhome = (lds_i32)(b + o[7]); L.rowhcol = (lds_i32)(b + o[8]); L.termPrev = (lds_i32)(b + o[9]);
-        L.colSlot = (lds_i32)(b + o[10]); L.colN = (lds_i32)(b + o[11]); L.colTix = (lds_i32)(b + o[12]);
-        L.colBase = (lds_i32)(b + o[13]); L.colLab = (lds_i32)(b + o[14]); L.colLast = (lds_i32)(b + o[15]);
-        L.labCol = (lds_i32)(b + o[16]); L.permL = (lds_i32)(b + o[17]);
-        L.mvSub = (lds_i32)(b + o[18]); L.mvAdd = L.mvSub + GR; L.mvInit = L.mvAdd + GR;
-        L.colLogF = (lds_f64)(b + o[19]);
-    }
-    LDS_AS GramShared &S = *L.S;
+    using P = GramPlan<KC, T>;
+    LDS_AS unsigned char *const lb = (LDS_AS unsigned char *)lds_raw;
+    LDS_AS GramShared &S = *(LDS_AS GramShared *)lb;
+    const lds_f64 etT = (lds_f64)(lb + P::oEt), wvv = (lds_f64)(lb + P::oWv), rowM = (lds_f64)(lb + P::oRowM),
+                  termInvD = (lds_f64)(lb + P::oInvD), colRCF = (lds_f64)(lb + P::oRcf);
+    const lds_i64 mvI = (lds_i64)(lb + P::oMvI);
+    const lds_i32 rowhome = (lds_i32)(lb + P::oRowHome), rowhcol = (lds_i32)(lb + P::oRowHcol),
+                  mvSub = (lds_i32)(lb + P::oMv), mvAdd = mvSub + GR, mvInit = mvAdd + GR,
+                  termPrev = (lds_i32)(lb + P::oTermPrev), colSlot = (lds_i32)(lb + P::oColSlot),
+                  colN = (lds_i32)(lb + P::oColN), colN0 = (lds_i32)(lb + P::oColN0), colBase = (lds_i32)(lb + P::oColBase),
+                  colLab = (lds_i32)(lb + P::oColLab), colLast = (lds_i32)(lb + P::oColLast),
+                  labCol = (lds_i32)(lb + P::oLabCol), permL = (lds_i32)(lb + P::oPermL);
     Ctrl *c = d.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long gld = d.gcols;
+    constexpr unsigned gld = KC;
 #ifdef BGMM_PROFILE
     long long tk = clock64(), tk2;
 #endif
@@ -306,8 +323,8 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
         c->gram_nmoves = 0;
         const Job &j = c->job;
         if (j.mode != MODE_DONE && c->error == 0) {
-            if (j.K + kGramColSlack > d.gcols || j.K + T / 2 + 2 > 64 * LPL) {
-                c->gram_stall = 1;              // more columns than allocated / labels than the draw wave holds
+            if (d.gcols != KC || j.K + kGramColSlack > KC || j.K + T / 2 + 2 > 64 * LPL) {
+                c->gram_stall = 1;              // more columns than the plan / labels than the draw wave holds
             } else {
                 S.active = 1;
                 S.pos0 = j.pos;
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                 S.K0 = j.K; S.K = j.K;
                 S.cprior = j.K;
                 S.ncols = j.K + 1;
-                S.err = 0; S.cur = 0; S.event = GEV_DONE; S.nmoves = 0; S.upd_n = 0;
+                S.err = 0; S.cur = 0; S.event = GEV_DONE; S.nmoves = 0; S.upd_n = 0; S.pub_mode = 0;
                 S.lik = 0;
                 S.ema_run = c->ema_run; S.last_mover = c->last_mover;
                 for (int k = 0; k < 8; ++k) S.prof[k] = 0;
@@ -338,30 +355,27 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
         rw_hcol = rw_home >= 0 ? d.label_of_slot[rw_home] : -1;
         rw_u = d.u[p];
         rw_En = d.gM[GR + lane];
-        L.rowhome[lane] = rw_home;
-        L.rowhcol[lane] = rw_hcol;
-        L.rowM[lane] = d.gM[lane];
+        rowhome[lane] = rw_home;
+        rowhcol[lane] = rw_hcol;
+        rowM[lane] = d.gM[lane];
     }
-    for (int j = tid; j < Kc; j += GRT) {
+    for (int j = tid; j < KC; j += GRT) {
         const int s = j < d.nslots ? d.perm[j] : -1;
-        L.permL[j] = s;
-        L.labCol[j] = j;
-        L.colLab[j] = j < K0 ? j : -1;
-        L.colTix[j] = -1;
-        L.colLast[j] = -1;
-        L.colBase[j] = j <= K0 ? j : K0;
-        L.colLogF[j] = 0.0;
+        permL[j] = s;
+        labCol[j] = j;
+        colLab[j] = j < K0 ? j : -1;
+        colLast[j] = -1;
+        colBase[j] = j <= K0 ? j : K0;
+        colRCF[j] = 1.0;
         if (j < K0) {
             const int n = d.n[s];
-            L.colSlot[j] = s;
-            L.colN[j] = n;
-            L.colLogdet[j] = d.sc[s].logdetC;
-            L.colIk[j] = 1.0 / (d.k0 + (double)n);
+            colSlot[j] = s;
+            colN[j] = n;
+            colN0[j] = n;
         } else {
-            L.colSlot[j] = j == K0 ? d.K_max : -1;
-            L.colN[j] = 0;
-            L.colLogdet[j] = d.sc[d.K_max].logdetC;
-            L.colIk[j] = 1.0 / d.k0;
+            colSlot[j] = j == K0 ? d.K_max : -1;
+            colN[j] = 0;
+            colN0[j] = 0;
         }
     }
     __syncthreads();
@@ -369,44 +383,40 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
 
     int cur = 0;
     // ---- wave 0's registers ------------------------------------------------------------------
-    int K = K0, ntix = 0, nterms = 0, nmoves = 0, mapver = 0, ncols = K0 + 1;
+    int K = K0, nterms = 0, nmoves = 0, mapver = 0, ncols = K0 + 1;
     long long lik = 0, last_mover = S.last_mover;
     double ema_run = S.ema_run;
-    int cls[LPL], tix[LPL], my_ver = -1;       // column / LDS line of the lane's labels lane * LPL + t
+    int cls[LPL], tix[LPL], my_ver = -1;       // column / current term (= LDS line) of the lane's labels lane * LPL + t
     double pf[LPL];                            // frozen weights of visit pf_row, fetched a visit ahead under the label map pf_ver
     int pf_row = -1, pf_ver = -2;
     // the pre-drawn visit pr_row: cumulative weight through each of the lane's labels, with the columns
-    // pr_x0 / pr_x1 (being updated by waves 1 / 2 meanwhile) left out
-    double pc[LPL], pr_tot = 0.0;
-    int pr_row = -1, pr_ver = -2, pr_x0 = -1, pr_x1 = -1, pr_lab0 = 0x7fffffff, pr_lab1 = 0x7fffffff, pr_tix0 = 0, pr_tix1 = 0;
+    // pr_x0 / pr_x1 (being updated by waves 1 / 2 meanwhile) left out; pm0 / pm1: 1.0 where the label
+    // lies at or behind pr_x0 / pr_x1
+    double pc[LPL], pm0[LPL], pm1[LPL], pr_tot = 0.0;
+    int pr_row = -1, pr_ver = -2, pr_x0 = -1, pr_x1 = -1, pr_tix0 = 0, pr_tix1 = 0;
 #pragma unroll
-    for (int t = 0; t < LPL; ++t) { cls[t] = 0; tix[t] = -1; pf[t] = 0.0; pc[t] = 0.0; }
-    // housekeeping a move leaves for the time the update waves work (lanes 0 / 1: one column each)
-    int hk = 0, hk_col = 0, hk_tix = 0, hk_term = 0, hk_prev = 0, hk_n = 0, hk_act = 0, hk_h = -1, hk_hcol = -1, hk_pcol = -1,
-        hk_dslot = -1, hk_t0x = 0, hk_t1x = 0, hk_has0 = 0;
+    for (int t = 0; t < LPL; ++t) { cls[t] = 0; tix[t] = -1; pf[t] = 0.0; pc[t] = 0.0; pm0[t] = 0.0; pm1[t] = 0.0; }
+    // what a move leaves for the time the update waves work
+    int hk = 0, hk_h = -1, hk_hcol = -1, hk_pcol = -1, hk_t0 = 0, hk_t1 = 0, hk_has0 = 0;
     long long hk_i = 0;
     // ---- wave 1's registers: the home side of the next visit, fetched ahead ----------------------
-    int hp_base = -1, hp_r = -1, hp_n = -1;
+    int hp_base = -1, hp_r = -1;
     double hp_crow = 0.0, hp_cd0 = 0.0;
-    SlotTab hp_tab = {};
-#ifdef BGMM_PROFILE
-    long long pq[5] = {0, 0, 0, 0, 0};
-#endif
 
     // Everything of visit r that does not depend on the columns x0 / x1: the lane's cumulative weights.
     // Needs the label cache (cls, tix) and the frozen weights pf of visit r; fetches those of visit r + 1.
     auto pre_draw = [&](int r, int x0, int x1, int tx0, int tx1) {
         double ev_l[LPL];
 #pragma unroll
-        for (int t = 0; t < LPL; ++t) ev_l[t] = L.etT[(tix[t] < 0 ? 0 : tix[t]) * GR + r];
+        for (int t = 0; t < LPL; ++t) ev_l[t] = etT[(tix[t] < 0 ? 0 : tix[t]) * GR + r];
         const double En = wv_readlane(rw_En, r);
-        pr_lab0 = x0 >= 0 ? L.colLab[x0] : 0x7fffffff;
-        pr_lab1 = x1 >= 0 ? L.colLab[x1] : 0x7fffffff;
+        const int lab0 = x0 >= 0 ? colLab[x0] : 0x7fffffff;
+        const int lab1 = x1 >= 0 ? colLab[x1] : 0x7fffffff;
         double pfn[LPL];
         {
-            const long long rn = r + 1 < nrows ? r + 1 : r;
+            const unsigned rn = r + 1 < nrows ? r + 1 : r;
 #pragma unroll
-            for (int t = 0; t < LPL; ++t) pfn[t] = d.ge0[rn * gld + cls[t]];
+            for (int t = 0; t < LPL; ++t) pfn[t] = gram_ld(d.ge0, rn * gld + (unsigned)cls[t]);
         }
         double run = 0.0;
 #pragma unroll
@@ -421,7 +431,12 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
         pr_tot = wv_readlane(incl, 63);
         const double off = incl - run;
 #pragma unroll
-        for (int t = 0; t < LPL; ++t) { pc[t] += off; pf[t] = pfn[t]; }
+        for (int t = 0; t < LPL; ++t) {
+            const int j = lane * LPL + t;
+            pc[t] += off; pf[t] = pfn[t];
+            pm0[t] = j >= lab0 ? 1.0 : 0.0;
+            pm1[t] = j >= lab1 ? 1.0 : 0.0;
+        }
         pf_row = r + 1; pf_ver = mapver;
         pr_row = r; pr_ver = mapver; pr_x0 = x0; pr_x1 = x1; pr_tix0 = tx0; pr_tix1 = tx1;
     };
@@ -439,28 +454,30 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
 #pragma unroll
                     for (int t = 0; t < LPL; ++t) {
                         const int j = lane * LPL + t;
-                        cls[t] = j < K ? L.labCol[j] : 0;
-                        tix[t] = j < K ? L.colTix[cls[t]] : -1;
+                        cls[t] = j < K ? labCol[j] : 0;
+                        tix[t] = j < K ? colLast[cls[t]] : -1;
                     }
                     my_ver = mapver;
                 }
-                const int nh = h >= 0 ? L.colN[hcol] : 0;
+                // (the count is read here, behind the barrier: the update waves have written it)
+                const int nh = h >= 0 ? colN[hcol] : 0;
+                const double a0 = pr_x0 >= 0 ? etT[pr_tix0 * GR + r] : 0.0;     // the two columns rewritten meanwhile
+                const double a1 = pr_x1 >= 0 ? etT[pr_tix1 * GR + r] : 0.0;
                 const bool home_live = nh >= 2, singleton = nh == 1;
                 const int Lr = singleton ? K - 1 : K;                // labels after the removal
                 int pick = Lr, pcol = -1;                             // fallback: the last entry (utils.py:20)
                 bool bad_tot = false;
                 if (!singleton) {
+                    double b0 = a0, b1 = a1;
                     if (!(pr_row == r && pr_ver == mapver)) {
                         if (!(pf_row == r && pf_ver == mapver)) {        // (first visit, or the map changed)
 #pragma unroll
-                            for (int t = 0; t < LPL; ++t) pf[t] = d.ge0[r * gld + cls[t]];
+                            for (int t = 0; t < LPL; ++t) pf[t] = gram_ld(d.ge0, (unsigned)r * gld + (unsigned)cls[t]);
                         }
                         pre_draw(r, -1, -1, 0, 0);
+                        b0 = 0.0; b1 = 0.0;
                     }
-                    // the two columns the update waves have just rewritten
-                    const double a0 = pr_x0 >= 0 ? L.etT[pr_tix0 * GR + r] : 0.0;
-                    const double a1 = pr_x1 >= 0 ? L.etT[pr_tix1 * GR + r] : 0.0;
-                    const double tot = pr_tot + (a0 + a1);
+                    const double tot = pr_tot + (b0 + b1);
                     bad_tot = !(tot > 1e-200 && tot < 1e200);            // M_r went stale: a fresh window
                     const double ut = u * tot;
                     int hit = 0x7fffffff, hitcol = -1;
@@ -468,7 +485,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                     for (int t = LPL - 1; t >= 0; --t) {
                         // (descending: the first label whose cumulative weight exceeds u wins)
                         const int j = lane * LPL + t;
-                        const double ct = pc[t] + ((j >= pr_lab0 ? a0 : 0.0) + (j >= pr_lab1 ? a1 : 0.0));
+                        const double ct = fma(pm1[t], b1, fma(pm0[t], b0, pc[t]));
                         const bool ok = j <= K && (ut - ct) < 0.0;
                         hit = ok ? j : hit;
                         hitcol = ok ? (j < K ? cls[t] : -1) : hitcol;
@@ -481,7 +498,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                     }
                 } else {
                     // (rare) the home is a singleton: its label's place is taken by the last label (swap with last)
-                    const int lab_h = L.colLab[hcol];
+                    const int lab_h = colLab[hcol];
                     const double En = wv_readlane(rw_En, r);
                     double e[LPL];
                     int ecol[LPL];
@@ -491,9 +508,9 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                         double v = 0.0;
                         int cl = 0;
                         if (j < Lr) {
-                            cl = L.labCol[j == lab_h ? K - 1 : j];
-                            const int tx = L.colTix[cl];
-                            v = tx >= 0 ? L.etT[tx * GR + r] : d.ge0[r * gld + cl];
+                            cl = labCol[j == lab_h ? K - 1 : j];
+                            const int tx = colLast[cl];
+                            v = tx >= 0 ? etT[tx * GR + r] : gram_ld(d.ge0, (unsigned)r * gld + (unsigned)cl);
                         } else if (j == Lr) {
                             v = En;
                         }
@@ -522,63 +539,41 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                         pick = __builtin_amdgcn_readlane(hit, fl);
                         pcol = __builtin_amdgcn_readlane(hitcol, fl);
                     }
-                    pr_row = -1;
                 }
+                pr_row = -1;
                 GPROF(1);
                 if (bad_tot) { ev = GEV_CUT; break; }
                 const bool stay = home_live && pick < Lr && pcol == hcol;
                 if (stay) { lik += K; continue; }
                 if (nterms + 2 > T) { ev = GEV_CUT; break; }
                 ev = GEV_MOVE;
-                const long long i_mv = wv_readlane_i64(rw_i, r);
-                const long long p = pos0 + r;
-                ema_run = ema_after_mover(ema_run, (double)(p - last_mover));
-                last_mover = p;
                 if (!singleton && pick < K) {
-                    // ---- the usual move: lane 0 = the column x leaves, lane 1 = the column it joins.  Before
-                    // the barrier only what the update waves need; the rest while they work. ----
-                    const bool has0 = h >= 0;
-                    const int mycol = (lane == 0 && has0) ? hcol : pcol;
-                    const int ctix = L.colTix[mycol], clast = L.colLast[mycol], cbase = L.colBase[mycol];
-                    const int cn = L.colN[mycol], cslot = L.colSlot[mycol];
-                    const double cik = L.colIk[mycol], cld = L.colLogdet[mycol], cf = L.colLogF[mycol];
-                    const int sg = lane == 0 ? -1 : 1;
-                    const int need = ctix < 0 ? 1 : 0;
-                    const int need0 = has0 ? __builtin_amdgcn_readlane(need, 0) : 0;
-                    const int need1 = __builtin_amdgcn_readlane(need, 1);
-                    const int my_tix = ctix >= 0 ? ctix : (lane == 0 ? ntix : ntix + need0);
-                    const int my_term = lane == 0 ? nterms : nterms + (has0 ? 1 : 0);
-                    const int my_k = lane == 0 ? 0 : (has0 ? 1 : 0);
-                    const bool actl = (lane == 0 && has0) || lane == 1;
-                    if (actl) {
-                        S.upd[my_k].col = mycol; S.upd[my_k].sigma = sg; S.upd[my_k].term = my_term; S.upd[my_k].tix = my_tix;
-                        S.upd[my_k].base = cbase; S.upd[my_k].slot = cslot; S.upd[my_k].n_new = cn + sg; S.upd[my_k].prev = clast;
-                        S.upd[my_k].ik = cik; S.upd[my_k].logdet0 = cld; S.upd[my_k].logf = cf;
+                    // ---- the usual move: published in two stores; the update waves look after their columns ----
+                    const int has0 = h >= 0 ? 1 : 0;
+                    if (lane == 0) {
+                        S.pub_mode = 0; S.pub_hcol = hcol; S.pub_pcol = pcol; S.pub_has0 = has0; S.pub_term = nterms;
+                        S.upd_n = 1 + has0;
                     }
-                    if (lane == 0) S.upd_n = has0 ? 2 : 1;
-                    hk = 1; hk_col = mycol; hk_tix = my_tix; hk_term = my_term; hk_prev = clast; hk_n = cn + sg; hk_act = actl ? 1 : 0;
-                    hk_h = h; hk_hcol = hcol; hk_pcol = pcol; hk_i = i_mv; hk_has0 = has0 ? 1 : 0;
-                    hk_dslot = __builtin_amdgcn_readlane(cslot, 1);
-                    hk_t0x = __builtin_amdgcn_readlane(my_tix, 0); hk_t1x = __builtin_amdgcn_readlane(my_tix, 1);
-                    ntix += need0 + need1;
-                    nterms += has0 ? 2 : 1;
-                    lik += K;
+                    hk = 1; hk_h = h; hk_hcol = hcol; hk_pcol = pcol; hk_has0 = has0;
+                    hk_t0 = nterms; hk_t1 = nterms + has0;
+                    nterms += 1 + has0;
                 } else {
                     // ---- (rare) a component is deleted and / or opened: lane 0, step by step ----
-                    int Kn = K, Krem = K, nu = 0, sub_slot = -1, add_slot = -1, add_init = 0, nt = nterms, nx = ntix, nc = ncols, err = 0;
+                    const long long i_mv = wv_readlane_i64(rw_i, r);
+                    int Kn = K, Krem = K, nu = 0, sub_slot = -1, add_slot = -1, add_init = 0, nt = nterms, nc = ncols, err = 0;
                     if (lane == 0) {
                         if (h >= 0) {
                             const int n1 = nh - 1;
-                            L.colN[hcol] = n1;
+                            colN[hcol] = n1;
                             if (n1 > 0) {
                                 sub_slot = h;
                                 S.upd[nu].col = hcol; S.upd[nu].sigma = -1; S.upd[nu].slot = h; S.upd[nu].n_new = n1; ++nu;
                             } else {                    // swap-with-last delete of its label (gaussian_components.py:188-205)
-                                const int lab = L.colLab[hcol], last = Kn - 1;
-                                const int c_last = L.labCol[last], s_last = L.permL[last];
-                                L.labCol[lab] = c_last; L.permL[lab] = s_last; L.colLab[c_last] = lab;
-                                L.labCol[last] = hcol; L.permL[last] = h; L.colLab[hcol] = -1;
-                                L.colSlot[hcol] = -1;       // retired: the slot may come back in a new column
+                                const int lab = colLab[hcol], last = Kn - 1;
+                                const int c_last = labCol[last], s_last = permL[last];
+                                labCol[lab] = c_last; permL[lab] = s_last; colLab[c_last] = lab;
+                                labCol[last] = hcol; permL[last] = h; colLab[hcol] = -1;
+                                colSlot[hcol] = -1;       // retired: the slot may come back in a new column
                                 d.perm[lab] = s_last; d.label_of_slot[s_last] = lab;
                                 d.perm[last] = h; d.label_of_slot[h] = last;
                                 d.n[h] = 0;
@@ -588,15 +583,15 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                         Krem = Kn;                       // labels the draw chose among
                         int dcol = -1;
                         if (pick >= Kn) {                // a new component
-                            if (Kn >= d.K_max || nc >= Kc) {
+                            if (Kn >= d.K_max || nc >= KC) {
                                 err = -3;
                             } else {
-                                const int t = L.permL[Kn];
+                                const int t = permL[Kn];
                                 dcol = nc++;
-                                L.colSlot[dcol] = t; L.colN[dcol] = 0; L.colBase[dcol] = cprior;
-                                L.colLogdet[dcol] = L.colLogdet[cprior]; L.colIk[dcol] = L.colIk[cprior]; L.colLogF[dcol] = 0.0;
-                                L.colTix[dcol] = -1; L.colLast[dcol] = -1;
-                                L.colLab[dcol] = Kn; L.labCol[Kn] = dcol;
+                                colSlot[dcol] = t; colN[dcol] = 0; colBase[dcol] = cprior;
+                                colN0[dcol] = 0; colRCF[dcol] = 1.0;
+                                colLast[dcol] = -1;
+                                colLab[dcol] = Kn; labCol[Kn] = dcol;
                                 d.label_of_slot[t] = Kn;
                                 d.nupd[t] = 0;
                                 add_init = 1;
@@ -606,34 +601,37 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
                             dcol = pcol;
                         }
                         if (dcol >= 0) {
-                            const int nn = L.colN[dcol] + 1;
-                            L.colN[dcol] = nn;
-                            add_slot = L.colSlot[dcol];
+                            const int nn = colN[dcol] + 1;
+                            colN[dcol] = nn;
+                            add_slot = colSlot[dcol];
                             S.upd[nu].col = dcol; S.upd[nu].sigma = 1; S.upd[nu].slot = add_slot; S.upd[nu].n_new = nn; ++nu;
                         }
                         for (int k = 0; k < nu; ++k) {
                             const int cl = S.upd[k].col;
-                            int tx = L.colTix[cl];
-                            if (tx < 0) { tx = nx++; L.colTix[cl] = tx; }
                             const int t = nt++;
-                            const int prev = L.colLast[cl];
-                            S.upd[k].tix = tx; S.upd[k].term = t; S.upd[k].prev = prev;
-                            S.upd[k].base = L.colBase[cl]; S.upd[k].ik = L.colIk[cl]; S.upd[k].logdet0 = L.colLogdet[cl];
-                            S.upd[k].logf = L.colLogF[cl];
-                            L.termPrev[t] = prev;
-                            L.colLast[cl] = t;
+                            const int prev = colLast[cl];
+                            S.upd[k].term = t; S.upd[k].prev = prev;
+                            S.upd[k].base = colBase[cl];
+                            const int ee = S.upd[k].n_new - colN0[cl] + 2;
+                            S.upd[k].eidx = (ee >= 0 && ee <= 4 && S.upd[k].n_new >= 1) ? ee : -1;
+                            S.upd[k].rcf = colRCF[cl];
+                            termPrev[t] = prev;
+                            colLast[cl] = t;
                         }
                         S.upd_n = nu;
+                        S.pub_mode = 1;
                         if (err) S.err = err;
-                        L.mvI[nmoves] = i_mv; L.mvSub[nmoves] = sub_slot; L.mvAdd[nmoves] = add_slot; L.mvInit[nmoves] = add_init;
+                        mvI[nmoves] = i_mv; mvSub[nmoves] = sub_slot; mvAdd[nmoves] = add_slot; mvInit[nmoves] = add_init;
                     }
                     K = __builtin_amdgcn_readlane(Kn, 0);
                     nterms = __builtin_amdgcn_readlane(nt, 0);
-                    ntix = __builtin_amdgcn_readlane(nx, 0);
                     ncols = __builtin_amdgcn_readlane(nc, 0);
                     nmoves += 1;
                     lik += __builtin_amdgcn_readlane(Krem, 0);
                     mapver += 1;                    // (labels and lines are re-read from LDS at the next draw)
+                    const long long p = pos0 + r;
+                    ema_run = ema_after_mover(ema_run, (double)(p - last_mover));
+                    last_mover = p;
                 }
                 break;
             }
@@ -651,124 +649,128 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
         if (wave == 0) {
             if (hk) {
                 // ---- what the move leaves to do, while the update waves work ----------------------
-                if (hk_act) {
-                    L.colN[hk_col] = hk_n;
-                    L.colTix[hk_col] = hk_tix;
-                    L.colLast[hk_col] = hk_term;
-                    L.termPrev[hk_term] = hk_prev;
-                }
 #pragma unroll
                 for (int t = 0; t < LPL; ++t) {
-                    tix[t] = (hk_has0 && cls[t] == hk_hcol) ? hk_t0x : tix[t];
-                    tix[t] = cls[t] == hk_pcol ? hk_t1x : tix[t];
+                    tix[t] = (hk_has0 && cls[t] == hk_hcol) ? hk_t0 : tix[t];
+                    tix[t] = cls[t] == hk_pcol ? hk_t1 : tix[t];
                 }
+                const long long p = pos0 + cur;
+                ema_run = ema_after_mover(ema_run, (double)(p - last_mover));
+                last_mover = p;
+                lik += K;
+                hk_i = wv_readlane_i64(rw_i, cur);
                 if (lane == 0) {
-                    L.mvI[nmoves] = hk_i; L.mvSub[nmoves] = hk_has0 ? hk_h : -1; L.mvAdd[nmoves] = hk_dslot; L.mvInit[nmoves] = 0;
+                    mvI[nmoves] = hk_i; mvSub[nmoves] = hk_has0 ? hk_h : -1; mvAdd[nmoves] = colSlot[hk_pcol]; mvInit[nmoves] = 0;
                 }
                 nmoves += 1;
-                // the next visit, without the two columns in the making
+                // the next visit, without the two columns in the making (a singleton home is found out behind the barrier)
                 const int rn = cur + 1;
-                if (rn < nrows && pf_row == rn && pf_ver == mapver) {
-                    const int hn = __builtin_amdgcn_readlane(rw_home, rn), hcn = __builtin_amdgcn_readlane(rw_hcol, rn);
-                    const int nhn = hn >= 0 ? L.colN[hcn] : 0;
-                    if (nhn != 1) pre_draw(rn, hk_has0 ? hk_hcol : -1, hk_pcol, hk_t0x, hk_t1x);
-                }
+                if (rn < nrows && pf_row == rn && pf_ver == mapver)
+                    pre_draw(rn, hk_has0 ? hk_hcol : -1, hk_pcol, hk_t0, hk_t1);
             }
             GPROF(5);
-        } else if ((wave == 1 || wave == 2) && wave - 1 < S.upd_n) {
+        } else if ((wave == 1 || wave == 2) && (S.pub_mode == 0 ? (wave == 2 || S.pub_has0) : wave - 1 < S.upd_n)) {
             // ---- one touched column: the new term and the column's weights for the later rows ----
-            const int k = wave - 1;
-            const int cl = S.upd[k].col, sg = S.upd[k].sigma, t = S.upd[k].term, tix_c = S.upd[k].tix;
-            const int base = S.upd[k].base, slot = S.upd[k].slot, prev0 = S.upd[k].prev;
-            const int n_new = __builtin_amdgcn_readfirstlane(S.upd[k].n_new);
-            const double ik = S.upd[k].ik, logdet0 = S.upd[k].logdet0, logf_old = S.upd[k].logf;
+            // (mode 0: wave 1 = the column x leaves, wave 2 = the column it joins)
+            const int mode = S.pub_mode;
             const int r = cur;
+            int cl, sg, t, base, slot, n_new, prev0, eidx;
+            double rcf_old;
+            if (mode == 0) {
+                const int k = wave - 1;
+                cl = k == 0 ? S.pub_hcol : S.pub_pcol;
+                sg = k == 0 ? -1 : 1;
+                t = S.pub_term + (k == 1 ? S.pub_has0 : 0);
+                prev0 = colLast[cl];
+                base = __builtin_amdgcn_readfirstlane(colBase[cl]);
+                const int n_old = colN[cl], n0 = colN0[cl];
+                slot = colSlot[cl];
+                rcf_old = colRCF[cl];
+                n_new = __builtin_amdgcn_readfirstlane(n_old + sg);
+                const int ee = n_new - n0 + 2;
+                eidx = __builtin_amdgcn_readfirstlane((ee >= 0 && ee <= 4 && n_new >= 1) ? ee : -1);
+            } else {
+                const int k = wave - 1;
+                cl = S.upd[k].col; sg = S.upd[k].sigma; t = S.upd[k].term; slot = S.upd[k].slot; prev0 = S.upd[k].prev;
+                base = __builtin_amdgcn_readfirstlane(S.upd[k].base);
+                n_new = __builtin_amdgcn_readfirstlane(S.upd[k].n_new);
+                eidx = __builtin_amdgcn_readfirstlane(S.upd[k].eidx);
+                rcf_old = S.upd[k].rcf;
+            }
             const bool act = lane >= r && lane < nrows;
             const int lrow = act ? lane : r;
+            // the row of the cross forms, the diagonal, the column's constants for its new count: one round trip
             double crow, cd0;
             if (wave == 1 && hp_base == base && hp_r == r) {
                 crow = hp_crow; cd0 = hp_cd0;
             } else {
-                crow = d.gC[((long long)base * GR + r) * GR + lrow];
-                cd0 = d.gq0[(long long)base * GR + lrow];
+                crow = gram_ld(d.gC, ((unsigned)base * GR + (unsigned)r) * GR + (unsigned)lrow);
+                cd0 = gram_ld(d.gq0, (unsigned)base * GR + (unsigned)lrow);
             }
-            const SlotTab tab = (wave == 1 && hp_n == n_new) ? hp_tab : load_slot_tab(d, n_new);
-#ifdef BGMM_PROFILE
-            if (k == 1 && lane == 0) { tk2 = clock64(); pq[0] += tk2 - tk; }
-#endif
-            const double rowM = L.rowM[lrow];
-            const bool own = L.rowhome[lrow] == slot && n_new >= 2;
-            // what depends on the count alone (Student-t constants of gaussian_components.py:228-251)
-            const double Dd = (double)d.D;
+            const double *__restrict__ cc = d.gcc + ((unsigned)base * 5 + (unsigned)(eidx >= 0 ? eidx : 2)) * 8;
+            const double ik0 = cc[0], c_ikn = cc[1], c_icv = cc[2], c_hv = cc[3], c_cb = cc[4], logdet0 = cc[6];
+            const double rM = rowM[lrow];
+            const bool own = rowhome[lrow] == slot && n_new >= 2;
             const double kN_new = d.k0 + (double)n_new;
-            const long long v = d.v0 + n_new - d.D + 1;
-            const double ikn = fm_div(1.0, kN_new);
-            const double inv_cv = fm_div(kN_new, kN_new + 1.0);
-            const double hv = 0.5 * (double)(v + d.D);
-            const double log_ratio = fm_log(1.0 - (double)sg * ikn);          // log(k_N before / k_N now)
-            const double cb = tab.seat + (tab.g - 0.5 * (Dd * tab.lc + logdet0)) - 0.5 * (logf_old + log_ratio) - rowM;
-            double acc = crow + ik, cdv = cd0 + ik;
-#ifdef BGMM_PROFILE
-            if (k == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) { tk2 = clock64(); pq[1] += tk2 - tk; } }
-#endif
-            for (int tt = prev0; tt >= 0; tt = L.termPrev[tt]) {
-                const double wr = L.wv[tt * GR + r], wl = L.wv[tt * GR + lrow], id = L.termInvD[tt];
+            double ikn = c_ikn, inv_cv = c_icv, hv = c_hv, cbase = c_cb;
+            if (eidx < 0) {
+                // (rare) a count further from the frozen one than the prepared constants reach
+                const SlotTab tab = load_slot_tab(d, n_new);
+                const long long v = d.v0 + n_new - d.D + 1;
+                ikn = fm_div(1.0, kN_new);
+                inv_cv = fm_div(kN_new, kN_new + 1.0);
+                hv = 0.5 * (double)(v + d.D);
+                cbase = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet0)) - 0.5 * log(fm_div(1.0, ik0 * kN_new));
+            }
+            double acc = crow + ik0, cdv = cd0 + ik0;
+            for (int tt = prev0; tt >= 0; tt = termPrev[tt]) {
+                const double wr = wvv[tt * GR + r], wl = wvv[tt * GR + lrow], id = termInvD[tt];
                 acc = fma(-(wl * wr), id, acc);
                 cdv = fma(-(wl * wl), id, cdv);
             }
-            // c_t(y, y) = cdv - acc^2 / Dt;  1 + q inv_cv = (Dt (1 + (cdv - 1/k_N) inv_cv) - acc^2 inv_cv) / Dt
-            const double wrr = wv_readlane(acc, r);
-            const double Dt = (double)sg + wrr;
-            const double aD = fabs(Dt);                                 // sigma Dt = 1 + sigma c_{t-1}(x, x) > 0
-            const double base1 = fma(cdv - ikn, inv_cv, 1.0);
-            const double numer = fabs(fma(Dt, base1, -(acc * acc) * inv_cv));
-#ifdef BGMM_PROFILE
-            if (k == 1 && lane == 0) { tk2 = clock64(); pq[2] += tk2 - tk; }
-#endif
-            const double lD = fm_log(aD), lN = fm_log(numer);
-#ifdef BGMM_PROFILE
-            if (k == 1 && lane == 0 && lN != 12345.0) { tk2 = clock64(); pq[3] += tk2 - tk; }
-#endif
-            double ee = fm_exp(cb + ((hv - 0.5) * lD - hv * lN));
-#ifdef BGMM_PROFILE
-            if (k == 1 && lane == 0 && ee != 12345.0) { tk2 = clock64(); pq[4] += tk2 - tk; }
-#endif
+            // c_t(y, y) = cdv - acc^2 / D_t,  D_t = sigma + c_{t-1}(x, x);  det S_N now = det S_N (frozen) k_N0 / k_N prod |D_t|
+            const double Dt = (double)sg + wv_readlane(acc, r);
             const double invD = fm_div(1.0, Dt);
+            const double qv = fma(-(acc * acc), invD, cdv) - ikn;        // quadratic form of the predictive
+            const double f = qv * inv_cv;
+            const double rcf_new = rcf_old * fm_rsqrt(fabs(Dt));
+            const bool fsmall = fabs(f) < 0.28;
+            const double l1 = __builtin_amdgcn_ballot_w64(!fsmall) == 0 ? fm_log1p_small(f) : fm_log(1.0 + f);
+            double ee = fm_exp((cbase - rM) - hv * l1) * rcf_new;
             const unsigned long long mown = __ballot(own && act && lane > r);
             if (mown) {
                 // (rare) rows whose home this column is: the visited point removed from it (slot_math.h, home form)
-                const double ct = fma(-(acc * acc), invD, cdv);
-                const double qv = ct - ikn;
+                const SlotTab tab = load_slot_tab(d, n_new);
+                const long long v = d.v0 + n_new - d.D + 1;
                 const double a1 = fm_div(kN_new, kN_new - 1.0);
                 const double den = 1.0 - a1 * qv;
                 const double hv1 = 0.5 * (double)(v - 1 + d.D);
-                const double cb1 = tab.seat1 + (tab.g1 - 0.5 * (Dd * tab.lc1 + logdet0)) - 0.5 * (logf_old + log_ratio + lD) - rowM;
+                const double logdet_now = logdet0 - log(ik0 * kN_new * (rcf_new * rcf_new));
+                const double cb1 = tab.seat1 + (tab.g1 - 0.5 * ((double)d.D * tab.lc1 + logdet_now)) - rM;
                 const double e1 = fm_exp(cb1 - 0.5 * fm_log(den) - hv1 * fm_log(1.0 + fm_div(a1 * qv, den)));
                 ee = own ? e1 : ee;
             }
-            if (act && lane > r) L.etT[tix_c * GR + lane] = ee;
-            L.wv[t * GR + lane] = act ? acc : 0.0;
+            if (act && lane > r) etT[t * GR + lane] = ee;
+            wvv[t * GR + lane] = act ? acc : 0.0;
             if (lane == 0) {
-                L.termInvD[t] = invD;
-                L.colLogF[cl] = logf_old + log_ratio + lD;
-                if (!((double)sg * Dt > 0.0) || !(lD == lD)) S.err = -4;
+                termInvD[t] = invD;
+                colRCF[cl] = rcf_new;
+                if (mode == 0) { termPrev[t] = prev0; colLast[cl] = t; colN[cl] = n_new; }
+                if (!((double)sg * Dt > 0.0) || !(rcf_new > 0.0)) S.err = -4;
             }
             if (wave == 1 && r + 1 < nrows) {
-                // the home side of the next visit (its column is known; wasted if that visit stays; the
-                // count is checked against the published one when it is used)
-                const int hc = L.rowhcol[r + 1];
+                // the home side of the next visit (its column is known; wasted if that visit stays)
+                const int hc = rowhcol[r + 1];
                 if (hc >= 0) {
-                    const int hb = L.colBase[hc];
-                    hp_n = __builtin_amdgcn_readfirstlane(L.colN[hc]) - 1;
+                    const int hb = __builtin_amdgcn_readfirstlane(colBase[hc]);
                     hp_base = hb; hp_r = r + 1;
                     const int l2 = (lane >= r + 1 && lane < nrows) ? lane : r + 1;
-                    hp_crow = d.gC[((long long)hb * GR + r + 1) * GR + l2];
-                    hp_cd0 = d.gq0[(long long)hb * GR + l2];
-                    if (hp_n >= 1) hp_tab = load_slot_tab(d, hp_n); else hp_n = -1;
+                    hp_crow = gram_ld(d.gC, ((unsigned)hb * GR + (unsigned)(r + 1)) * GR + (unsigned)l2);
+                    hp_cd0 = gram_ld(d.gq0, (unsigned)hb * GR + (unsigned)l2);
                 }
             }
 #ifdef BGMM_PROFILE
-            if (lane == 0) { tk2 = clock64(); S.prof[3 + k] += tk2 - tk; }
+            if (lane == 0) { tk2 = clock64(); S.prof[3 + (wave - 1)] += tk2 - tk; }
 #endif
         }
         gram_lds_barrier();
@@ -778,9 +780,6 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
         tk = clock64();
 #endif
     }
-#ifdef BGMM_PROFILE
-    if (wave == 2 && lane == 0) for (int k = 0; k < 5; ++k) c->prof[9 + k] += pq[k];
-#endif
     if (wave == 0 && lane == 0) {
         S.K = K; S.nmoves = nmoves; S.lik = lik; S.ema_run = ema_run; S.last_mover = last_mover; S.ncols = ncols;
     }
@@ -790,14 +789,14 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d, int T) {
     const int consumed = S.event == GEV_MOVE ? S.cur + 1 : S.cur;     // (an error stops behind the visit that raised it)
     for (int k = tid; k < S.nmoves; k += GRT) {
         GramMove mv;
-        mv.i = L.mvI[k]; mv.sub_slot = L.mvSub[k]; mv.add_slot = L.mvAdd[k]; mv.add_init = L.mvInit[k]; mv.pad = 0;
+        mv.i = mvI[k]; mv.sub_slot = mvSub[k]; mv.add_slot = mvAdd[k]; mv.add_init = mvInit[k]; mv.pad = 0;
         d.gmoves[k] = mv;
         d.z[mv.i] = mv.add_slot;
     }
     // counts of every column that changed; the live ones go on the finish kernel's list
     for (int cl = tid; cl < S.ncols; cl += GRT) {
-        if (cl == cprior || L.colTix[cl] < 0 || L.colSlot[cl] < 0) continue;
-        const int s = L.colSlot[cl], n = L.colN[cl];
+        if (cl == cprior || colLast[cl] < 0 || colSlot[cl] < 0) continue;
+        const int s = colSlot[cl], n = colN[cl];
         d.n[s] = n;
         if (n > 0) d.gtouched[atomicAdd(&c->gram_ntouched, 1)] = s;
     }
@@ -846,14 +845,18 @@ static void configure_gram_t() {
         (void)hipFuncSetAttribute((const void *)gram_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
+template <int LPL, int KC, int T>
+static void configure_resolve_t() {
+    (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GramPlan<KC, T>::bytes);
+}
+
 // Kernel attributes are per device: set for the device of the calling context (current device).
 void gram_configure(const Dev &d, int resolve_lds) {
     configure_gram_t<5>(); configure_gram_t<6>(); configure_gram_t<7>(); configure_gram_t<8>();
-    (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, resolve_lds);
-    (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, resolve_lds);
-    (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, resolve_lds);
-    (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, resolve_lds);
-    (void)d;
+    configure_resolve_t<2, kPlanA_KC, kPlanA_T>(); configure_resolve_t<4, kPlanA_KC, kPlanA_T>();
+    configure_resolve_t<6, kPlanA_KC, kPlanA_T>(); configure_resolve_t<8, kPlanB_KC, kPlanB_T>();
+    (void)d; (void)resolve_lds;
 }
 
 // One frozen-factor step: cross forms, weights, the sequential walk, statistics + factors of the touched
@@ -876,10 +879,13 @@ bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
     // labels per lane of the draw wave: the labels a window can reach (room for the components a
     // batch of windows may open before the host looks again: the kernel stalls the step otherwise)
     const int reach = d.gram_K + d.gram_terms / 2 + 2 + 32;
-    if (reach <= 128) hipLaunchKernelGGL(gram_resolve_kernel<2>, dim3(1), dim3(GRT), resolve_lds, st, d, d.gram_terms);
-    else if (reach <= 256) hipLaunchKernelGGL(gram_resolve_kernel<4>, dim3(1), dim3(GRT), resolve_lds, st, d, d.gram_terms);
-    else if (reach <= 384) hipLaunchKernelGGL(gram_resolve_kernel<6>, dim3(1), dim3(GRT), resolve_lds, st, d, d.gram_terms);
-    else hipLaunchKernelGGL(gram_resolve_kernel<8>, dim3(1), dim3(GRT), resolve_lds, st, d, d.gram_terms);
+    if (d.gcols == kPlanA_KC) {
+        if (reach <= 128) hipLaunchKernelGGL((gram_resolve_kernel<2, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+        else if (reach <= 256) hipLaunchKernelGGL((gram_resolve_kernel<4, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+        else hipLaunchKernelGGL((gram_resolve_kernel<6, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+    } else {
+        hipLaunchKernelGGL((gram_resolve_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+    }
     launch_gram_finish(d, st);
     return true;
 }

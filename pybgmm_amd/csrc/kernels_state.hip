@@ -11,6 +11,7 @@
 // separately so that the statistics stay bit-identical to numpy's.
 #include "bgmm_device.h"
 #include "slot_math.h"
+#include "refresh_blocked.h"
 
 #define TPB 256
 
@@ -101,8 +102,11 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
 // LDS: W[D][D+1] + 6 D + 4 doubles.
 // ------------------------------------------------------------------------------------------
 int refresh_lds_bytes(int D) {
-    const int full = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double), diag = 2 * 256 * (int)sizeof(double);
-    return full > diag ? full : diag;
+    const int Dp = (D + 15) / 16 * 16;
+    const int rank1 = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double), diag = 2 * 256 * (int)sizeof(double);
+    const int blocked = refresh_blocked_lds_doubles(Dp) * (int)sizeof(double);
+    int v = rank1 > diag ? rank1 : diag;
+    return v > blocked ? v : blocked;
 }
 
 __device__ void refresh_slot(const Dev &d, int s, double *sm) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
-    else refresh_slot(d, s, sm);
+    else refresh_slot_blocked(d, s, sm);
 }
 
 // From-scratch rebuild of every live slot that has taken rank-1 steps since its last rebuild.  Run
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
     const int s = d.perm[blockIdx.x];
     if (d.nupd[s] == 0) return;
     if (threadIdx.x == 0) { d.ctrl->tables_valid = 0; atomicAdd((unsigned long long *)&d.ctrl->state_epoch, 1ull); }   // (means and bounds change; the homes do not)
-    refresh_slot(d, s, sm);
+    refresh_slot_blocked(d, s, sm);
 }
 
 __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
-    else if (kind == REFRESH_SCRATCH) refresh_slot(d, s, sm);
+    else if (kind == REFRESH_SCRATCH) refresh_slot_blocked(d, s, sm);
     else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
 
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
         }
     }
     __syncthreads();
-    refresh_slot(d, s, sm);
+    refresh_slot_blocked(d, s, sm);
 }
 
 void launch_gram_finish(const Dev &d, hipStream_t st) {
