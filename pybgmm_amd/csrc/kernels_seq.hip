@@ -534,6 +534,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
         sc.A1 = C[5 * cap]; sc.half_vd1 = C[6 * cap]; sc.coef1 = C[7 * cap]; sc.a1 = C[8 * cap];
         sc.logdetC = C[9 * cap]; sc.inv_lam = C[10 * cap]; sc.mu2 = C[11 * cap];
         d.sc[s] = sc;
+        for (int a = DD; a < d.Dp; ++a) d.cvec[(long long)s * d.Dp + a] = 0.0;   // (the MFMA-shaped kernels read all Dp entries)
 #pragma unroll
         for (int a = 0; a < DD; ++a) {
             const double mv = F[(Ly::OM + a) * cap + j];
