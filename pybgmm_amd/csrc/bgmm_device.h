@@ -255,6 +255,19 @@ __host__ __device__ inline bool job_is_pruned(const Dev &d, int mode, int prune_
 
 __host__ __device__ inline int bgmm_nfrag(int Dp) { int nJ = Dp / 16; return 2 * nJ * (nJ + 1); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT DEVICE only: what a launcher has
+// already asked for is remembered per device (contexts on different GPUs of one process are independent).
+struct PerDeviceLds {
+    int have[64] = {};
+    bool raise(int lds) {               // true: the attribute must be (re)set on the current device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (lds <= have[dev]) return false;
+        have[dev] = lds;
+        return true;
+    }
+};
+
 // ---- host-side launchers (each defined next to its kernels) -------------------------------
 void launch_init_stats(const Dev &d, const int *members, const long long *offsets, int K_init,
                        hipStream_t st);

@@ -303,10 +303,8 @@ void launch_choice(const Dev &d, long long max_rows, hipStream_t st) {
     const int R = d.choice_rows;
     const unsigned gx = (unsigned)((max_rows + R - 1) / R);
     const int lds = (d.K_max + 2) * R * (int)sizeof(double);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    static PerDeviceLds attr;
+    if (lds > 64 * 1024 && attr.raise(lds))
         (void)hipFuncSetAttribute((const void *)choice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(choice_kernel, dim3(gx), dim3(64 * R), lds, st, d);
 }

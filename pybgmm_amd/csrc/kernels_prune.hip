@@ -669,11 +669,9 @@ static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
     const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (176 + d.keep_stride)) * (int)sizeof(double);
     auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
-    static int attr_lds = 0;
-    if (lds > 64 * 1024 && lds > attr_lds) {
+    static PerDeviceLds attr;
+    if (lds > 64 * 1024 && attr.raise(lds))
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
-    }
     hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }
 

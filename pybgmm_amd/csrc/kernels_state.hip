@@ -194,8 +194,8 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
 
-static void ensure_lds(const void *fn, int bytes) {
-    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+static void ensure_lds(const void *fn, int bytes, PerDeviceLds &attr) {
+    if (bytes > 64 * 1024 && attr.raise(bytes)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // Frozen-factor windows (kernels_gram.hip), last kernel of a step: block b brings slot gtouched[b] up to
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
 
 void launch_gram_finish(const Dev &d, hipStream_t st) {
     const int lds = refresh_lds_bytes(d.D);
-    (void)hipFuncSetAttribute((const void *)gram_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static PerDeviceLds attr;
+    ensure_lds((const void *)gram_finish_kernel, lds, attr);
     hipLaunchKernelGGL(gram_finish_kernel, dim3(kGramMaxTerms), dim3(TPB), lds, st, d);
 }
 
@@ -238,20 +239,23 @@ void launch_gram_finish(const Dev &d, hipStream_t st) {
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) {
     if (n <= 0) return;
     const int lds = refresh_lds_bytes(d.D);
-    ensure_lds((const void *)refresh_list_kernel, lds);
+    static PerDeviceLds attr;
+    ensure_lds((const void *)refresh_list_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_list_kernel, dim3(n), dim3(TPB), lds, st, d, slots, n);
 }
 
 void launch_refresh_stale(const Dev &d, int K, hipStream_t st) {
     if (K <= 0) return;
     const int lds = refresh_lds_bytes(d.D);
-    ensure_lds((const void *)refresh_stale_kernel, lds);
+    static PerDeviceLds attr;
+    ensure_lds((const void *)refresh_stale_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_stale_kernel, dim3(K), dim3(TPB), lds, st, d);
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
     const int lds = refresh_lds_bytes(d.D);
-    ensure_lds((const void *)refresh_ctrl_kernel, lds);
+    static PerDeviceLds attr;
+    ensure_lds((const void *)refresh_ctrl_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
 }
 
