@@ -6,21 +6,36 @@ bench.py -- collapsed-Gibbs sweeps/s of the CRP Gaussian mixture on MI355X.
   (N > 1: launched by torch.distributed.run, one rank per GPU, one independent chain per rank)
 
 A "step" is one full Gibbs sweep (N_data reassignment visits) of BASELINE.json's headline
-configuration, configs[3]: CRPMM, D=64, N=1e6, K~200, synthetic isotropic mixture
-(SURVEY.md 8d recipe), chain initialised at the true labelling (the steady-state regime the
-reference CPU numbers in BASELINE.md were taken in).  Inputs (X, the per-visit uniforms of all
-timed sweeps) are resident in HBM before the timed region; the PCIe-inclusive rate is reported
-separately in `extra`.  The chains are replicas: no data-path collective; one RCCL
-all-gather of the final labels after the timed region.
+configuration, configs[3]: CRPMM, D=64, N=1e6, K~200, synthetic isotropic mixture (SURVEY.md 8d
+recipe).  Inputs (X, the per-visit uniforms of all timed sweeps) are resident in HBM before the timed
+region; the PCIe-inclusive rate is reported separately in `extra`.  The chains are replicas
+(SURVEY.md 8e): no data-path collective; one RCCL all-gather of the final labels after the timed region.
 
+What `value` measures (--mode):
+  evaluated (default)  the chain at the truth, every visit EVALUATED every sweep: its row of X is read,
+                       the predictive under its own component computed exactly (v_mfma_f64), every other
+                       component excluded by an exact bound -- score_mfma_prune_kernel.  Certified stays
+                       (visits proven to stay from cached state, X untouched) are OFF: that shortcut
+                       makes the sweep a memo lookup on well separated data and is reported in `extra` only.
+  certified            the library's default configuration (certified stays on)
+  full                 every (visit, component) pair through the full quadratic form -- score_mfma_kernel
 The JSON line also carries
-  roofline     -- the likelihood (score) kernel, timed with HIP events on the library's stream
+  roofline     -- the dominant likelihood kernel of the timed mode, its launches timed with HIP events on the
+                  library's stream inside this run; `traffic` from rocprofv3 --pmc passes of this same
+                  script (FETCH_SIZE, WRITE_SIZE, separate passes) run as child processes
+  burnin       -- the mover-dense regime: the same workload from the reference's default "rand"
+                  initialisation (igmm.py:86-94), sweep by sweep until fewer than 1 % of the visits move
   cpu_baseline -- the C oracle (a port of the reference algorithm, 1 thread) on a bounded sample
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,14 +50,26 @@ WORKLOADS = {
     "C2": (100000, 2, 20, "CRPMM"),
     "C5": (2000000, 128, 200, "PCRPMM"),
 }
+MODES = {"evaluated": 3, "certified": 0, "full": 1}     # -> prune_mode of bgmm_set_tuning
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense FP64 matrix peak (spec); see DESIGN.md section 4
-SUSTAINED_FP64_MFMA_TFLOPS = 49.0 # pure v_mfma_f64_16x16x4 loop measured on the box (tools/mfma_f64_peak.hip)
 PEAK_HBM_GBPS = 8000.0
+REFERENCE_US_PER_VISIT = {"C4": 802.0, "C3": 209.0, "C2": 220.0}   # BASELINE.md, measured in the survey container
 
 
-def flops_per_lik_eval(D):
-    """per (visit, component) work of the predictive: 2D^2 + 3D + 12."""
-    return 2.0 * D * D + 3.0 * D + 12.0
+def survey_bytes_per_visit(D):
+    """algorithmic HBM bytes of one visit (row of X, uniform, prior score, label in + out)."""
+    return 8.0 * D + 24.0
+
+
+def survey_flops_per_visit(D, K):
+    """K (2 D^2 + 3 D + 12) + 4 D^2 (the reference's two einsums against a dense inverse)."""
+    return K * (2.0 * D * D + 3.0 * D + 12.0) + 4.0 * D * D
+
+
+def kernel_flops_per_pair(D):
+    """This library's formulation of one (visit, component) pair: y = cvec - Winv x through the lower
+    triangle (D (D + 1) flop), q = |y|^2 (2 D), the Student-t tail (~ D + 12)."""
+    return D * (D + 1.0) + 3.0 * D + 12.0
 
 
 def prior_for(cov, D):
@@ -75,25 +102,142 @@ def cpu_baseline(D, K, seed, budget_visits, cov="full"):
     return dt / budget_visits, n_cpu, t_init, int(o.lik_evals.value)
 
 
+def make_context(args, X, z0, local_rank, mode):
+    from pybgmm_amd import _lib
+    from pybgmm_amd.gaussian.gaussian_components import reference_tables
+    N, D, K, _ = WORKLOADS[args.workload]
+    m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, device=local_rank,
+                       tables=reference_tables(v_0, N) if args.cov != "fixed" else None, cov_type=args.cov)
+    ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
+                   prune_mode=MODES[mode])
+    ctx.set_assignments(z0)
+    return ctx
+
+
+def heavy_kernel_name(args, mode, D):
+    if args.cov != "full":
+        return "score_diag_kernel" if mode == "full" else "score_diag_prune_kernel"
+    mfma = args.kernel == 2 or (args.kernel == 0 and D >= 12)
+    if mode == "full":
+        return "score_mfma_kernel" if mfma else "score_valu_kernel"
+    return "score_mfma_prune_kernel"
+
+
+def pmc_traffic(args, mode, kernel_name, timeout_s=240):
+    """HBM bytes per working launch of `kernel_name`, measured NOW: two child runs of this script under
+    rocprofv3 --pmc (FETCH_SIZE; WRITE_SIZE -- they do not fit one pass), as MI355X_MICROARCH.md
+    prescribes; FETCH_SIZE doubled for gfx950.  None when rocprofv3 is missing or a pass fails."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="bgmm_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--inner-pmc", "--workload", args.workload, "--mode", mode,
+               "--cov", args.cov, "--kernel", str(args.kernel), "--seed", str(args.seed)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=timeout_s)
+        except Exception as e:       # noqa: BLE001 (timeout, missing binary ...)
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, "rocprofv3 pass failed: %r" % (e,)
+        hits = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        vals = []
+        if hits:
+            with open(hits[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Kernel_Name"].split("(")[0].split("<")[0].split(" ")[-1] != kernel_name:
+                        continue
+                    if row["Counter_Name"] != counter:
+                        continue
+                    dur_us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
+                    vals.append((float(row["Counter_Value"]), dur_us))
+        shutil.rmtree(tmp, ignore_errors=True)
+        if not vals:
+            return None, "no %s rows for %s (rc %d)" % (counter, kernel_name, r.returncode)
+        longest = max(v[1] for v in vals)
+        work = [v[0] for v in vals if v[1] >= 0.5 * longest]       # (the launches that did a whole window)
+        out[counter] = sum(work) / len(work)
+    # counters are in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950
+    return int(1024 * (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"])), \
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this script, FETCH_SIZE x 2 for gfx950"
+
+
+def inner_pmc(args):
+    """Child of pmc_traffic: set the workload up and run a few sweeps in the requested mode."""
+    from pybgmm_amd.utils import gendata
+    N, D, K, model = WORKLOADS[args.workload]
+    X, z_true = gendata.synth_mixture(N, D, K, seed=args.seed)
+    rs = np.random.RandomState(1000 + args.seed)
+    ctx = make_context(args, X, z_true, 0, args.mode)
+    for it in range(3):
+        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
+        ctx.sweep(rs.random_sample(N), order, 1.01 if (model == "PCRPMM" and it > 0) else None)
+    ctx.close()
+
+
+def burnin_leg(args, X, local_rank, K_true, seed):
+    """The same data from the reference's default initialisation ("rand": uniform labels over K, igmm.py:86-94),
+    swept until fewer than 1 % of the visits move (at most 6 sweeps)."""
+    N, D, K, model = WORKLOADS[args.workload]
+    rs = np.random.RandomState(7000 + seed)
+    z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    ctx = make_context(args, X, z0, local_rank, "certified")          # the library's default configuration
+    sweeps = []
+    until = None
+    for it in range(6):
+        u = rs.random_sample(N)
+        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
+        power = 1.01 if (model == "PCRPMM" and it > 0) else None
+        ctx.stage(u, order)
+        ctx.synchronize()
+        t0 = time.time()
+        ctx.sweep_staged(power)
+        ctx.synchronize()
+        dt = time.time() - t0
+        st, ps = ctx.sweep_stats(), ctx.path_stats()
+        sweeps.append({"seconds": round(dt, 4), "moves": st["moves"], "K": ctx.K,
+                       "frozen_factor_windows": ps["frozen_windows"],
+                       "us_per_move": round(dt * 1e6 / max(st["moves"], 1), 3)})
+        if st["moves"] < 0.01 * N:
+            until = it + 1
+            break
+    lm = ctx.log_marg()
+    ctx.close()
+    first = sweeps[0]
+    ref = REFERENCE_US_PER_VISIT.get(args.workload)
+    return {"init": "rand (K=%d)" % K, "first_sweep_s": first["seconds"], "first_sweep_moves": first["moves"],
+            "first_sweep_us_per_move": first["us_per_move"],
+            "sweeps_until_moves_below_1pct": until, "sweeps": sweeps, "log_marg_after": lm,
+            "reference_python_first_sweep_s": round(ref * N * 1e-6, 1) if ref else None,
+            "speedup_over_reference_python": round(ref * N * 1e-6 / first["seconds"], 1) if ref else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="evaluated", choices=sorted(MODES))
     ap.add_argument("--init", default="true", choices=["true", "rand"])
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 VALU, 2 MFMA")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--prune", type=int, default=0,
-                    help="0 auto (exact pruning + certified stays), 1 off, 3 pruning without certified stays")
-    ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 off, 2 always")
-    ap.add_argument("--cpu-visits", type=int, default=20000,
-                    help="visits of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 per-mover kernels, 2 in-launch resolver, 3 frozen-factor windows")
+    ap.add_argument("--cpu-visits", type=int, default=20000, help="visits of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cov", default="full", choices=["full", "diag", "fixed"],
                     help="covariance_type (diag / fixed: SURVEY 8f rows, not BASELINE configs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-burnin", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true")
+    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.inner_pmc:
+        inner_pmc(args)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,14 +250,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
-    from pybgmm_amd import _lib
     from pybgmm_amd.chains import gather_chains
-    from pybgmm_amd.gaussian.gaussian_components import reference_tables
     from pybgmm_amd.utils import gendata
 
     N, D, K, model = WORKLOADS[args.workload]
     X, z_true = gendata.synth_mixture(N, D, K, seed=args.seed)          # replicated data set
-    m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
     n_sweeps = args.warmup + args.steps
     # chain c: its own uniform (and permutation) streams, seeds seed + c
     rs = np.random.RandomState(1000 + args.seed + rank)
@@ -123,17 +264,10 @@ def main():
     if model == "PCRPMM":
         order_all = np.stack([rs.permutation(N) for _ in range(n_sweeps)]).astype(np.int64)
         power = 1.01
-    if args.init == "true":
-        z0 = z_true
-    else:
-        z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    z0 = z_true if args.init == "true" else np.unique(rs.randint(0, K, N), return_inverse=True)[1]
 
     t0 = time.time()
-    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, device=local_rank,
-                       tables=reference_tables(v_0, N) if args.cov != "fixed" else None, cov_type=args.cov)
-    ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
-                   prune_mode=args.prune)
-    ctx.set_assignments(z0)
+    ctx = make_context(args, X, z0, local_rank, args.mode)
     t_setup = time.time() - t0
     t0 = time.time()
     ctx.upload_streams(u_all, order_all)
@@ -153,11 +287,12 @@ def main():
         ctx.sweep_resident(it, sweep_power(it))
     barrier()
     t0 = time.time()
-    lik = moves = 0
+    decided = executed = moves = 0
     for it in range(args.warmup, n_sweeps):
         ctx.sweep_resident(it, sweep_power(it))
         st = ctx.sweep_stats()
-        lik += st["lik_evals"]
+        decided += st["lik_evals"]
+        executed += ctx.path_stats()["pairs_executed"]
         moves += st["moves"]
     barrier()
     elapsed = time.time() - t0
@@ -165,187 +300,159 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(lik), float(moves)], dtype=torch.float64, device="cuda")
+        agg = torch.tensor([float(decided), float(executed), float(moves)], dtype=torch.float64, device="cuda")
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        lik_total, moves_total = float(agg[0].item()), float(agg[1].item())
+        decided_total, executed_total, moves_total = (float(v) for v in agg.tolist())
     else:
-        lik_total, moves_total = float(lik), float(moves)
+        decided_total, executed_total, moves_total = float(decided), float(executed), float(moves)
     last_stats = ctx.sweep_stats()
-    last_stats.update({"certified_visits": ctx.prune_stats()["certified_visits"]})
+    last_stats.update({"certified_visits": ctx.prune_stats()["certified_visits"],
+                       "pairs_executed": ctx.path_stats()["pairs_executed"]})
     log_marg = ctx.log_marg()
     K_final = ctx.K
 
-    # --- likelihood-kernel roofline: one more sweep with HIP events around every launch ---
-    def kernel_roofline(prune_mode):
-        """One extra sweep with the likelihood kernel bracketed by HIP events (on the library's
-        stream).  prune_mode 0 = as benchmarked, 1 = force the full evaluation of every pair."""
+    def set_mode(mode):
         ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
-                       prune_mode=prune_mode)
+                       prune_mode=MODES[mode])
+
+    def kernel_roofline(mode):
+        """One extra sweep in `mode` with every launch of its dominant likelihood kernel bracketed by HIP
+        events on the library's stream."""
+        set_mode(mode)
         ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))          # settle the window policy
         ctx.set_kernel_timing(True)
         ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
         n_launch, ms = ctx.kernel_timing()
-        st = ctx.sweep_stats()
+        st, ps, pa = ctx.sweep_stats(), ctx.prune_stats(), ctx.path_stats()
         ctx.set_kernel_timing(False)
         if n_launch <= 0 or ms <= 0:
             return None
-        if args.cov != "full" and st["bound_blocks"] == 0 and ctx.prune_stats()["certified_visits"] == 0:
-            # D logarithms per (visit, component): an FP64 VALU / transcendental kernel, no MFMA
-            logs = st["scored"] * float(D)
-            return {"kernel": "score_diag_kernel", "bound": "valu-transcendental",
-                    "achieved": round(logs / (ms * 1e-3) / 1e9, 2), "peak": None, "unit": "Glog/s",
-                    "frac": None, "traffic": None, "launches": n_launch,
-                    "avg_launch_ms": round(ms / n_launch, 4),
-                    "lik_evals_per_launch": round(st["scored"] / n_launch, 1),
-                    "note": "covariance_type=%s is a SURVEY 8f row, not a BASELINE config" % args.cov}
-        flops = st["scored"] * flops_per_lik_eval(D)
-        achieved = flops / (ms * 1e-3) / 1e12
-        is_mfma = (args.kernel == 2 or (args.kernel == 0 and D >= 12)) and args.cov == "full"
-        nJ = (D + 15) // 16
-        # flops the kernel really issues per evaluation: block-lower-triangular MFMA tiles
-        # (2 nJ (nJ+1) tiles of 16x16x4 per 16 rows), or the exact triangle on the VALU path
-        exec_per_eval = (2 * nJ * (nJ + 1) * 2048.0 / 16.0) if is_mfma else (D * (D + 1) + 2.0 * D)
-        ps = ctx.prune_stats()
-        pruning = bool(st["bound_blocks"] > 0 or ps["certified_visits"] > 0)
-        # per (visit, component) in this library's formulation: y = cvec - Winv x through the lower
-        # triangle (D (D + 1) flop), q = |y|^2 (2 D), the Student-t tail (~ D + 12)
-        flops_kernel_alg = D * (D + 1.0) + 3.0 * D + 12.0
-        hbm = st["scored"] / max(K_final, 1) * (8.0 * D + 24.0) / (ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch_pruned" if pruning else "hbm_bytes_per_launch")
-        n_visits_timed = st["scored"] / max(K_final, 1)
-        common = {"traffic": traffic, "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                  "lik_evals_per_launch": round(st["scored"] / n_launch, 1)}
-        if pruning:
-            # Pruned windows (DESIGN.md section 4).  A visit that certify_kernel proves to keep its component
-            # costs 17 B while nothing at all has moved (tier 1: the 16-byte record of the draw kernel's exact
-            # alternative weight, the flag 1) or 61 B after a move somewhere (tier 2: its label, the 32-byte
-            # per-point cache and its prior score on top), and X is not read; any other visit is also
-            # sorted (32-byte record) and streamed once by the pruning kernel: 45 + 32 B and its row and
-            # bookkeeping, 8 D + 24 B, on top.  `achieved` = those bytes / the launch time of the two kernels together;
-            # the same visits priced at SURVEY's 8 D + 24 B each are reported next to it.  The matrix work
-            # still issued (counted in the kernel, 2048 flop per instruction) and what the same decisions
-            # would cost without pruning are given as well.
-            n_cert = float(ps["certified_visits"])
-            cert_bytes = 17.0 if st["moves"] == 0 else 61.0
-            need_bytes = n_cert * cert_bytes + (n_visits_timed - n_cert) * (8.0 * D + 24.0 + 77.0)
-            need = need_bytes / (ms * 1e-3) / 1e9
-            executed = ps["mfma_instructions"] * 2048.0 / (ms * 1e-3) / 1e12
-            heavy = "score_mfma_prune_kernel" if args.cov == "full" else "score_diag_prune_kernel"
-            out = {"kernel": ("certify_kernel + " + heavy) if n_cert > 0 else heavy,
-                   "bound": "hbm",
-                   "achieved": round(need, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                   "frac": round(need / PEAK_HBM_GBPS, 4),
-                   "algorithmic_bytes_per_visit": round(need_bytes / max(n_visits_timed, 1), 1),
-                   "survey_bytes_per_visit": 8.0 * D + 24.0,
-                   "survey_equivalent_gbps": round(hbm, 2),
-                   "fraction_of_visits_certified_to_stay": round(n_cert / max(n_visits_timed, 1), 5),
-                   "fraction_scored_in_full": round(st["kept_blocks"] / max(st["bound_blocks"], 1), 5),
-                   "mfma_instructions_per_launch": round(ps["mfma_instructions"] / n_launch, 1),
-                   "mfma_executed_tflops": round(executed, 3),
-                   "mfma_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
-                   "unpruned_equivalent_tflops": round(st["scored"] * flops_kernel_alg / (ms * 1e-3) / 1e12, 2)}
-            out.update(common)
-            if n_cert > 0:
-                out["traffic"] = tj.get("hbm_bytes_per_launch_certified") if traffic is not None else None
-            if args.cov != "full":          # no matrix work on this path; the PMC file is the full-covariance kernel's
-                for key in ("mfma_instructions_per_launch", "mfma_executed_tflops", "mfma_frac_of_spec_peak",
-                            "unpruned_equivalent_tflops"):
-                    out.pop(key)
-                out["traffic"] = None
-            return out
-        alg = st["scored"] * flops_kernel_alg / (ms * 1e-3) / 1e12
-        executed = st["scored"] * exec_per_eval / (ms * 1e-3) / 1e12
-        out = {"kernel": "score_mfma_kernel" if is_mfma else "score_valu_kernel", "bound": "mfma",
-               "achieved": round(alg, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": round(alg / PEAK_FP64_MFMA_TFLOPS, 4),
-               "flops_per_lik_eval": flops_kernel_alg,
-               "executed_tflops_incl_tile_padding": round(executed, 3),
-               "executed_frac_of_spec_peak": round(executed / PEAK_FP64_MFMA_TFLOPS, 4),
-               "executed_frac_of_sustained_mfma": round(executed / SUSTAINED_FP64_MFMA_TFLOPS, 4),
-               "survey_formulation_flops_per_lik_eval": flops_per_lik_eval(D),
-               "survey_formulation_tflops": round(achieved, 3),
-               "hbm_gbps_algorithmic": round(hbm, 2)}
-        out.update(common)
-        return out
+        name = heavy_kernel_name(args, mode, D)
+        visits = float(N)
+        common = {"kernel": name, "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
+                  "visits_per_launch": round(visits / n_launch, 1), "traffic": None}
+        if mode == "full":
+            pairs = float(pa["pairs_executed"])
+            if args.cov != "full":
+                logs = pairs * float(D)
+                common.update({"bound": "valu-transcendental", "achieved": round(logs / (ms * 1e-3) / 1e9, 2),
+                               "peak": None, "unit": "Glog/s", "frac": None})
+                return common
+            alg = pairs * kernel_flops_per_pair(D) / (ms * 1e-3) / 1e12
+            nJ = (D + 15) // 16
+            executed_tf = pairs * (2 * nJ * (nJ + 1) * 2048.0 / 16.0) / (ms * 1e-3) / 1e12
+            common.update({"bound": "mfma", "achieved": round(alg, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(alg / PEAK_FP64_MFMA_TFLOPS, 4),
+                           "flops_per_pair": kernel_flops_per_pair(D),
+                           "flop_formula": "D (D + 1) + 3 D + 12 per (visit, component) pair: the inverse Cholesky "
+                                           "factor's lower triangle, |y|^2, the Student-t tail",
+                           "pairs_per_launch": round(pairs / n_launch, 1),
+                           "executed_tflops_incl_tile_padding": round(executed_tf, 3)})
+            return common
+        # pruned windows: an HBM stream.  Algorithmic bytes = SURVEY 8(d): 8 D + 24 per visit the kernel handles.
+        n_cert = float(ps["certified_visits"])
+        handled = visits - n_cert
+        need = handled * survey_bytes_per_visit(D) / (ms * 1e-3) / 1e9
+        common.update({"bound": "hbm", "achieved": round(need, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                       "frac": round(need / PEAK_HBM_GBPS, 4),
+                       "algorithmic_bytes_per_visit": survey_bytes_per_visit(D),
+                       "visits_through_kernel_per_launch": round(handled / n_launch, 1),
+                       "fraction_of_visits_certified_to_stay": round(n_cert / visits, 5),
+                       "pairs_scored_in_full_per_visit": round(pa["pairs_executed"] / visits, 3),
+                       "mfma_instructions_per_launch": round(ps["mfma_instructions"] / n_launch, 1)})
+        if n_cert > 0:
+            common["kernel"] = "certify_kernel + " + name
+        return common
 
-    roofline = roofline_full = roofline_pruned = None
+    roofline = None
+    rates = {}
+    extra_rooflines = {}
+    single = rank == 0 and n_gpus == 1
     if not args.no_kernel_timing:
-        roofline = kernel_roofline(args.prune)
-        if roofline and roofline["kernel"].endswith("_prune_kernel"):
-            if roofline.get("fraction_of_visits_certified_to_stay", 0) > 0:
-                # the same sweep without certified stays: every visit streamed by the pruning kernel
-                roofline_pruned = kernel_roofline(3)
-            # the same kernel family with pruning off: every (visit, component) pair through the
-            # full quadratic form -- the MFMA-efficiency number
-            roofline_full = kernel_roofline(1)
-        ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
-                       prune_mode=args.prune)
-
-    # --- the same chain with the exact shortcuts switched off, whole sweeps timed the same way ---
-    # (the trajectory is identical in all modes; tests/test_gpu_parity.py, tools/soak.py)
-    by_mode = None
-    # (Replaying a sweep's uniforms is only a fair timing when the chain is at rest: a chain that
-    # moves would mostly stay on the replay.  Mover-dense workloads report the benchmarked rate only.)
-    if rank == 0 and n_gpus == 1 and not args.no_kernel_timing and args.prune == 0 and moves > 0:
-        by_mode = {"as_benchmarked": round(args.steps / elapsed, 2),
-                   "note": "the chain moves: the shortcut-free modes are not timed by replay"}
-    elif rank == 0 and n_gpus == 1 and not args.no_kernel_timing and args.prune == 0:
-        by_mode = {"as_benchmarked": round(args.steps / elapsed, 2)}
-        for name, mode, reps in (("certified_stays_off", 3, 5), ("pruning_off_every_pair_evaluated", 1, 3)):
-            ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
-                           prune_mode=mode)
-            ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+        roofline = kernel_roofline(args.mode)
+        if single and roofline and not args.no_pmc and args.cov == "full":
+            traffic, note = pmc_traffic(args, args.mode, heavy_kernel_name(args, args.mode, D))
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = note
+            if traffic:
+                roofline["traffic_over_algorithmic"] = round(
+                    traffic / (roofline.get("visits_through_kernel_per_launch", roofline["visits_per_launch"])
+                               * survey_bytes_per_visit(D)), 3) if roofline["bound"] == "hbm" else None
+    # --- the same chain in the other modes, whole sweeps timed the same way (identical trajectory in all
+    #     of them: tests/test_gpu_parity.py); only for a chain at rest -- a replayed sweep of a moving chain
+    #     would mostly stay
+    if single and not args.no_kernel_timing and moves_total == 0:
+        for mode, reps in (("evaluated", 5), ("certified", 20), ("full", 3)):
+            if mode == args.mode:
+                rates[mode] = round(args.steps / elapsed, 2)
+                continue
+            set_mode(mode)
+            for _ in range(3):
+                ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
             barrier()
             t0 = time.time()
             for _ in range(reps):
                 ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
             barrier()
-            by_mode[name] = round(reps / (time.time() - t0), 2)
-        ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
-                       prune_mode=args.prune)
+            rates[mode] = round(reps / (time.time() - t0), 2)
+            if mode == "full" or (mode == "evaluated" and args.mode == "certified"):
+                extra_rooflines[mode] = kernel_roofline(mode)
+        set_mode(args.mode)
 
     # --- the one collective: final label gather (RCCL over xGMI), outside the timed region ---
     t0 = time.time()
     z_all, lm_all = gather_chains(ctx.assignments(), np.array([log_marg]),
                                   device=torch.device("cuda", local_rank) if world > 1 else None)
     t_gather = time.time() - t0
+    ctx.close()
+
+    burnin = None
+    if single and not args.no_burnin and args.cov == "full":
+        burnin = burnin_leg(args, X, local_rank, K, args.seed)
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and args.cpu_visits > 0:
+    if single and args.cpu_visits > 0:
         per_visit, n_cpu, t_init, cpu_lik = cpu_baseline(D, K, args.seed + 7, args.cpu_visits, args.cov)
         cpu = {"value": round(1.0 / (per_visit * N), 8), "unit": "sweeps/s", "cores": 1,
                "kind": "port",
-               "sample": "%d visits of one sweep on a N=%d twin (same D=%d, K=%d, prior, init at truth); "
-                         "%.1f us/visit extrapolated to N=%d" % (args.cpu_visits, n_cpu, D, K,
-                                                                 per_visit * 1e6, N),
+               "sample": "%d visits of one sweep on a N=%d twin (same D=%d, K=%d, prior, init at truth), every "
+                         "(visit, component) pair evaluated; %.1f us/visit extrapolated to N=%d"
+                         % (args.cpu_visits, n_cpu, D, K, per_visit * 1e6, N),
                "us_per_visit": round(per_visit * 1e6, 2),
                "lik_evals_per_s": round(cpu_lik / (per_visit * args.cpu_visits), 1),
-               "reference_python_us_per_visit_survey_container": 802.0 if args.workload == "C4" else None}
+               "reference_python_us_per_visit_survey_container": REFERENCE_US_PER_VISIT.get(args.workload)}
 
     if rank == 0:
         sweeps_total = args.steps * n_gpus
         value = sweeps_total / elapsed
+        t_sweep = elapsed / args.steps
         out = {
             "metric": "gibbs_sweeps_per_sec", "value": round(value, 4), "unit": "sweeps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(t_sweep * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s D=%d N=%d K~%d%s, one independent chain per GPU, init=%s"
+            "config": {"workload": "%s: %s D=%d N=%d K~%d%s, one independent chain per GPU, init=%s, mode=%s"
                                    % (args.workload, model, D, N, K,
-                                      " covariance_type=%s" % args.cov if args.cov != "full" else "", args.init),
+                                      " covariance_type=%s" % args.cov if args.cov != "full" else "", args.init,
+                                      args.mode),
                        "parallelism": "replica_chains_x%d" % n_gpus,
-                       "certified_stays": bool(args.prune == 0),
-                       "exact_pruning": bool(args.prune == 0 and (args.cov != "full" or (args.kernel != 1 and (D >= 12 or args.kernel == 2))))},
-            "lik_evals_per_sec": round(lik_total / elapsed, 1),
-            "us_per_visit": round(elapsed / args.steps / N * 1e6, 5),
+                       "mode": args.mode,
+                       "certified_stays": bool(args.mode == "certified"),
+                       "exact_pruning": bool(args.mode != "full")},
+            # pairs whose quadratic form was EXECUTED per second / pairs DECIDED per second (sum over visits of K)
+            "lik_evals_per_sec": round(executed_total / elapsed, 1),
+            "lik_evals_decided_per_sec": round(decided_total / elapsed, 1),
+            "us_per_visit": round(t_sweep / N * 1e6, 5),
+            # SURVEY 8(d): whole-sweep fractions of the two rooflines under ITS accounting
+            "survey_8d": {"bytes_sweep": N * survey_bytes_per_visit(D), "flops_sweep": N * survey_flops_per_visit(D, K),
+                          "hbm_frac": round(N * survey_bytes_per_visit(D) / t_sweep / (PEAK_HBM_GBPS * 1e9), 4),
+                          "fp64_frac": round(N * survey_flops_per_visit(D, K) / t_sweep / (PEAK_FP64_MFMA_TFLOPS * 1e12), 4),
+                          "formula": "bytes_visit = 8 D + 24; flops_visit = K (2 D^2 + 3 D + 12) + 4 D^2 (the reference's "
+                                     "formulation; in mode `evaluated` / `certified` the flops fraction prices pairs that "
+                                     "exact bounds decided without executing them -- only mode `full` executes them all)"},
             "roofline": roofline,
-            "roofline_pruned_evaluation": roofline_pruned,
-            "roofline_full_evaluation": roofline_full,
+            "burnin": burnin,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
                       "K_final": K_final, "log_marg_rank0": log_marg,
@@ -353,14 +460,12 @@ def main():
                       "h2d_streams_s": round(t_h2d, 4),
                       "pcie_inclusive_sweeps_per_s": round(
                           sweeps_total / (elapsed + t_h2d * args.steps / n_sweeps), 4),
-                      "sweeps_per_s_by_mode": by_mode,
+                      "sweeps_per_s_by_mode": rates or None,
+                      "roofline_other_modes": extra_rooflines or None,
                       "label_gather_s": round(t_gather, 4),
                       "gathered_shape": list(z_all.shape)},
         }
-        if cpu:
-            out["extra"]["gpu_over_cpu_port"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
-    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

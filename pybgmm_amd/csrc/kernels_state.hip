@@ -203,25 +203,49 @@ static void ensure_lds(const void *fn, int bytes, PerDeviceLds &attr) {
 // apply_rank1 (bit-identical statistics), then the derived state rebuilt from scratch.
 __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ long long mv_i[kGramMaxTerms];
+    __shared__ int mv_op[kGramMaxTerms];          // 1: x leaves this slot, 2: joins it, 3: joins and opens it
+    __shared__ int n_ops;
     const Ctrl *c = d.ctrl;
     if ((int)blockIdx.x >= c->gram_ntouched) return;
     const int s = d.gtouched[blockIdx.x];
     const int D = d.D, nm = c->gram_nmoves;
+    // this slot's moves, in visiting order (one load per thread, compacted by a ballot scan)
+    if (threadIdx.x == 0) n_ops = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < nm; k0 += TPB) {
+        const int k = k0 + threadIdx.x;
+        int op = 0;
+        long long i = 0;
+        if (k < nm) {
+            const GramMove mv = d.gmoves[k];
+            op = mv.sub_slot == s ? 1 : (mv.add_slot == s ? (mv.add_init ? 3 : 2) : 0);
+            i = mv.i;
+        }
+        // (nm <= 64 moves per window: the first wavefront holds them all, in order)
+        const unsigned long long m = __ballot(op != 0);
+        if (threadIdx.x < 64 && op != 0) {
+            const int pos = n_ops + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            mv_i[pos] = i; mv_op[pos] = op;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) n_ops += __popcll(m);
+        __syncthreads();
+    }
     double *m = d.m + (long long)s * D;
     double *S = d.S + (long long)s * D * D;
-    for (int k = 0; k < nm; ++k) {
-        const GramMove mv = d.gmoves[k];
-        const bool sub = mv.sub_slot == s, add = mv.add_slot == s;
-        if (!sub && !add) continue;                          // (block uniform)
-        const double *__restrict__ x = d.X + mv.i * D;
+    const int nops = n_ops;
+    for (int k = 0; k < nops; ++k) {
+        const int op = mv_op[k];
+        const double *__restrict__ x = d.X + mv_i[k] * D;
         for (int a = threadIdx.x; a < D; a += TPB) {
-            if (sub) m[a] = __dsub_rn(m[a], x[a]);
-            else m[a] = __dadd_rn(mv.add_init ? d.prior_m[a] : m[a], x[a]);
+            if (op == 1) m[a] = __dsub_rn(m[a], x[a]);
+            else m[a] = __dadd_rn(op == 3 ? d.prior_m[a] : m[a], x[a]);
         }
         for (int e = threadIdx.x; e < D * D; e += TPB) {
             const double xx = __dmul_rn(x[e / D], x[e % D]);
-            if (sub) S[e] = __dsub_rn(S[e], xx);
-            else S[e] = __dadd_rn(mv.add_init ? d.prior_S[e] : S[e], xx);
+            if (op == 1) S[e] = __dsub_rn(S[e], xx);
+            else S[e] = __dadd_rn(op == 3 ? d.prior_S[e] : S[e], xx);
         }
     }
     __syncthreads();

@@ -104,6 +104,12 @@ __device__ inline void refresh_slot_blocked(const Dev &d, int s, double *sm) {
     double *Wd = A + Dp * LD;
     double *mu = Wd + nJ * 288, *row = mu + Dp;
     double *scal = row + Dp;                       // [0] logdet, [1] bad flag, [2] Gershgorin bound
+#ifdef BGMM_PROFILE
+    long long rb_t0 = clock64(), rb_t1;
+#define RBPROF(i) do { if (tid == 0 && blockIdx.x == 0) { rb_t1 = clock64(); d.ctrl->prof[i] += rb_t1 - rb_t0; rb_t0 = rb_t1; } } while (0)
+#else
+#define RBPROF(i) do { } while (0)
+#endif
     const double k_N = d.k0 + (double)d.n[s];
     const double *m = d.m + (long long)s * D;
     const double *S = d.S + (long long)s * D * D;
@@ -117,7 +123,9 @@ __device__ inline void refresh_slot_blocked(const Dev &d, int s, double *sm) {
         A[a * LD + b] = v;
     }
     __syncthreads();
+    RBPROF(10);
     gershgorin_bound<256>(A, LD, D, row, &scal[2], tid, true);
+    RBPROF(11);
     double logdet = 0.0;
     bool bad = false;
     for (int J = 0; J < nJ; ++J) {
@@ -146,6 +154,7 @@ __device__ inline void refresh_slot_blocked(const Dev &d, int s, double *sm) {
             }
     }
     __syncthreads();
+    RBPROF(12);
     if (tid == 0) {
         scal[0] = logdet;
         *(int *)&scal[1] = (bad || !(logdet == logdet)) ? 1 : 0;
@@ -191,7 +200,9 @@ __device__ inline void refresh_slot_blocked(const Dev &d, int s, double *sm) {
         }
     }
     __syncthreads();
+    RBPROF(13);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
     write_slot<256>(d, s, A, LD, mu, scal[0], scal[2], tid, nullptr, true);
     if (tid == 0) d.nupd[s] = 0;
+    RBPROF(14);
 }

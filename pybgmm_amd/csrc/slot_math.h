@@ -127,11 +127,16 @@ __device__ inline void write_slot(const Dev &d, int s, const double *W, int ld, 
 template <int NT>
 __device__ inline void gershgorin_bound(const double *A, int ld, int D, double *rowbuf, double *out,
                                         int tid, bool active) {
+    // 4 threads per row (a quad of lanes), partial sums folded with two shuffles
     if (active)
-        for (int i = tid; i < D; i += NT) {
+        for (int i0 = 0; i0 < D; i0 += NT / 4) {
+            const int i = i0 + (tid >> 2), part = tid & 3;
             double sacc = 0.0;
-            for (int j = 0; j < D; ++j) sacc += fabs(j <= i ? A[i * ld + j] : A[j * ld + i]);
-            rowbuf[i] = sacc;
+            if (i < D)
+                for (int j = part; j < D; j += 4) sacc += fabs(j <= i ? A[i * ld + j] : A[j * ld + i]);
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            if (i < D && part == 0) rowbuf[i] = sacc;
         }
     __syncthreads();
     if (active && tid == 0) {

@@ -50,5 +50,5 @@ if any(pc):
     w = max(pc[8], 1)
     print("resolver ticks per window: prologue %.0f  draws %.0f  bookkeeping %.0f  update(home) %.0f  update(dest) %.0f  | windows %d" % (
         pc[0] / w, pc[1] / w, pc[2] / w, pc[3] / w, pc[4] / w, pc[8]))
-    print("  dest update timeline (ticks per window from the barrier): loads issued %.0f, landed %.0f, terms done %.0f, logs done %.0f, exp done %.0f" % tuple(pc[9 + k] / w for k in range(5)))
+    print("  rebuild of a slot (ticks per window, block 0): load + S_N %.0f, Gershgorin %.0f, factorisation %.0f, inverse %.0f, outputs %.0f" % tuple(pc[10 + k] / w for k in range(5)))
     print("  wave 0 behind the barrier (housekeeping + the next visit ahead): %.0f" % (pc[5] / w))
