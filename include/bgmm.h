@@ -137,6 +137,19 @@ int bgmm_add_item(bgmm_ctx *ctx, int64_t i, int32_t k);
 int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
 
 /*
+ * GaussianComponents.restore_component_from_stats (gaussian_components.py:144-152): overwrite the
+ * sufficient statistics of component k (label numbering of bgmm_get_stats) with m_N_numerator[D],
+ * S_N_partial[D*D] (diag: [D]) and count.  The reference also copies the cached logdet / inverse; here
+ * they are rebuilt from the statistics (bit-identical m / S, logdet / inverse to rounding).  Assignments are
+ * not touched -- as in the reference, the caller keeps them consistent (cache, del_item, restore).
+ * Not offered for covariance_type="fixed".
+ */
+int bgmm_set_stats(bgmm_ctx *ctx, int32_t k, const double *m, const double *S, int64_t count);
+/* `components.assignments[i] = k` (igmm/crpmm.py:85): the label of point i alone, no statistics touched
+ * (k = -1: unassigned).  With bgmm_set_stats it completes the reference's cache / del_item / restore idiom. */
+int bgmm_set_label(bgmm_ctx *ctx, int64_t i, int32_t k);
+
+/*
  * Per-sweep clustering metrics of the record dict (gmm/gmm.py:85-104), SURVEY.md 8f rank 2.
  *   bgmm_contingency: table[t * K + k] = #{i : true_idx[i] == t and label(i) == k}, the K_true x K
  *     contingency table from which mutual_information / normalized_mutual_information /

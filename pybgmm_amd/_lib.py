@@ -46,6 +46,8 @@ SIGNATURES = {
     "bgmm_log_post_pred": (ctypes.c_int, [_vp, ctypes.c_int64, _vp]),
     "bgmm_add_item": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32]),
     "bgmm_del_item": (ctypes.c_int, [_vp, ctypes.c_int64]),
+    "bgmm_set_stats": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int64]),
+    "bgmm_set_label": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32]),
     "bgmm_contingency": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, _vp]),
     "bgmm_cluster_dispersion": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
@@ -246,6 +248,15 @@ class Context(object):
 
     def del_item(self, i):
         self._ck(self.L.bgmm_del_item(self.h, int(i)))
+
+    def set_stats(self, k, m, S, count):
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        assert m.shape == (self.D,) and S.shape == ((self.D,) if self.diag else (self.D, self.D))
+        self._ck(self.L.bgmm_set_stats(self.h, int(k), _ptr(m), _ptr(S), int(count)))
+
+    def set_label(self, i, k):
+        self._ck(self.L.bgmm_set_label(self.h, int(i), int(k)))
 
     # -- record-dict metrics --------------------------------------------------
     def contingency(self, true_idx, K_true):

@@ -24,6 +24,8 @@ int choice_rows_for(int K_max);
 void launch_contingency(const Dev &d, const long long *true_idx, int K_true, unsigned long long *table,
                         hipStream_t st);
 void launch_dispersion(const Dev &d, double *out, hipStream_t st);
+void launch_set_stats(const Dev &d, int label, const double *m_in, const double *S_in, int count, hipStream_t st);
+void launch_set_label(const Dev &d, long long i, int label, hipStream_t st);
 void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st);
 void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
                          double *inv_out, hipStream_t st);
@@ -1033,6 +1035,53 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
     c->assigned = true;
     c->moves_prev = -1;          // (the state changed behind the sweeps' back: the next sweep's caches are cold)
     return rc;
+}
+
+extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const double *S, int64_t count) {
+    if (!c || !m || !S) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    if (c->d.cov_type == COV_FIXED) return fail(c, BGMM_EUNSUPPORTED, "bgmm_set_stats: not offered for fixed-variance components");
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
+    if (count < 1 || count > c->d.N) return fail(c, BGMM_EINVAL, "count must be in 1 .. N");
+    const int D = c->d.D;
+    const size_t DD = c->d.cov_type == COV_FULL ? (size_t)D * D : (size_t)D;
+    double *dm = nullptr;
+    CK(c, hipMalloc((void **)&dm, sizeof(double) * (D + DD)));
+    hipError_t e = hipMemcpyAsync(dm, m, sizeof(double) * D, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dm + D, S, sizeof(double) * DD, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_set_stats(c->d, k, dm, dm + D, (int)count, c->stream);
+        launch_refresh_ctrl(c->d, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(dm);
+    CK(c, e);
+    rc = fetch_ctrl(c);
+    if (rc) return rc;
+    rc = check_device_error(c);
+    if (rc) {   // (a matrix that is not positive definite: the flag is cleared, the statistics stay as given)
+        c->ctrl_host->error = 0;
+        (void)hipMemcpy(&c->d.ctrl->error, &c->ctrl_host->error, sizeof(int), hipMemcpyHostToDevice);
+    }
+    c->moves_prev = -1;
+    c->lean_ok = false;
+    return rc;
+}
+
+extern "C" int bgmm_set_label(bgmm_ctx *c, int64_t i, int32_t k) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (k < -1 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
+    launch_set_label(c->d, i, k, c->stream);
+    CK(c, hipStreamSynchronize(c->stream));
+    c->moves_prev = -1;
+    c->lean_ok = false;
+    return 0;
 }
 
 extern "C" int bgmm_add_item(bgmm_ctx *c, int64_t i, int32_t k) { return item_op(c, 1, i, k); }

@@ -844,6 +844,35 @@ __global__ __launch_bounds__(TPB) void item_kernel(Dev d, int op, long long i, i
     if (ok) apply_rank1(d, mp);
 }
 
+// restore_component_from_stats: statistics of label `label` overwritten from device buffers; the slot goes
+// on the refresh list (rebuilt from scratch by the launch behind this one)
+__global__ __launch_bounds__(TPB) void set_stats_kernel(Dev d, int label, const double *__restrict__ m_in,
+                                                        const double *__restrict__ S_in, int count) {
+    Ctrl *c = d.ctrl;
+    const int s = d.perm[label], D = d.D;
+    const int DD = d.cov_type == COV_FULL ? D * D : D;
+    for (int a = threadIdx.x; a < D; a += TPB) d.m[(long long)s * D + a] = m_in[a];
+    for (int e = threadIdx.x; e < DD; e += TPB) d.S[(long long)s * DD + e] = S_in[e];
+    if (threadIdx.x == 0) {
+        d.n[s] = count;
+        c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1;
+        c->n_refresh = 1; c->refresh[0] = s; c->refresh_kind[0] = REFRESH_SCRATCH;
+    }
+}
+
+__global__ void set_label_kernel(Dev d, long long i, int label) {
+    Ctrl *c = d.ctrl;
+    d.z[i] = label < 0 ? -1 : d.perm[label];
+    c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; c->n_refresh = 0;
+}
+void launch_set_label(const Dev &d, long long i, int label, hipStream_t st) {
+    hipLaunchKernelGGL(set_label_kernel, dim3(1), dim3(1), 0, st, d, i, label);
+}
+
+void launch_set_stats(const Dev &d, int label, const double *m_in, const double *S_in, int count, hipStream_t st) {
+    hipLaunchKernelGGL(set_stats_kernel, dim3(1), dim3(TPB), 0, st, d, label, m_in, S_in, count);
+}
+
 void launch_item_op(const Dev &d, int op, long long i, int label, hipStream_t st) {
     hipLaunchKernelGGL(item_kernel, dim3(1), dim3(TPB), 0, st, d, op, i, label);
 }

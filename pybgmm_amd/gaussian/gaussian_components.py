@@ -128,10 +128,16 @@ class GaussianComponents(object):
         m, S, ld, iv = self._ctx.stats(True)
         return (m[k].copy(), S[k].copy(), ld[k], iv[k].copy(), int(self._ctx.counts()[k]))
 
-    def restore_component_from_stats(self, *args, **kwargs):
-        raise NotImplementedError(
-            "component statistics live on the GPU; the sweep kernel keeps a visit that "
-            "stays an exact no-op, so no restore entry point exists")
+    def restore_component_from_stats(self, k, m_N_numerator, S_N_partial, logdet_covar, inv_covar, count):
+        """Restore component ``k`` from statistics taken with ``cache_component_stats``
+        (gaussian_components.py:144-152).  The statistics and the count are written to the GPU as
+        given; ``logdet_covar`` / ``inv_covar`` are rebuilt from them there (``bgmm_set_stats``)."""
+        self._ctx.set_stats(k, m_N_numerator, S_N_partial, count)
+
+    def set_assignment(self, i, k):
+        """``components.assignments[i] = k`` of the reference's sampler loop (crpmm.py:85): the
+        ``assignments`` attribute here is a download, so the write has its own method."""
+        self._ctx.set_label(i, k)
 
     def log_prior(self, i):
         """Probability of ``X[i]`` under the prior alone."""
@@ -151,6 +157,19 @@ class GaussianComponents(object):
         """log p(X | z): sum of the per-component marginals."""
         return float(sum(self._ctx.log_marg_k(k) for k in range(self.K)))
 
+    def map_all(self):
+        """``[map(k) for k in range(K)]`` from ONE download of the statistics (a distribution-dict
+        snapshot asks for every component)."""
+        m, S, _, _ = self._ctx.stats(False)
+        counts = self._ctx.counts()
+        out = []
+        for k in range(len(counts)):
+            k_N = self.prior.k_0 + int(counts[k])
+            v_N = self.prior.v_0 + int(counts[k])
+            m_N = m[k] / k_N
+            out.append((m_N, (S[k] - k_N * np.outer(m_N, m_N)) / (v_N + self.D + 2)))
+        return out
+
     def map(self, k):
         """MAP estimate (mean, covariance) of component ``k`` (Murphy 4.215)."""
         m, S, _, _ = self._ctx.stats(False)
@@ -161,8 +180,22 @@ class GaussianComponents(object):
         sigma = (S[k] - k_N * np.outer(m_N, m_N)) / (v_N + self.D + 2)
         return (m_N, sigma)
 
-    def rand_k(self, k):
-        raise NotImplementedError("posterior parameter draws (plots) are outside the Gibbs hot path")
+    def rand_k(self, k, rng=None, nprng=None):
+        """A random (mean, covariance) from the posterior NIW of component ``k``
+        (gaussian_components.py:291-303): consumes the caller's ``np.random`` / ``random`` streams
+        exactly as the reference does (prior/wishart.py)."""
+        from ..prior import wishart
+        nprng_ = np.random if nprng is None else nprng
+        m, S, _, _ = self._ctx.stats(False)
+        n = int(self._ctx.counts()[k])
+        k_N = self.prior.k_0 + n
+        v_N = self.prior.v_0 + n
+        m_N = m[k] / k_N
+        S_N = S[k] - k_N * np.outer(m_N, m_N)
+        sigma = np.linalg.solve(np.linalg.cholesky(S_N).T, np.eye(self.D))
+        sigma = wishart.iwishrnd(sigma, v_N, sigma, rng=rng, nprng=nprng)
+        mu = nprng_.multivariate_normal(m_N, sigma / k_N)
+        return mu, sigma
 
 
 class GaussianComponentsDiag(GaussianComponents):
@@ -194,3 +227,27 @@ class GaussianComponentsDiag(GaussianComponents):
 
     def map(self, k):
         raise NotImplementedError("the reference's diagonal class has no map()")
+
+    def map_all(self):
+        raise NotImplementedError("the reference's diagonal class has no map()")
+
+    def rand_k(self, k, rng=None, nprng=None):
+        """A random (mean vector, variance vector) from the posterior product of
+        normal-inverse-chi-squared distributions of component ``k``
+        (gaussian_components_diag.py:305-322, 388-400): per dimension one ``np.random.gamma`` and one
+        ``np.random.normal``, in that order.  The reference is Python 2: its ``alpha = df/2`` is an
+        integer division for the integer degrees of freedom it is called with, kept here."""
+        nprng = np.random if nprng is None else nprng
+        m, S, _, _ = self._ctx.stats(False)
+        n = int(self._ctx.counts()[k])
+        k_N = self.prior.k_0 + n
+        v_N = self.prior.v_0 + n
+        m_N = m[k] / k_N
+        S_N = S[k] - k_N * np.square(m_N)
+        mean, var = np.zeros(self.D), np.zeros(self.D)
+        for i in range(self.D):
+            scale = S_N[i] / v_N
+            a = v_N // 2 if float(v_N).is_integer() else v_N / 2
+            var[i] = 1.0 / nprng.gamma(a, 1.0 / (v_N * scale / 2.0), 1)[0]
+            mean[i] = nprng.normal(m_N[i], np.sqrt(var[i] / k_N))
+        return mean, var

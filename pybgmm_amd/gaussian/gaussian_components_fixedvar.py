@@ -82,3 +82,21 @@ class GaussianComponentsFixedVar(GaussianComponents):
 
     def map(self, k):
         raise NotImplementedError("the reference's fixed-variance class has no map()")
+
+    def map_all(self):
+        raise NotImplementedError("the reference's fixed-variance class has no map()")
+
+    def restore_component_from_stats(self, *args, **kwargs):
+        raise NotImplementedError("bgmm_set_stats is not offered for fixed-variance components")
+
+    def rand_k(self, k, rng=None, nprng=None):
+        """A random mean vector from the posterior product of normals of component ``k``
+        (gaussian_components_fixedvar.py:266-276): D draws of ``np.random.normal``."""
+        nprng = np.random if nprng is None else nprng
+        m, pN, _, _ = self._ctx.stats(False)
+        mu_N = m[k] / pN[k]
+        var_N = 1.0 / pN[k]
+        mean = np.zeros(self.D)
+        for i in range(self.D):
+            mean[i] = nprng.normal(mu_N[i], np.sqrt(var_N[i]))
+        return mean

@@ -81,10 +81,8 @@ class IGMM(GMM):
         label-switch ordering (igmm.py:128-197).  The matplotlib output of the
         reference for D == 2 is not produced; the ``np.random`` Dirichlet draw is,
         so the caller-visible stream stays aligned."""
-        K = self.components.K
         means, sds = [], []
-        for k in range(K):
-            mu, sigma = self.components.map(k)
+        for mu, sigma in self.components.map_all():
             means.append(mu)
             sds.append(sigma)
         sds = np.array(sds).flatten()

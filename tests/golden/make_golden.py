@@ -473,7 +473,68 @@ def case_adap():
              true_assignments=z_true)
 
 
+def three_blobs_1d(n_each, seed):
+    """Three well separated 1-D clusters: the chain sits at K = 3, where the reference snapshots
+    its distribution dict (num_saved = 3 is the default of every sampler)."""
+    rs = np.random.RandomState(seed)
+    X = np.concatenate([rs.normal(-6.0, 0.5, n_each), rs.normal(0.0, 0.5, n_each), rs.normal(6.0, 0.5, n_each)])
+    y = np.repeat(np.arange(3), n_each)
+    p = rs.permutation(3 * n_each)
+    return X[p].reshape(-1, 1), y[p]
+
+
+def api_case(name, model, weight_first, seeds, n_iter=25, alpha=0.05):
+    """Class-level fixture: the whole public path with the distribution dict ON (num_saved == K,
+    reference igmm/igmm.py:128-197, crpmm.py:49-50), then rand_k of every component
+    (gaussian_components.py:291-303, prior/wishart.py:16-32), then a few draws from both global
+    streams -- what the caller would see next."""
+    from pybgmm.igmm import CRPMM, PCRPMM
+    from pybgmm.prior import NIW
+    X, y = three_blobs_1d(50, seeds[0] + 100)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(1)
+    random.seed(seeds[0])
+    np.random.seed(seeds[1])
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    mm = cls(X, NIW(m_0, k_0, v_0, S_0), alpha, None, assignments="rand", K=3, K_max=40)
+    record, dist = mm.collapsed_gibbs_sampler(n_iter, y, num_saved=3, weight_first=weight_first)
+    K = mm.components.K
+    rk_mu, rk_sigma = [], []
+    for k in range(K):
+        mu, sigma = mm.components.rand_k(k)
+        rk_mu.append(np.asarray(mu, dtype=np.float64).ravel())
+        rk_sigma.append(np.asarray(sigma, dtype=np.float64).ravel())
+    after_random = np.array([random.random() for _ in range(4)])
+    after_numpy = np.random.random_sample(4)
+    out = {"case": name, "model": model, "weight_first": bool(weight_first), "n_iter": n_iter,
+           "seed_random": seeds[0], "seed_numpy": seeds[1], "X": X, "true_assignments": y,
+           "m_0": m_0, "k_0": float(k_0), "v_0": int(v_0), "S_0": S_0, "alpha": alpha, "K_arg": 3, "K_max": 40,
+           "rec_components": np.array(record["components"], dtype=np.int64),
+           "rec_log_marg": np.array(record["log_marg"], dtype=np.float64),
+           "dist_mean": dist["mean"], "dist_variance": dist["variance"], "dist_weights": dist["weights"],
+           "final_z": np.array(mm.components.assignments, dtype=np.int64), "final_K": K,
+           "rand_k_mu": np.stack(rk_mu), "rand_k_sigma": np.stack(rk_sigma),
+           "after_random": after_random, "after_numpy": after_numpy}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-22s %s weight_first=%d: K per sweep %s, %d snapshots, rand_k of %d components -> %s" % (
+        name, model, weight_first, list(out["rec_components"]), dist["mean"].shape[1], K, os.path.basename(path)))
+    assert dist["mean"].shape[1] >= 3, "the distribution dict was hardly exercised"
+
+
+def case_api_crp_wf():
+    api_case("api_distdict_crpmm_wf", "CRPMM", True, (21, 21))
+
+
+def case_api_crp_mf():
+    api_case("api_distdict_crpmm_mf", "CRPMM", False, (22, 22))
+
+
+def case_api_pcrp_wf():
+    api_case("api_distdict_pcrpmm_wf", "PCRPMM", True, (23, 23))
+
+
 CASES = {
+    "api_crp_wf": case_api_crp_wf, "api_crp_mf": case_api_crp_mf, "api_pcrp_wf": case_api_pcrp_wf,
     "kat1": case_kat1, "kat3": case_kat3, "kat4": case_kat4, "c1": case_c1,
     "c2twin": case_c2_twin, "c3twin": case_c3_twin, "c3rand": case_c3_rand,
     "c4twin": case_c4_twin, "c4rand": case_c4_rand,

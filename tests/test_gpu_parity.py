@@ -16,7 +16,7 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
-from golden_util import ALL_CASES, DIAG_CASES, FIXED_CASES, Golden
+from golden_util import ALL_CASES, API_CASES, DIAG_CASES, FIXED_CASES, GOLDEN_DIR, Golden
 from pybgmm_amd.gaussian.gaussian_components import reference_tables
 
 pytestmark = pytest.mark.gpu
@@ -1099,3 +1099,70 @@ def test_soak_default_against_full_evaluation():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "24", "11"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", API_CASES)
+def test_distribution_dict_rand_k_and_streams_match_reference(case):
+    """the whole class path with the distribution dict ON (num_saved == K:
+    igmm/igmm.py:128-197, crpmm.py:49-50 -- MAP estimates, label-switch ordering, the np.random Dirichlet
+    draw), then rand_k of every component (gaussian_components.py:291-303, prior/wishart.py), then the next
+    draws of BOTH global streams: everything as captured from the reference by tests/golden/make_golden.py."""
+    import random
+    from pybgmm_amd.igmm import CRPMM, PCRPMM
+    from pybgmm_amd.prior import NIW
+    g = np.load(os.path.join(GOLDEN_DIR, case + ".npz"), allow_pickle=False)
+    random.seed(int(g["seed_random"]))
+    np.random.seed(int(g["seed_numpy"]))
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[str(g["model"])]
+    mm = cls(g["X"], NIW(g["m_0"], float(g["k_0"]), int(g["v_0"]), g["S_0"]), float(g["alpha"]), None,
+             assignments="rand", K=int(g["K_arg"]), K_max=int(g["K_max"]))
+    record, dist = mm.collapsed_gibbs_sampler(int(g["n_iter"]), g["true_assignments"], num_saved=3,
+                                              weight_first=bool(g["weight_first"]))
+    npt.assert_array_equal(np.array(record["components"]), g["rec_components"])
+    npt.assert_allclose(np.array(record["log_marg"]), g["rec_log_marg"], rtol=1e-9)
+    npt.assert_array_equal(mm.components.assignments, g["final_z"])
+    for key in ("mean", "variance", "weights"):
+        assert dist[key].shape == g["dist_" + key].shape
+        npt.assert_allclose(dist[key], g["dist_" + key], rtol=1e-9, atol=1e-12)
+    for k in range(int(g["final_K"])):
+        mu, sigma = mm.components.rand_k(k)
+        npt.assert_allclose(np.ravel(mu), g["rand_k_mu"][k], rtol=1e-8)
+        npt.assert_allclose(np.ravel(sigma), g["rand_k_sigma"][k], rtol=1e-8)
+    npt.assert_array_equal(np.array([random.random() for _ in range(4)]), g["after_random"])
+    npt.assert_array_equal(np.random.random_sample(4), g["after_numpy"])
+
+
+@pytest.mark.parametrize("cov", ["full", "diag"])
+def test_cache_del_restore_is_the_reference_idiom(cov):
+    """igmm/crpmm.py:60-65, 82-85: cache_component_stats, del_item, restore_component_from_stats,
+    assignments[i] = k_old -- afterwards the state is what it was (statistics bit-identical), and a sweep
+    from there equals a sweep of an untouched twin."""
+    from pybgmm_amd.gaussian.gaussian_components import GaussianComponents, GaussianComponentsDiag
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    N, D, K = 600, 5, 4
+    X, zt = gendata.synth_mixture(N, D, K, seed=77, mu_scale=2.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    if cov == "diag":
+        S_0 = np.ascontiguousarray(np.diag(S_0))
+    cls = GaussianComponents if cov == "full" else GaussianComponentsDiag
+    comps = [cls(X, NIW(m_0, k_0, v_0, S_0), zt.copy(), 16) for _ in range(2)]
+    a = comps[0]
+    for i in (3, 250, 599):
+        k_old = int(a.assignments[i])
+        stats_old = a.cache_component_stats(k_old)
+        a.del_item(i)
+        assert int(a.assignments[i]) == -1 and int(a.counts[k_old]) == stats_old[4] - 1
+        a.restore_component_from_stats(k_old, *stats_old)
+        a.set_assignment(i, k_old)
+    for x, y in zip(a._ctx.stats(True)[:2], comps[1]._ctx.stats(True)[:2]):
+        npt.assert_array_equal(x, y)
+    for x, y in zip(a._ctx.stats(True)[2:], comps[1]._ctx.stats(True)[2:]):
+        npt.assert_allclose(x, y, rtol=1e-10, atol=1e-12)
+    npt.assert_array_equal(a.counts, comps[1].counts)
+    u = np.random.RandomState(5).random_sample(N)
+    for c in comps:
+        c._ctx.sweep(u)
+    npt.assert_array_equal(comps[0].assignments, comps[1].assignments)
+    for c in comps:
+        c._ctx.close()

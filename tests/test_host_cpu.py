@@ -134,3 +134,64 @@ def test_synth_recipes_are_deterministic():
     npt.assert_array_equal(z1, z2)
     assert X1.flags["C_CONTIGUOUS"] and X1.dtype == np.float64
     assert np.bincount(z1).min() >= 300 // 7
+
+
+def test_short_log_exp_against_libm(tmp_path):
+    """pybgmm_amd/csrc/fast_math.h (the log / exp / log1p of the mover-dense path's update waves) compiled for
+    the host and compared with libm in long double: below one ulp."""
+    import ctypes
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "fm.cpp"
+    hdr = os.path.join(ROOT, "pybgmm_amd", "csrc", "fast_math.h")
+    src.write_text('#include "%s"\n#include <cmath>\n'
+                   'static double ulps(double got, long double ref) { double r = (double)ref; '
+                   'return std::fabs((double)((long double)got - ref)) / std::fabs(std::nextafter(r, 1e300) - r); }\n'
+                   'extern "C" double err_log(double x) { return ulps(fm_log(x), logl((long double)x)); }\n'
+                   'extern "C" double err_exp(double x) { return ulps(fm_exp(x), expl((long double)x)); }\n'
+                   'extern "C" double err_log1p(double x) { return ulps(fm_log1p_small(x), log1pl((long double)x)); }\n'
+                   'extern "C" double val_exp(double x) { return fm_exp(x); }\n' % hdr)
+    lib = tmp_path / "fm.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(lib), str(src)], check=True)
+    L = ctypes.CDLL(str(lib))
+    for f in (L.err_log, L.err_exp, L.err_log1p, L.val_exp):
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_double]
+    rs = np.random.RandomState(3)
+    worst = {"log": 0.0, "exp": 0.0, "log1p": 0.0}
+    for x in np.concatenate([np.exp(rs.uniform(-30, 30, 20000)), 1.0 + rs.uniform(-0.2, 0.2, 20000)]):
+        worst["log"] = max(worst["log"], L.err_log(float(x)))
+    for x in np.concatenate([rs.uniform(-690, 690, 20000), rs.uniform(-2, 2, 20000)]):
+        worst["exp"] = max(worst["exp"], L.err_exp(float(x)))
+    for x in np.concatenate([rs.uniform(-0.28, 0.28, 20000), rs.uniform(-1e-4, 1e-4, 20000)]):
+        worst["log1p"] = max(worst["log1p"], L.err_log1p(float(x)))
+    assert worst["log"] < 1.0 and worst["exp"] < 1.0 and worst["log1p"] < 1.0, worst
+    assert L.val_exp(-800.0) == 0.0 and L.val_exp(0.0) == 1.0
+
+
+def test_wishart_draws_consume_the_streams_like_the_reference():
+    """prior/wishart.py:16-32 restated: row r of the Bartlett factor takes r normals from np.random, then one
+    random.gammavariate(0.5 (v_0 - D + 1), 2.0); the factor is float32."""
+    import random
+    from pybgmm_amd.prior import wishart
+    D, v0 = 4, 9
+    sigma = np.diag([1.0, 2.0, 0.5, 3.0])
+    random.seed(5)
+    np.random.seed(6)
+    W = wishart.wishrnd(sigma, v0)
+    random.seed(5)
+    np.random.seed(6)
+    a = np.zeros((D, D), dtype=np.float32)
+    for r in range(D):
+        if r:
+            a[r, :r] = np.random.normal(size=(r,))
+        a[r, r] = np.sqrt(random.gammavariate(0.5 * (v0 - D + 1), 2.0))
+    C = np.linalg.cholesky(sigma)
+    npt.assert_array_equal(W, C.dot(a).dot(a.T).dot(C.T))
+    after = (random.random(), np.random.random_sample())
+    random.seed(5)
+    np.random.seed(6)
+    wishart.iwishrnd(sigma, v0, C)
+    assert (random.random(), np.random.random_sample()) == after
