@@ -45,10 +45,11 @@ class ADAPCRPMM(IGMM):
                 distribution_dict = self.update_distribution_dict(distribution_dict, weight_first)
             powered = flag_adapcrp and i_iter > adapcrp_burnin
             if powered:
-                adapcrp_thres = self.components.N * adapcrp_perct
-                adapcrp_nk = self.components.counts[:self.components.K]
-                small_perct = len(adapcrp_nk[np.where(adapcrp_nk <= adapcrp_thres)[0]]) * 1.0 / len(adapcrp_nk)
-                adapcrp_power = 1.0 + (r_up - 1.0) * small_perct
+                # the exponent grows with the share of "small" clusters -- those holding at most
+                # adapcrp_perct of the data -- from 1 (none small) up to r_up (all small): adapcrpmm.py:100-103
+                sizes = np.asarray(self.components._ctx.counts())
+                share_small = np.count_nonzero(sizes <= adapcrp_perct * self.components.N) / float(sizes.size)
+                adapcrp_power = 1.0 + share_small * (r_up - 1.0)
                 if i_iter % 20 == 0:
                     logging.info('Ada-pCRP power: {}'.format(adapcrp_power))
             order = None

@@ -1166,3 +1166,36 @@ def test_cache_del_restore_is_the_reference_idiom(cov):
     npt.assert_array_equal(comps[0].assignments, comps[1].assignments)
     for c in comps:
         c._ctx.close()
+
+
+@pytest.mark.parametrize("model", ["CRPMM", "PCRPMM"])
+def test_chain_c_equals_a_global_seed_run(model):
+    """chain c (its own random.Random / RandomState, pybgmm_amd/chains.py) equals a plain run
+    under random.seed(s + c); np.random.seed(s + c) -- labels, K, log marginals -- and the gathered stack
+    equals the per-chain outputs.  Both chains' contexts are alive on the device at the same time (the
+    per-device kernel attributes and the contexts' state are independent)."""
+    import random
+    from pybgmm_amd import chains
+    from pybgmm_amd.igmm import CRPMM, PCRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    N, D, K, s, n_iter = 1500, 6, 5, 40, 4
+    X, zt = gendata.synth_mixture(N, D, K, seed=3, mu_scale=1.5)
+    prior = NIW(*gendata.demo_prior_params(D))
+    runs = [chains.run_chain(cls, X, prior, 1.0, n_iter, s, c, 0, true_assignments=zt, K=K, K_max=60)
+            for c in range(2)]
+    zs = [m.components.assignments for m, _ in runs]
+    lms = [np.array(r["log_marg"]) for _, r in runs]
+    assert not np.array_equal(zs[0], zs[1]), "the two chains must differ"
+    for c in range(2):
+        random.seed(s + c)
+        np.random.seed(s + c)
+        ref = cls(X, prior, 1.0, None, assignments="rand", K=K, K_max=60)
+        rec, _ = ref.collapsed_gibbs_sampler(n_iter, zt, num_saved=0)
+        npt.assert_array_equal(ref.components.assignments, zs[c])
+        npt.assert_array_equal(np.array(rec["components"]), np.array(runs[c][1]["components"]))
+        npt.assert_array_equal(np.array(rec["log_marg"]), lms[c])
+    Z, LM = chains.gather_chains(zs[0], lms[0])                 # (single process: the stack of one)
+    npt.assert_array_equal(Z[0], zs[0])
+    npt.assert_array_equal(np.stack(zs), np.stack([Z[0], zs[1]]))
