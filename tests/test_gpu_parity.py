@@ -382,15 +382,21 @@ def test_c2_full_size_against_c_oracle(init):
 
 
 # ---- BASELINE sizes: size-independent properties -------------------------------------------
-@pytest.mark.parametrize("N,D,K", [(100000, 2, 20), (1000000, 16, 100), (1000000, 64, 200), (2000000, 128, 200)],
+@pytest.mark.parametrize("N,D,K,pcrp", [(100000, 2, 20, False), (1000000, 16, 100, True), (1000000, 64, 200, False),
+                                        (2000000, 128, 200, True)],
                          ids=["C2", "C3", "C4", "C5"])
-def test_full_size_properties(N, D, K):
+def test_full_size_properties(N, D, K, pcrp):
+    """C3 and C5 are PCRPMM configurations: a fresh permutation every sweep and the powered seating
+    weights from the second sweep on (pcrpmm.py:86-112) -- the storage-order certificates of a lean step
+    against the permuted visiting order of the full evaluation."""
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
     X, z_true = gendata.synth_mixture(N, D, K, seed=1)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     rs = np.random.RandomState(1)
-    us = rs.random_sample((3, N))
+    n_sw = 4 if pcrp else 3
+    us = rs.random_sample((n_sw, N))
+    orders = [rs.permutation(N).astype(np.int64) for _ in range(n_sw)] if pcrp else [None] * n_sw
     tabs = reference_tables(v_0, N)
     # perturb the true labelling so that the sweep has real moves to make
     z0 = z_true.copy()
@@ -402,15 +408,17 @@ def test_full_size_properties(N, D, K):
         ctx.set_tuning(max_window=window, kernel_kind=kind, prune_mode=prune)
         ctx.set_assignments(z0)
         moves = 0
-        for it in range(3):     # (sweeps 2 and 3 of the default configuration run on certified stays)
-            ctx.sweep(us[it])
+        certified = 0
+        for it in range(n_sw):     # (the later sweeps of the default configuration run on certified stays)
+            ctx.sweep(us[it], orders[it], 1.01 if (pcrp and it > 0) else None)
             moves += ctx.sweep_stats()["moves"]
+            certified += ctx.prune_stats()["certified_visits"]
         z = ctx.assignments()
         c = ctx.counts()
         lm = ctx.log_marg()
         results.append((z, c, lm, moves))
         if kind == 0 and D >= 64:           # (C3's clusters are too close for certificates at the 2^-53 level)
-            assert ctx.prune_stats()["certified_visits"] > 0
+            assert certified > 0
         assert c.sum() == N and z.min() >= 0 and z.max() == len(c) - 1
         npt.assert_array_equal(np.bincount(z, minlength=len(c)), c)
         if kind == 0:
@@ -424,6 +432,68 @@ def test_full_size_properties(N, D, K):
     npt.assert_array_equal(za, zb)      # kernel kind and window size do not change the chain
     assert mva == mvb and mva > 0
     assert abs(lma - lmb) <= 1e-9 * abs(lma)
+
+
+@pytest.mark.parametrize("N,D,K,pcrp", [(1000000, 64, 200, False), (1000000, 16, 100, True)], ids=["C4-rand", "C3-rand"])
+def test_full_size_burnin_two_mover_paths(N, D, K, pcrp):
+    """The reference's default start ("rand", igmm.py:86-94) at BASELINE size: nearly every visit of the first
+    sweep moves.  The default configuration (frozen-factor windows, kernels_gram.hip) against the
+    one-workgroup resolver that updates both factors in LDS per move (kernels_resolve.hip), pruning off,
+    windows of 2048: two independent implementations of the mover path, same labels."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, _ = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(2)
+    z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    u = rs.random_sample(N)
+    order = rs.permutation(N).astype(np.int64) if pcrp else None
+    tabs = reference_tables(v_0, N)
+    out = []
+    for resolver, window, prune in ((0, 0, 0), (2, 2048, 1)):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
+        ctx.set_tuning(max_window=window, resolver_mode=resolver, prune_mode=prune)
+        ctx.set_assignments(z0)
+        ctx.sweep(u, order, None)
+        st, ps = ctx.sweep_stats(), ctx.path_stats()
+        out.append((ctx.assignments(), ctx.counts(), ctx.log_marg(), st["moves"], ps["frozen_windows"]))
+        ctx.close()
+    (za, ca, lma, mva, fa), (zb, cb, lmb, mvb, fb) = out
+    assert fa > N // 80 and fb == 0             # (the first went through the frozen-factor windows, the second did not)
+    assert mva > 0.9 * N
+    bad = np.nonzero(za != zb)[0]
+    assert bad.size == 0, "%d labels differ, first at i=%d" % (bad.size, bad[0])
+    npt.assert_array_equal(ca, cb)
+    assert mva == mvb and abs(lma - lmb) <= 1e-9 * abs(lma)
+
+
+@pytest.mark.parametrize("N,D,K,sep", [(30000, 64, 200, 4.0), (10000, 128, 60, 4.0), (60000, 16, 100, 1.0)],
+                         ids=["D64-K200", "D128", "D16-overlapping"])
+def test_burnin_against_c_oracle(N, D, K, sep):
+    """Frozen-factor windows against the C port of the reference, two sweeps from a random start at the
+    BASELINE dimensions (every visit of the first sweep moves; components die and are born)."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, _ = gendata.synth_mixture(N, D, K, seed=31 + D, mu_scale=sep)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D)
+    z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(z0)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+    for it in range(2):
+        u = rs.random_sample(N)
+        ctx.sweep(u)
+        o.sweep(u)
+        z = ctx.assignments()
+        bad = np.nonzero(z != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        if it == 0:
+            assert ctx.path_stats()["frozen_windows"] > N // 80
+    ctx.close()
 
 
 # ---- covariance_type="diag" (SURVEY.md 8f rank 1) -------------------------------------------
