@@ -111,6 +111,7 @@ def make_context(args, X, z0, local_rank, mode):
                        tables=reference_tables(v_0, N) if args.cov != "fixed" else None, cov_type=args.cov)
     ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
                    prune_mode=MODES[mode])
+    ctx.set_home_pass(args.home)
     ctx.set_assignments(z0)
     return ctx
 
@@ -226,6 +227,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 VALU, 2 MFMA")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--resolver", type=int, default=0, help="0 auto, 1 per-mover kernels, 2 in-launch resolver, 3 frozen-factor windows")
+    ap.add_argument("--home", type=int, default=0, help="first pass of pruned windows: 0 auto, 1 always, 2 never")
     ap.add_argument("--cpu-visits", type=int, default=20000, help="visits of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cov", default="full", choices=["full", "diag", "fixed"],
                     help="covariance_type (diag / fixed: SURVEY 8f rows, not BASELINE configs)")

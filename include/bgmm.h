@@ -211,6 +211,11 @@ int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int3
  * happens, never the trajectory (the tests use it to exercise the hand-over). */
 int bgmm_set_seq_plan(bgmm_ctx *ctx, int32_t max_labels);
 
+/* The first pass of a pruned window (home_kernel: visits whose only live candidates are the home component
+ * and a new one).  0 = the context decides sweep by sweep from how many visits the pass settled in the last
+ * sweep it ran (the default), 1 = always, 2 = never.  It never changes the trajectory. */
+int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
+
 /* Blocks until all work queued on the context's stream has finished. */
 int bgmm_synchronize(bgmm_ctx *ctx);
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgmm_hip.so")
 SOURCES = ["bgmm_api.hip", "kernels_state.hip", "kernels_score.hip", "kernels_prune.hip", "kernels_choice.hip",
-           "kernels_resolve.hip", "kernels_rng.hip", "kernels_seq.hip", "kernels_gram.hip"]
+           "kernels_resolve.hip", "kernels_rng.hip", "kernels_seq.hip", "kernels_gram.hip", "kernels_home.hip"]
 HEADERS = [os.path.join(CSRC, "bgmm_device.h"), os.path.join(CSRC, "slot_math.h"),
            os.path.join(CSRC, "score_common.h"), os.path.join(CSRC, "wave_ops.h"),
            os.path.join(os.path.dirname(HERE), "include", "bgmm.h")]

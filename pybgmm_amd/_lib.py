@@ -58,6 +58,7 @@ SIGNATURES = {
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "bgmm_set_seq_plan": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_set_home_pass": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_synchronize": (ctypes.c_int, [_vp]),
 }
 
@@ -314,6 +315,9 @@ class Context(object):
 
     def set_seq_plan(self, max_labels=0):
         self._ck(self.L.bgmm_set_seq_plan(self.h, int(max_labels)))
+
+    def set_home_pass(self, mode=0):
+        self._ck(self.L.bgmm_set_home_pass(self.h, int(mode)))
 
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))

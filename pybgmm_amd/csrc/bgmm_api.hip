@@ -89,6 +89,9 @@ struct bgmm_ctx {
     int gram_lds = 0;
     bool gram_off = false;           // this context cannot use them (too many labels for the LDS plan)
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
+    bool home_pass = true;           // home_kernel in front of the pruning kernel (kernels_home.hip)
+    int home_retry = 0;
+    int home_mode = 0;               // bgmm_set_home_pass: 0 auto, 1 always, 2 never
 };
 
 // Mean distance between movers below which the frozen-factor windows take over from the per-mover
@@ -267,6 +270,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_slot, ng * 16);
         DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
         DALLOC(c, d.wrec, (size_t)rows);
+        DALLOC(c, d.wrecR, (size_t)rows);
+        DALLOC(c, d.wpermR, (size_t)rows);
         DALLOC(c, d.pr_counts, 1024);
         CK(c, hipMemsetAsync(d.pr_counts, 0, 1024 * sizeof(unsigned long long), c->stream));
         DALLOC(c, d.cert, (size_t)rows);
@@ -780,6 +785,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (pmode != 2) lean = false;
         d.lean_step = lean ? 1 : 0;
         d.publish = lean ? 1 : 0;
+        d.use_home = (d.cov_type == COV_FULL && c->kind == KERNEL_MFMA && c->home_pass) ? 1 : 0;
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
@@ -793,6 +799,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (pmode >= 1 && use_certify) launch_certify(d, grid_rows, st);
             if (pmode >= 1 && !lean) launch_bucket_rows(d, grid_rows, st);
+            if (pmode >= 1 && !lean && d.use_home) launch_home(d, grid_rows, st);
             if (pmode >= 1) { if (!lean) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st); }
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
@@ -842,6 +849,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
     c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
+    // home_kernel pays while the table bound decides most visits (well separated components); when it had to
+    // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 16th sweep
+    if (c->home_mode) c->home_pass = c->home_mode == 1;
+    else if (h.home_in > 0) c->home_pass = 2 * h.home_out < h.home_in;
+    else if (!c->home_pass && (++c->home_retry & 63) == 0) c->home_pass = true;
     c->moves_prev = h.n_moves;
     c->lean_ok = use_certify && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
     return check_device_error(c);
@@ -1151,6 +1163,13 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
         CK(c, hipMemcpy(&c->d.ctrl->win_cap, &c->ctrl_host->win_cap, sizeof(int), hipMemcpyHostToDevice));
         CK(c, hipMemcpy(&c->d.ctrl->win_size, &c->ctrl_host->win_size, sizeof(int), hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+extern "C" int bgmm_set_home_pass(bgmm_ctx *c, int32_t mode) {
+    if (!c || mode < 0 || mode > 2) return BGMM_EINVAL;
+    c->home_mode = mode;
+    c->home_pass = mode != 2;
     return 0;
 }
 

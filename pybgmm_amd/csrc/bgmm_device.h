@@ -114,6 +114,8 @@ struct Ctrl {
     int retry_full;       // a lean step (certify only) met a visit it could not certify: queue full steps
     long long state_epoch;  // bumped by every change of the sampler's state (move, rebuild, new seating weights)
     int n_sorted;         // rows of the open pruned window that went through the bucket sort (the uncertified ones)
+    long long home_in, home_out;   // this sweep: rows home_kernel looked at / rows it had to pass on
+    int n_resid;          // of those, the rows home_kernel could not decide (the pruning kernel's work list; kernels_home.hip)
     long long wsort_base, wsort_hi;
     unsigned long long n_prune_mfma;    // v_mfma_f64_16x16x4 instructions the pruning kernel issued
     unsigned long long n_certified;     // visits decided by certify_kernel (provably stay, nothing scored)
@@ -223,6 +225,9 @@ struct Dev {
     struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
     unsigned long long *pr_counts;  // 4 x 256 spread counters (kept, bound, MFMA instructions, certified visits) of the pruned-window kernels
     int *wperm;                  // pruned windows: k-th row in evaluation order -> window row (grouped by home)
+    struct WRec *wrecR;          // the residual list home_kernel leaves (same record / row format)
+    int *wpermR;
+    int use_home;                // 1: home_kernel runs in front of the pruning kernel, which then works on the residual list
     const double *u;
     const long long *order;      // may be null (identity)
     int use_power;
@@ -247,6 +252,11 @@ struct Dev {
                                  // decides per window (job.prune; both kernel sets are launched), 2 every
                                  // window (only the pruned-window kernels are launched)
 };
+
+// The list the pruning kernel and the sparse draw kernel work through
+__host__ __device__ inline const WRec *prune_list(const Dev &d) { return d.use_home ? d.wrecR : d.wrec; }
+__host__ __device__ inline const int *prune_rows(const Dev &d) { return d.use_home ? d.wpermR : d.wperm; }
+__device__ inline long long prune_count(const Dev &d) { return d.use_home ? d.ctrl->n_resid : d.ctrl->n_sorted; }
 
 // Is the (fresh) window described by (mode, prune flag) evaluated by the pruned-window kernels?
 __host__ __device__ inline bool job_is_pruned(const Dev &d, int mode, int prune_flag) {
@@ -292,6 +302,7 @@ bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstr
                          hipStream_t st);
 void launch_certify(const Dev &d, long long max_rows, hipStream_t st);
 void launch_prune_tables(const Dev &d, hipStream_t st);
+void launch_home(const Dev &d, long long max_rows, hipStream_t st);            // kernels_home.hip
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   // pruned windows
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);

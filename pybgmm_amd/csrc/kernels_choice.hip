@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256) void choice_sparse_kernel(Dev d) {
     if (blockIdx.x == 0)
         for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;
     const long long win_base = c->job.win_base;
-    const long long nrows = c->n_sorted;                 // (rows certify_kernel proved to stay are not here)
+    const long long nrows = prune_count(d);              // (rows certified to stay or decided by home_kernel are not here)
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nrows) return;
     const int K = c->job.K;
-    const long long p = win_base + d.wperm[k];
-    const WRec rec = d.wrec[k];                          // (index, home, its label, new-table score)
+    const long long p = win_base + prune_rows(d)[k];
+    const WRec rec = prune_list(d)[k];                   // (index, home, its label, new-table score)
     SparseVisit sv;
     sv.d = &d;
     sv.K = K;

@@ -286,12 +286,6 @@ __device__ __forceinline__ double gram_ld(const double *base, unsigned idx) {
 #define GPROF(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ long long wv_readlane_i64(long long v, int t) {
-    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), t);
-    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), t);
-    return ((long long)hi << 32) | (unsigned int)lo;
-}
-
 // LPL: labels per lane of the draw wave (label j = lane * LPL + t): 64 LPL - 1 bounds the labels a window can
 // reach.  KC / T: the LDS plan (columns, terms; a term's index is also its line of weights).
 template <int LPL, int KC, int T>

@@ -163,12 +163,9 @@ void launch_certify(const Dev &d, long long max_rows, hipStream_t st) {
 // A fragments x[row lr][4kk + lk] are read back; row stride Ds = 4 mod 32 doubles).
 __host__ __device__ constexpr int prune_row_stride(int Dp) { return ((Dp + 27) / 32) * 32 + 4; }
 
-template <int NJ, int RB, int MINW>
-__global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
-                                                                  double *__restrict__ q, long long qstride) {
+template <int NJ, int RB>
+__device__ __forceinline__ void prune_tile(const Dev &d, const JobView &job, double *__restrict__ q, unsigned bx) {
     extern __shared__ __attribute__((aligned(16))) double xs_all[];
-    const JobView job = load_job(jobp);
-    if (!job_is_pruned(d, job.mode, job.prune)) return;
     const int chunk = blockIdx.y;
     const int ngroups = (job.nlist + 15) >> 4;
     if (chunk >= job.chunks || chunk >= ngroups) return;
@@ -177,8 +174,8 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     constexpr int NKK = NJ * 4;
     constexpr int NK0 = NKK < 8 ? NKK : 8;                        // fragments of the level-0 bound (32 dimensions)
     constexpr int Ds = prune_row_stride(NJ * 16);
-    const long long nrows = d.ctrl->n_sorted;                     // the rows the bucket sort kept (not certified)
-    const long long kb = (long long)blockIdx.x * (4 * ROWS_W);
+    const long long nrows = prune_count(d);                       // the rows left to this kernel (not certified, not decided by home_kernel)
+    const long long kb = (long long)bx * (4 * ROWS_W);
     if (kb >= nrows) return;
     const int D = d.D;
     const int lane = threadIdx.x & 63;
@@ -192,7 +189,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     double *__restrict__ xs = xs_all + w * (ROWS_W * Ds);
     const long long kmine = kw + (lane & (ROWS_W - 1));
     WRec rmine;
-    if (kmine < nrows) rmine = d.wrec[kmine];
+    if (kmine < nrows) rmine = prune_list(d)[kmine];
     else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = INFINITY; }
     const long long imine = rmine.i;
     // gathers behind the bound, one value per row of the wave: the lower bound of the visit's best log
@@ -657,22 +654,50 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
     }
     if (lane == 0) {
         // (counters spread over 256 addresses; apply_kernel folds them)
-        atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_kept);
-        atomicAdd(&d.pr_counts[256 + (blockIdx.x & 255)], (unsigned long long)n_bound);
-        atomicAdd(&d.pr_counts[512 + (blockIdx.x & 255)], (unsigned long long)n_mfma);
+        atomicAdd(&d.pr_counts[bx & 255], (unsigned long long)n_kept);
+        atomicAdd(&d.pr_counts[256 + (bx & 255)], (unsigned long long)n_bound);
+        atomicAdd(&d.pr_counts[512 + (bx & 255)], (unsigned long long)n_mfma);
     }
+}
+
+// One 128-row tile per workgroup; behind home_kernel, whose residual list is usually short, the host launches
+// a short grid of the WALK variant instead, whose workgroups walk the tiles of the list.
+template <int NJ, int RB, int MINW, bool WALK>
+__global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
+                                                                  double *__restrict__ q, long long qstride) {
+    const JobView job = load_job(jobp);
+    if (!job_is_pruned(d, job.mode, job.prune)) return;
+    if constexpr (!WALK) {
+        prune_tile<NJ, RB>(d, job, q, blockIdx.x);
+    } else {
+        const long long ntiles = (prune_count(d) + 4 * 16 * RB - 1) / (4 * 16 * RB);
+        bool first = true;
+        for (long long bx = blockIdx.x; bx < ntiles; bx += gridDim.x) {
+            if (!first) __syncthreads();                            // (the staging area is reused)
+            first = false;
+            prune_tile<NJ, RB>(d, job, q, (unsigned)bx);
+        }
+    }
+    (void)qstride;
+}
+
+template <int NJ, bool WALK>
+static void launch_mfma_prune_v(const Dev &d, const Job *job, double *q, long long qstride, unsigned gx, hipStream_t st) {
+    const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (176 + d.keep_stride)) * (int)sizeof(double);
+    auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1), WALK>;
+    static PerDeviceLds attr;
+    if (lds > 64 * 1024 && attr.raise(lds))
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }
 
 template <int NJ>
 static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long qstride, long long max_rows,
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (176 + d.keep_stride)) * (int)sizeof(double);
-    auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1)>;
-    static PerDeviceLds attr;
-    if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
+    // (home_kernel has decided most of the window's rows: a short grid walks what is left)
+    if (d.use_home && gx > 512) launch_mfma_prune_v<NJ, true>(d, job, q, qstride, 512, st);
+    else launch_mfma_prune_v<NJ, false>(d, job, q, qstride, gx, st);
 }
 
 static void launch_diag_prune(const Dev &d, const Job *job, double *q, long long max_rows, hipStream_t st);

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->lik_evals = 0; c->n_moves = 0; c->n_windows = 0; c->n_steps = 0;
         c->n_score_launches = 0; c->n_scored = 0;
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
+        c->n_resid = 0; c->home_in = 0; c->home_out = 0;
         c->n_pairs_exact = 0; c->gram_rows_total = 0; c->gram_windows = 0; c->gram_ntouched = 0; c->gram_nmoves = 0;
         if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
@@ -734,6 +735,8 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     if (threadIdx.x == 0) {
         do_move = 0;
         Job &j = c->job;
+        if (d.use_home && job_is_pruned(d, j.mode, j.prune) && !c->skip_apply) { c->home_in += c->n_sorted; c->home_out += c->n_resid; }
+        c->n_resid = 0;                 // (home_kernel's list of this step has been worked through)
         c->n_refresh = 0;               // (a consumed or idle step must not re-run a refresh)
         if (c->skip_apply) {
             c->skip_apply = 0;          // the resolver already consumed this step

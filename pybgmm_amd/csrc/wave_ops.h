@@ -10,6 +10,12 @@ __device__ __forceinline__ double wv_readlane(double v, int t) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ long long wv_readlane_i64(long long v, int t) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), t);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), t);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double wv_dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);

@@ -24,11 +24,12 @@ pytestmark = pytest.mark.gpu
 LM_RTOL = 1e-6
 
 
-def make_ctx(g, kind=0, window=0, tables=True, resolver=0, prune=0):
+def make_ctx(g, kind=0, window=0, tables=True, resolver=0, prune=0, home=0):
     from pybgmm_amd import _lib
     ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max,
                        tables=reference_tables(g.v_0, g.N) if tables else None, cov_type=g.cov_type)
     ctx.set_tuning(max_window=window, kernel_kind=kind, resolver_mode=resolver, prune_mode=prune)
+    ctx.set_home_pass(home)
     ctx.set_assignments(g.z_init)
     return ctx
 
@@ -99,12 +100,13 @@ def test_pruning_does_not_change_trajectory(case, prune):
 
 @pytest.mark.parametrize("case", ["crpmm_12d", "c3twin_pcrpmm_16d", "c3rand_pcrpmm_16d", "c4twin_crpmm_64d",
                                   "c4rand_crpmm_64d"])
-def test_every_window_pruned(case):
-    """prune_mode 2: the pruned-window kernels (bucket sort, bounds, block-sparse scores, sparse draw)
-    evaluate EVERY window, also in the mover-dense sweeps of these fixtures -- singleton homes,
-    deletions and new components included."""
+@pytest.mark.parametrize("home", [1, 2], ids=["home-pass", "no-home-pass"])
+def test_every_window_pruned(case, home):
+    """prune_mode 2: the pruned-window kernels (home pass or not, bucket sort, bounds, block-sparse scores,
+    sparse draw) evaluate EVERY window, also in the mover-dense sweeps of these fixtures -- singleton
+    homes, deletions and new components included."""
     g = Golden(case)
-    ctx = make_ctx(g, kind=2, prune=2)
+    ctx = make_ctx(g, kind=2, prune=2, home=home)
     for it in range(g.n_iter):
         ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
         z = ctx.assignments()
@@ -121,7 +123,8 @@ def test_every_window_pruned(case):
     (8000, 48, 300, 4.0, "K > 256: several coarse passes"),
     (4000, 128, 20, 4.0, "D = 128"),
 ])
-def test_every_window_pruned_against_c_oracle(N, D, K, sep, label):
+@pytest.mark.parametrize("home", [1, 2], ids=["home-pass", "no-home-pass"])
+def test_every_window_pruned_against_c_oracle(N, D, K, sep, label, home):
     from oracle import c_oracle
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
@@ -136,6 +139,7 @@ def test_every_window_pruned_against_c_oracle(N, D, K, sep, label):
     o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max)
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, tables=reference_tables(v_0, N))
     ctx.set_tuning(kernel_kind=2, prune_mode=2)
+    ctx.set_home_pass(home)
     ctx.set_assignments(z0)
     for it in range(2):
         power = 1.03 if it == 1 else None
