@@ -263,7 +263,7 @@ __host__ __device__ inline bool job_is_pruned(const Dev &d, int mode, int prune_
     return mode == MODE_FRESH && (d.prune_enabled == 2 || (d.prune_enabled == 1 && prune_flag != 0));
 }
 
-__host__ __device__ inline int bgmm_nfrag(int Dp) { int nJ = Dp / 16; return 2 * nJ * (nJ + 1); }
+__host__ __device__ constexpr int bgmm_nfrag(int Dp) { return 2 * (Dp / 16) * (Dp / 16 + 1); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT DEVICE only: what a launcher has
 // already asked for is remembered per device (contexts on different GPUs of one process are independent).

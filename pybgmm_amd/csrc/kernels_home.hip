@@ -13,234 +13,399 @@
 // sweep.  Visits the table bound cannot decide (and unassigned / singleton ones) are appended to the
 // residual list, which score_mfma_prune_kernel / choice_sparse_kernel work through as before.
 //
-// Per wavefront 64 rows, lane = row for everything scalar (the record, the tail).  The matrix part takes
-// them 16 RB at a time: staged through a wave-private LDS tile (row-contiguous 512-byte loads in, A
-// fragments out), per distinct home among them (one, at a boundary two) the inverse factor's tiles
-// streamed through a register ring; quadratic forms and distances meet their rows' lanes through LDS.
+// Shape of the launch.  The rows of X are a random gather (512 bytes each at D = 64): what bounds the kernel is
+// how many of them are in flight.  Loads return in order per wavefront (one vmcnt), so a wavefront that
+// streams factor tiles from L2 behind a row prefetch waits for the prefetch at the first tile.  Hence:
+//   * persistent workgroups (as many as are resident), each with a contiguous run of 256-row blocks, the runs
+//     dealt so that the workgroups of one XCD (one L2) hold neighbouring ones;
+//   * the inverse factor of the block's home -- the MFMA B operand, 20 KB at D = 64, 72 KB at D = 128 -- sits in
+//     LDS, loaded when the home changes (the rows are grouped by home: about once per workgroup), together
+//     with the home's constants; the matrix loop reads it with ds_read (lgkmcnt), the only traffic on vmcnt
+//     are the rows, their records and the uniforms;
+//   * every wavefront (64 rows of the block, 16 at a time) has the next one or two 16-row tiles on their way
+//     while the current one is in the matrix pipe; records and uniforms a block ahead;
+//   * a block that straddles two homes (or holds unassigned rows) takes the general path: factor tiles from L2
+//     through a register ring, home by home.
+// Per wavefront lane = row for everything scalar (the record, the tail).  A tile of 16 rows is staged through a
+// wave-private LDS tile (row-contiguous 512-byte loads in, A fragments out); quadratic forms and distances
+// meet their rows' lanes through LDS.
 #include "score_common.h"
 #include "wave_ops.h"
 #include "fast_math.h"
 
+#define LDS_AS __attribute__((address_space(3)))
+
+#ifdef BGMM_HOME_PROF
+#define HP(k) { const long long tk1_ = clock64(); pf[k] += tk1_ - tk0; tk0 = tk1_; }
+#else
+#define HP(k)
+#endif
+
 static constexpr double kHomeMargin = 80.0;          // = kPruneMargin of kernels_prune.hip
 
 __host__ __device__ constexpr int home_row_stride(int Dp) { return ((Dp + 27) / 32) * 32 + 4; }
-__host__ __device__ constexpr int home_wave_doubles(int Dp, int RB) { return 16 * home_row_stride(Dp) + 64 + 64 + 32 + 0 * RB; }
+__host__ __device__ constexpr int home_wave_doubles(int Dp) { return 16 * home_row_stride(Dp) + 64 + 64 + 32; }
+// per workgroup: the home's factor fragments, cvec, mu (zero padded), its row of ftab, 16 scalars
+__host__ __device__ constexpr int home_shared_doubles(int Dp) { return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16; }
+__host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles(Dp)) * 8; }
+// tiles of 16 rows a wavefront keeps in flight (two while their staging registers fit next to the A fragments)
+__host__ __device__ constexpr int home_depth(int NJ) { return NJ <= 4 ? 2 : 1; }
+// workgroups per CU: registers (256 at two per SIMD) and LDS (160 KB)
+__host__ __device__ constexpr int home_wgs_per_cu(int NJ) { return 2 * home_lds_bytes(NJ * 16) <= 160 * 1024 ? 2 : 1; }
 
-template <int NJ, int RB>
-__global__ __launch_bounds__(256, 2) void home_kernel(Dev d) {
+// The scalar tail of one row: its home's score with the row removed (slot_math.h: home form), the new table,
+// the table bound on everything else, the draw.  Returns true when the visit is decided.
+struct HomeConsts { SlotConst sc; int n, ver; double finv; };
+
+template <int NJ>
+__global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
-    constexpr int NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, Ds = home_row_stride(NJ * 16);
-    constexpr int PFK = pick_ring(NF, 10);
-    constexpr int CH = 16 * RB, NCH = 64 / CH;                        // rows per chunk, chunks per wave
+    constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, Ds = home_row_stride(Dp);
+    constexpr int PFK = pick_ring(NF, 10);                            // factor tiles in flight from L2 (general path)
+    constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
+    constexpr int NP = (Dp + 63) / 64;
+    constexpr int DEPTH = home_depth(NJ);
     const long long nrows = c->n_sorted;
-    const long long kb = (long long)blockIdx.x * 256;
-    if (kb >= nrows) return;
+    const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long kw = kb + w * 64;
-    if (kw >= nrows) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the workgroup's run of blocks
+    long long b0, b1;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        const int per = nb >> 3, rem = nb & 7, xcd = b & 7;
+        const int lb = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+        const long long bpw = (nblocks + nb - 1) / nb;
+        b0 = (long long)lb * bpw;
+        b1 = b0 + bpw < nblocks ? b0 + bpw : nblocks;
+    }
+    if (b0 >= b1) return;
     const int lr = lane & 15, lk = lane >> 4;
-    double *__restrict__ xs = lds_all + w * home_wave_doubles(NJ * 16, RB);   // [16][Ds] staging tile
-    double *__restrict__ sideQ = xs + 16 * Ds;                        // exact home form of row rho [64]
-    double *__restrict__ sideRho = sideQ + 64;                        // |x - mu_home|^2 [64]
-    int *__restrict__ sideH = (int *)(sideRho + 64);                  // home slot [64]
+    LDS_AS double *const L = (LDS_AS double *)lds_all;
+    LDS_AS double *const Bf = L;                                      // [NF][64] the home's factor fragments
+    LDS_AS double *const hcv = Bf + NF * 64;                          // cvec [Dp]
+    LDS_AS double *const hmu = hcv + Dp;                              // mu [Dp], zero beyond D
+    LDS_AS double *const hft = hmu + Dp;                              // ftab[label of the home][64]
+    LDS_AS double *const hsc = hft + 64;                              // SlotConst (12), finv, (n, version)
+    LDS_AS double *const xs = hsc + 16 + w * home_wave_doubles(Dp);   // [16][Ds] staging tile
+    LDS_AS double *const sideQ = xs + 16 * Ds;                        // exact home form of row rho [64]
+    LDS_AS double *const sideRho = sideQ + 64;                        // |x - mu_home|^2 [64]
+    LDS_AS int *const sideH = (LDS_AS int *)(sideRho + 64);           // home slot [64]
+    const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
+    const long long win_base = c->job.win_base;
+    const long long epoch = c->state_epoch;
 
-    // lane rho owns row kw + rho
-    const long long kmine = kw + lane;
-    WRec rmine;
-    int wrow = 0;
-    if (kmine < nrows) { rmine = d.wrec[kmine]; wrow = d.wperm[kmine]; }
-    else { rmine.i = -1; rmine.home = -2; rmine.home_label = -1; rmine.mlb0 = -INFINITY; }
-    const long long imine = rmine.i;
-    const int hmine = rmine.home;
-    sideH[lane] = hmine;
+    // lane rho's row of the current block and of the next one (record, window row, uniform: a block ahead),
+    // the homes of the block's first and last row
+    WRec rcur, rnext;
+    int wrow_cur = 0, wrow_next = 0, hf_cur = -3, hl_cur = -3, hf_next = -3, hl_next = -3;
+    double u_cur = 0.0;
+#define HOME_LOAD_REC(B, R, WR, HF, HL)                                                    \
+    {                                                                                      \
+        const long long kf_ = (B) * 256, k_ = kf_ + w * 64 + lane;                         \
+        R.i = -1; R.home = -2; R.home_label = -1; R.mlb0 = -INFINITY; R.pad = 0.0; WR = 0; HF = -3; HL = -3; \
+        if ((B) < b1) {                                                                    \
+            const long long kl_ = kf_ + 255 < nrows ? kf_ + 255 : nrows - 1;               \
+            HF = d.wrec[kf_].home; HL = d.wrec[kl_].home;                                  \
+            if (k_ < nrows) { R = d.wrec[k_]; WR = d.wperm[k_]; }                          \
+        }                                                                                  \
+    }
+    HOME_LOAD_REC(b0, rcur, wrow_cur, hf_cur, hl_cur)
+    HOME_LOAD_REC(b0 + 1, rnext, wrow_next, hf_next, hl_next)
+    if (rcur.i >= 0) u_cur = d.u[win_base + wrow_cur];
+    // rows of a tile on their way in: 16 rows, each a contiguous wave-wide load (lane l: entries l, l + 64)
+    double stg[DEPTH][16][NP];
+    unsigned loff[NP];                                               // (unsigned: scalar row base + 32-bit lane offset)
+#pragma unroll
+    for (int pss = 0; pss < NP; ++pss) loff[pss] = pss * 64 + lane < D ? (unsigned)(pss * 64 + lane) : 0u;
+#define HOME_ISSUE(BUF, ISRC, RBASE)                                                       \
+    _Pragma("unroll") for (int row = 0; row < 16; ++row) {                                 \
+        const double *__restrict__ xrow = d.X + wv_readlane_i64(ISRC, (RBASE) + row);      \
+        _Pragma("unroll") for (int pss = 0; pss < NP; ++pss)                               \
+            stg[BUF][row][pss] = __builtin_nontemporal_load(xrow + loff[pss]);             \
+    }
+    // (element offset of the lane's row in X: one 64-bit multiply per record instead of one per load)
+    long long xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D, xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) HOME_ISSUE(dd, xo_cur, 16 * dd)
     unsigned n_mfma = 0, n_homes = 0;
-    constexpr int NP = (NJ * 16 + 63) / 64;
+    int cur_home = -1;
+#ifdef BGMM_HOME_PROF
+    long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk0 = clock64();
+#endif
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int r0 = ch * CH;                                      // first row of the chunk
-        if (kw + r0 >= nrows) break;
-        // rows -> A fragments, 16 rows at a time through the wave's tile
-        double xf[RB][NKK];
-#pragma unroll
-        for (int R = 0; R < RB; ++R) {
-            double tmp[16][NP];
-#pragma unroll
-            for (int row = 0; row < 16; ++row) {
-                const long long i = wv_readlane_i64(imine, r0 + R * 16 + row);
-                const double *__restrict__ xrow = d.X + (i >= 0 ? i : 0) * D;
-#pragma unroll
-                for (int pss = 0; pss < NP; ++pss) {
-                    const int l = pss * 64 + lane;
-                    tmp[row][pss] = xrow[l < D ? l : 0];
-                }
+    for (long long b = b0; b < b1; ++b) {
+        const long long imine = rcur.i;
+        const int hmine = rcur.home;
+        sideH[lane] = hmine;
+        const int hf = __builtin_amdgcn_readfirstlane(hf_cur), hl = __builtin_amdgcn_readfirstlane(hl_cur);
+        const bool one_home = hf == hl && hf >= 0;                    // (the same decision in all four wavefronts)
+        HP(6)
+        if (one_home && hf != cur_home) {
+            __syncthreads();                                          // everybody is done with the previous home
+            const double *__restrict__ src = d.Wfrag + (long long)hf * (NF * 64);
+            for (int e = tid; e < NF * 64; e += 256) Bf[e] = src[e];
+            const int a = d.label_of_slot[hf];
+            for (int e = tid; e < Dp; e += 256) {
+                hcv[e] = d.cvec[(long long)hf * d.Dp + e];
+                hmu[e] = e < D ? d.mu[(long long)hf * D + e] : 0.0;
             }
-#pragma unroll
-            for (int row = 0; row < 16; ++row) {
-                const long long i = wv_readlane_i64(imine, r0 + R * 16 + row);
-#pragma unroll
-                for (int pss = 0; pss < NP; ++pss) {
-                    const int l = pss * 64 + lane;
-                    const double v = (i >= 0 && l < D) ? tmp[row][pss] : 0.0;
-                    if (NJ * 16 >= (pss + 1) * 64 || l < NJ * 16) xs[row * Ds + l] = v;
-                }
+            if (tid < 64) hft[tid] = d.ftab[(long long)a * 64 + tid];
+            if (tid == 64) {
+                const SlotConst sc = d.sc[hf];
+                hsc[0] = sc.A; hsc[1] = sc.half_vd; hsc[2] = sc.inv_cv; hsc[3] = sc.A1; hsc[4] = sc.half_vd1;
+                hsc[5] = sc.coef1; hsc[6] = sc.a1; hsc[7] = sc.logdetC; hsc[8] = sc.logseat; hsc[9] = sc.logseat1;
+                hsc[10] = sc.inv_lam; hsc[11] = sc.mu2; hsc[12] = d.finv[a];
+                LDS_AS int *hi = (LDS_AS int *)(hsc + 13);
+                hi[0] = d.n[hf]; hi[1] = d.mu_ver[hf];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the tile is private to the wave)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) xf[R][kk] = xs[lr * Ds + 4 * kk + lk];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cur_home = hf;
+            __syncthreads();
         }
-        // homes of the rows this lane's accumulator rows / fragment row belong to
-        int hq[RB][4], hd[RB];
-#pragma unroll
-        for (int R = 0; R < RB; ++R) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hq[R][r] = sideH[r0 + R * 16 + lk + 4 * r];
-            hd[R] = sideH[r0 + R * 16 + lr];
-        }
-        // ---- the homes present in the chunk, one after the other (the rows are grouped by home)
-        unsigned long long pending = __ballot(lane >= r0 && lane < r0 + CH && hmine >= 0);
+        HP(7)
 #pragma unroll 1
-        while (pending) {
-            const int first = __ffsll((long long)pending) - 1;
-            const int s = __builtin_amdgcn_readlane(hmine, first);
-            pending &= ~__ballot(hmine == s);
-            const double *__restrict__ wf = d.Wfrag + (long long)s * (NF * 64) + lane;
-            double ringk[PFK];
+        for (int tt = 0; tt < 4; tt += DEPTH) {
 #pragma unroll
-            for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
-            const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
-            const double *__restrict__ mup = d.mu + (long long)s * D;
-            double cjk[NJ];
+            for (int dd = 0; dd < DEPTH; ++dd) {
+                const int t = tt + dd, r0 = 16 * t;                       // tile t of the block: rows r0 .. r0 + 15 of the wavefront
+                // rows -> A fragments through the wave's tile
+                double xf[NKK];
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
-            // squared distance of the rows to this home's mean, from the fragments (lane: NKK of the row's entries)
-            double dpart[RB];
+                for (int row = 0; row < 16; ++row) {
 #pragma unroll
-            for (int R = 0; R < RB; ++R) dpart[R] = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const int l = 4 * kk + lk;
-                const double m = l < D ? mup[l] : 0.0;
-#pragma unroll
-                for (int R = 0; R < RB; ++R) { const double t = xf[R][kk] - m; dpart[R] = fma(t, t, dpart[R]); }
-            }
-            double qp[RB][4];
-#pragma unroll
-            for (int R = 0; R < RB; ++R)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) qp[R][r] = 0.0;
-#pragma unroll
-            for (int J = 0; J < NJ; ++J) {
-                v4d acc[RB];
-#pragma unroll
-                for (int R = 0; R < RB; ++R) acc[R] = (v4d){cjk[J], cjk[J], cjk[J], cjk[J]};
-#pragma unroll
-                for (int kk = 0; kk < 4 * (J + 1); ++kk) {
-                    const int f = 2 * J * (J + 1) + kk;
-                    const double bfr = ringk[f % PFK];
-                    if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
-#pragma unroll
-                    for (int R = 0; R < RB; ++R)
-                        acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[R][kk], bfr, acc[R], 0, 0, 0);
+                    for (int pss = 0; pss < NP; ++pss) {
+                        const int l = pss * 64 + lane;
+                        const double v = l < D ? stg[dd][row][pss] : 0.0;
+                        if (Dp >= (pss + 1) * 64 || l < Dp) xs[row * Ds + l] = v;
+                    }
                 }
-#pragma unroll
-                for (int R = 0; R < RB; ++R)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) qp[R][r] = fma(acc[R][r], acc[R][r], qp[R][r]);
-            }
-            n_mfma += RB * NF;
-            n_homes += RB;
-            // row sums: quadratic forms (accumulator rows lk + 4 r, complete in all 16 lanes of the row group),
-            // distances (fragment row lr: summed over the 4 lk groups) -- to the rows' own lanes through LDS
-#pragma unroll
-            for (int R = 0; R < RB; ++R) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = row16_sum(qp[R][r]);
-                    if (lr == r && hq[R][r] == s) sideQ[r0 + R * 16 + lk + 4 * r] = v;
+                HP(0)
+                // the tile DEPTH further on sets off now: it travels while this one is in the matrix pipe
+                {
+                    const int tn = t + DEPTH;
+                    const long long isrc = tn >= 4 ? xo_next : xo_cur;
+                    HOME_ISSUE(dd, isrc, 16 * (tn & 3))
                 }
-                double dd = dpart[R];
-                dd += __shfl_xor(dd, 16);
-                dd += __shfl_xor(dd, 32);
-                if (lk == 0 && hd[R] == s) sideRho[r0 + R * 16 + lr] = dd;
+                HP(1)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the tile is private to the wave)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) xf[kk] = xs[lr * Ds + 4 * kk + lk];
+#ifdef BGMM_HOME_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                HP(2)
+                if (one_home) {
+                    // ---- every row of the tile under the block's home: factor and constants from LDS
+                    double dpart = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < NKK; ++kk) { const double tq = xf[kk] - hmu[4 * kk + lk]; dpart = fma(tq, tq, dpart); }
+                    LDS_AS const double *const wf = Bf + lane;
+                    double ringk[LRING];
+#pragma unroll
+                    for (int i = 0; i < LRING; ++i) ringk[i] = wf[i * 64];
+                    double qp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int J = 0; J < NJ; ++J) {
+                        const double cj = hcv[16 * J + lr];
+                        v4d acc = (v4d){cj, cj, cj, cj};
+#pragma unroll
+                        for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                            const int f = 2 * J * (J + 1) + kk;
+                            const double bfr = ringk[f % LRING];
+                            if (f + LRING < NF) ringk[f % LRING] = wf[(f + LRING) * 64];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
+                    }
+                    n_mfma += NF;
+                    n_homes += 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = row16_sum(qp[r]);
+                        if (lr == r) sideQ[r0 + lk + 4 * r] = v;
+                    }
+                    dpart += __shfl_xor(dpart, 16);
+                    dpart += __shfl_xor(dpart, 32);
+                    if (lk == 0) sideRho[r0 + lr] = dpart;
+                } else {
+                    // ---- the homes present in the tile, one after the other; factor tiles from L2
+                    int hq[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq[r] = sideH[r0 + lk + 4 * r];
+                    const int hd = sideH[r0 + lr];
+                    unsigned long long pending = __ballot(lane >= r0 && lane < r0 + 16 && hmine >= 0);
+#pragma unroll 1
+                    while (pending) {
+                        const int first = __ffsll((long long)pending) - 1;
+                        const int s = __builtin_amdgcn_readlane(hmine, first);
+                        pending &= ~__ballot(hmine == s);
+                        const double *__restrict__ wf = d.Wfrag + (long long)s * (NF * 64) + lane;
+                        double ringk[PFK];
+#pragma unroll
+                        for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
+                        const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
+                        const double *__restrict__ mup = d.mu + (long long)s * D;
+                        double cjk[NJ];
+#pragma unroll
+                        for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
+                        double dpart = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < NKK; ++kk) {
+                            const int l = 4 * kk + lk;
+                            const double m = l < D ? mup[l] : 0.0;
+                            const double tq = xf[kk] - m;
+                            dpart = fma(tq, tq, dpart);
+                        }
+                        double qp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int J = 0; J < NJ; ++J) {
+                            v4d acc = (v4d){cjk[J], cjk[J], cjk[J], cjk[J]};
+#pragma unroll
+                            for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                                const int f = 2 * J * (J + 1) + kk;
+                                const double bfr = ringk[f % PFK];
+                                if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
+                        }
+                        n_mfma += NF;
+                        n_homes += 1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double v = row16_sum(qp[r]);
+                            if (lr == r && hq[r] == s) sideQ[r0 + lk + 4 * r] = v;
+                        }
+                        dpart += __shfl_xor(dpart, 16);
+                        dpart += __shfl_xor(dpart, 32);
+                        if (lk == 0 && hd == s) sideRho[r0 + lr] = dpart;
+                    }
+                }
+                HP(3)
             }
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- the scalar tail: lane = row
-    const bool live = imine >= 0;
-    bool easy = false;
-    if (live && hmine >= 0) {
-        const double q_t = sideQ[lane], rho2_t = sideRho[lane];
-        const int nh = d.n[hmine];
-        const int a = rmine.home_label;
-        // per-point cache for certify_kernel (bgmm_device.h: PCache)
-        PCache pc;
-        pc.tag = ((long long)hmine << 32) | (unsigned int)d.mu_ver[hmine];
-        pc.qhome = q_t; pc.rho2 = rho2_t; pc.pad = 0.0;
-        d.pcache[imine] = pc;
-        if (nh >= 2) {
-            const SlotConst sc = d.sc[hmine];
-            // the visited point removed from its own component (slot_math.h: home form)
-            const double den = 1.0 - sc.a1 * q_t;
-            const double vh = sc.logseat1 + sc.A1 - 0.5 * fm_log(den) - sc.half_vd1 * fm_log(1.0 + fm_div(sc.coef1 * q_t, den));
-            const double vnew = rmine.mlb0;
-            const double mx = fmax(vh, vnew);
-            const double rad = sqrt(rho2_t * (1.0 + 1e-9)) * (1.0 + 1e-9);
-            const double jf = rad * d.finv[a];
-            if (den > 0.0 && jf < 62.0 && d.ftab[(long long)a * 64 + (int)jf + 1] < mx - kHomeMargin) {
-                // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20)
-                easy = true;
-                const double eh = fm_exp(vh - mx), en = fm_exp(vnew - mx);
-                const double lse = fm_log(eh + en) + mx;
-                const long long p = c->job.win_base + wrow;
-                double uu = d.u[p];
-                uu -= fm_exp(vh - lse);
-                const int pick = uu < 0.0 ? a : K;
-                d.choice[wrow] = pick;
-                PCacheExact pe;
-                pe.epoch = c->state_epoch;
-                // log of the alternatives' total weight relative to the home's: the new table exactly, every other
-                // label below e^-80 of the best
-                pe.log_alt = mx - vh + fm_log(en + (double)K * 1.8048513878454153e-35);
-                d.pcache2[imine] = pe;
-                if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- the scalar tail: lane = row
+        const bool live = imine >= 0;
+        bool easy = false;
+        if (live && hmine >= 0) {
+            const double q_t = sideQ[lane], rho2_t = sideRho[lane];
+            const int a = rcur.home_label;
+            int nh, ver;
+            double a1, coef1, half_vd1, base1, finv_a;
+            if (one_home) {
+                LDS_AS const int *hi = (LDS_AS const int *)(hsc + 13);
+                nh = hi[0]; ver = hi[1];
+                a1 = hsc[6]; coef1 = hsc[5]; half_vd1 = hsc[4]; base1 = hsc[9] + hsc[3]; finv_a = hsc[12];
+            } else {
+                nh = d.n[hmine]; ver = d.mu_ver[hmine];
+                const SlotConst sc = d.sc[hmine];
+                a1 = sc.a1; coef1 = sc.coef1; half_vd1 = sc.half_vd1; base1 = sc.logseat1 + sc.A1; finv_a = d.finv[a];
+            }
+            if (keep_caches) {
+                // per-point cache for certify_kernel (bgmm_device.h: PCache)
+                PCache pc;
+                pc.tag = ((long long)hmine << 32) | (unsigned int)ver;
+                pc.qhome = q_t; pc.rho2 = rho2_t; pc.pad = 0.0;
+                d.pcache[imine] = pc;
+            }
+            if (nh >= 2) {
+                // the visited point removed from its own component (slot_math.h: home form)
+                const double den = 1.0 - a1 * q_t;
+                const double vh = base1 - 0.5 * fm_log(den) - half_vd1 * fm_log(1.0 + fm_div(coef1 * q_t, den));
+                const double vnew = rcur.mlb0;
+                const double mx = fmax(vh, vnew);
+                const double rad = sqrt(rho2_t * (1.0 + 1e-9)) * (1.0 + 1e-9);
+                const double jf = rad * finv_a;
+                double bound = INFINITY;
+                if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftab[(long long)a * 64 + (int)jf + 1];
+                if (den > 0.0 && bound < mx - kHomeMargin) {
+                    // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20)
+                    easy = true;
+                    const double eh = fm_exp(vh - mx), en = fm_exp(vnew - mx);
+                    const double lse = fm_log(eh + en) + mx;
+                    const long long p = win_base + wrow_cur;
+                    double uu = u_cur;
+                    uu -= fm_exp(vh - lse);
+                    const int pick = uu < 0.0 ? a : K;
+                    d.choice[wrow_cur] = pick;
+                    if (keep_caches) {
+                        PCacheExact pe;
+                        pe.epoch = epoch;
+                        // log of the alternatives' total weight relative to the home's: the new table exactly, every other
+                        // label below e^-80 of the best
+                        pe.log_alt = mx - vh + fm_log(en + (double)K * 1.8048513878454153e-35);
+                        d.pcache2[imine] = pe;
+                    }
+                    if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
+                }
             }
         }
-    }
-    // ---- what the table bound could not decide goes on the residual list, a contiguous run per wave
-    const bool hard = live && !easy;
-    const unsigned long long mhard = __ballot(hard);
-    if (mhard) {
-        const int fl = __ffsll((long long)mhard) - 1;
-        int base = 0;
-        if (lane == fl) base = atomicAdd(&c->n_resid, __popcll(mhard));
-        base = __builtin_amdgcn_readlane(base, fl);
-        if (hard) {
-            const int pos = base + __popcll(mhard & ((1ull << lane) - 1ull));
-            d.wrecR[pos] = rmine;
-            d.wpermR[pos] = wrow;
+        // ---- what the table bound could not decide goes on the residual list, a contiguous run per wavefront
+        const bool hard = live && !easy;
+        const unsigned long long mhard = __ballot(hard);
+        if (mhard) {
+            const int fl = __ffsll((long long)mhard) - 1;
+            int base = 0;
+            if (lane == fl) base = atomicAdd(&c->n_resid, __popcll(mhard));
+            base = __builtin_amdgcn_readlane(base, fl);
+            if (hard) {
+                const int pos = base + __popcll(mhard & ((1ull << lane) - 1ull));
+                d.wrecR[pos] = rcur;
+                d.wpermR[pos] = wrow_cur;
+            }
         }
+        HP(4)
+        // the next block's row becomes the current one; its uniform and the record after it set off
+        rcur = rnext; wrow_cur = wrow_next; hf_cur = hf_next; hl_cur = hl_next; xo_cur = xo_next;
+        u_cur = 0.0;
+        if (rcur.i >= 0) u_cur = d.u[win_base + wrow_cur];
+        HOME_LOAD_REC(b + 2, rnext, wrow_next, hf_next, hl_next)
+        xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
+        HP(5)
     }
+#ifdef BGMM_HOME_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&c->prof[k], (unsigned long long)pf[k]);
+        atomicAdd((unsigned long long *)&c->prof[15], 1ull);
+    }
+#endif
+#undef HOME_LOAD_REC
+#undef HOME_ISSUE
     if (lane == 0) {
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_homes);
         atomicAdd(&d.pr_counts[512 + (blockIdx.x & 255)], (unsigned long long)n_mfma);
     }
 }
 
+// as many workgroups as are resident, unless the window is shorter than that
+static int home_cu_count() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 template <int NJ>
 static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
-    constexpr int RB = NJ <= 5 ? 2 : 1;
-    const unsigned gx = (unsigned)((max_rows + 255) / 256);
-    const int lds = 4 * home_wave_doubles(NJ * 16, RB) * (int)sizeof(double);
+    const long long want = (max_rows + 255) / 256;
+    const long long cap = (long long)home_wgs_per_cu(NJ) * home_cu_count();
+    const unsigned gx = (unsigned)(want < cap ? want : cap);
+    constexpr int lds = home_lds_bytes(NJ * 16);
     static PerDeviceLds attr;
     if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)home_kernel<NJ, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((home_kernel<NJ, RB>), dim3(gx), dim3(256), lds, st, d);
+        (void)hipFuncSetAttribute((const void *)home_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((home_kernel<NJ>), dim3(gx), dim3(256), lds, st, d);
 }
 
 void launch_home(const Dev &d, long long max_rows, hipStream_t st) {
