@@ -13,22 +13,31 @@
 // sweep.  Visits the table bound cannot decide (and unassigned / singleton ones) are appended to the
 // residual list, which score_mfma_prune_kernel / choice_sparse_kernel work through as before.
 //
-// Shape of the launch.  The rows of X are a random gather (512 bytes each at D = 64): what bounds the kernel is
-// how many of them are in flight.  Loads return in order per wavefront (one vmcnt), so a wavefront that
-// streams factor tiles from L2 behind a row prefetch waits for the prefetch at the first tile.  Hence:
+// Shape of the launch.  The rows of X are a random gather (512 bytes each at D = 64), and on this chip the
+// FP64 matrix pipe is no faster than the gather (2 560 pipe cycles per 16 rows at D = 64 against ~80 us for the
+// 512 MB): both have to be kept busy at once.  Loads return in order per wavefront (one vmcnt), so a wavefront
+// that streams factor tiles from L2 behind a row prefetch waits for the prefetch at the first tile.  Hence:
 //   * persistent workgroups (as many as are resident), each with a contiguous run of 256-row blocks, the runs
 //     dealt so that the workgroups of one XCD (one L2) hold neighbouring ones;
 //   * the inverse factor of the block's home -- the MFMA B operand, 20 KB at D = 64, 72 KB at D = 128 -- sits in
 //     LDS, loaded when the home changes (the rows are grouped by home: about once per workgroup), together
 //     with the home's constants; the matrix loop reads it with ds_read (lgkmcnt), the only traffic on vmcnt
 //     are the rows, their records and the uniforms;
-//   * every wavefront (64 rows of the block, 16 at a time) has the next one or two 16-row tiles on their way
-//     while the current one is in the matrix pipe; records and uniforms a block ahead;
+//   * the rows go from memory STRAIGHT into A-operand registers: lane (lr, lk) of a 16-row tile takes 16 bytes
+//     of row lr at column 8 j + 2 lk, j = 0 .. D/8 - 1 (64 contiguous bytes per row and instruction; measured
+//     5.1 TB/s for this pattern against 6.5 for whole-row loads, tools/gather_bw.hip).  The two doubles are the
+//     lane's entries of k-slices 2 j and 2 j + 1, i.e. the 16 columns of a block are dealt to the four k-lanes as
+//     {0,2,4,6 | 1,3,5,7 | 8,10,12,14 | 9,11,13,15} instead of {0..3 | 4..7 | ...}; the factor fragments are
+//     permuted to match when they are copied into LDS (a sum over the same products in another order).  No
+//     staging tile, no transposition, a tile in flight costs its 2 D/16 registers and nothing else;
+//   * every wavefront (64 rows of the block, 16 at a time) has the next tiles on their way while the current one
+//     is in the matrix pipe; records and uniforms a block ahead;
 //   * a block that straddles two homes (or holds unassigned rows) takes the general path: factor tiles from L2
 //     through a register ring, home by home.
-// Per wavefront lane = row for everything scalar (the record, the tail).  A tile of 16 rows is staged through a
-// wave-private LDS tile (row-contiguous 512-byte loads in, A fragments out); quadratic forms and distances
-// meet their rows' lanes through LDS.
+// Per wavefront lane = row for everything scalar (the record, the tail); quadratic forms and distances meet their
+// rows' lanes through LDS.  The tail is short on purpose: FP64 VALU instructions queue behind the other
+// wavefronts' MFMAs (the same pipe), so a visit whose new table weighs less than 2^-53 of its home is decided
+// without the exponentials (their outcome is exactly 1).
 #include "score_common.h"
 #include "wave_ops.h"
 #include "fast_math.h"
@@ -43,30 +52,33 @@
 
 static constexpr double kHomeMargin = 80.0;          // = kPruneMargin of kernels_prune.hip
 
-__host__ __device__ constexpr int home_row_stride(int Dp) { return ((Dp + 27) / 32) * 32 + 4; }
-__host__ __device__ constexpr int home_wave_doubles(int Dp) { return 16 * home_row_stride(Dp) + 64 + 64 + 32; }
-// per workgroup: the home's factor fragments, cvec, mu (zero padded), its row of ftab, 16 scalars
+// LDS plan (doubles).  Per workgroup: the home's factor fragments (permuted), cvec, mu (permuted, zero padded),
+// its row of ftab, 16 scalars; per wavefront: quadratic forms, distances, home slots of its 64 rows.
+__host__ __device__ constexpr int home_wave_doubles() { return 64 + 64 + 32; }
 __host__ __device__ constexpr int home_shared_doubles(int Dp) { return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16; }
-__host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles(Dp)) * 8; }
-// tiles of 16 rows a wavefront keeps in flight (two while their staging registers fit next to the A fragments)
-__host__ __device__ constexpr int home_depth(int NJ) { return NJ <= 4 ? 2 : 1; }
-// workgroups per CU: registers (256 at two per SIMD) and LDS (160 KB)
-__host__ __device__ constexpr int home_wgs_per_cu(int NJ) { return 2 * home_lds_bytes(NJ * 16) <= 160 * 1024 ? 2 : 1; }
+__host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles()) * 8; }
+// wavefronts per SIMD (a tile of 16 rows is 2 D/16 registers; one in the matrix pipe, one on its way): two up to
+// D = 64, one above (at two the D = 128 kernel spills, and a scratch access waits for every row load in flight)
+__host__ __device__ constexpr int home_waves_per_simd(int NJ) {
+    const int by_lds = (160 * 1024) / home_lds_bytes(NJ * 16);
+    const int want = NJ <= 4 ? 2 : 1;
+    return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
+}
 
-// The scalar tail of one row: its home's score with the row removed (slot_math.h: home form), the new table,
-// the table bound on everything else, the draw.  Returns true when the visit is decided.
-struct HomeConsts { SlotConst sc; int n, ver; double finv; };
+// column of X (inside its block of 16) that k-lane lk holds in k-slice kq (0..3) of the block
+__host__ __device__ constexpr int home_col(int kq, int lk) { return 8 * (kq >> 1) + 2 * lk + (kq & 1); }
 
-template <int NJ>
-__global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
+typedef double home_d2 __attribute__((ext_vector_type(2), aligned(8)));
+
+// WHOLE: D is a multiple of 16 (no padded columns: every 16-byte piece of a tile lies inside its row)
+template <int NJ, bool WHOLE>
+__global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
-    constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, Ds = home_row_stride(Dp);
-    constexpr int PFK = pick_ring(NF, 10);                            // factor tiles in flight from L2 (general path)
+    constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, NJ8 = NJ * 2;
+    constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
-    constexpr int NP = (Dp + 63) / 64;
-    constexpr int DEPTH = home_depth(NJ);
     const long long nrows = c->n_sorted;
     const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
@@ -85,18 +97,22 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
     if (b0 >= b1) return;
     const int lr = lane & 15, lk = lane >> 4;
     LDS_AS double *const L = (LDS_AS double *)lds_all;
-    LDS_AS double *const Bf = L;                                      // [NF][64] the home's factor fragments
+    LDS_AS double *const Bf = L;                                      // [NF][64] the home's factor fragments, permuted
     LDS_AS double *const hcv = Bf + NF * 64;                          // cvec [Dp]
-    LDS_AS double *const hmu = hcv + Dp;                              // mu [Dp], zero beyond D
+    LDS_AS double *const hmu = hcv + Dp;                              // hmu[4 kk + lk] = mu[column of (kk, lk)], zero beyond D
     LDS_AS double *const hft = hmu + Dp;                              // ftab[label of the home][64]
     LDS_AS double *const hsc = hft + 64;                              // SlotConst (12), finv, (n, version)
-    LDS_AS double *const xs = hsc + 16 + w * home_wave_doubles(Dp);   // [16][Ds] staging tile
-    LDS_AS double *const sideQ = xs + 16 * Ds;                        // exact home form of row rho [64]
+    LDS_AS double *const sideQ = hsc + 16 + w * home_wave_doubles();  // exact home form of row rho [64]
     LDS_AS double *const sideRho = sideQ + 64;                        // |x - mu_home|^2 [64]
     LDS_AS int *const sideH = (LDS_AS int *)(sideRho + 64);           // home slot [64]
     const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
     const long long win_base = c->job.win_base;
     const long long epoch = c->state_epoch;
+    // where lane (lr, lk) finds its entry of permuted fragment kk in a factor stored in the standard order
+    // (Wfrag: fragment kk, lane (ln, lk) = column 4 kk + lk): source fragment 2 (kk / 2) + (lk >> 1) of the block,
+    // source k-lane (2 lk + (kk & 1)) & 3
+    const int src_lane[2] = {lr + 16 * ((2 * lk) & 3), lr + 16 * ((2 * lk + 1) & 3)};
+    const int src_frag = lk >> 1;
 
     // lane rho's row of the current block and of the next one (record, window row, uniform: a block ahead),
     // the homes of the block's first and last row
@@ -114,23 +130,40 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
         }                                                                                  \
     }
     HOME_LOAD_REC(b0, rcur, wrow_cur, hf_cur, hl_cur)
-    HOME_LOAD_REC(b0 + 1, rnext, wrow_next, hf_next, hl_next)
-    if (rcur.i >= 0) u_cur = d.u[win_base + wrow_cur];
-    // rows of a tile on their way in: 16 rows, each a contiguous wave-wide load (lane l: entries l, l + 64)
-    double stg[DEPTH][16][NP];
-    unsigned loff[NP];                                               // (unsigned: scalar row base + 32-bit lane offset)
+    rnext = rcur; wrow_next = 0;
+    // A tile on its way in: lane (lr, lk) fetches 16 bytes of row lr per instruction.  The lane's row offset comes
+    // from the lane that owns the row's record (ds_bpermute); columns beyond D read column 0 and are zeroed.
+    double xf[NKK], xn[NKK];                                         // the tile in the matrix pipe, the tile on its way
+    int coff[WHOLE ? 1 : NKK];                                       // (padded columns: where the lane's entries are, -1 = none)
+    if (!WHOLE) {
 #pragma unroll
-    for (int pss = 0; pss < NP; ++pss) loff[pss] = pss * 64 + lane < D ? (unsigned)(pss * 64 + lane) : 0u;
-#define HOME_ISSUE(BUF, ISRC, RBASE)                                                       \
-    _Pragma("unroll") for (int row = 0; row < 16; ++row) {                                 \
-        const double *__restrict__ xrow = d.X + wv_readlane_i64(ISRC, (RBASE) + row);      \
-        _Pragma("unroll") for (int pss = 0; pss < NP; ++pss)                               \
-            stg[BUF][row][pss] = __builtin_nontemporal_load(xrow + loff[pss]);             \
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int col = 16 * (kk >> 2) + home_col(kk & 3, lk);
+            coff[WHOLE ? 0 : kk] = col < D ? col : -1;
+        }
     }
-    // (element offset of the lane's row in X: one 64-bit multiply per record instead of one per load)
-    long long xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D, xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) HOME_ISSUE(dd, xo_cur, 16 * dd)
+#define HOME_ISSUE(XO, TN)                                                                 \
+    {                                                                                      \
+        const int src_ = 16 * (TN) + lr;                                                   \
+        const long long o_ = ((long long)__shfl((int)((XO) >> 32), src_) << 32) | (unsigned int)__shfl((int)(XO), src_); \
+        if (WHOLE) {                                                                       \
+            const home_d2 *__restrict__ xrow = (const home_d2 *)(d.X + o_ + 2 * lk);       \
+            _Pragma("unroll") for (int j = 0; j < NJ8; ++j) {                              \
+                const home_d2 v_ = __builtin_nontemporal_load(xrow + 4 * j);               \
+                xn[2 * j] = v_.x; xn[2 * j + 1] = v_.y;                                    \
+            }                                                                              \
+        } else {                                                                           \
+            const double *__restrict__ xrow = d.X + o_;                                    \
+            _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk) {                           \
+                const int co_ = coff[WHOLE ? 0 : kk];                                      \
+                const double a_ = __builtin_nontemporal_load(xrow + (co_ >= 0 ? co_ : 0)); \
+                xn[kk] = co_ >= 0 ? a_ : 0.0;                                              \
+            }                                                                              \
+        }                                                                                  \
+    }
+    // (element offset of the lane's row in X: one 64-bit multiply per record)
+    long long xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D;
+    HOME_ISSUE(xo_cur, 0)
     unsigned n_mfma = 0, n_homes = 0;
     int cur_home = -1;
 #ifdef BGMM_HOME_PROF
@@ -141,17 +174,33 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
         const long long imine = rcur.i;
         const int hmine = rcur.home;
         sideH[lane] = hmine;
+        // The next block's records and this block's uniforms set off here, BEFORE the block's row loads: loads return
+        // in order, and they are wanted at the last tile (the next block's first rows) and in the tail -- by then
+        // everything older has been consumed anyway, and nothing younger is held up.
+        HOME_LOAD_REC(b + 1, rnext, wrow_next, hf_next, hl_next)
+        u_cur = 0.0;
+        if (imine >= 0) u_cur = d.u[win_base + wrow_cur];
         const int hf = __builtin_amdgcn_readfirstlane(hf_cur), hl = __builtin_amdgcn_readfirstlane(hl_cur);
         const bool one_home = hf == hl && hf >= 0;                    // (the same decision in all four wavefronts)
         HP(6)
         if (one_home && hf != cur_home) {
             __syncthreads();                                          // everybody is done with the previous home
             const double *__restrict__ src = d.Wfrag + (long long)hf * (NF * 64);
-            for (int e = tid; e < NF * 64; e += 256) Bf[e] = src[e];
+            // (read in storage order, two doubles per thread and step; written where the permutation puts them:
+            //  column c16 = 4 (ks % 4) + lks of its block goes to k-slice 2 (c16 / 8) + (c16 & 1), k-lane (c16 & 7) / 2)
+            for (int e2 = tid; e2 < NF * 32; e2 += 256) {
+                const home_d2 v = ((const home_d2 *)src)[e2];
+                const int e = 2 * e2, f = e >> 6, ln = e & 63;           // lanes ln, ln + 1: same fragment, same k-lane
+                const int ks = f & 3, lks = ln >> 4;                      // (2 J (J + 1) is a multiple of 4)
+                const int c16 = 4 * ks + lks;
+                const int dst = (f - ks + 2 * (c16 >> 3) + (c16 & 1)) * 64 + (ln & 15) + 16 * ((c16 & 7) >> 1);
+                Bf[dst] = v.x; Bf[dst + 1] = v.y;
+            }
             const int a = d.label_of_slot[hf];
             for (int e = tid; e < Dp; e += 256) {
                 hcv[e] = d.cvec[(long long)hf * d.Dp + e];
-                hmu[e] = e < D ? d.mu[(long long)hf * D + e] : 0.0;
+                const int col = 16 * (e >> 4) + home_col((e >> 2) & 3, e & 3);     // e = 4 kk + lk
+                hmu[e] = col < D ? d.mu[(long long)hf * D + col] : 0.0;
             }
             if (tid < 64) hft[tid] = d.ftab[(long long)a * 64 + tid];
             if (tid == 64) {
@@ -167,127 +216,117 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
         }
         HP(7)
 #pragma unroll 1
-        for (int tt = 0; tt < 4; tt += DEPTH) {
+        for (int t = 0; t < 4; ++t) {
+            const int r0 = 16 * t;
+            asm volatile("" ::: "memory");          // (keeps the home's LDS constants from being hoisted into registers)
+            // the tile that sets off now was loaded as `xn` a tile ago: it moves into the pipe's registers and the
+            // one after it takes its place (the loads of a block's last tile reach into the next block)
 #pragma unroll
-            for (int dd = 0; dd < DEPTH; ++dd) {
-                const int t = tt + dd, r0 = 16 * t;                       // tile t of the block: rows r0 .. r0 + 15 of the wavefront
-                // rows -> A fragments through the wave's tile
-                double xf[NKK];
+            for (int kk = 0; kk < NKK; ++kk) xf[kk] = xn[kk];
+            HP(0)
+            if (t < 3) {
+                HOME_ISSUE(xo_cur, t + 1)
+            } else {
+                const long long xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
+                HOME_ISSUE(xo_next, 0)
+            }
+            HP(1)
+            if (one_home) {
+                // ---- every row of the tile under the block's home: factor and constants from LDS
+                double dpart = 0.0;
+                LDS_AS const double *const wf = Bf + lane;
+                double ringk[LRING];
 #pragma unroll
-                for (int row = 0; row < 16; ++row) {
+                for (int i = 0; i < LRING; ++i) ringk[i] = wf[i * 64];
+                double qp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int pss = 0; pss < NP; ++pss) {
-                        const int l = pss * 64 + lane;
-                        const double v = l < D ? stg[dd][row][pss] : 0.0;
-                        if (Dp >= (pss + 1) * 64 || l < Dp) xs[row * Ds + l] = v;
+                for (int J = 0; J < NJ; ++J) {
+                    // (the distance to the home's mean, one block of 16 columns per block row: four constants live at a
+                    //  time instead of D/4, and the FP64 VALU work spread between the MFMAs)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int kk = 4 * J; kk < 4 * J + 4; ++kk) { const double tq = xf[kk] - hmu[4 * kk + lk]; dpart = fma(tq, tq, dpart); }
+                    const double cj = hcv[16 * J + lr];
+                    v4d acc = (v4d){cj, cj, cj, cj};
+#pragma unroll
+                    for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                        const int f = 2 * J * (J + 1) + kk;
+                        const double bfr = ringk[f % LRING];
+                        if (f + LRING < NF) ringk[f % LRING] = wf[(f + LRING) * 64];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
                     }
-                }
-                HP(0)
-                // the tile DEPTH further on sets off now: it travels while this one is in the matrix pipe
-                {
-                    const int tn = t + DEPTH;
-                    const long long isrc = tn >= 4 ? xo_next : xo_cur;
-                    HOME_ISSUE(dd, isrc, 16 * (tn & 3))
-                }
-                HP(1)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the tile is private to the wave)
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) xf[kk] = xs[lr * Ds + 4 * kk + lk];
-#ifdef BGMM_HOME_PROF
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                HP(2)
-                if (one_home) {
-                    // ---- every row of the tile under the block's home: factor and constants from LDS
+                    for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
+                }
+                n_mfma += NF;
+                n_homes += 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = row16_sum(qp[r]);
+                    if (lr == r) sideQ[r0 + lk + 4 * r] = v;
+                }
+                dpart += __shfl_xor(dpart, 16);
+                dpart += __shfl_xor(dpart, 32);
+                if (lk == 0) sideRho[r0 + lr] = dpart;
+            } else {
+                // ---- the homes present in the tile, one after the other; factor tiles from L2 (standard order:
+                // every lane fetches the entry the permutation assigns to it)
+                int hq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hq[r] = sideH[r0 + lk + 4 * r];
+                const int hd = sideH[r0 + lr];
+                unsigned long long pending = __ballot(lane >= r0 && lane < r0 + 16 && hmine >= 0);
+#pragma unroll 1
+                while (pending) {
+                    const int first = __ffsll((long long)pending) - 1;
+                    const int s = __builtin_amdgcn_readlane(hmine, first);
+                    pending &= ~__ballot(hmine == s);
+                    const double *__restrict__ wfs = d.Wfrag + (long long)s * (NF * 64) + src_frag * 64;
+                    // (permuted fragment f = 2 J (J + 1) + kk: the parities of f and kk agree)
+#define HOME_BSRC(F) wfs[((F) & ~1) * 64 + src_lane[(F) & 1]]
+                    double ringk[PFK];
+#pragma unroll
+                    for (int i = 0; i < PFK; ++i) ringk[i] = HOME_BSRC(i);
+                    const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
+                    const double *__restrict__ mup = d.mu + (long long)s * D;
                     double dpart = 0.0;
-#pragma unroll
-                    for (int kk = 0; kk < NKK; ++kk) { const double tq = xf[kk] - hmu[4 * kk + lk]; dpart = fma(tq, tq, dpart); }
-                    LDS_AS const double *const wf = Bf + lane;
-                    double ringk[LRING];
-#pragma unroll
-                    for (int i = 0; i < LRING; ++i) ringk[i] = wf[i * 64];
                     double qp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int J = 0; J < NJ; ++J) {
-                        const double cj = hcv[16 * J + lr];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int kk = 4 * J; kk < 4 * J + 4; ++kk) {
+                            const int l = 16 * J + home_col(kk & 3, lk);
+                            const double m = l < D ? mup[l] : 0.0;
+                            const double tq = xf[kk] - m;
+                            dpart = fma(tq, tq, dpart);
+                        }
+                        const double cj = cvp[16 * J];
                         v4d acc = (v4d){cj, cj, cj, cj};
 #pragma unroll
                         for (int kk = 0; kk < 4 * (J + 1); ++kk) {
                             const int f = 2 * J * (J + 1) + kk;
-                            const double bfr = ringk[f % LRING];
-                            if (f + LRING < NF) ringk[f % LRING] = wf[(f + LRING) * 64];
+                            const double bfr = ringk[f % PFK];
+                            if (f + PFK < NF) ringk[f % PFK] = HOME_BSRC(f + PFK);
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
                     }
+#undef HOME_BSRC
                     n_mfma += NF;
                     n_homes += 1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double v = row16_sum(qp[r]);
-                        if (lr == r) sideQ[r0 + lk + 4 * r] = v;
+                        if (lr == r && hq[r] == s) sideQ[r0 + lk + 4 * r] = v;
                     }
                     dpart += __shfl_xor(dpart, 16);
                     dpart += __shfl_xor(dpart, 32);
-                    if (lk == 0) sideRho[r0 + lr] = dpart;
-                } else {
-                    // ---- the homes present in the tile, one after the other; factor tiles from L2
-                    int hq[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hq[r] = sideH[r0 + lk + 4 * r];
-                    const int hd = sideH[r0 + lr];
-                    unsigned long long pending = __ballot(lane >= r0 && lane < r0 + 16 && hmine >= 0);
-#pragma unroll 1
-                    while (pending) {
-                        const int first = __ffsll((long long)pending) - 1;
-                        const int s = __builtin_amdgcn_readlane(hmine, first);
-                        pending &= ~__ballot(hmine == s);
-                        const double *__restrict__ wf = d.Wfrag + (long long)s * (NF * 64) + lane;
-                        double ringk[PFK];
-#pragma unroll
-                        for (int i = 0; i < PFK; ++i) ringk[i] = wf[i * 64];
-                        const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
-                        const double *__restrict__ mup = d.mu + (long long)s * D;
-                        double cjk[NJ];
-#pragma unroll
-                        for (int J = 0; J < NJ; ++J) cjk[J] = cvp[16 * J];
-                        double dpart = 0.0;
-#pragma unroll
-                        for (int kk = 0; kk < NKK; ++kk) {
-                            const int l = 4 * kk + lk;
-                            const double m = l < D ? mup[l] : 0.0;
-                            const double tq = xf[kk] - m;
-                            dpart = fma(tq, tq, dpart);
-                        }
-                        double qp[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int J = 0; J < NJ; ++J) {
-                            v4d acc = (v4d){cjk[J], cjk[J], cjk[J], cjk[J]};
-#pragma unroll
-                            for (int kk = 0; kk < 4 * (J + 1); ++kk) {
-                                const int f = 2 * J * (J + 1) + kk;
-                                const double bfr = ringk[f % PFK];
-                                if (f + PFK < NF) ringk[f % PFK] = wf[(f + PFK) * 64];
-                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
-                        }
-                        n_mfma += NF;
-                        n_homes += 1;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double v = row16_sum(qp[r]);
-                            if (lr == r && hq[r] == s) sideQ[r0 + lk + 4 * r] = v;
-                        }
-                        dpart += __shfl_xor(dpart, 16);
-                        dpart += __shfl_xor(dpart, 32);
-                        if (lk == 0 && hd == s) sideRho[r0 + lr] = dpart;
-                    }
+                    if (lk == 0 && hd == s) sideRho[r0 + lr] = dpart;
                 }
-                HP(3)
             }
+            HP(3)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- the scalar tail: lane = row
@@ -325,16 +364,25 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
                 double bound = INFINITY;
                 if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftab[(long long)a * 64 + (int)jf + 1];
                 if (den > 0.0 && bound < mx - kHomeMargin) {
-                    // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20)
+                    // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20).
+                    // With eh = exp(vh - mx), en = exp(vnew - mx) one of the two is exp(0) = 1; and when the new table
+                    // lies more than 37 nats below the home, 1 + en rounds to 1, the log-sum-exp to vh, the home's
+                    // probability to exp(0) = 1 and u - 1 is negative for every uniform: the visit stays.
                     easy = true;
-                    const double eh = fm_exp(vh - mx), en = fm_exp(vnew - mx);
-                    const double lse = fm_log(eh + en) + mx;
+                    const double dv = vnew - vh;                       // (mx = vh iff dv <= 0)
+                    int pick = a;
+                    double en = 0.0;
+                    if (!(dv < -37.0)) {
+                        const double eo = fm_exp(-fabs(dv));
+                        const double eh = dv <= 0.0 ? 1.0 : eo;
+                        en = dv <= 0.0 ? eo : 1.0;
+                        const double lse = fm_log(eh + en) + mx;
+                        pick = u_cur - fm_exp(vh - lse) < 0.0 ? a : K;
+                    }
                     const long long p = win_base + wrow_cur;
-                    double uu = u_cur;
-                    uu -= fm_exp(vh - lse);
-                    const int pick = uu < 0.0 ? a : K;
                     d.choice[wrow_cur] = pick;
                     if (keep_caches) {
+                        if (dv < -37.0) en = fm_exp(dv);
                         PCacheExact pe;
                         pe.epoch = epoch;
                         // log of the alternatives' total weight relative to the home's: the new table exactly, every other
@@ -362,11 +410,8 @@ __global__ __launch_bounds__(256, home_wgs_per_cu(NJ)) void home_kernel(Dev d) {
         }
         HP(4)
         // the next block's row becomes the current one; its uniform and the record after it set off
-        rcur = rnext; wrow_cur = wrow_next; hf_cur = hf_next; hl_cur = hl_next; xo_cur = xo_next;
-        u_cur = 0.0;
-        if (rcur.i >= 0) u_cur = d.u[win_base + wrow_cur];
-        HOME_LOAD_REC(b + 2, rnext, wrow_next, hf_next, hl_next)
-        xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
+        rcur = rnext; wrow_cur = wrow_next; hf_cur = hf_next; hl_cur = hl_next;
+        xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D;
         HP(5)
     }
 #ifdef BGMM_HOME_PROF
@@ -396,29 +441,29 @@ static int home_cu_count() {
     return cus[dev];
 }
 
-template <int NJ>
+template <int NJ, bool WHOLE>
 static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
     const long long want = (max_rows + 255) / 256;
-    const long long cap = (long long)home_wgs_per_cu(NJ) * home_cu_count();
+    const long long cap = (long long)home_waves_per_simd(NJ) * home_cu_count();      // (a workgroup = one wavefront per SIMD)
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     constexpr int lds = home_lds_bytes(NJ * 16);
     static PerDeviceLds attr;
     if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)home_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((home_kernel<NJ>), dim3(gx), dim3(256), lds, st, d);
+        (void)hipFuncSetAttribute((const void *)home_kernel<NJ, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((home_kernel<NJ, WHOLE>), dim3(gx), dim3(256), lds, st, d);
 }
 
 void launch_home(const Dev &d, long long max_rows, hipStream_t st) {
     if (max_rows <= 0) return;
     switch (d.Dp / 16) {
-        case 1: launch_home_t<1>(d, max_rows, st); return;
-        case 2: launch_home_t<2>(d, max_rows, st); return;
-        case 3: launch_home_t<3>(d, max_rows, st); return;
-        case 4: launch_home_t<4>(d, max_rows, st); return;
-        case 5: launch_home_t<5>(d, max_rows, st); return;
-        case 6: launch_home_t<6>(d, max_rows, st); return;
-        case 7: launch_home_t<7>(d, max_rows, st); return;
-        case 8: launch_home_t<8>(d, max_rows, st); return;
+        case 1: if (d.D == d.Dp) launch_home_t<1, true>(d, max_rows, st); else launch_home_t<1, false>(d, max_rows, st); return;
+        case 2: if (d.D == d.Dp) launch_home_t<2, true>(d, max_rows, st); else launch_home_t<2, false>(d, max_rows, st); return;
+        case 3: if (d.D == d.Dp) launch_home_t<3, true>(d, max_rows, st); else launch_home_t<3, false>(d, max_rows, st); return;
+        case 4: if (d.D == d.Dp) launch_home_t<4, true>(d, max_rows, st); else launch_home_t<4, false>(d, max_rows, st); return;
+        case 5: if (d.D == d.Dp) launch_home_t<5, true>(d, max_rows, st); else launch_home_t<5, false>(d, max_rows, st); return;
+        case 6: if (d.D == d.Dp) launch_home_t<6, true>(d, max_rows, st); else launch_home_t<6, false>(d, max_rows, st); return;
+        case 7: if (d.D == d.Dp) launch_home_t<7, true>(d, max_rows, st); else launch_home_t<7, false>(d, max_rows, st); return;
+        case 8: if (d.D == d.Dp) launch_home_t<8, true>(d, max_rows, st); else launch_home_t<8, false>(d, max_rows, st); return;
         default: return;
     }
 }
