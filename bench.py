@@ -14,7 +14,8 @@ region; the PCIe-inclusive rate is reported separately in `extra`.  The chains a
 What `value` measures (--mode):
   evaluated (default)  the chain at the truth, every visit EVALUATED every sweep: its row of X is read,
                        the predictive under its own component computed exactly (v_mfma_f64), every other
-                       component excluded by an exact bound -- score_mfma_prune_kernel.  Certified stays
+                       component excluded by an exact bound -- home_kernel, with score_mfma_prune_kernel behind it
+                       for the visits the per-home bound table cannot decide.  Certified stays
                        (visits proven to stay from cached state, X untouched) are OFF: that shortcut
                        makes the sweep a memo lookup on well separated data and is reported in `extra` only.
   certified            the library's default configuration (certified stays on)
@@ -125,8 +126,17 @@ def heavy_kernel_name(args, mode, D):
     return "score_mfma_prune_kernel"
 
 
-def pmc_traffic(args, mode, kernel_name, timeout_s=240):
-    """HBM bytes per working launch of `kernel_name`, measured NOW: two child runs of this script under
+def pruned_window_kernels(args, mode, D, home_decided, handled):
+    """The kernels that stream the rows of a pruned window: home_kernel in front (kernels_home.hip) while it
+    decides most visits, score_mfma_prune_kernel on what it passes on."""
+    name = heavy_kernel_name(args, mode, D)
+    if name == "score_mfma_prune_kernel" and handled > 0 and home_decided > 0.5 * handled:
+        return ("home_kernel", name)
+    return (name,)
+
+
+def pmc_traffic(args, mode, kernel_names, timeout_s=240):
+    """HBM bytes per working launch of the kernels `kernel_names` together, measured NOW: two child runs of this script under
     rocprofv3 --pmc (FETCH_SIZE; WRITE_SIZE -- they do not fit one pass), as MI355X_MICROARCH.md
     prescribes; FETCH_SIZE doubled for gfx950.  None when rocprofv3 is missing or a pass fails."""
     exe = shutil.which("rocprofv3")
@@ -145,22 +155,26 @@ def pmc_traffic(args, mode, kernel_name, timeout_s=240):
             shutil.rmtree(tmp, ignore_errors=True)
             return None, "rocprofv3 pass failed: %r" % (e,)
         hits = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-        vals = []
+        vals = {k: [] for k in kernel_names}
         if hits:
             with open(hits[0]) as f:
                 for row in csv.DictReader(f):
-                    if row["Kernel_Name"].split("(")[0].split("<")[0].split(" ")[-1] != kernel_name:
-                        continue
-                    if row["Counter_Name"] != counter:
+                    name = row["Kernel_Name"].split("(")[0].split("<")[0].split(" ")[-1]
+                    if name not in vals or row["Counter_Name"] != counter:
                         continue
                     dur_us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
-                    vals.append((float(row["Counter_Value"]), dur_us))
+                    vals[name].append((float(row["Counter_Value"]), dur_us))
         shutil.rmtree(tmp, ignore_errors=True)
-        if not vals:
-            return None, "no %s rows for %s (rc %d)" % (counter, kernel_name, r.returncode)
-        longest = max(v[1] for v in vals)
-        work = [v[0] for v in vals if v[1] >= 0.5 * longest]       # (the launches that did a whole window)
-        out[counter] = sum(work) / len(work)
+        if not vals[kernel_names[0]]:
+            return None, "no %s rows for %s (rc %d)" % (counter, kernel_names[0], r.returncode)
+        # the launches of the leading kernel that did a whole window; the kernels behind it run once per such launch
+        longest = max(v[1] for v in vals[kernel_names[0]])
+        n_work = len([v for v in vals[kernel_names[0]] if v[1] >= 0.5 * longest])
+        total = sum(v[0] for v in vals[kernel_names[0]] if v[1] >= 0.5 * longest)
+        for k in kernel_names[1:]:
+            rows = sorted(vals[k], key=lambda v: -v[1])[:n_work]       # (its n_work longest launches)
+            total += sum(v[0] for v in rows)
+        out[counter] = total / n_work
     # counters are in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950
     return int(1024 * (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"])), \
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this script, FETCH_SIZE x 2 for gfx950"
@@ -362,8 +376,13 @@ def main():
                        "fraction_of_visits_certified_to_stay": round(n_cert / visits, 5),
                        "pairs_scored_in_full_per_visit": round(pa["pairs_executed"] / visits, 3),
                        "mfma_instructions_per_launch": round(ps["mfma_instructions"] / n_launch, 1)})
+        names = pruned_window_kernels(args, mode, D, float(pa.get("home_decided", 0)), handled)
+        common["kernel"] = " + ".join(names)
+        common["kernels_for_traffic"] = list(names)
+        if len(names) > 1:
+            common["visits_decided_by_home_kernel"] = float(pa["home_decided"])
         if n_cert > 0:
-            common["kernel"] = "certify_kernel + " + name
+            common["kernel"] = "certify_kernel + " + common["kernel"]
         return common
 
     roofline = None
@@ -373,7 +392,8 @@ def main():
     if not args.no_kernel_timing:
         roofline = kernel_roofline(args.mode)
         if single and roofline and not args.no_pmc and args.cov == "full":
-            traffic, note = pmc_traffic(args, args.mode, heavy_kernel_name(args, args.mode, D))
+            traffic, note = pmc_traffic(args, args.mode,
+                                        tuple(roofline.get("kernels_for_traffic") or [heavy_kernel_name(args, args.mode, D)]))
             roofline["traffic"] = traffic
             roofline["traffic_source"] = note
             if traffic:

@@ -293,7 +293,8 @@ class Context(object):
     def path_stats(self):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_path_stats(self.h, _ptr(out)))
-        return {"pairs_executed": int(out[0]), "frozen_windows": int(out[1]), "frozen_window_visits": int(out[2])}
+        return {"pairs_executed": int(out[0]), "frozen_windows": int(out[1]), "frozen_window_visits": int(out[2]),
+                "home_decided": int(out[3])}
 
     def phase_clocks(self):
         out = np.zeros(16, dtype=np.int64)

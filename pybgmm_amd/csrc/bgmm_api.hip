@@ -849,6 +849,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->prune_mfma = (long long)h.n_prune_mfma;
     c->certified = (long long)h.n_certified;
     c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
+    c->stats2[3] = h.home_in - h.home_out;          // visits home_kernel decided on its own
     // home_kernel pays while the table bound decides most visits (well separated components); when it had to
     // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 16th sweep
     if (c->home_mode) c->home_pass = c->home_mode == 1;

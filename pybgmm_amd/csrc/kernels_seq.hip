@@ -6,6 +6,7 @@
 // laid out for a state that fits in LDS.
 #include "bgmm_device.h"
 #include "slot_math.h"
+#include "fast_math.h"
 
 // ------------------------------------------------------------------------------------------
 // Sequential sweep for tiny dimensions (D <= 4, full covariance): ONE workgroup walks the N visits
@@ -46,6 +47,10 @@ __device__ __forceinline__ double readlane_f64(double v, int t) {
 
 __device__ __forceinline__ constexpr int seq_pk(int r, int l) { return r * (r + 1) / 2 + l; }
 
+// The visit is one dependent instruction chain: the short forms of fast_math.h (about a quarter of the library
+// routines' instructions, error below 1 ulp) wherever their argument is in range.
+__device__ __forceinline__ double seq_log(double x) { return (x > 1e-300 && x < 1e300) ? fm_log(x) : log(x); }
+
 // Wave-wide reductions without LDS round trips (a visit is one long dependent chain: what counts is
 // latency): all-reduce inside each row of 16 lanes with DPP, the four row results through v_readlane.
 template <int CTRL>
@@ -80,6 +85,33 @@ __device__ __forceinline__ double seq_wave_scan(double v, int lane) {
     return v + (lane < 16 ? 0.0 : (lane < 32 ? t0 : (lane < 48 ? t01 : t01 + t2)));
 }
 
+// make_consts_from (slot_math.h) with the short division
+__device__ __forceinline__ SlotConst seq_consts(const Dev &d, int n, const SlotTab &t, double logdetC, double lam,
+                                                double mu2) {
+    SlotConst c;
+    const double Dd = (double)d.D;
+    const double k_N = d.k0 + (double)n;
+    const long long v = d.v0 + n - d.D + 1;
+    c.logdetC = logdetC;
+    c.A = t.g - 0.5 * (Dd * t.lc + logdetC);
+    c.half_vd = 0.5 * (double)(v + d.D);
+    c.inv_cv = fm_div(k_N, k_N + 1.0);                 // 1 / (cs v),  cs = (k_N + 1) / (k_N v)
+    c.logseat = t.seat;
+    c.logseat1 = t.seat1;
+    c.A1 = 0.0; c.half_vd1 = 0.0; c.coef1 = 0.0; c.a1 = 0.0;
+    if (n >= 2) {
+        const double k1 = k_N - 1.0;
+        const double a = fm_div(k_N, k1);
+        c.a1 = a;
+        c.A1 = t.g1 - 0.5 * (Dd * t.lc1 + logdetC);
+        c.half_vd1 = 0.5 * (double)(v - 1 + d.D);
+        c.coef1 = a * a * fm_div(k1, k_N);             // a^2 / (c1 v1),  c1 = k_N / (k1 v1)
+    }
+    c.inv_lam = (lam > 0.0 && lam < 1e300) ? fm_div(1.0, lam) : 0.0;
+    c.mu2 = mu2;
+    return c;
+}
+
 // Derived state of one label from its statistics (registers: st[0..DD) = m, st[DD..DD+T) = packed
 // lower triangle of S) and count n; written to the label's LDS fields.  Called by one lane per
 // touched label, both lanes in lockstep.  tab: the table entries of count n.
@@ -89,8 +121,9 @@ __device__ __forceinline__ void seq_rebuild_label(const Dev &d, double *F, int c
     using Ly = SeqLayout<DD>;
     const double k_N = d.k0 + (double)n;
     double mu[DD], A[DD][DD], W[DD][DD];
+    const double inv_kN = fm_div(1.0, k_N);
 #pragma unroll
-    for (int a = 0; a < DD; ++a) mu[a] = st[a] / k_N;
+    for (int a = 0; a < DD; ++a) mu[a] = st[a] * inv_kN;
 #pragma unroll
     for (int a = 0; a < DD; ++a)
 #pragma unroll
@@ -110,10 +143,10 @@ __device__ __forceinline__ void seq_rebuild_label(const Dev &d, double *F, int c
         const double djj = A[j][j];
         if (!(djj > 0.0)) bad = true;
         piv_prod *= djj;
-        const double piv = sqrt(djj);
+        const double rpiv = fm_rsqrt(djj > 0.0 ? djj : 1.0);
 #pragma unroll
-        for (int i = j + 1; i < DD; ++i) A[i][j] = A[i][j] / piv;
-        A[j][j] = piv;
+        for (int i = j + 1; i < DD; ++i) A[i][j] = A[i][j] * rpiv;
+        A[j][j] = rpiv;                                // (the reciprocal of the pivot: all the inverse below needs)
 #pragma unroll
         for (int i = j + 1; i < DD; ++i)
 #pragma unroll
@@ -123,17 +156,17 @@ __device__ __forceinline__ void seq_rebuild_label(const Dev &d, double *F, int c
     // sum of logs when the product leaves the comfortable range)
     double ldt;
     if (piv_prod > 1e-200 && piv_prod < 1e200) {
-        ldt = log(piv_prod);
+        ldt = fm_log(piv_prod);
     } else {
         ldt = 0.0;
 #pragma unroll
-        for (int j = 0; j < DD; ++j) ldt += log(A[j][j]);
+        for (int j = 0; j < DD; ++j) ldt -= log(A[j][j]);
         ldt *= 2.0;
     }
     if (bad || !(ldt == ldt)) atomicCAS(&d.ctrl->error, 0, -4);
 #pragma unroll
     for (int i = 0; i < DD; ++i) {                     // inverse of the factor, row by row
-        const double inv_d = 1.0 / A[i][i];
+        const double inv_d = A[i][i];
 #pragma unroll
         for (int cc = 0; cc <= i; ++cc) {
             double acc = 0.0;
@@ -145,7 +178,7 @@ __device__ __forceinline__ void seq_rebuild_label(const Dev &d, double *F, int c
     double mu2 = 0.0;
 #pragma unroll
     for (int l = 0; l < DD; ++l) mu2 = fma(mu[l], mu[l], mu2);
-    const SlotConst sc = make_consts_from(d, n, tab, ldt, lam, mu2);
+    const SlotConst sc = seq_consts(d, n, tab, ldt, lam, mu2);
 #pragma unroll
     for (int j = 0; j < DD; ++j) {
         double acc = 0.0;
@@ -328,19 +361,19 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
                     const bool homeform = home_live && jj == lab_h && (is_lab || is_aux);
                     const double den = homeform ? 1.0 - C[8 * cap] * qv : 1.0;
                     const double num = homeform ? C[7 * cap] * qv : qv * C[3 * cap];
-                    double arg = 1.0 + num / den;
+                    double arg = 1.0 + fm_div(num, den);
                     double hv = homeform ? C[6 * cap] : C[2 * cap];
                     double base = homeform ? C[4 * cap] + C[5 * cap] : C[0] + C[cap];
                     if (is_aux) arg = den;
                     if (!is_lab) { hv = 0.0; base = lane == L ? d.log_alpha + lp : -INFINITY; if (!is_aux) arg = 1.0; }
-                    const double lg = log(arg);
+                    const double lg = seq_log(arg);
                     const double lg_aux = readlane_f64(lg, L + 1);
                     if (homeform && is_lab) base = base - 0.5 * lg_aux;
                     const double v = base - hv * lg;
                     const double mx = seq_wave_max(v);
-                    const double e = exp(v - mx);
+                    const double e = fm_exp(v - mx);
                     const double tot = seq_wave_sum(e);
-                    const double cum = seq_wave_scan(e / tot, lane);
+                    const double cum = seq_wave_scan(fm_div(e, tot), lane);
                     const unsigned long long mhit = __ballot(lane <= L && (u - cum) < 0.0);
                     if (mhit) pick = __ffsll((long long)mhit) - 1;
                 } else {
@@ -407,6 +440,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
         // evaluated against a state that is about to change and is evaluated again.
         if (lane == 0) sh_res[round & 1][w] = res;
         __syncthreads();
+        PF(6)
         const int r_l = lane < NW ? sh_res[round & 1][lane] : -1;
         const unsigned long long mmov = __ballot(r_l != -1);
         const int f = mmov ? __ffsll((long long)mmov) - 1 : NW;
@@ -508,6 +542,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
             }
         }
         __syncthreads();
+        PF(7)
         K = __builtin_amdgcn_readfirstlane(sh_K);
         K_hi = __builtin_amdgcn_readfirstlane(sh_Khi);
         stop = __builtin_amdgcn_readfirstlane(sh_stop);
