@@ -50,7 +50,11 @@
 #define HP(k)
 #endif
 
-static constexpr double kHomeMargin = 80.0;          // = kPruneMargin of kernels_prune.hip
+// A visit is decided here when every component but its home lies, by the table bound, more than
+// 38 + log(K + 1) nats below the better of its two candidates -- certify_kernel's margin (kernels_prune.hip):
+// together they weigh less than e^-38 = 0.28 * 2^-53 of the total.  (The pruning kernel behind this one keeps
+// its 80 nats: it drops labels one by one.)
+static constexpr double kHomeFar = 80.0;             // beyond this the excluded labels count as K e^-80 in log_alt
 
 // LDS plan (doubles).  Per workgroup: the home's factor fragments (permuted), cvec, mu (permuted, zero padded),
 // its row of ftab, 16 scalars; per wavefront: quadratic forms, distances, home slots of its 64 rows.
@@ -64,6 +68,9 @@ __host__ __device__ constexpr int home_waves_per_simd(int NJ) {
     const int want = NJ <= 4 ? 2 : 1;
     return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
 }
+
+// register slots for tiles (one in the matrix pipe, the others on their way; 2 D/16 registers each)
+__host__ __device__ constexpr int home_slots(int NJ) { return NJ <= 2 ? 4 : 2; }
 
 // column of X (inside its block of 16) that k-lane lk holds in k-slice kq (0..3) of the block
 __host__ __device__ constexpr int home_col(int kq, int lk) { return 8 * (kq >> 1) + 2 * lk + (kq & 1); }
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, NJ8 = NJ * 2;
     constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
+    constexpr int NS = home_slots(NJ);
     const long long nrows = c->n_sorted;
     const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
     const long long win_base = c->job.win_base;
     const long long epoch = c->state_epoch;
+    const double margin = 38.0 + fm_log((double)K + 1.0);
     // where lane (lr, lk) finds its entry of permuted fragment kk in a factor stored in the standard order
     // (Wfrag: fragment kk, lane (ln, lk) = column 4 kk + lk): source fragment 2 (kk / 2) + (lk >> 1) of the block,
     // source k-lane (2 lk + (kk & 1)) & 3
@@ -118,22 +127,26 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     // the homes of the block's first and last row
     WRec rcur, rnext;
     int wrow_cur = 0, wrow_next = 0, hf_cur = -3, hl_cur = -3, hf_next = -3, hl_next = -3;
-    double u_cur = 0.0;
-#define HOME_LOAD_REC(B, R, WR, HF, HL)                                                    \
+    // (Unconditional loads from clamped indices, validity kept on the side: a load inside a divergent branch is
+    //  waited for where the branch joins -- and with it every row load in flight.)
+#define HOME_LOAD_REC(B, R, WR, HF, HL, OK)                                                \
     {                                                                                      \
-        const long long kf_ = (B) * 256, k_ = kf_ + w * 64 + lane;                         \
-        R.i = -1; R.home = -2; R.home_label = -1; R.mlb0 = -INFINITY; R.pad = 0.0; WR = 0; HF = -3; HL = -3; \
-        if ((B) < b1) {                                                                    \
-            const long long kl_ = kf_ + 255 < nrows ? kf_ + 255 : nrows - 1;               \
-            HF = d.wrec[kf_].home; HL = d.wrec[kl_].home;                                  \
-            if (k_ < nrows) { R = d.wrec[k_]; WR = d.wperm[k_]; }                          \
-        }                                                                                  \
+        const bool bok_ = (B) < b1;                                                        \
+        const long long kf_ = bok_ ? (B) * 256 : 0, k_ = kf_ + w * 64 + lane;              \
+        const long long kl_ = kf_ + 255 < nrows ? kf_ + 255 : nrows - 1;                   \
+        const long long kc_ = k_ < nrows ? k_ : nrows - 1;                                 \
+        HF = d.wrec[kf_].home; HL = d.wrec[kl_].home;                                      \
+        R = d.wrec[kc_]; WR = d.wperm[kc_];                                                \
+        OK = bok_ && k_ < nrows;                                                           \
     }
-    HOME_LOAD_REC(b0, rcur, wrow_cur, hf_cur, hl_cur)
+    bool ok_cur, ok_next = false;
+    HOME_LOAD_REC(b0, rcur, wrow_cur, hf_cur, hl_cur, ok_cur)
     rnext = rcur; wrow_next = 0;
     // A tile on its way in: lane (lr, lk) fetches 16 bytes of row lr per instruction.  The lane's row offset comes
     // from the lane that owns the row's record (ds_bpermute); columns beyond D read column 0 and are zeroed.
-    double xf[NKK], xn[NKK];                                         // the tile in the matrix pipe, the tile on its way
+    // NS register slots hold tiles: tile t of a block sits in slot t % NS (4 tiles per block, NS = 2 or 4: the slot
+    // of a tile is a compile-time constant), NS - 1 tiles are on their way while one is in the matrix pipe.
+    double xt[NS][NKK];
     int coff[WHOLE ? 1 : NKK];                                       // (padded columns: where the lane's entries are, -1 = none)
     if (!WHOLE) {
 #pragma unroll
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             coff[WHOLE ? 0 : kk] = col < D ? col : -1;
         }
     }
-#define HOME_ISSUE(XO, TN)                                                                 \
+#define HOME_ISSUE(DST, XO, TN)                                                            \
     {                                                                                      \
         const int src_ = 16 * (TN) + lr;                                                   \
         const long long o_ = ((long long)__shfl((int)((XO) >> 32), src_) << 32) | (unsigned int)__shfl((int)(XO), src_); \
@@ -150,20 +163,28 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             const home_d2 *__restrict__ xrow = (const home_d2 *)(d.X + o_ + 2 * lk);       \
             _Pragma("unroll") for (int j = 0; j < NJ8; ++j) {                              \
                 const home_d2 v_ = __builtin_nontemporal_load(xrow + 4 * j);               \
-                xn[2 * j] = v_.x; xn[2 * j + 1] = v_.y;                                    \
+                DST[2 * j] = v_.x; DST[2 * j + 1] = v_.y;                                  \
             }                                                                              \
         } else {                                                                           \
             const double *__restrict__ xrow = d.X + o_;                                    \
             _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk) {                           \
                 const int co_ = coff[WHOLE ? 0 : kk];                                      \
                 const double a_ = __builtin_nontemporal_load(xrow + (co_ >= 0 ? co_ : 0)); \
-                xn[kk] = co_ >= 0 ? a_ : 0.0;                                              \
+                DST[kk] = co_ >= 0 ? a_ : 0.0;                                             \
             }                                                                              \
         }                                                                                  \
     }
     // (element offset of the lane's row in X: one 64-bit multiply per record)
-    long long xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D;
-    HOME_ISSUE(xo_cur, 0)
+    // of the current block's rows, of the next block's (wanted NS - 1 tiles before that block starts: its record
+    // index is fetched a block earlier than the rest of the record)
+    long long xo_cur = (ok_cur && rcur.i >= 0 ? rcur.i : 0) * D, xo_next, i_after = 0;
+    {
+        const long long k_ = (b0 + 1) * 256 + w * 64 + lane;
+        const long long i1 = d.wrec[k_ < nrows ? k_ : nrows - 1].i;
+        xo_next = (b0 + 1 < b1 && k_ < nrows && i1 >= 0 ? i1 : 0) * D;
+    }
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) HOME_ISSUE(xt[t], xo_cur, t)
     unsigned n_mfma = 0, n_homes = 0;
     int cur_home = -1;
 #ifdef BGMM_HOME_PROF
@@ -171,15 +192,16 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #endif
 #pragma unroll 1
     for (long long b = b0; b < b1; ++b) {
-        const long long imine = rcur.i;
-        const int hmine = rcur.home;
+        const long long imine = ok_cur ? rcur.i : -1;
+        const int hmine = ok_cur ? rcur.home : -2;
         sideH[lane] = hmine;
         // The next block's records and this block's uniforms set off here, BEFORE the block's row loads: loads return
         // in order, and they are wanted at the last tile (the next block's first rows) and in the tail -- by then
         // everything older has been consumed anyway, and nothing younger is held up.
-        HOME_LOAD_REC(b + 1, rnext, wrow_next, hf_next, hl_next)
-        u_cur = 0.0;
-        if (imine >= 0) u_cur = d.u[win_base + wrow_cur];
+        HOME_LOAD_REC(b + 1, rnext, wrow_next, hf_next, hl_next, ok_next)
+        const long long k_after = (b + 2) * 256 + w * 64 + lane;
+        const bool ok_after = b + 2 < b1 && k_after < nrows;
+        i_after = d.wrec[ok_after ? k_after : 0].i;
         const int hf = __builtin_amdgcn_readfirstlane(hf_cur), hl = __builtin_amdgcn_readfirstlane(hl_cur);
         const bool one_home = hf == hl && hf >= 0;                    // (the same decision in all four wavefronts)
         HP(6)
@@ -215,23 +237,18 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             __syncthreads();
         }
         HP(7)
-#pragma unroll 1
-        for (int t = 0; t < 4; ++t) {
-            const int r0 = 16 * t;
-            asm volatile("" ::: "memory");          // (keeps the home's LDS constants from being hoisted into registers)
-            // the tile that sets off now was loaded as `xn` a tile ago: it moves into the pipe's registers and the
-            // one after it takes its place (the loads of a block's last tile reach into the next block)
+        if (one_home) {
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) xf[kk] = xn[kk];
-            HP(0)
-            if (t < 3) {
-                HOME_ISSUE(xo_cur, t + 1)
-            } else {
-                const long long xo_next = (rnext.i >= 0 ? rnext.i : 0) * D;
-                HOME_ISSUE(xo_next, 0)
-            }
-            HP(1)
-            if (one_home) {
+            for (int t = 0; t < 4; ++t) {
+                const int r0 = 16 * t;
+                asm volatile("" ::: "memory");      // (keeps the home's LDS constants from being hoisted into registers)
+                const double (&xf)[NKK] = xt[t % NS];
+                HP(0)
+                // tile t + NS - 1 sets off into the slot tile t - 1 has left (beyond the block: the next block's rows)
+                if (t + NS - 1 < 4) { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_cur, t + NS - 1) }
+                else { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_next, t + NS - 1 - 4) }
+                HP(1)
+                {
                 // ---- every row of the tile under the block's home: factor and constants from LDS
                 double dpart = 0.0;
                 LDS_AS const double *const wf = Bf + lane;
@@ -268,9 +285,20 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 dpart += __shfl_xor(dpart, 16);
                 dpart += __shfl_xor(dpart, 32);
                 if (lk == 0) sideRho[r0 + lr] = dpart;
-            } else {
-                // ---- the homes present in the tile, one after the other; factor tiles from L2 (standard order:
-                // every lane fetches the entry the permutation assigns to it)
+                }
+                HP(3)
+            }
+        } else {
+            // ---- the general path (a block that straddles homes, or holds unassigned rows): tile by tile with its
+            // own loads -- the prefetched slots are left alone and refilled for the next block afterwards
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {
+                const int r0 = 16 * t;
+                double xf[NKK];
+                HOME_ISSUE(xf, xo_cur, t)
+                // the homes present in the tile, one after the other; factor tiles from L2 (standard order: every lane
+                // fetches the entry the permutation assigns to it)
+                {
                 int hq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hq[r] = sideH[r0 + lk + 4 * r];
@@ -325,7 +353,10 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     dpart += __shfl_xor(dpart, 32);
                     if (lk == 0 && hd == s) sideRho[r0 + lr] = dpart;
                 }
+                }
             }
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t) HOME_ISSUE(xt[t], xo_next, t)
             HP(3)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double jf = rad * finv_a;
                 double bound = INFINITY;
                 if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftab[(long long)a * 64 + (int)jf + 1];
-                if (den > 0.0 && bound < mx - kHomeMargin) {
+                if (den > 0.0 && bound < mx - margin) {
                     // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20).
                     // With eh = exp(vh - mx), en = exp(vnew - mx) one of the two is exp(0) = 1; and when the new table
                     // lies more than 37 nats below the home, 1 + en rounds to 1, the log-sum-exp to vh, the home's
@@ -372,22 +403,27 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     const double dv = vnew - vh;                       // (mx = vh iff dv <= 0)
                     int pick = a;
                     double en = 0.0;
+                    const long long p = win_base + wrow_cur;
                     if (!(dv < -37.0)) {
+                        // (the visit's uniform is fetched only here: a scattered 8-byte read per visit otherwise, for a
+                        //  draw whose outcome does not depend on it)
+                        const double u_cur = d.u[p];
                         const double eo = fm_exp(-fabs(dv));
                         const double eh = dv <= 0.0 ? 1.0 : eo;
                         en = dv <= 0.0 ? eo : 1.0;
                         const double lse = fm_log(eh + en) + mx;
                         pick = u_cur - fm_exp(vh - lse) < 0.0 ? a : K;
                     }
-                    const long long p = win_base + wrow_cur;
-                    d.choice[wrow_cur] = pick;
+                    // (apply_kernel reads the drawn label of the window's first mover only: a stay leaves nothing behind)
+                    if (pick != a) d.choice[wrow_cur] = pick;
                     if (keep_caches) {
                         if (dv < -37.0) en = fm_exp(dv);
                         PCacheExact pe;
                         pe.epoch = epoch;
                         // log of the alternatives' total weight relative to the home's: the new table exactly, every other
-                        // label below e^-80 of the best
-                        pe.log_alt = mx - vh + fm_log(en + (double)K * 1.8048513878454153e-35);
+                        // label below its table bound (e^-80 of the best when the bound is that far down)
+                        const double rest = bound < mx - kHomeFar ? 1.8048513878454153e-35 : fm_exp(bound - mx);
+                        pe.log_alt = mx - vh + fm_log(en + (double)K * rest);
                         d.pcache2[imine] = pe;
                     }
                     if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
@@ -410,8 +446,9 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         }
         HP(4)
         // the next block's row becomes the current one; its uniform and the record after it set off
-        rcur = rnext; wrow_cur = wrow_next; hf_cur = hf_next; hl_cur = hl_next;
-        xo_cur = (rcur.i >= 0 ? rcur.i : 0) * D;
+        rcur = rnext; wrow_cur = wrow_next; hf_cur = hf_next; hl_cur = hl_next; ok_cur = ok_next;
+        xo_cur = xo_next;
+        xo_next = (ok_after && i_after >= 0 ? i_after : 0) * D;
         HP(5)
     }
 #ifdef BGMM_HOME_PROF

@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ 
 // The same rows fetched straight into MFMA A-fragment order: lane (lr = lane % 16, lk = lane / 16) takes 16 bytes
 // of row lr at column 8 j + 2 lk, j = 0 .. D/8 - 1 (64 contiguous bytes per row and instruction); T tiles of 16
 // rows in flight per wavefront.
-template <int T, int NJ8>
+template <int T, int NJ8, bool QUAD>
 __global__ __launch_bounds__(256) void frag_kernel(const double *__restrict__ X, const int *__restrict__ idx, long long nrows,
                                                    int D, double *out) {
-    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    // QUAD: four consecutive lanes share a row (64 contiguous bytes per quad) instead of lanes l, l + 16, l + 32, l + 48
+    const int lane = threadIdx.x & 63, lr = QUAD ? lane >> 2 : lane & 15, lk = QUAD ? lane & 3 : lane >> 4;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const long long ntiles = (nrows + 15) / 16;
@@ -150,16 +151,18 @@ int main(int argc, char **argv) {
         run<8, 1, true>(X, idx_r, N, D, out, "random");
         run<16, 1, true>(X, idx_s, N, D, out, "by-home");
         for (int wg : {512, 768, 1024, 2048}) {
-            double ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<1, 8>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
+            double ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<1, 8, false>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
             printf("by-home fragment order T=1, %4d workgroups  : %8.1f us  %6.2f TB/s\n", wg, ms * 1e3, bytes / ms / 1e9);
-            ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<2, 8>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
+            ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<2, 8, false>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
             printf("by-home fragment order T=2, %4d workgroups  : %8.1f us  %6.2f TB/s\n", wg, ms * 1e3, bytes / ms / 1e9);
+            ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<1, 8, true>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
+            printf("by-home quad order     T=1, %4d workgroups  : %8.1f us  %6.2f TB/s\n", wg, ms * 1e3, bytes / ms / 1e9);
         }
     } else if (D == 128) {
         run<16, 2, true>(X, idx_r, N, D, out, "random");
         run<16, 2, true>(X, idx_s, N, D, out, "by-home");
         for (int wg : {256, 512, 1024}) {
-            double ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<1, 16>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
+            double ms = time_ms([&] { hipLaunchKernelGGL((frag_kernel<1, 16, false>), dim3(wg), dim3(256), 0, 0, X, idx_s, N, D, out); });
             printf("by-home fragment order T=1, %4d workgroups  : %8.1f us  %6.2f TB/s\n", wg, ms * 1e3, bytes / ms / 1e9);
         }
     } else if (D == 16) {
