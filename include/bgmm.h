@@ -198,7 +198,16 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
  * regime); exact pruning of components whose weight in a draw is provably
  * below e^-80 (0 auto: on while movers are sparse, plus certified stays in converged chains; 1 off;
  * 2 in every window whatever the regime -- slow when movers are dense, meant for tests; 3 as 0
- * but without certified stays, for measurements).  None of them changes the sampled trajectory.
+ * but without certified stays, for measurements).  None of them changes the sampled trajectory, in this
+ * sense: counts and sufficient statistics are bit-identical to the reference's in every mode, while the
+ * floats of the predictive (rank-1 factor updates with a from-scratch rebuild every 64 steps: log
+ * determinant to 1e-8 relative, inverse to 1e-7; wave-order sums; components dropped below e^-80 / e^-38 of
+ * the best entering a draw as 0) differ from the reference's LAPACK route at the 1e-13 level, so a uniform
+ * that lands within that distance of a boundary of the draw's cumulative distribution can pick the
+ * neighbouring label -- in one mode and not in another, or against the reference.  That is an event of
+ * probability ~1e-13 per visit; the golden trajectories, the soak runs (default configuration against plain
+ * full evaluation) and the full-size tests have never met one.  prune_mode 1 with kernel_kind 1 (every pair
+ * through the VALU kernel, dense draw kernel) is the configuration closest to the reference's arithmetic.
  * With everything on auto, full-covariance problems of D <= 4 whose staged visiting order is a
  * permutation (or absent) are swept by one workgroup that keeps the labels' state in LDS
  * (sweep_seq_kernel); forcing a kernel or a resolver mode, or prune_mode 2, selects the windowed
@@ -218,6 +227,25 @@ int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
 
 /* Blocks until all work queued on the context's stream has finished. */
 int bgmm_synchronize(bgmm_ctx *ctx);
+
+/*
+ * Multi-chain final label gather (the reference has no counterpart: its chains would be
+ * separate processes).  Chains are replicas -- nothing is exchanged during sampling; after the last sweep ONE
+ * RCCL all-gather (over xGMI between the GPUs of a node) collects the final labels.  RCCL is loaded on first
+ * use (dlopen of librccl.so.1: a process that already carries one, e.g. PyTorch's, shares it), so single-chain
+ * users never touch it.
+ *   bgmm_comm_unique_id   128 bytes from ncclGetUniqueId: rank 0 makes them, the caller ships them to the other
+ *                         ranks by whatever it has (a file, MPI, torch.distributed ...)
+ *   bgmm_comm_create      ncclCommInitRank on `device` (the device of this rank's chain)
+ *   bgmm_gather_labels    z_all[r * N + i] = label of point i in rank r's chain (int64, label numbering of
+ *                         bgmm_get_assignments, -1 = unassigned), on every rank, in host memory
+ *   bgmm_comm_destroy
+ * Errors: BGMM_EDEVICE with the RCCL message in bgmm_last_error(ctx) (or (NULL) for the calls without a context).
+ */
+int bgmm_comm_unique_id(void *id128_out);
+int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id128, int32_t device, void **comm_out);
+int bgmm_gather_labels(bgmm_ctx *ctx, void *comm, int32_t world_size, int64_t *z_all_out);
+int bgmm_comm_destroy(void *comm);
 
 #ifdef __cplusplus
 }

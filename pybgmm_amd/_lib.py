@@ -59,6 +59,10 @@ SIGNATURES = {
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "bgmm_set_seq_plan": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_set_home_pass": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_comm_unique_id": (ctypes.c_int, [_vp]),
+    "bgmm_comm_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp]),
+    "bgmm_gather_labels": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, _vp]),
+    "bgmm_comm_destroy": (ctypes.c_int, [_vp]),
     "bgmm_synchronize": (ctypes.c_int, [_vp]),
 }
 
@@ -320,5 +324,41 @@ class Context(object):
     def set_home_pass(self, mode=0):
         self._ck(self.L.bgmm_set_home_pass(self.h, int(mode)))
 
+    def gather_labels(self, comm, world_size):
+        """Final labels of every chain of the communicator (``Comm``): int64[world_size, N] on every rank."""
+        out = np.empty((int(world_size), self.N), dtype=np.int64)
+        self._ck(self.L.bgmm_gather_labels(self.h, comm.h, int(world_size), _ptr(out)))
+        return out
+
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))
+
+
+class Comm(object):
+    """RCCL communicator of the final label gather (include/bgmm.h: bgmm_comm_*).  ``unique_id()`` on rank 0,
+    ship the 128 bytes to the other ranks, then ``Comm(rank, world_size, id_bytes, device)`` on every rank."""
+
+    @staticmethod
+    def unique_id():
+        L = load()
+        buf = ctypes.create_string_buffer(128)
+        rc = L.bgmm_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+        if rc != 0:
+            raise BGMMError(rc, (L.bgmm_last_error(None) or b"").decode())
+        return buf.raw
+
+    def __init__(self, rank, world_size, id_bytes, device=0):
+        self.L = load()
+        self.world_size = int(world_size)
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
+        rc = self.L.bgmm_comm_create(int(rank), int(world_size), ctypes.cast(buf, ctypes.c_void_p), int(device),
+                                     ctypes.byref(h))
+        if rc != 0:
+            raise BGMMError(rc, (self.L.bgmm_last_error(None) or b"").decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bgmm_comm_destroy(self.h)
+            self.h = None

@@ -46,6 +46,21 @@ def gather_chains(z_local, log_marg_local, device=None):
             l_all.cpu().numpy().reshape((G,) + lm_local.shape))
 
 
+def gather_labels_rccl(ctx, rank, world_size, device_index, exchange_id):
+    """
+    The same label gather through the C-ABI alone (``bgmm_comm_*`` / ``bgmm_gather_labels``, include/bgmm.h): for
+    hosts that have no ``torch.distributed``.  ``exchange_id(id_bytes_or_None) -> id_bytes`` ships rank 0's 128
+    bytes to every rank (rank 0 passes them in, the others pass None).  Returns int64[world_size, N].
+    """
+    from . import _lib
+    ident = exchange_id(_lib.Comm.unique_id() if rank == 0 else None)
+    comm = _lib.Comm(rank, world_size, ident, device=device_index)
+    try:
+        return ctx.gather_labels(comm, world_size)
+    finally:
+        comm.close()
+
+
 def run_chain(model_cls, X, prior, alpha, n_iter, seed, rank, device_index, true_assignments=None,
               assignments="rand", K=1, K_max=None, sampler_kwargs=None):
     """Build chain ``rank`` on GPU ``device_index`` with its own seeded generators and

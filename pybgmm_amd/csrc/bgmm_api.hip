@@ -14,6 +14,7 @@
 #include "bgmm_device.h"
 
 #include <cmath>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -437,12 +438,17 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
         std::vector<long long> cur(offsets.begin(), offsets.end() - 1);
         for (long long i = 0; i < N; ++i) if (z[i] >= 0) members[(size_t)cur[z[i]]++] = (int)i;
     }
-    long long *dz, *doff;
-    int *dmem;
+    long long *dz = nullptr, *doff = nullptr;
+    int *dmem = nullptr;
     hipError_t e1 = hipMalloc((void **)&dz, sizeof(long long) * N);
     hipError_t e2 = hipMalloc((void **)&doff, sizeof(long long) * (K + 1));
     hipError_t e3 = hipMalloc((void **)&dmem, sizeof(int) * members.size());
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, BGMM_EDEVICE, "hipMalloc failed");
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        if (e1 == hipSuccess) (void)hipFree(dz);
+        if (e2 == hipSuccess) (void)hipFree(doff);
+        if (e3 == hipSuccess) (void)hipFree(dmem);
+        return fail(c, BGMM_EDEVICE, "hipMalloc failed");
+    }
     int rc = 0;
     do {
         if (hipMemcpy(dz, z, sizeof(long long) * N, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1185,4 +1191,97 @@ extern "C" int bgmm_synchronize(bgmm_ctx *c) {
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Final label gather of independent chains (include/bgmm.h): RCCL through dlopen, so that the
+// library carries no link-time dependency on it (and shares the copy a host process already loaded).
+// ------------------------------------------------------------------------------------------
+struct Id128 { char b[128]; };                          // ncclUniqueId (passed by value)
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(nullptr, BGMM_EDEVICE, "librccl.so.1 not found (multi-chain gather needs RCCL)");
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(h, "ncclCommInitRank");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    r.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+        return fail(nullptr, BGMM_EDEVICE, "librccl.so.1 lacks the nccl* entry points");
+    g_rccl = r;
+    return 0;
+}
+
+static int rccl_fail(bgmm_ctx *c, const char *what, int code) {
+    std::string msg = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error");
+    return fail(c, BGMM_EDEVICE, msg.c_str());
+}
+
+extern "C" int bgmm_comm_unique_id(void *id128_out) {
+    if (!id128_out) return BGMM_EINVAL;
+    int rc = rccl_load();
+    if (rc) return rc;
+    const int e = g_rccl.GetUniqueId(id128_out);
+    return e == 0 ? 0 : rccl_fail(nullptr, "ncclGetUniqueId", e);
+}
+
+extern "C" int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id128, int32_t device, void **comm_out) {
+    if (!id128 || !comm_out || world_size < 1 || rank < 0 || rank >= world_size) return BGMM_EINVAL;
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, BGMM_EDEVICE, "hipSetDevice failed");
+    Id128 id;
+    memcpy(id.b, id128, sizeof(id.b));
+    void *comm = nullptr;
+    const int e = g_rccl.CommInitRank(&comm, world_size, id, rank);
+    if (e != 0) return rccl_fail(nullptr, "ncclCommInitRank", e);
+    *comm_out = comm;
+    return 0;
+}
+
+extern "C" int bgmm_gather_labels(bgmm_ctx *c, void *comm, int32_t world_size, int64_t *z_all_out) {
+    if (!c || !comm || !z_all_out || world_size < 1) return BGMM_EINVAL;
+    int rc = rccl_load();
+    if (rc) return rc;
+    CK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->d.N;
+    long long *dz = nullptr, *dall = nullptr;
+    CK(c, hipMalloc((void **)&dz, sizeof(long long) * N));
+    hipError_t e = hipMalloc((void **)&dall, sizeof(long long) * N * (size_t)world_size);
+    if (e != hipSuccess) { (void)hipFree(dz); CK(c, e); }
+    launch_labels(c->d, dz, nullptr, c->stream);
+    const int ne = g_rccl.AllGather(dz, dall, N, /* ncclInt64 */ 4, comm, c->stream);
+    if (ne == 0) {
+        e = hipMemcpyAsync(z_all_out, dall, sizeof(long long) * N * (size_t)world_size, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(dz); (void)hipFree(dall);
+    if (ne != 0) return rccl_fail(c, "ncclAllGather", ne);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_comm_destroy(void *comm) {
+    if (!comm) return BGMM_EINVAL;
+    int rc = rccl_load();
+    if (rc) return rc;
+    const int e = g_rccl.CommDestroy(comm);
+    return e == 0 ? 0 : rccl_fail(nullptr, "ncclCommDestroy", e);
 }

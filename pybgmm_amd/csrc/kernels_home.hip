@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
     const long long win_base = c->job.win_base;
     const long long epoch = c->state_epoch;
-    const double margin = 38.0 + fm_log((double)K + 1.0);
+    // (With certified stays on, a visit decided here should come back certified next sweep: that needs its
+    //  alternatives' weight known to e^-37.75 of the home's (tier 1), which the table bound delivers only when it lies
+    //  far below -- so the wide margin there, and the rows in between go to the pruning kernel, whose draw kernel
+    //  sums the alternatives exactly.)
+    const double margin = keep_caches ? kHomeFar : 38.0 + fm_log((double)K + 1.0);
     // where lane (lr, lk) finds its entry of permuted fragment kk in a factor stored in the standard order
     // (Wfrag: fragment kk, lane (ln, lk) = column 4 kk + lk): source fragment 2 (kk / 2) + (lk >> 1) of the block,
     // source k-lane (2 lk + (kk & 1)) & 3

@@ -778,8 +778,17 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
                 c->lik_evals += j.K;                 // K after the removal
                 const int rc = plan_seat(d, c, mp.i, lab, mp);
                 if (rc != 0) {
+                    // (K_max reached: the reference raises from add_item with the point already taken out by
+                    //  del_item -- counts, statistics and derived state are left exactly like that: the removal
+                    //  is applied, the point stays unassigned, the sweep ends with the sticky error)
                     atomicCAS(&c->error, 0, rc);
                     j.mode = MODE_DONE;
+                    mp.add_slot = -1; mp.add_init = 0;
+                    do_move = mp.sub_slot >= 0 ? 1 : 0;
+                    c->tables_valid = 0;
+                    c->wsort_valid = 0;
+                    c->state_epoch += 1;
+                    set_refresh(d, c, mp, false);
                 } else {
                     do_move = 1;
                     c->tables_valid = 0;

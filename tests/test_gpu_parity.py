@@ -122,6 +122,8 @@ def test_every_window_pruned(case, home):
     (20000, 16, 40, 0.9, "overlapping clusters: survivors of every bound level, long work lists"),
     (8000, 48, 300, 4.0, "K > 256: several coarse passes"),
     (4000, 128, 20, 4.0, "D = 128"),
+    (12000, 40, 30, 4.0, "D = 40: padded columns in the rows' 16-byte pieces (home_kernel's general loads)"),
+    (9000, 32, 25, 4.0, "D = 32: four tiles in flight per wavefront"),
 ])
 @pytest.mark.parametrize("home", [1, 2], ids=["home-pass", "no-home-pass"])
 def test_every_window_pruned_against_c_oracle(N, D, K, sep, label, home):
@@ -317,6 +319,39 @@ def test_k_max_overflow_is_an_error():
     with pytest.raises(_lib.BGMMError) as ei:
         ctx.sweep(np.full(50, 0.999999))
     assert ei.value.code == -3 and "K_max" in str(ei.value)
+    ctx.close()
+
+
+def test_k_max_overflow_leaves_a_consistent_state():
+    """The reference raises from add_item (gaussian_components.py:158-160) with the point already taken out by
+    del_item: after BGMM_EKMAX the counts, statistics and derived state are those of the labelling the getters
+    return (the visited point unassigned), not a half-applied move."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D = 80, 6
+    X, _ = gendata.synth_mixture(N, D, 2, seed=3)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1e300, 3, tables=reference_tables(v_0, N))   # always a new table
+    ctx.set_tuning(kernel_kind=2)
+    ctx.set_assignments(np.zeros(N, dtype=np.int64))
+    with pytest.raises(_lib.BGMMError) as ei:
+        ctx.sweep(np.full(N, 0.999999))
+    assert ei.value.code == -3
+    z = ctx.assignments()
+    assert np.count_nonzero(z < 0) == 1 and ctx.K == 3
+    counts = ctx.counts()
+    assert counts.sum() == N - 1
+    m, S, logdet, _ = ctx.stats(want_inv=False)
+    for k in range(3):
+        idx = np.nonzero(z == k)[0]
+        assert counts[k] == idx.size
+        np.testing.assert_allclose(m[k], k_0 * m_0 + X[idx].sum(axis=0), rtol=1e-12, atol=1e-12)
+        S_ref = S_0 + k_0 * np.outer(m_0, m_0) + X[idx].T @ X[idx]
+        np.testing.assert_allclose(S[k], S_ref, rtol=1e-11, atol=1e-11)
+        k_N = k_0 + idx.size
+        v_N = v_0 + idx.size
+        covar = (S_ref - np.outer(m[k], m[k]) / k_N) * (k_N + 1.0) / (k_N * (v_N - D + 1.0))     # gaussian_components.py:319-331
+        assert abs(logdet[k] - np.linalg.slogdet(covar)[1]) <= 1e-8 * max(1.0, abs(logdet[k]))
     ctx.close()
 
 
@@ -1273,3 +1308,20 @@ def test_chain_c_equals_a_global_seed_run(model):
     Z, LM = chains.gather_chains(zs[0], lms[0])                 # (single process: the stack of one)
     npt.assert_array_equal(Z[0], zs[0])
     npt.assert_array_equal(np.stack(zs), np.stack([Z[0], zs[1]]))
+
+
+def test_label_gather_through_the_c_abi():
+    """bgmm_comm_* + bgmm_gather_labels (RCCL all-gather of the final labels).  One GPU here, so a
+    communicator of one rank: the gathered stack is the chain's own labelling (unassigned points as -1)."""
+    from pybgmm_amd import _lib
+    g = Golden("kat1_igmm_2d")
+    ctx = _lib.Context(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.K_max, tables=reference_tables(g.v_0, g.N))
+    ctx.set_assignments(g.z_init)
+    ctx.sweep(g.u[0], g.sweep_order(0), g.sweep_power(0))
+    ctx.del_item(3)
+    comm = _lib.Comm(0, 1, _lib.Comm.unique_id(), device=0)
+    z_all = ctx.gather_labels(comm, 1)
+    assert z_all.shape == (1, g.N) and z_all.dtype == np.int64
+    assert np.array_equal(z_all[0], ctx.assignments()) and z_all[0, 3] == -1
+    comm.close()
+    ctx.close()
