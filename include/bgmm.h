@@ -232,8 +232,9 @@ int bgmm_synchronize(bgmm_ctx *ctx);
  * Multi-chain final label gather (the reference has no counterpart: its chains would be
  * separate processes).  Chains are replicas -- nothing is exchanged during sampling; after the last sweep ONE
  * RCCL all-gather (over xGMI between the GPUs of a node) collects the final labels.  RCCL is loaded on first
- * use (dlopen of librccl.so.1: a process that already carries one, e.g. PyTorch's, shares it), so single-chain
- * users never touch it.
+ * use (dlopen of the librccl.so.1 that sits next to the HIP runtime this library is linked against -- not a copy
+ * another runtime in the process may have brought along, e.g. PyTorch's bundled one), so single-chain users never
+ * touch it.
  *   bgmm_comm_unique_id   128 bytes from ncclGetUniqueId: rank 0 makes them, the caller ships them to the other
  *                         ranks by whatever it has (a file, MPI, torch.distributed ...)
  *   bgmm_comm_create      ncclCommInitRank on `device` (the device of this rank's chain)

@@ -1212,9 +1212,19 @@ static Rccl g_rccl;
 
 static int rccl_load() {
     if (g_rccl.lib) return 0;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    // The copy that belongs to THIS library's HIP runtime (the one next to the libamdhip64 we are linked against): a
+    // process may carry another RCCL built against another runtime (PyTorch bundles both), and streams and device
+    // pointers of one runtime mean nothing to the other.
+    void *h = nullptr;
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) h = dlopen((dir.substr(0, slash) + "/librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+    }
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(nullptr, BGMM_EDEVICE, "librccl.so.1 not found (multi-chain gather needs RCCL)");
     Rccl r;
     r.lib = h;
@@ -1247,6 +1257,7 @@ extern "C" int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id
     int rc = rccl_load();
     if (rc) return rc;
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, BGMM_EDEVICE, "hipSetDevice failed");
+    (void)hipGetLastError();                            // (RCCL reports a stale error of the thread as its own)
     Id128 id;
     memcpy(id.b, id128, sizeof(id.b));
     void *comm = nullptr;
@@ -1267,6 +1278,7 @@ extern "C" int bgmm_gather_labels(bgmm_ctx *c, void *comm, int32_t world_size, i
     hipError_t e = hipMalloc((void **)&dall, sizeof(long long) * N * (size_t)world_size);
     if (e != hipSuccess) { (void)hipFree(dz); CK(c, e); }
     launch_labels(c->d, dz, nullptr, c->stream);
+    (void)hipGetLastError();
     const int ne = g_rccl.AllGather(dz, dall, N, /* ncclInt64 */ 4, comm, c->stream);
     if (ne == 0) {
         e = hipMemcpyAsync(z_all_out, dall, sizeof(long long) * N * (size_t)world_size, hipMemcpyDeviceToHost, c->stream);
