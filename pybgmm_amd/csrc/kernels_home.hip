@@ -22,7 +22,7 @@
 //   * the inverse factor of the block's home -- the MFMA B operand, 20 KB at D = 64, 72 KB at D = 128 -- sits in
 //     LDS, loaded when the home changes (the rows are grouped by home: about once per workgroup), together
 //     with the home's constants; the matrix loop reads it with ds_read (lgkmcnt), the only traffic on vmcnt
-//     are the rows, their records and the uniforms;
+//     are the rows and their records;
 //   * the rows go from memory STRAIGHT into A-operand registers: lane (lr, lk) of a 16-row tile takes 16 bytes
 //     of row lr at column 8 j + 2 lk, j = 0 .. D/8 - 1 (64 contiguous bytes per row and instruction; measured
 //     5.1 TB/s for this pattern against 6.5 for whole-row loads, tools/gather_bw.hip).  The two doubles are the
@@ -31,7 +31,8 @@
 //     permuted to match when they are copied into LDS (a sum over the same products in another order).  No
 //     staging tile, no transposition, a tile in flight costs its 2 D/16 registers and nothing else;
 //   * every wavefront (64 rows of the block, 16 at a time) has the next tiles on their way while the current one
-//     is in the matrix pipe; records and uniforms a block ahead;
+//     is in the matrix pipe (three of them up to D = 32); records a block ahead, issued before the block's row loads;
+//     the visit's uniform is fetched only when its draw depends on it;
 //   * a block that straddles two homes (or holds unassigned rows) takes the general path: factor tiles from L2
 //     through a register ring, home by home.
 // Per wavefront lane = row for everything scalar (the record, the tail); quadratic forms and distances meet their
