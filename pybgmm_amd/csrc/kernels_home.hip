@@ -214,14 +214,25 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             __syncthreads();                                          // everybody is done with the previous home
             const double *__restrict__ src = d.Wfrag + (long long)hf * (NF * 64);
             // (read in storage order, two doubles per thread and step; written where the permutation puts them:
-            //  column c16 = 4 (ks % 4) + lks of its block goes to k-slice 2 (c16 / 8) + (c16 & 1), k-lane (c16 & 7) / 2)
-            for (int e2 = tid; e2 < NF * 32; e2 += 256) {
-                const home_d2 v = ((const home_d2 *)src)[e2];
-                const int e = 2 * e2, f = e >> 6, ln = e & 63;           // lanes ln, ln + 1: same fragment, same k-lane
-                const int ks = f & 3, lks = ln >> 4;                      // (2 J (J + 1) is a multiple of 4)
-                const int c16 = 4 * ks + lks;
-                const int dst = (f - ks + 2 * (c16 >> 3) + (c16 & 1)) * 64 + (ln & 15) + 16 * ((c16 & 7) >> 1);
-                Bf[dst] = v.x; Bf[dst + 1] = v.y;
+            //  column c16 = 4 (ks % 4) + lks of its block goes to k-slice 2 (c16 / 8) + (c16 & 1), k-lane (c16 & 7) / 2
+            //  -- six loads in flight per thread: one round trip to L2 per batch instead of one per piece)
+            constexpr int FB = 6;
+            for (int e0 = tid; e0 < NF * 32; e0 += 256 * FB) {
+                home_d2 v[FB];
+#pragma unroll
+                for (int k = 0; k < FB; ++k) {
+                    const int e2 = e0 + 256 * k;
+                    v[k] = ((const home_d2 *)src)[e2 < NF * 32 ? e2 : tid];
+                }
+#pragma unroll
+                for (int k = 0; k < FB; ++k) {
+                    const int e2 = e0 + 256 * k;
+                    const int e = 2 * e2, f = e >> 6, ln = e & 63;       // lanes ln, ln + 1: same fragment, same k-lane
+                    const int ks = f & 3, lks = ln >> 4;                  // (2 J (J + 1) is a multiple of 4)
+                    const int c16 = 4 * ks + lks;
+                    const int dst = (f - ks + 2 * (c16 >> 3) + (c16 & 1)) * 64 + (ln & 15) + 16 * ((c16 & 7) >> 1);
+                    if (e2 < NF * 32) { Bf[dst] = v[k].x; Bf[dst + 1] = v[k].y; }
+                }
             }
             const int a = d.label_of_slot[hf];
             for (int e = tid; e < Dp; e += 256) {
