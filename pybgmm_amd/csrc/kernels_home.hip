@@ -78,6 +78,30 @@ __host__ __device__ constexpr int home_col(int kq, int lk) { return 8 * (kq >> 1
 
 typedef double home_d2 __attribute__((ext_vector_type(2), aligned(8)));
 
+// Four values per lane, each to be summed over the 16 lanes of its row: a transposing reduction -- after two
+// exchange steps inside the quads a lane carries ONE of the four (the one numbered lane & 3), two rotations by whole
+// quads finish it.  5 additions and 10 DPP moves instead of 16 and 32 (FP64 VALU instructions share the pipe with the
+// other wavefronts' MFMAs).  Returns the sum of a[lane & 3] over the row, in every lane.
+template <int CTRL>
+__device__ __forceinline__ double home_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double home_row_sum4(const double (&a)[4], int lane) {
+    const bool p = lane & 1, q = lane & 2;
+    const double k0 = p ? a[1] : a[0], s0 = p ? a[0] : a[1];
+    const double k1 = p ? a[3] : a[2], s1 = p ? a[2] : a[3];
+    const double b0 = k0 + home_dpp<0xB1>(s0);          // quad_perm [1,0,3,2]: pair sums of a[p]
+    const double b1 = k1 + home_dpp<0xB1>(s1);          //                                   a[2 + p]
+    const double kk = q ? b1 : b0, ss = q ? b0 : b1;
+    double c = kk + home_dpp<0x4E>(ss);                 // quad_perm [2,3,0,1]: quad sum of a[lane & 3]
+    c += home_dpp<0x124>(c);                            // row_ror:4
+    c += home_dpp<0x128>(c);                            // row_ror:8
+    return c;
+}
+
 // WHOLE: D is a multiple of 16 (no padded columns: every 16-byte piece of a tile lies inside its row)
 template <int NJ, bool WHOLE>
 __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev d) {
@@ -293,10 +317,10 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 }
                 n_mfma += NF;
                 n_homes += 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = row16_sum(qp[r]);
-                    if (lr == r) sideQ[r0 + lk + 4 * r] = v;
+                {
+                    // (row lk + 4 r of the tile, r = lane & 3, in the row group's lanes 0 .. 3)
+                    const double v = home_row_sum4(qp, lane);
+                    if (lr < 4) sideQ[r0 + lk + 4 * lr] = v;
                 }
                 dpart += __shfl_xor(dpart, 16);
                 dpart += __shfl_xor(dpart, 32);
@@ -315,9 +339,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 // the homes present in the tile, one after the other; factor tiles from L2 (standard order: every lane
                 // fetches the entry the permutation assigns to it)
                 {
-                int hq[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hq[r] = sideH[r0 + lk + 4 * r];
                 const int hd = sideH[r0 + lr];
                 unsigned long long pending = __ballot(lane >= r0 && lane < r0 + 16 && hmine >= 0);
 #pragma unroll 1
@@ -360,10 +381,9 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #undef HOME_BSRC
                     n_mfma += NF;
                     n_homes += 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double v = row16_sum(qp[r]);
-                        if (lr == r && hq[r] == s) sideQ[r0 + lk + 4 * r] = v;
+                    {
+                        const double v = home_row_sum4(qp, lane);
+                        if (lr < 4 && sideH[r0 + lk + 4 * lr] == s) sideQ[r0 + lk + 4 * lr] = v;
                     }
                     dpart += __shfl_xor(dpart, 16);
                     dpart += __shfl_xor(dpart, 32);
