@@ -230,6 +230,41 @@ def burnin_leg(args, X, local_rank, K_true, seed):
             "speedup_over_reference_python": round(ref * N * 1e-6 / first["seconds"], 1) if ref else None}
 
 
+def launch_plan(gpus, env, devices_visible):
+    """What `--gpus N` means for this process.  ("run", world, rank, local_rank): it is a rank (the only one for
+    N = 1, or one that torch.distributed.run started); ("spawn",): N > 1 and no launcher in the environment, so this
+    process must become one.  Raises SystemExit with a message when the request cannot be met: fewer devices visible
+    than ranks, or a launcher whose world size is not N.  `devices_visible` None skips the device check (--launch-check)."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+        rank, local_rank = int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+        if devices_visible is not None and local_rank >= devices_visible:
+            raise SystemExit("bench.py: rank %d wants GPU %d but only %d HIP device(s) are visible"
+                             % (rank, local_rank, devices_visible))
+        return ("run", world, rank, local_rank)
+    if devices_visible is not None and devices_visible < gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible (one chain per GPU; no "
+                         "oversubscription, no CPU fallback)" % (gpus, devices_visible))
+    if gpus == 1:
+        return ("run", 1, 0, 0)
+    return ("spawn",)
+
+
+def torchrun_argv(gpus, argv):
+    """python -m torch.distributed.run ... bench.py <argv>: the command the driver itself uses for N > 1."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,18 +285,31 @@ def main():
     ap.add_argument("--no-burnin", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous of the --gpus N ranks over gloo and exit (no GPU work; the CPU test of the launcher)")
     args = ap.parse_args()
     if args.inner_pmc:
         inner_pmc(args)
         return
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    plan = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if not args.launch_check else None)
+    if plan[0] == "spawn":
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU)
+        os.execv(sys.executable, [sys.executable] + torchrun_argv(args.gpus, sys.argv[1:]))
+    world, rank, local_rank = plan[1:]
     dist = None
-    if world > 1:
+    if world > 1 or args.launch_check:
         import torch.distributed as dist
+        if args.launch_check:           # rendezvous only (CPU, gloo): what tests/test_bench_launch.py drives
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t)
+            if rank == 0:
+                print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item())}))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
@@ -312,7 +360,12 @@ def main():
         moves += st["moves"]
     barrier()
     elapsed = time.time() - t0
+    per_rank_rate = [round(args.steps / elapsed, 3)]
     if dist is not None:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_rate = [round(args.steps / float(v), 3) for v in every.tolist()]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -426,6 +479,19 @@ def main():
     z_all, lm_all = gather_chains(ctx.assignments(), np.array([log_marg]),
                                   device=torch.device("cuda", local_rank) if world > 1 else None)
     t_gather = time.time() - t0
+    # ... and the same gather through the C-ABI alone (bgmm_comm_* / bgmm_gather_labels: ncclAllGather of the
+    # device-side labels); the two must agree
+    from pybgmm_amd import _lib
+    t0 = time.time()
+    ident = [_lib.Comm.unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(ident, src=0)
+    comm = _lib.Comm(rank, world, ident[0], device=local_rank)
+    z_abi = ctx.gather_labels(comm, world)
+    comm.close()
+    t_gather_abi = time.time() - t0
+    if not np.array_equal(z_abi, z_all):
+        raise SystemExit("bench.py: bgmm_gather_labels and chains.gather_chains disagree on rank %d" % rank)
     ctx.close()
 
     burnin = None
@@ -485,6 +551,9 @@ def main():
                       "sweeps_per_s_by_mode": rates or None,
                       "roofline_other_modes": extra_rooflines or None,
                       "label_gather_s": round(t_gather, 4),
+                      "label_gather_c_abi_s": round(t_gather_abi, 4),
+                      "label_gathers_agree": True,
+                      "sweeps_per_s_per_rank": per_rank_rate,
                       "gathered_shape": list(z_all.shape)},
         }
         print(json.dumps(out))

@@ -23,6 +23,9 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#define BGMM_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -49,10 +52,10 @@ enum { BGMM_COV_FIXED = 2 };   /* covariance_type="fixed" (igmm.py:108-109, gaus
                                   precision_Ns, log_prod_precision_preds, precision_preds                           */
 
 /* Library / build identification, e.g. "bgmm-hip 0.1 gfx950". */
-const char *bgmm_version(void);
+BGMM_API const char *bgmm_version(void);
 
 /* Message of the last failing call on this context (or of a failed bgmm_create when ctx==NULL). */
-const char *bgmm_last_error(const bgmm_ctx *ctx);
+BGMM_API const char *bgmm_last_error(const bgmm_ctx *ctx);
 
 /*
  * GaussianComponents.__init__ + _cache (gaussian_components.py:75-127) without the
@@ -63,11 +66,11 @@ const char *bgmm_last_error(const bgmm_ctx *ctx);
  *   log(n) for n = [1, 1, 2, ..., v_0+N+1] (exactly the reference's `_cached_gammaln_by_2`
  *   and `_cached_log_v`); pass NULL to have the library fill them with libm.
  */
-int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
+BGMM_API int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
                 const double *X, const double *m_0, double k_0, int64_t v_0, const double *S_0,
                 double alpha, const double *lgamma_tab, const double *log_tab);
 
-void bgmm_destroy(bgmm_ctx *ctx);
+BGMM_API void bgmm_destroy(bgmm_ctx *ctx);
 
 /*
  * Initial component assignment (gaussian_components.py:96-111): labels must be -1 or cover
@@ -75,7 +78,7 @@ void bgmm_destroy(bgmm_ctx *ctx);
  * accumulated in the reference's order (k ascending, i ascending, starting from
  * S_0 + k_0 m_0 m_0^T) so that counts / m_N_numerators / S_N_partials are bit-identical.
  */
-int bgmm_set_assignments(bgmm_ctx *ctx, const int64_t *z);
+BGMM_API int bgmm_set_assignments(bgmm_ctx *ctx, const int64_t *z);
 
 /*
  * One full Gibbs sweep = the body of `for i_iter` in CRPMM.collapsed_gibbs_sampler
@@ -86,11 +89,11 @@ int bgmm_set_assignments(bgmm_ctx *ctx, const int64_t *z);
  *           use_power=0 for the plain CRP weight log(n_k) (crpmm.py:70, pcrpmm.py:109-112).
  * Result: identical assignment trajectory to the reference for identical (order, u).
  */
-int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, int32_t use_power, double power);
+BGMM_API int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, int32_t use_power, double power);
 
 /* Same sweep split in two so that the H2D copy of (order, u) can sit outside a timed region. */
-int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
-int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
+BGMM_API int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
+BGMM_API int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
 
 /*
  * The sweep's uniforms continued ON THE DEVICE from the caller's Mersenne Twister: replaces the
@@ -100,41 +103,41 @@ int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
  * CPython's genrand_res53.  `order` as in bgmm_stage_sweep_inputs (NULL = identity).  Follow with
  * bgmm_sweep_staged.
  */
-int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *key624, int32_t *pos);
+BGMM_API int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *key624, int32_t *pos);
 /* The N uniforms currently staged for the next sweep (whichever way they got there). */
-int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
+BGMM_API int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
 
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
  * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no
  * host-to-device traffic inside the call. */
-int bgmm_upload_streams(bgmm_ctx *ctx, int32_t n_sweeps, const double *u_all, const int64_t *order_all);
-int bgmm_sweep_resident(bgmm_ctx *ctx, int32_t index, int32_t use_power, double power);
+BGMM_API int bgmm_upload_streams(bgmm_ctx *ctx, int32_t n_sweeps, const double *u_all, const int64_t *order_all);
+BGMM_API int bgmm_sweep_resident(bgmm_ctx *ctx, int32_t index, int32_t use_power, double power);
 
 /* IGMM.log_marg (igmm/igmm.py:199-215) = CRP log P(z) + sum_k log_marg_k
  * (gaussian_components.py:253-289). */
-int bgmm_log_marg(bgmm_ctx *ctx, double *out);
+BGMM_API int bgmm_log_marg(bgmm_ctx *ctx, double *out);
 /* GaussianComponents.log_marg_k(k) (gaussian_components.py:253-276). */
-int bgmm_log_marg_k(bgmm_ctx *ctx, int32_t k, double *out);
+BGMM_API int bgmm_log_marg_k(bgmm_ctx *ctx, int32_t k, double *out);
 
 /* components.K / .assignments / .counts[:K] (labels in the reference's numbering, i.e.
  * after its swap-with-last deletes, gaussian_components.py:188-205). */
-int bgmm_get_K(bgmm_ctx *ctx, int32_t *K);
-int bgmm_get_assignments(bgmm_ctx *ctx, int64_t *z_out);
-int bgmm_get_counts(bgmm_ctx *ctx, int64_t *counts_out /* K entries */);
+BGMM_API int bgmm_get_K(bgmm_ctx *ctx, int32_t *K);
+BGMM_API int bgmm_get_assignments(bgmm_ctx *ctx, int64_t *z_out);
+BGMM_API int bgmm_get_counts(bgmm_ctx *ctx, int64_t *counts_out /* K entries */);
 
 /* components.m_N_numerators[:K], S_N_partials[:K], logdet_covars[:K], inv_covars[:K]
  * (gaussian_components.py:86-89) in label order; any pointer may be NULL. */
-int bgmm_get_stats(bgmm_ctx *ctx, double *m_out, double *S_out, double *logdet_out, double *inv_out);
+BGMM_API int bgmm_get_stats(bgmm_ctx *ctx, double *m_out, double *S_out, double *logdet_out, double *inv_out);
 
 /* components.cached_log_prior (gaussian_components.py:125-127), N entries. */
-int bgmm_get_log_prior(bgmm_ctx *ctx, double *out);
+BGMM_API int bgmm_get_log_prior(bgmm_ctx *ctx, double *out);
 
 /* GaussianComponents.log_post_pred(i) (gaussian_components.py:228-251): K entries. */
-int bgmm_log_post_pred(bgmm_ctx *ctx, int64_t i, double *out);
+BGMM_API int bgmm_log_post_pred(bgmm_ctx *ctx, int64_t i, double *out);
 
 /* GaussianComponents.add_item(i, k) / del_item(i) (gaussian_components.py:154-186). */
-int bgmm_add_item(bgmm_ctx *ctx, int64_t i, int32_t k);
-int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
+BGMM_API int bgmm_add_item(bgmm_ctx *ctx, int64_t i, int32_t k);
+BGMM_API int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
 
 /*
  * GaussianComponents.restore_component_from_stats (gaussian_components.py:144-152): overwrite the
@@ -144,10 +147,10 @@ int bgmm_del_item(bgmm_ctx *ctx, int64_t i);
  * not touched -- as in the reference, the caller keeps them consistent (cache, del_item, restore).
  * Not offered for covariance_type="fixed".
  */
-int bgmm_set_stats(bgmm_ctx *ctx, int32_t k, const double *m, const double *S, int64_t count);
+BGMM_API int bgmm_set_stats(bgmm_ctx *ctx, int32_t k, const double *m, const double *S, int64_t count);
 /* `components.assignments[i] = k` (igmm/crpmm.py:85): the label of point i alone, no statistics touched
  * (k = -1: unassigned).  With bgmm_set_stats it completes the reference's cache / del_item / restore idiom. */
-int bgmm_set_label(bgmm_ctx *ctx, int64_t i, int32_t k);
+BGMM_API int bgmm_set_label(bgmm_ctx *ctx, int64_t i, int32_t k);
 
 /*
  * Per-sweep clustering metrics of the record dict (gmm/gmm.py:85-104), SURVEY.md 8f rank 2.
@@ -158,8 +161,8 @@ int bgmm_set_label(bgmm_ctx *ctx, int64_t i, int32_t k);
  *   bgmm_cluster_dispersion: out[k] = sum_{i in k} |x_i - mean_k|^2 from the component's sufficient
  *     statistics -- what utils.cluster_loss_inertia (utils/utils.py:31-88) takes the square root of.
  */
-int bgmm_contingency(bgmm_ctx *ctx, const int64_t *true_idx, int32_t K_true, int64_t *table_out);
-int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
+BGMM_API int bgmm_contingency(bgmm_ctx *ctx, const int64_t *true_idx, int32_t K_true, int64_t *table_out);
+BGMM_API int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
 
 /*
  * Measurement hooks.
@@ -177,19 +180,19 @@ int bgmm_cluster_dispersion(bgmm_ctx *ctx, double *out /* K entries */);
  *     the context's own stream; get returns the number of timed launches that did work and the
  *     sum of their durations in milliseconds since the last reset.
  */
-int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out8);
-int bgmm_get_prune_stats(bgmm_ctx *ctx, int64_t *out4);
+BGMM_API int bgmm_get_sweep_stats(bgmm_ctx *ctx, int64_t *out8);
+BGMM_API int bgmm_get_prune_stats(bgmm_ctx *ctx, int64_t *out4);
 /*   path_stats: of the last sweep -- [0] (visit, component) pairs whose quadratic form was EXECUTED (dense
  *     windows: every pair; pruned windows: the pairs scored in full; frozen-factor windows: rows x
  *     (components + the prior); certified visits contribute nothing), [1] frozen-factor windows
  *     (the mover-dense path), [2] visits they consumed, [3] reserved. */
-int bgmm_get_path_stats(bgmm_ctx *ctx, int64_t *out4);
+BGMM_API int bgmm_get_path_stats(bgmm_ctx *ctx, int64_t *out4);
 /*   phase clocks: shader-clock ticks the one-workgroup kernels of the mover-dense path spent per phase,
  *     accumulated since bgmm_create -- all zero unless the library was built with -DBGMM_PROFILE
  *     (a development aid: every probe costs the kernel a global read-modify-write). */
-int bgmm_get_phase_clocks(bgmm_ctx *ctx, int64_t *out16);
-int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
-int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
+BGMM_API int bgmm_get_phase_clocks(bgmm_ctx *ctx, int64_t *out16);
+BGMM_API int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
+BGMM_API int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
  * kernel (0 auto, 1 VALU, 2 MFMA); mover-dense path (0 auto: frozen-factor windows while the mean
@@ -212,21 +215,21 @@ int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms)
  * permutation (or absent) are swept by one workgroup that keeps the labels' state in LDS
  * (sweep_seq_kernel); forcing a kernel or a resolver mode, or prune_mode 2, selects the windowed
  * kernels instead.  In that path sweep_stats [2], [3] and [4] are 1. */
-int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
+BGMM_API int bgmm_set_tuning(bgmm_ctx *ctx, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                     int32_t prune_mode);
 
 /* Labels (components + 1) the one-workgroup small-D sweep keeps in LDS before it hands the sweep over to
  * the windowed kernels; 0 = as many as fit (the default).  A smaller plan changes where the hand-over
  * happens, never the trajectory (the tests use it to exercise the hand-over). */
-int bgmm_set_seq_plan(bgmm_ctx *ctx, int32_t max_labels);
+BGMM_API int bgmm_set_seq_plan(bgmm_ctx *ctx, int32_t max_labels);
 
 /* The first pass of a pruned window (home_kernel: visits whose only live candidates are the home component
  * and a new one).  0 = the context decides sweep by sweep from how many visits the pass settled in the last
  * sweep it ran (the default), 1 = always, 2 = never.  It never changes the trajectory. */
-int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
+BGMM_API int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
 
 /* Blocks until all work queued on the context's stream has finished. */
-int bgmm_synchronize(bgmm_ctx *ctx);
+BGMM_API int bgmm_synchronize(bgmm_ctx *ctx);
 
 /*
  * Multi-chain final label gather (the reference has no counterpart: its chains would be
@@ -243,10 +246,10 @@ int bgmm_synchronize(bgmm_ctx *ctx);
  *   bgmm_comm_destroy
  * Errors: BGMM_EDEVICE with the RCCL message in bgmm_last_error(ctx) (or (NULL) for the calls without a context).
  */
-int bgmm_comm_unique_id(void *id128_out);
-int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id128, int32_t device, void **comm_out);
-int bgmm_gather_labels(bgmm_ctx *ctx, void *comm, int32_t world_size, int64_t *z_all_out);
-int bgmm_comm_destroy(void *comm);
+BGMM_API int bgmm_comm_unique_id(void *id128_out);
+BGMM_API int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id128, int32_t device, void **comm_out);
+BGMM_API int bgmm_gather_labels(bgmm_ctx *ctx, void *comm, int32_t world_size, int64_t *z_all_out);
+BGMM_API int bgmm_comm_destroy(void *comm);
 
 #ifdef __cplusplus
 }

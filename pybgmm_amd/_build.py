@@ -5,6 +5,7 @@ The shared object is git-ignored but travels to the GPU box with the gpurun
 snapshot.  ``build()`` is idempotent: it recompiles only sources newer than
 their objects.
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -15,12 +16,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgmm_hip.so")
 SOURCES = ["bgmm_api.hip", "kernels_state.hip", "kernels_score.hip", "kernels_prune.hip", "kernels_choice.hip",
            "kernels_resolve.hip", "kernels_rng.hip", "kernels_seq.hip", "kernels_gram.hip", "kernels_home.hip"]
-HEADERS = [os.path.join(CSRC, "bgmm_device.h"), os.path.join(CSRC, "slot_math.h"),
-           os.path.join(CSRC, "score_common.h"), os.path.join(CSRC, "wave_ops.h"),
-           os.path.join(os.path.dirname(HERE), "include", "bgmm.h")]
+# every header next to the sources + the public one: editing any of them rebuilds every object
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "bgmm.h")]
 # -ffp-contract=off: the sufficient-statistics updates must round product and sum
 # separately (bit-identical m / S to the reference); hot loops call fma() explicitly.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+# -fvisibility=hidden: the shared object exports the BGMM_API entry points of include/bgmm.h and nothing else.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-result"]
 
 

@@ -362,3 +362,15 @@ class Comm(object):
         if getattr(self, "h", None):
             self.L.bgmm_comm_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

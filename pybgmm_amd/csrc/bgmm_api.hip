@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,7 +89,8 @@ struct bgmm_ctx {
     // frozen-factor windows (kernels_gram.hip): buffers sized for `gcols` columns, re-allocated when the labels outgrow them
     void *gram_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gram_lds = 0;
-    bool gram_off = false;           // this context cannot use them (too many labels for the LDS plan)
+    bool gram_off = false;           // this context cannot use them (their buffers failed to allocate three times)
+    int gram_alloc_fail = 0;
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
     bool home_pass = true;           // home_kernel in front of the pruning kernel (kernels_home.hip)
     int home_retry = 0;
@@ -577,7 +579,7 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
     Dev &d = c->d;
     if (c->gram_off) return false;
     int cols = 0, T = 0, lds = 0;
-    if (!gram_plan_for(K, &cols, &T, &lds)) { c->gram_off = true; return false; }
+    if (!gram_plan_for(K, &cols, &T, &lds)) return false;      // (too many labels NOW: asked again at the next batch)
     if (d.gcols != cols || !c->gram_mem[0]) {
         (void)hipStreamSynchronize(c->stream);
         for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
@@ -589,7 +591,7 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
             if (hipMalloc(&c->gram_mem[t], sz[t] + 64) != hipSuccess) {
                 for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
                 d.gcols = 0;
-                c->gram_off = true;
+                if (++c->gram_alloc_fail >= 3) c->gram_off = true;      // (latched only when memory keeps failing)
                 return false;
             }
         d.gC = (double *)c->gram_mem[0]; d.gq0 = (double *)c->gram_mem[1];
@@ -690,6 +692,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     double recent_rate = c->last_move_rate;
     long long batch_pos0 = 0, batch_moves0 = 0;
     bool first_batch = true;               // (sweep_begin has just opened a fresh window at visit 0)
+    bool gram_skip = false;                // frozen-factor windows made no progress in this sweep: not queued again
     if (seq_ran) {
         first_batch = false;
         pos = c->ctrl_host->job.pos;
@@ -717,7 +720,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             c->prune_mode != 2 && d.Dp / 16 <= 8 && (c->resolver_mode == 3 || c->kernel_kind != KERNEL_VALU)) {
             const Ctrl &hc = *c->ctrl_host;
             const bool dense = c->resolver_mode == 3 || hc.ema_run < kGramRun || recent_rate * kGramRun > 1.0;
-            if (dense) use_gram = ensure_gram(c, hc.job.K);
+            if (dense && !gram_skip) use_gram = ensure_gram(c, hc.job.K);
             gram_possible = !c->gram_off;
         }
         // (the frozen-factor windows take over once the movers prove dense: look again soon)
@@ -753,12 +756,16 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
                 }
             }
             steps_done = h.n_steps;
+            const bool stalled = h.gram_stall != 0;
             if (h.gram_stall) {            // the labels outgrew the columns: larger buffers, or the classic kernels
                 c->ctrl_host->gram_stall = 0;
                 CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
                 // (the plan -- columns, terms, the draw wave's width -- is re-picked for the labels there are now)
             }
             if (h.error != 0 || h.job.mode == MODE_DONE) break;
+            // (a batch of windows that consumed no visit and asked for no new plan would be queued again forever:
+            // the classic kernels take the rest of this sweep)
+            if (h.job.pos == pos && !stalled) gram_skip = true;
             pos = h.job.pos;
             win = h.win_size > 0 ? h.win_size : win;
             rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
@@ -857,7 +864,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
     c->stats2[3] = h.home_in - h.home_out;          // visits home_kernel decided on its own
     // home_kernel pays while the table bound decides most visits (well separated components); when it had to
-    // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 16th sweep
+    // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 64th sweep
     if (c->home_mode) c->home_pass = c->home_mode == 1;
     else if (h.home_in > 0) c->home_pass = 2 * h.home_out < h.home_in;
     else if (!c->home_pass && (++c->home_retry & 63) == 0) c->home_pass = true;
@@ -1209,8 +1216,10 @@ struct Rccl {
 };
 }  // namespace
 static Rccl g_rccl;
+static std::mutex g_rccl_mutex;          // (chains driven from threads meet here on first use)
 
 static int rccl_load() {
+    std::lock_guard<std::mutex> guard(g_rccl_mutex);
     if (g_rccl.lib) return 0;
     // The copy that belongs to THIS library's HIP runtime (the one next to the libamdhip64 we are linked against): a
     // process may carry another RCCL built against another runtime (PyTorch bundles both), and streams and device

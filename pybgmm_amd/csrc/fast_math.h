@@ -6,6 +6,16 @@
 // as published in FreeBSD msun e_log.c / e_exp.c: restated here, ~35 instructions each).
 // Arguments: log -- finite, positive, normal; exp -- any finite (underflows to 0 below -700).
 // Host-compilable (tests/test_fast_math.py checks them against libm on the CPU).
+//
+// The constants and the reduction scheme of fm_log / fm_exp are those of fdlibm's e_log.c / e_exp.c, whose
+// notice asks to be kept:
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <cmath>
 

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     if (threadIdx.x == 0) {
         do_move = 0;
         Job &j = c->job;
-        if (d.use_home && job_is_pruned(d, j.mode, j.prune) && !c->skip_apply) { c->home_in += c->n_sorted; c->home_out += c->n_resid; }
+        if (d.use_home && !d.lean_step && job_is_pruned(d, j.mode, j.prune) && !c->skip_apply) { c->home_in += c->n_sorted; c->home_out += c->n_resid; }
         c->n_resid = 0;                 // (home_kernel's list of this step has been worked through)
         c->n_refresh = 0;               // (a consumed or idle step must not re-run a refresh)
         if (c->skip_apply) {

@@ -11,8 +11,9 @@ Differences a caller can observe:
     ``max(1024, 4*K_init)`` (the reference's default ``K_max = N`` allocates
     N x D x D floats, gaussian_components.py:81-89).
   * ``_cached_outer`` (N x D x D, :116-118) is never materialised.
-  * ``restore_component_from_stats`` is not offered: the sweep kernel keeps a
-    visit that stays an exact no-op by construction.
+  * ``cache_component_stats`` / ``restore_component_from_stats`` download / upload one
+    component's statistics (``bgmm_get_stats`` / ``bgmm_set_stats``); the sweep kernels do
+    not need them -- a visit that stays is an exact no-op by construction.
 """
 import numpy as np
 from scipy.special import gammaln
@@ -247,7 +248,8 @@ class GaussianComponentsDiag(GaussianComponents):
         mean, var = np.zeros(self.D), np.zeros(self.D)
         for i in range(self.D):
             scale = S_N[i] / v_N
-            a = v_N // 2 if float(v_N).is_integer() else v_N / 2
+            # (Python 2: only an int-typed v_N floor-divides; a float v_0 = 5.0 gives true division)
+            a = v_N // 2 if isinstance(v_N, (int, np.integer)) else v_N / 2.0
             var[i] = 1.0 / nprng.gamma(a, 1.0 / (v_N * scale / 2.0), 1)[0]
             mean[i] = nprng.normal(m_N[i], np.sqrt(var[i] / k_N))
         return mean, var

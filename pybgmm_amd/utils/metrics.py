@@ -10,7 +10,9 @@ pybgmm/utils/utils.py:31-88 including their quirks:
   * the inertia "loss" is the sum of per-cluster ``sqrt(sum (x-mean)^2)`` values
     TRUNCATED to integers, because the reference stores them in an int array
     (utils.py:39-48).
-(host-side for now; a device contingency kernel is a later row.)
+(SURVEY.md 8f rank 2.  ``table_metrics`` takes the K_true x K table that ``bgmm_contingency`` builds on
+the device and the per-cluster dispersions of ``bgmm_cluster_dispersion``; the label-vector functions
+are the same formulas for callers that hold labels on the host.)
 """
 import math
 
