@@ -105,6 +105,14 @@ BGMM_API int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
  */
 BGMM_API int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *key624, int32_t *pos);
 /* The N uniforms currently staged for the next sweep (whichever way they got there). */
+/* bgmm_stage_mt19937 cuts a long request into chains of 64 blocks (39 936 words) that run side by side from
+ * jumped-ahead generator states (the state J words ahead is a GF(2) convolution of the next 20 560 words with the
+ * coefficients of t^J modulo the generator's characteristic polynomial; the polynomials are built on the host once
+ * per process).  0 = run the chains one after the other instead -- same doubles, same final state. */
+BGMM_API int bgmm_set_mt_jump(bgmm_ctx *ctx, int32_t enabled);
+/* The coefficient bits (19 937 of them, bit i = word i / 32, bit i % 32) of t^(chain * 39 936) modulo the characteristic
+ * polynomial of MT19937: host arithmetic only, no device needed (what the CPU tests check against numpy's generator). */
+BGMM_API int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624);
 BGMM_API int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
 
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
@@ -191,14 +199,25 @@ BGMM_API int bgmm_get_path_stats(bgmm_ctx *ctx, int64_t *out4);
  *     accumulated since bgmm_create -- all zero unless the library was built with -DBGMM_PROFILE
  *     (a development aid: every probe costs the kernel a global read-modify-write). */
 BGMM_API int bgmm_get_phase_clocks(bgmm_ctx *ctx, int64_t *out16);
+/*   safe_stats: of the last sweep -- safe-stay windows (crpmm.py:82-85: a visit that keeps its component changes
+ *     nothing, so visits PROVEN to stay under the frozen state plus a budget of logged rank-1 terms are left off the
+ *     sequential chain): [0] windows, [1] visits the proof pass examined, [2] unproven visits walked in order,
+ *     [3] windows ended because a component ran out of budget, [4] the budget in force x 1e6, [5] visits the next
+ *     proof pass will examine. */
+BGMM_API int bgmm_get_safe_stats(bgmm_ctx *ctx, int64_t *out6);
+/* Budget of a safe-stay window per component: the sum over the rank-1 terms it takes of |log |D_t|| (D_t = the
+ * Sherman-Morrison denominator of the term).  0 = follows the chain (the default); > 0 pins it.  A larger budget
+ * lets a window absorb more (or more eccentric) moves and proves fewer visits; it never changes the trajectory. */
+BGMM_API int bgmm_set_safe_budget(bgmm_ctx *ctx, double cap);
 BGMM_API int bgmm_set_kernel_timing(bgmm_ctx *ctx, int32_t enabled);
 BGMM_API int bgmm_get_kernel_timing(bgmm_ctx *ctx, int64_t *n_launches, double *total_ms);
 
 /* Tuning knobs (0 keeps the default): cap on the speculative window; forced likelihood
- * kernel (0 auto, 1 VALU, 2 MFMA); mover-dense path (0 auto: frozen-factor windows while the mean
- * distance between movers is short, 1 never: the per-mover kernel chain, 2 the one-workgroup resolver
- * that updates both factors in LDS whenever it fits (D <= 64), 3 frozen-factor windows in every
- * regime); exact pruning of components whose weight in a draw is provably
+ * kernel (0 auto, 1 VALU, 2 MFMA); mover path (0 auto: safe-stay windows while between one visit in
+ * 65 536 and one in four moves, plain frozen-factor windows above that, 1 never: the per-mover kernel
+ * chain, 2 the one-workgroup resolver that updates both factors in LDS whenever it fits (D <= 64),
+ * 3 plain frozen-factor windows in every regime, 4 safe-stay windows in every regime, 5 as 0 without
+ * safe-stay windows); exact pruning of components whose weight in a draw is provably
  * below e^-80 (0 auto: on while movers are sparse, plus certified stays in converged chains; 1 off;
  * 2 in every window whatever the regime -- slow when movers are dense, meant for tests; 3 as 0
  * but without certified stays, for measurements).  None of them changes the sampled trajectory, in this

@@ -32,6 +32,8 @@ SIGNATURES = {
     "bgmm_sweep": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
     "bgmm_stage_mt19937": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "bgmm_set_mt_jump": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
     "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
@@ -54,6 +56,8 @@ SIGNATURES = {
     "bgmm_get_prune_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_path_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_phase_clocks": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_safe_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_set_safe_budget": (ctypes.c_int, [_vp, ctypes.c_double]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -99,6 +103,16 @@ def load(build_if_missing=True):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+def mt19937_jump_poly(chain):
+    """Coefficient words (uint32[624]) of t^(chain * 39936) mod the characteristic polynomial of MT19937 (host only)."""
+    L = load()
+    out = np.zeros(624, dtype=np.uint32)
+    rc = L.bgmm_mt19937_jump_poly(int(chain), _ptr(out))
+    if rc != 0:
+        raise BGMMError(rc, (L.bgmm_last_error(None) or b"").decode())
+    return out
 
 
 class Context(object):
@@ -181,6 +195,9 @@ class Context(object):
             assert order.shape == (self.N,)
         self._ck(self.L.bgmm_stage_mt19937(self.h, _ptr(order), _ptr(key), ctypes.byref(p)))
         return key, int(p.value)
+
+    def set_mt_jump(self, on=True):
+        self._ck(self.L.bgmm_set_mt_jump(self.h, 1 if on else 0))
 
     def staged_uniforms(self):
         u = np.empty(self.N, dtype=np.float64)
@@ -299,6 +316,15 @@ class Context(object):
         self._ck(self.L.bgmm_get_path_stats(self.h, _ptr(out)))
         return {"pairs_executed": int(out[0]), "frozen_windows": int(out[1]), "frozen_window_visits": int(out[2]),
                 "home_decided": int(out[3])}
+
+    def safe_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._ck(self.L.bgmm_get_safe_stats(self.h, _ptr(out)))
+        return {"windows": int(out[0]), "visits_examined": int(out[1]), "unproven_walked": int(out[2]),
+                "budget_cuts": int(out[3]), "budget": out[4] * 1e-6, "next_stretch": int(out[5])}
+
+    def set_safe_budget(self, cap=0.0):
+        self._ck(self.L.bgmm_set_safe_budget(self.h, float(cap)))
 
     def phase_clocks(self):
         out = np.zeros(16, dtype=np.int64)

@@ -13,6 +13,7 @@
 #include "../../include/bgmm.h"
 #include "bgmm_device.h"
 
+#include <chrono>
 #include <cmath>
 #include <dlfcn.h>
 #include <cstdio>
@@ -80,7 +81,10 @@ struct bgmm_ctx {
     long long *true_dev = nullptr;   // bgmm_contingency: the reference labelling, kept between calls
     unsigned long long *table_dev = nullptr;
     size_t table_cells = 0;
-    unsigned *mt_words = nullptr;    // device scratch of bgmm_stage_mt19937: 624 state words, position, flag, 2N outputs
+    unsigned *mt_words = nullptr;    // device scratch of bgmm_stage_mt19937 (layout there)
+    unsigned *mt_coef = nullptr, *mt_seeds = nullptr;   // jump polynomials / seeds of the chains of a long request
+    int mt_chains = 0;
+    bool mt_jump_on = true;          // bgmm_set_mt_jump: false = the chains run one after the other (the r02 route, for comparison)
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     std::vector<char> res_perm;      // per resident sweep: its order is a permutation (or absent)
@@ -91,6 +95,12 @@ struct bgmm_ctx {
     int gram_lds = 0;
     bool gram_off = false;           // this context cannot use them (their buffers failed to allocate three times)
     int gram_alloc_fail = 0;
+    bool tables_robust = false;      // the pruning tables on the device carry a safe-stay batch's robust constants
+    int safe_rest = 0;               // sweeps to go without safe-stay windows: a batch of them covered fewer visits per
+                                     // millisecond than the per-mover kernel chain is known to (they are tried again a sweep later)
+    // safe-stay windows (kernels_safe.hip)
+    double safe_cap_user = 0.0;      // bgmm_set_safe_budget: > 0 pins the per-component budget of a window (0: it follows the chain)
+    long long safe_stats[6] = {0, 0, 0, 0, 0, 0};
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
     bool home_pass = true;           // home_kernel in front of the pruning kernel (kernels_home.hip)
     int home_retry = 0;
@@ -100,6 +110,10 @@ struct bgmm_ctx {
 // Mean distance between movers below which the frozen-factor windows take over from the per-mover
 // kernel chain: a window costs ~60 us plus ~1.5 us per mover and covers 64 visits, the chain ~190 us per mover.
 constexpr double kGramRun = 192.0;
+// Safe-stay windows (kernels_safe.hip) cover the regime in between: from one mover in kSafeRun visits up to every
+// fourth visit moving (beyond that the proof pass proves too little to pay: plain frozen-factor windows).
+constexpr double kSafeRun = 65536.0;
+constexpr double kSafeDenseRate = 0.25;
 
 #define CK(ctx, call)                                                                       \
     do {                                                                                    \
@@ -184,6 +198,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->mt_words) (void)hipFree(c->mt_words);
+    if (c->mt_coef) (void)hipFree(c->mt_coef);
+    if (c->mt_seeds) (void)hipFree(c->mt_seeds);
     for (void *p : c->gram_mem) if (p) (void)hipFree(p);
     if (c->true_dev) (void)hipFree(c->true_dev);
     if (c->table_dev) (void)hipFree(c->table_dev);
@@ -272,6 +288,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_const, ng * 128);
         DALLOC(c, d.pr_slot, ng * 16);
         DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
+        DALLOC(c, d.pr_rms, (size_t)d.nslots);
         DALLOC(c, d.wrec, (size_t)rows);
         DALLOC(c, d.wrecR, (size_t)rows);
         DALLOC(c, d.wpermR, (size_t)rows);
@@ -281,6 +298,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.ftab, (size_t)d.nslots * 64);
         DALLOC(c, d.finv, (size_t)d.nslots);
     }
+    DALLOC(c, d.glist, (size_t)kGramRows);
+    DALLOC(c, d.rtab, ns * 8);
+    DALLOC(c, d.ftabR, ns * 64);
+    d.safe_mode = 0; d.safe_cap = 0.0;
     d.keep_stride = (d.nslots + 63) / 64;
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
     DALLOC(c, d.bucket_bins, ns + 4);
@@ -356,6 +377,10 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     init.win_size = c->win_rows;
     init.ema_run = (double)c->win_rows * 4.0;
     init.last_mover = -1;
+    init.safe_L = 4096;
+    init.safe_cap_built = -1.0;
+    init.safe_cap = 0.25;
+    init.safe_mult = 4.0;
     CK(c, hipMemcpy(d.ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice));
     std::vector<int> ident(ns);
     for (size_t i = 0; i < ns; ++i) ident[i] = (int)i;
@@ -513,10 +538,26 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
     CK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->d.N;
-    if (!c->mt_words) CK(c, hipMalloc((void **)&c->mt_words, sizeof(unsigned) * (640 + 2 * N)));
-    unsigned *dkey = c->mt_words, *dwords = c->mt_words + 640;
-    int *dpos = (int *)(c->mt_words + 624), *dflag = (int *)(c->mt_words + 625);
-    int host_tail[2] = {*pos, 0};
+    // device scratch: [key in 624 | key out 624 | pos out, zero flag, pad 16 | raw | 2 N tempered words], and -- requests of
+    // more than one chain -- the jump polynomials' coefficient words and the chains' seeds
+    const size_t raw_n = (size_t)mt19937_raw_words();
+    if (!c->mt_words) CK(c, hipMalloc((void **)&c->mt_words, sizeof(unsigned) * (1264 + raw_n + 2 * N)));
+    unsigned *dkey = c->mt_words, *dkey_out = c->mt_words + 624, *draw = c->mt_words + 1264, *dwords = draw + raw_n;
+    int *dpos = (int *)(c->mt_words + 1248), *dflag = (int *)(c->mt_words + 1249);
+    const int chains_max = mt19937_chains_for(624, (long long)N);
+    if (chains_max >= 2 && c->mt_chains < chains_max) {
+        std::vector<unsigned> coef;
+        const bool have = mt19937_jump_coefficients(chains_max, coef);
+        if (c->mt_coef) { (void)hipFree(c->mt_coef); c->mt_coef = nullptr; }
+        if (c->mt_seeds) { (void)hipFree(c->mt_seeds); c->mt_seeds = nullptr; }
+        CK(c, hipMalloc((void **)&c->mt_seeds, sizeof(unsigned) * 624 * (size_t)(chains_max + 1)));
+        if (have) {
+            CK(c, hipMalloc((void **)&c->mt_coef, sizeof(unsigned) * coef.size()));
+            CK(c, hipMemcpy(c->mt_coef, coef.data(), sizeof(unsigned) * coef.size(), hipMemcpyHostToDevice));
+        }
+        c->mt_chains = chains_max;
+    }
+    int host_tail[2] = {0, 0};
     CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
     CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
     c->have_order = order != nullptr;
@@ -525,8 +566,11 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     c->order_is_perm = okind == 1;
     if (order)
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
-    launch_mt19937(dkey, dpos, dwords, c->d_u, (long long)N, dflag, c->stream);
-    CK(c, hipMemcpyAsync(key624, dkey, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, c->stream));
+    const int chains = mt19937_chains_for(*pos, (long long)N);
+    launch_mt19937(dkey, *pos, dkey_out, dpos, dwords, c->d_u, (long long)N, dflag,
+                   (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, draw, c->mt_seeds, c->stream);
+    CK(c, hipGetLastError());
+    CK(c, hipMemcpyAsync(key624, dkey_out, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, c->stream));
     CK(c, hipMemcpyAsync(host_tail, dpos, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
     *pos = host_tail[0];
@@ -693,6 +737,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     long long batch_pos0 = 0, batch_moves0 = 0;
     bool first_batch = true;               // (sweep_begin has just opened a fresh window at visit 0)
     bool gram_skip = false;                // frozen-factor windows made no progress in this sweep: not queued again
+    bool safe_skip = c->safe_rest > 0;     // the same for safe-stay windows (or they did poorly a sweep ago: bgmm_ctx::safe_rest)
+    if (c->safe_rest > 0) c->safe_rest -= 1;
     if (seq_ran) {
         first_batch = false;
         pos = c->ctrl_host->job.pos;
@@ -715,13 +761,78 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (first_batch && Tl > 8) Tl = 8;
         // Mover-dense stretches (burn-in, overlapping clusters): frozen-factor windows (kernels_gram.hip).
         // Four launches per window of 64 visits, no per-mover kernel chain.  resolver_mode 3 forces them.
-        bool use_gram = false, gram_possible = false;
-        if (d.cov_type == COV_FULL && (c->resolver_mode == 0 || c->resolver_mode == 3) && c->order_is_perm &&
+        bool use_gram = false, gram_possible = false, use_safe = false;
+        d.safe_mode = 0;
+        const bool rm_gram = c->resolver_mode == 0 || c->resolver_mode >= 3;      // (3 / 4 force a kind, 5: never safe-stay)
+        if (d.cov_type == COV_FULL && rm_gram && c->order_is_perm &&
             c->prune_mode != 2 && d.Dp / 16 <= 8 && (c->resolver_mode == 3 || c->kernel_kind != KERNEL_VALU)) {
             const Ctrl &hc = *c->ctrl_host;
+            const bool safe_ok = c->resolver_mode != 3 && c->resolver_mode != 5 && c->kind == KERNEL_MFMA &&
+                                 c->prune_mode != 1 && !safe_skip;
+            const bool very_dense = recent_rate > kSafeDenseRate || hc.ema_run < 1.0 / kSafeDenseRate;
+            const bool moderate = hc.ema_run < kSafeRun || recent_rate * kSafeRun > 1.0;
+            const bool want_safe = c->resolver_mode == 4 || (safe_ok && moderate && !very_dense);
+            if (want_safe && !safe_skip) use_safe = ensure_gram(c, hc.job.K);
             const bool dense = c->resolver_mode == 3 || hc.ema_run < kGramRun || recent_rate * kGramRun > 1.0;
-            if (dense && !gram_skip) use_gram = ensure_gram(c, hc.job.K);
+            if (!use_safe && dense && !gram_skip && c->resolver_mode != 4) use_gram = ensure_gram(c, hc.job.K);
             gram_possible = !c->gram_off;
+        }
+        if (use_safe) {
+            const Ctrl &hc = *c->ctrl_host;
+            // windows still needed: from the visits a window has covered on average so far in this sweep
+            double vpw = hc.safe_windows > 0 ? (double)(pos > 0 ? pos : 1) / (double)hc.safe_windows : (double)hc.safe_L;
+            if (vpw < 64.0) vpw = 64.0;
+            long long Tg = (long long)std::ceil((double)remaining / vpw) + 1;
+            if (first_batch && Tg > 8) Tg = 8;
+            if (Tg > 256) Tg = 256;
+            if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
+            d.safe_mode = 1; d.lean_step = 0; d.publish = 0; d.prune_enabled = 2; d.use_certify = 0; d.use_home = 1;
+            d.safe_cap = c->safe_cap_user;
+            d.gram_K = hc.job.K;
+            {   // launch grids: room for the stretch to double twice inside the batch
+                long long r = 4096;
+                while (r < 4ll * hc.safe_L && r < c->win_rows) r <<= 1;
+                if (r > c->win_rows) r = c->win_rows;
+                d.batch_rows = (int)r;
+            }
+            lean = false;
+            first_batch = false;
+            const long long w0 = hc.safe_windows, mv0 = hc.n_moves;
+            const auto t_batch0 = std::chrono::steady_clock::now();
+            launch_safe_open(d, st);
+            for (int t = 0; t < (int)Tg; ++t)
+                if (!launch_safe_step(d, c->gram_lds, d.batch_rows, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
+                    return fail(c, BGMM_EDEVICE, "safe-stay window launch failed");
+            CK(c, hipGetLastError());
+            int rc = fetch_ctrl(c);
+            if (rc) return rc;
+            const Ctrl &h = *c->ctrl_host;
+            steps_done = h.n_steps;
+            const bool stalled = h.gram_stall != 0;
+            if (stalled) {
+                c->ctrl_host->gram_stall = 0;
+                CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
+            }
+            if (h.error != 0 || h.job.mode == MODE_DONE) { d.safe_mode = 0; break; }
+            if (h.job.pos == pos && !stalled) safe_skip = true;
+            if (c->resolver_mode == 0 && h.safe_windows - w0 >= 16 && h.job.pos > pos) {
+                // Did these windows pay?  Where movers are few and far between, the per-mover kernel chain (~0.2 ms per
+                // mover at D = 64, pruned windows in between) is the yardstick: a stretch in which the proofs keep failing
+                // (components a handful of nats apart, or too small to vouch for their members) is better left to it.
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch0).count();
+                const double visits = (double)(h.job.pos - pos), mrate = (double)(h.n_moves - mv0) / visits;
+                const double dscale = d.Dp > 64 ? (double)d.Dp / 64.0 : 1.0;
+                const double rate_chain = 1.0 / (mrate * 0.2 * dscale + 3e-4);
+                if (mrate < 2e-3 && visits / ms < 0.6 * rate_chain) { safe_skip = true; c->safe_rest = 1; }
+            }
+            pos = h.job.pos;
+            win = h.win_size > 0 ? h.win_size : win;
+            rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
+            if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
+            batch_pos0 = pos; batch_moves0 = h.n_moves;
+            d.safe_mode = 0;
+            c->tables_robust = true;
+            continue;
         }
         // (the frozen-factor windows take over once the movers prove dense: look again soon)
         if (gram_possible && rate > 0.0 && Tl > 24) Tl = 24;
@@ -795,6 +906,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             d.batch_rows = rows_for(win, open_rows, rate == 0.0 ? 16 : 8);
         }
         const long long grid_rows = d.batch_rows;
+        if (pmode >= 1 && c->tables_robust) {
+            // (a safe-stay batch left its robust bound constants in the pruning tables: valid, but looser)
+            CK(c, hipMemsetAsync(&d.ctrl->tables_valid, 0, sizeof(int), st));
+            c->tables_robust = false;
+        }
         if (pmode != 2) lean = false;
         d.lean_step = lean ? 1 : 0;
         d.publish = lean ? 1 : 0;
@@ -863,6 +979,9 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->certified = (long long)h.n_certified;
     c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
     c->stats2[3] = h.home_in - h.home_out;          // visits home_kernel decided on its own
+    c->safe_stats[0] = h.safe_windows; c->safe_stats[1] = h.safe_scanned; c->safe_stats[2] = h.safe_rows;
+    c->safe_stats[3] = h.safe_cuts; c->safe_stats[4] = (long long)(1e6 * (c->safe_cap_user > 0.0 ? c->safe_cap_user : h.safe_cap));
+    c->safe_stats[5] = h.safe_L;
     // home_kernel pays while the table bound decides most visits (well separated components); when it had to
     // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 64th sweep
     if (c->home_mode) c->home_pass = c->home_mode == 1;
@@ -1140,6 +1259,32 @@ extern "C" int bgmm_get_path_stats(bgmm_ctx *c, int64_t *out4) {
     return 0;
 }
 
+extern "C" int bgmm_get_safe_stats(bgmm_ctx *c, int64_t *out6) {
+    if (!c || !out6) return BGMM_EINVAL;
+    for (int t = 0; t < 6; ++t) out6[t] = c->safe_stats[t];
+    return 0;
+}
+
+extern "C" int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624) {
+    if (chain < 1 || chain > 4096 || !coef624) return BGMM_EINVAL;
+    std::vector<unsigned> coef;
+    if (!mt19937_jump_coefficients(chain + 1, coef)) return fail(nullptr, BGMM_EUNSUPPORTED, "the generator's characteristic polynomial could not be established");
+    memcpy(coef624, coef.data() + (size_t)chain * 624, sizeof(unsigned) * 624);
+    return 0;
+}
+
+extern "C" int bgmm_set_mt_jump(bgmm_ctx *c, int32_t enabled) {
+    if (!c) return BGMM_EINVAL;
+    c->mt_jump_on = enabled != 0;
+    return 0;
+}
+
+extern "C" int bgmm_set_safe_budget(bgmm_ctx *c, double cap) {
+    if (!c || !(cap >= 0.0) || cap > 8.0) return BGMM_EINVAL;
+    c->safe_cap_user = cap;
+    return 0;
+}
+
 extern "C" int bgmm_set_kernel_timing(bgmm_ctx *c, int32_t enabled) {
     if (!c) return BGMM_EINVAL;
     c->timing = enabled != 0;
@@ -1160,7 +1305,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
     if (!c) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
-    if (resolver_mode < 0 || resolver_mode > 3) return fail(c, BGMM_EINVAL, "resolver_mode must be 0 .. 3");
+    if (resolver_mode < 0 || resolver_mode > 5) return fail(c, BGMM_EINVAL, "resolver_mode must be 0 .. 5");
     if (prune_mode < 0 || prune_mode > 3) return fail(c, BGMM_EINVAL, "prune_mode must be 0 .. 3");
     c->kernel_kind = kernel_kind;
     c->resolver_mode = resolver_mode;

@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #define BGMM_MAX_D 128
 #define BGMM_LOG_PI 1.1447298858494001741434273513530587116472948129153
@@ -50,6 +51,10 @@ static constexpr int kChoiceRowsMax = 8;   // rows per block of the draw kernel 
 static constexpr int kGramRows = 64;
 static constexpr int kGramMaxTerms = 128;
 static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a window may open (new components + the prior)
+// safe-stay windows: how far a column's count may drift from its frozen value inside one window (the bounds of
+// the proof pass hold for every count in that range)
+static constexpr int kSafeDn = 16;
+static constexpr int kSafeSmall = 8;     // labels with fewer members prove nothing for them (their bounds: kernels_safe.hip)
 
 // Per-slot scalar constants.  (Diagonal covariance uses A = D*(lgamma terms) - 0.5 log prod var,
 // half_vd = (v_N+1)/2, logdetC = sum log S_N,d, A1 = log prod var, the seating weights; rest 0.)
@@ -127,6 +132,22 @@ struct Ctrl {
     int gram_pad;
     unsigned long long n_pairs_exact;   // (visit, component) pairs whose quadratic form was executed this sweep
     long long gram_rows_total, gram_windows;   // rows consumed by / number of frozen-factor windows this sweep
+    // safe-stay windows (kernels_safe.hip): frozen-factor windows over the visits that cannot be PROVEN to stay
+    int gl_n;              // rows on the list of the open window (<= kGramRows)
+    int safe_L;            // visits the next proof pass looks at (adapts to the density of unproven visits)
+    long long gl_end;      // the window reaches up to (not including) this visit: everything before it that is not listed stays
+    double safe_cap;       // the budget per component and window; follows the chain (gram_resolve_kernel) unless Dev::safe_cap pins it
+    // the budget's controller (gram_resolve_kernel): what counts is how far a window gets -- a small budget ends windows
+    // early, a large one proves fewer visits.  Phases of a dozen windows at the current budget alternate with half a
+    // dozen at twice / half of it; the trial value is kept when its windows covered 15 % more visits each.
+    // The budget is kept as a multiple of the mean |log |D_t|| of the terms seen (safe_wbar): that puts it at the scale of
+    // the chain at hand ((D + 1) / n for a typical member that moves, near 1 for an outlier that leaves).
+    double safe_mult, safe_mult_base, safe_wbar, safe_adv_sum, safe_base_rate;
+    int safe_phase_cnt, safe_try, safe_next_dir, safe_pad;
+    double safe_cap_built; // the budget the robust tables were built for -- the one the resolver enforces ...
+    long long safe_epoch_built;   // ... and the state epoch: valid while both still match
+    long long safe_windows, safe_scanned, safe_rows, safe_cuts;   // this sweep: windows, visits examined by the proof pass,
+                                                                  // rows walked by the resolver, windows ended by the budget
 };
 
 // One reassignment logged by a frozen-factor window, in visiting order: the finish kernel replays
@@ -221,6 +242,7 @@ struct Dev {
     // ids pr_slot[G][16] (-1 beyond the last label)
     double *pr_mufrag, *pr_const;
     double *pr_dcc;              // pr_dcc[a * nslots + b] = |mu_a - mu_b| between LABELS a, b (coarse triangle bound)
+    double *pr_rms;              // pr_rms[a] = sqrt(tr S_N / n) of label a (radius grid of its bound table)
     int *pr_slot;
     struct WRec *wrec;           // pruned windows: the k-th row in evaluation order (one 32-byte record)
     unsigned long long *pr_counts;  // 4 x 256 spread counters (kept, bound, MFMA instructions, certified visits) of the pruned-window kernels
@@ -247,11 +269,21 @@ struct Dev {
     int *gtouched;               // [kGramMaxTerms]
     int gram_terms;              // terms the resolver's LDS plan holds (<= kGramMaxTerms)
     int gram_K;                  // labels when the current batch of windows was queued (host side: picks the draw wave's width)
+    // safe-stay windows (kernels_safe.hip)
+    int safe_mode;               // 1: this batch of steps runs them (home_kernel classifies instead of drawing, the
+                                 // frozen-factor kernels take their rows from glist)
+    double safe_cap;             // > 0: pins the budget per column and window (sum of |log |D_t|| over the rank-1 terms it
+                                 // takes); 0: Ctrl::safe_cap, which follows the chain
+    long long *glist;            // [kGramRows] visit positions of the window's rows, ascending
+    double *rtab;                // [nslots][8] per label of the frozen state: robust constants (kernels_safe.hip)
+    double *ftabR;               // [nslots][64] per home label: robust upper bound of every other label's score
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
                                  // queued steps: 0 never (only the dense kernels are launched), 1 the device
                                  // decides per window (job.prune; both kernel sets are launched), 2 every
                                  // window (only the pruned-window kernels are launched)
 };
+
+__device__ inline double safe_cap_now(const Dev &d, const Ctrl *c) { return d.safe_cap > 0.0 ? d.safe_cap : c->safe_cap; }
 
 // The list the pruning kernel and the sparse draw kernel work through
 __host__ __device__ inline const WRec *prune_list(const Dev &d) { return d.use_home ? d.wrecR : d.wrec; }
@@ -313,5 +345,12 @@ bool gram_plan_for(int K, int *gcols, int *terms, int *lds);   // LDS plan of th
 bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
 void gram_configure(const Dev &d, int resolve_lds);      // per-device kernel attributes (once per context and plan)
 void launch_gram_finish(const Dev &d, hipStream_t st);
-void launch_mt19937(unsigned *key_io, int *pos_io, unsigned *words, double *u, long long n, int *zero_flag,
-                    hipStream_t st);
+void launch_safe_open(const Dev &d, hipStream_t st);                     // kernels_safe.hip
+bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
+// kernels_rng.hip: the caller's MT19937 continued on the device (chains of 64 blocks from jumped-ahead states)
+int mt19937_chains_for(long long pos, long long n);
+int mt19937_raw_words();
+bool mt19937_jump_coefficients(int n_chains, std::vector<unsigned> &out);
+void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos_out, unsigned *words, double *u, long long n,
+                    int *zero_flag, const unsigned *coef_dev, int n_chains, unsigned *raw, unsigned *seeds, hipStream_t st);

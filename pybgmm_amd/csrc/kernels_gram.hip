@@ -40,6 +40,17 @@ typedef LDS_AS int *lds_i32;
 
 static constexpr int GR = kGramRows;
 
+// The window's rows: the next GR visits, or -- safe-stay windows (kernels_safe.hip) -- the listed ones: the visits of
+// [job.pos, gl_end) that the proof pass could not prove to stay; every visit in between stays whatever the listed ones do.
+__device__ __forceinline__ int gram_nrows(const Dev &d, const Ctrl *c) {
+    if (d.safe_mode) return c->gl_n;
+    const long long left = c->n_visits - c->job.pos;
+    return left < GR ? (int)left : GR;
+}
+__device__ __forceinline__ long long gram_pos(const Dev &d, long long pos0, int row) {
+    return d.safe_mode ? d.glist[row] : pos0 + row;
+}
+
 // ------------------------------------------------------------------------------------------
 // gram_kernel<NJ>: grid = columns, 256 threads (wave w: rows 16 w .. 16 w + 15).
 // Fragment conventions as in kernels_score.hip.  LDS: Ys[64][Dp + 2] (row stride = 2 mod 32 doubles:
@@ -56,8 +67,8 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
     if (col > K) return;
     const int s = col < K ? d.perm[col] : d.K_max;
     const long long pos0 = c->job.pos;
-    const long long left = c->n_visits - pos0;
-    const int nrows = left < GR ? (int)left : GR;
+    const int nrows = gram_nrows(d, c);
+    if (nrows <= 0) return;
     constexpr int Dp = 16 * NJ, LD = Dp + 2, NF = 2 * NJ * (NJ + 1), PF = pick_pf(NF);
     const int D = d.D;
     const int lane = threadIdx.x & 63;
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
     {
         const int row = w * 16 + lr;
         const bool live = row < nrows;
-        const long long p = pos0 + row;
+        const long long p = live ? gram_pos(d, pos0, row) : 0;
         const long long i = live ? (d.order ? d.order[p] : p) : 0;
         const double *__restrict__ xrow = d.X + i * D;
 #pragma unroll
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
         if (lr == r && row < nrows) {
             d.gq0[(long long)col * GR + row] = v;
             if (col < K) {
-                const long long p = pos0 + row;
+                const long long p = gram_pos(d, pos0, row);
                 const long long i = d.order ? d.order[p] : p;
                 const bool own = d.z[i] == s && d.n[s] >= 2;
                 d.glp0[(long long)row * d.gcols + col] = slot_score_exact(d.sc[s], v, own);
@@ -166,11 +177,10 @@ __global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) {
     const int K = c->job.K;
     if (K + kGramColSlack > d.gcols) return;
     const long long pos0 = c->job.pos;
-    const long long left = c->n_visits - pos0;
-    const int nrows = left < GR ? (int)left : GR;
+    const int nrows = gram_nrows(d, c);
     const int r = blockIdx.x;
     if (r >= nrows) return;
-    const long long p = pos0 + r;
+    const long long p = gram_pos(d, pos0, r);
     const long long i = d.order ? d.order[p] : p;
     const int h = d.z[i];
     const int excl = (h >= 0 && d.n[h] == 1) ? d.label_of_slot[h] : -1;
@@ -223,6 +233,11 @@ struct GramUpd {
 struct GramShared {
     int active, nrows, K0, ncols, cprior, err, event, cur;
     int pub_mode, pub_hcol, pub_pcol, pub_has0, pub_term, upd_n, K, nmoves;
+    int cut, pad_;                 // safe-stay windows: a column ran out of budget (1) / drifted too far or was opened (2):
+                                   // the window ends behind this move
+    double cap;                    // the budget the robust tables of this window were built for
+    double wsum2[2];               // sum of |log |D_t|| over the window's terms, and their number (per update wave)
+    int wterms2[2];
     GramUpd upd[2];
     long long pos0, lik, last_mover;
     double ema_run;
@@ -238,7 +253,8 @@ struct GramPlan {
     static constexpr unsigned oRowM = oWv + T * GR * 8;           // rowM[64]
     static constexpr unsigned oInvD = oRowM + GR * 8;             // termInvD[T]
     static constexpr unsigned oRcf = oInvD + T * 8;               // colRCF[KC]
-    static constexpr unsigned oMvI = oRcf + KC * 8;               // move log: data index [64]
+    static constexpr unsigned oColW = oRcf + KC * 8;              // colW[KC]: sum of |log |D_t|| over the column's terms (its budget)
+    static constexpr unsigned oMvI = oColW + KC * 8;              // move log: data index [64]
     static constexpr unsigned oRowHome = oMvI + GR * 8;           // [64]
     static constexpr unsigned oRowHcol = oRowHome + GR * 4;       // [64]
     static constexpr unsigned oMv = oRowHcol + GR * 4;            // move log: sub slot, add slot, init flag [3][64]
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     LDS_AS unsigned char *const lb = (LDS_AS unsigned char *)lds_raw;
     LDS_AS GramShared &S = *(LDS_AS GramShared *)lb;
     const lds_f64 etT = (lds_f64)(lb + P::oEt), wvv = (lds_f64)(lb + P::oWv), rowM = (lds_f64)(lb + P::oRowM),
-                  termInvD = (lds_f64)(lb + P::oInvD), colRCF = (lds_f64)(lb + P::oRcf);
+                  termInvD = (lds_f64)(lb + P::oInvD), colRCF = (lds_f64)(lb + P::oRcf), colW = (lds_f64)(lb + P::oColW);
     const lds_i64 mvI = (lds_i64)(lb + P::oMvI);
     const lds_i32 rowhome = (lds_i32)(lb + P::oRowHome), rowhcol = (lds_i32)(lb + P::oRowHcol),
                   mvSub = (lds_i32)(lb + P::oMv), mvAdd = mvSub + GR, mvInit = mvAdd + GR,
@@ -322,8 +338,10 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             } else {
                 S.active = 1;
                 S.pos0 = j.pos;
-                const long long left = c->n_visits - j.pos;
-                S.nrows = left < GR ? (int)left : GR;
+                S.nrows = gram_nrows(d, c);
+                S.cut = 0;
+                S.cap = c->safe_cap_built;
+                S.wsum2[0] = 0.0; S.wsum2[1] = 0.0; S.wterms2[0] = 0; S.wterms2[1] = 0;
                 S.K0 = j.K; S.K = j.K;
                 S.cprior = j.K;
                 S.ncols = j.K + 1;
@@ -340,10 +358,11 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     const long long pos0 = S.pos0;
     // rows: lane r of wave 0 keeps row r's inputs in registers; the update waves read home / home column / M_r from LDS
     int rw_home = -1, rw_hcol = -1;
-    long long rw_i = 0;
+    long long rw_i = 0, rw_p = 0;
     double rw_u = 0.0, rw_En = 0.0;
     if (wave == 0 && lane < nrows) {
-        const long long p = pos0 + lane;
+        const long long p = gram_pos(d, pos0, lane);
+        rw_p = p;
         rw_i = d.order ? d.order[p] : p;
         rw_home = d.z[rw_i];
         rw_hcol = rw_home >= 0 ? d.label_of_slot[rw_home] : -1;
@@ -361,6 +380,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         colLast[j] = -1;
         colBase[j] = j <= K0 ? j : K0;
         colRCF[j] = 1.0;
+        colW[j] = 0.0;
         if (j < K0) {
             const int n = d.n[s];
             colSlot[j] = s;
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                                 const int t = permL[Kn];
                                 dcol = nc++;
                                 colSlot[dcol] = t; colN[dcol] = 0; colBase[dcol] = cprior;
-                                colN0[dcol] = 0; colRCF[dcol] = 1.0;
+                                colN0[dcol] = 0; colRCF[dcol] = 1.0; colW[dcol] = 0.0;
                                 colLast[dcol] = -1;
                                 colLab[dcol] = Kn; labCol[Kn] = dcol;
                                 d.label_of_slot[t] = Kn;
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     nmoves += 1;
                     lik += __builtin_amdgcn_readlane(Krem, 0);
                     mapver += 1;                    // (labels and lines are re-read from LDS at the next draw)
-                    const long long p = pos0 + r;
+                    const long long p = wv_readlane_i64(rw_p, r);
                     ema_run = ema_after_mover(ema_run, (double)(p - last_mover));
                     last_mover = p;
                 }
@@ -648,7 +668,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     tix[t] = (hk_has0 && cls[t] == hk_hcol) ? hk_t0 : tix[t];
                     tix[t] = cls[t] == hk_pcol ? hk_t1 : tix[t];
                 }
-                const long long p = pos0 + cur;
+                const long long p = wv_readlane_i64(rw_p, cur);
                 ema_run = ema_after_mover(ema_run, (double)(p - last_mover));
                 last_mover = p;
                 lik += K;
@@ -751,6 +771,23 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 colRCF[cl] = rcf_new;
                 if (mode == 0) { termPrev[t] = prev0; colLast[cl] = t; colN[cl] = n_new; }
                 if (!((double)sg * Dt > 0.0) || !(rcf_new > 0.0)) S.err = -4;
+                else if (d.safe_mode) {
+                    // The visits between the listed rows were proven to stay under the frozen state and ANY terms within
+                    // the budget (kernels_safe.hip): |log c_t(y, y) - log c_0(y, y)| <= sum |log |D_i||  for every y.
+                    // A column that leaves its budget (or drifts kSafeDn members from its frozen count) ends the window
+                    // right behind this move -- and so does a component OPENED by it: the proofs are about the frozen labels.
+                    const double dn_tab = cl < K0 ? d.rtab[(long long)cl * 8 + 7] : 0.0;
+                    const bool small_col = dn_tab < 0.0;                         // (a small label: what leaves it is free)
+                    const double wterm = fabs(log(fabs(Dt)));
+                    const double wsum = colW[cl] + ((small_col && sg < 0) ? 0.0 : wterm);
+                    colW[cl] = wsum;
+                    S.wsum2[wave - 1] += wterm;                                  // (waves 1 and 2 each keep their own)
+                    S.wterms2[wave - 1] += 1;
+                    const int dn = n_new - colN0[cl];
+                    const int dn_cap = (int)fabs(dn_tab);
+                    if (wsum > S.cap) S.cut = 1;                                 // (out of budget: the budget follows, below)
+                    else if (cl >= K0 || dn > dn_cap || (!small_col && dn < -dn_cap)) S.cut = 2;
+                }
             }
             if (wave == 1 && r + 1 < nrows) {
                 // the home side of the next visit (its column is known; wasted if that visit stays)
@@ -768,7 +805,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
 #endif
         }
         gram_lds_barrier();
-        if (S.err < 0) break;
+        if (S.err < 0 || S.cut) break;
         cur += 1;
 #ifdef BGMM_PROFILE
         tk = clock64();
@@ -781,6 +818,15 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
 
     // ---- close the window ------------------------------------------------------------------
     const int consumed = S.event == GEV_MOVE ? S.cur + 1 : S.cur;     // (an error stops behind the visit that raised it)
+    // where the next window starts.  Listed rows: behind the move that ended the window, AT the row that could not be
+    // drawn (stale reference point / no room for its terms), or -- every listed row walked -- at the end of the stretch
+    // the proof pass vouched for.
+    long long next_pos = pos0 + consumed;
+    if (d.safe_mode) {
+        if (S.event == GEV_MOVE) next_pos = d.glist[S.cur] + 1;
+        else if (S.event == GEV_CUT) next_pos = d.glist[S.cur];
+        else next_pos = c->gl_end;
+    }
     for (int k = tid; k < S.nmoves; k += GRT) {
         GramMove mv;
         mv.i = mvI[k]; mv.sub_slot = mvSub[k]; mv.add_slot = mvAdd[k]; mv.add_init = mvInit[k]; mv.pad = 0;
@@ -805,6 +851,50 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         c->lik_evals += S.lik;
         c->n_moves += S.nmoves;
         c->gram_nmoves = S.nmoves;
+        if (d.safe_mode) {
+            const long long adv = next_pos - pos0;
+            c->safe_windows += 1;
+            c->safe_rows += consumed;
+            c->safe_cuts += S.cut ? 1 : 0;
+            c->lik_evals += (adv - consumed) * (long long)j.K;         // (pairs decided without being scored)
+            if (!(d.safe_cap > 0.0)) {
+                // the budget follows the chain (bgmm_device.h: the controller's fields)
+                if (S.wterms2[0] + S.wterms2[1] > 0) {
+                    const double wm = (S.wsum2[0] + S.wsum2[1]) / (double)(S.wterms2[0] + S.wterms2[1]);
+                    c->safe_wbar = c->safe_wbar > 0.0 ? 0.9 * c->safe_wbar + 0.1 * wm : wm;
+                }
+                c->safe_adv_sum += (double)adv;
+                c->safe_phase_cnt += 1;
+                if (c->safe_try == 0 && c->safe_phase_cnt >= 12) {
+                    c->safe_base_rate = c->safe_adv_sum / (double)c->safe_phase_cnt;
+                    int dir = c->safe_next_dir >= 0 ? 1 : -1;
+                    double trial = dir > 0 ? c->safe_mult * 2.0 : c->safe_mult * 0.5;
+                    if (trial > 64.0 || trial < 1.0) { dir = -dir; trial = dir > 0 ? c->safe_mult * 2.0 : c->safe_mult * 0.5; }
+                    c->safe_mult_base = c->safe_mult;
+                    c->safe_mult = trial;
+                    c->safe_try = dir;
+                    c->safe_adv_sum = 0.0; c->safe_phase_cnt = 0;
+                } else if (c->safe_try != 0 && c->safe_phase_cnt >= 6) {
+                    const double rate = c->safe_adv_sum / (double)c->safe_phase_cnt;
+                    if (rate > 1.1 * c->safe_base_rate) c->safe_next_dir = c->safe_try;          // keep it, and try further the same way
+                    else { c->safe_mult = c->safe_mult_base; c->safe_next_dir = -c->safe_try; }
+                    c->safe_try = 0;
+                    c->safe_adv_sum = 0.0; c->safe_phase_cnt = 0;
+                }
+                if (c->safe_wbar > 0.0) {
+                    double cap = c->safe_mult * c->safe_wbar;
+                    cap = cap < 1.0 / 1024.0 ? 1.0 / 1024.0 : (cap > 4.0 ? 4.0 : cap);
+                    // (quantised to a twelfth of an octave: the robust tables are rebuilt only when the budget really moves)
+                    c->safe_cap = exp2(rint(log2(cap) * 12.0) / 12.0);
+                }
+            }
+            // (the proof pass sized the next stretch from the density of unproven visits it saw; a window the budget ended
+            // early wastes what was examined behind the cut: no further than eight times what this one covered)
+            long long L = c->safe_L;
+            if (S.cut && L > 8 * adv + 64) L = 8 * adv + 64;
+            if (L < 256) L = 256;
+            c->safe_L = (int)L;
+        }
         c->ema_run = S.ema_run;
         c->last_mover = S.last_mover;
         if (S.nmoves > 0) { c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; }
@@ -821,7 +911,8 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             c->job.mode = MODE_DONE;
         } else {
             c->win_size = (int)window_for_rate(c);
-            start_window(d, c, pos0 + consumed);
+            start_window(d, c, next_pos);
+            if (d.safe_mode) safe_open_window(d, c);
         }
     }
 }
@@ -856,6 +947,10 @@ void gram_configure(const Dev &d, int resolve_lds) {
 // One frozen-factor step: cross forms, weights, the sequential walk, statistics + factors of the touched
 // slots.  ev0 / ev1 (optional) bracket the likelihood kernel.
 bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    return launch_gram_core(d, resolve_lds, st, ev0, ev1);
+}
+
+bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, st);
     switch (d.Dp / 16) {
         case 1: launch_gram_t<1>(d, st); break;

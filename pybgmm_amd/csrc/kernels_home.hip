@@ -60,7 +60,7 @@ static constexpr double kHomeFar = 80.0;             // beyond this the excluded
 // LDS plan (doubles).  Per workgroup: the home's factor fragments (permuted), cvec, mu (permuted, zero padded),
 // its row of ftab, 16 scalars; per wavefront: quadratic forms, distances, home slots of its 64 rows.
 __host__ __device__ constexpr int home_wave_doubles() { return 64 + 64 + 32; }
-__host__ __device__ constexpr int home_shared_doubles(int Dp) { return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16; }
+__host__ __device__ constexpr int home_shared_doubles(int Dp) { return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16 + 8; }
 __host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles()) * 8; }
 // wavefronts per SIMD (a tile of 16 rows is 2 D/16 registers; one in the matrix pipe, one on its way): two up to
 // D = 64, one above (at two the D = 128 kernel spills, and a scratch access waits for every row load in flight)
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     LDS_AS double *const hmu = hcv + Dp;                              // hmu[4 kk + lk] = mu[column of (kk, lk)], zero beyond D
     LDS_AS double *const hft = hmu + Dp;                              // ftab[label of the home][64]
     LDS_AS double *const hsc = hft + 64;                              // SlotConst (12), finv, (n, version)
-    LDS_AS double *const sideQ = hsc + 16 + w * home_wave_doubles();  // exact home form of row rho [64]
+    LDS_AS double *const hsr = hsc + 16;                              // safe-stay windows: the home's robust constants (rtab row)
+    LDS_AS double *const sideQ = hsr + 8 + w * home_wave_doubles();   // exact home form of row rho [64]
     LDS_AS double *const sideRho = sideQ + 64;                        // |x - mu_home|^2 [64]
     LDS_AS int *const sideH = (LDS_AS int *)(sideRho + 64);           // home slot [64]
     const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const int col = 16 * (e >> 4) + home_col((e >> 2) & 3, e & 3);     // e = 4 kk + lk
                 hmu[e] = col < D ? d.mu[(long long)hf * D + col] : 0.0;
             }
-            if (tid < 64) hft[tid] = d.ftab[(long long)a * 64 + tid];
+            if (tid < 64) hft[tid] = (d.safe_mode ? d.ftabR : d.ftab)[(long long)a * 64 + tid];
+            if (d.safe_mode && tid >= 128 && tid < 136) hsr[tid - 128] = d.rtab[(long long)a * 8 + (tid - 128)];
             if (tid == 64) {
                 const SlotConst sc = d.sc[hf];
                 hsc[0] = sc.A; hsc[1] = sc.half_vd; hsc[2] = sc.inv_cv; hsc[3] = sc.A1; hsc[4] = sc.half_vd1;
@@ -399,7 +401,55 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         // ---- the scalar tail: lane = row
         const bool live = imine >= 0;
         bool easy = false;
-        if (live && hmine >= 0) {
+        if (d.safe_mode) {
+            // ---- proof pass of a safe-stay window (kernels_safe.hip): does the visit stay under the frozen state AND
+            // every state the window's budget allows?  Nothing is drawn here; the rows left unproven are walked in order
+            // by the frozen-factor resolver.
+            bool safe = false, resid = false;
+#ifdef BGMM_SAFE_DEBUG
+            int why = live ? 1 : 0;
+#endif
+            if (live && hmine >= 0) {
+                const double q_t = sideQ[lane], rho2_t = sideRho[lane];
+                const int a = rcur.home_label;
+                double lb0, hv1m, okf, ik0, finv_a;
+                if (one_home) { lb0 = hsr[4]; hv1m = hsr[5]; okf = hsr[6]; ik0 = hsr[3]; finv_a = hsc[12]; }
+                else {
+                    const double *__restrict__ g = d.rtab + (long long)a * 8;
+                    lb0 = g[4]; hv1m = g[5]; okf = g[6]; ik0 = g[3]; finv_a = d.finv[a];
+                }
+                const double *__restrict__ gg = d.rtab + (long long)(d.nslots - 1) * 8;
+                const double chi = (q_t + ik0) * gg[1];                 // c_0(x, x) e^cap
+                if (okf > 0.5 && q_t >= 0.0 && chi < 1.0) {
+                    const double lb = lb0 + hv1m * log(1.0 - chi);      // the home's score, from below
+                    const double rad = sqrt(rho2_t * (1.0 + 1e-9)) * (1.0 + 1e-9);
+                    const double jf = rad * finv_a;
+                    double bound = INFINITY;
+                    if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftabR[(long long)a * 64 + (int)jf + 1];
+                    // everything but the home, relative to it: the other labels (together below `bound`), the new table
+                    // (exact); a component opened inside the window ends it (kernels_gram.hip)
+                    const double R = (exp(bound - lb) + exp(rcur.mlb0 - lb)) * (1.0 + 1e-6);
+                    const double u_cur = d.u[win_base + wrow_cur];
+                    safe = R < 0.25 && u_cur >= R + 1e-12 && u_cur <= 1.0 - R - 1e-12;
+                    // the table's triangle bound may be what fails: such a visit goes on the residual list, where the
+                    // components it cannot exclude are scored exactly (score_mfma_prune_kernel, safe_choice_kernel)
+                    resid = !safe && u_cur >= 1e-9 && u_cur <= 1.0 - 1e-9 && exp(rcur.mlb0 - lb) < 0.25;
+#ifdef BGMM_SAFE_DEBUG
+                    why = safe ? 7 : (!(jf < 62.0) ? 3 : (exp(bound - lb) >= 0.125 ? 4 : (exp(rcur.mlb0 - lb) >= 0.125 ? 5 : 6)));
+                } else {
+                    why = okf > 0.5 ? 2 : 1;
+#endif
+                }
+            }
+#ifdef BGMM_SAFE_DEBUG
+            for (int k = 1; k <= 7; ++k) {
+                const unsigned long long mk = __ballot(why == k);
+                if (lane == 0 && mk) atomicAdd((unsigned long long *)&c->prof[k], (unsigned long long)__popcll(mk));
+            }
+#endif
+            if (live) d.cert[wrow_cur] = safe ? 1 : 0;
+            easy = !resid;
+        } else if (live && hmine >= 0) {
             const double q_t = sideQ[lane], rho2_t = sideRho[lane];
             const int a = rcur.home_label;
             int nh, ver;

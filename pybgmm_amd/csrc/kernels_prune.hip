@@ -405,8 +405,19 @@ __device__ __forceinline__ void prune_tile(const Dev &d, const JobView &job, dou
                     if (lr == 0) {
                         const int row = R * 16 + lk + 4 * r;
                         const bool own = sideH[row] == s;
+                        if (d.safe_mode) {
+                            // proof pass of a safe-stay window (kernels_safe.hip): bounds and margins must hold for every
+                            // state inside the window's budget -- the best-score bound is raised by the home's ROBUST
+                            // lower bound only (the bound constants of the tables are the robust ones, too)
+                            if (own) {
+                                const double *__restrict__ rt = d.rtab + (long long)label * 8;
+                                const double chi = (v[r] + rt[3]) * d.rtab[(long long)(d.nslots - 1) * 8 + 1];
+                                if (rt[6] > 0.5 && chi < 1.0) sideM[row] = fmax(sideM[row], rt[4] + rt[5] * log(1.0 - chi));
+                            }
+                        } else {
                         if (!own || ns >= 2) sideM[row] = fmax(sideM[row], slot_score_lower(scs, v[r], own));
                         if (own) d.pcache[sideI[row]].qhome = v[r];     // (tag written with the distance)
+                        }
                     }
                 }
                 // one 128-byte line per (block, label): lane (lk, lr < 4) stores visit lk + 4 lr

@@ -1,0 +1,299 @@
+// Safe-stay windows: the regime between "nothing moves" and "everything moves" (0.01 % .. 25 % movers).
+//
+// A frozen-factor window (kernels_gram.hip) walks 64 CONSECUTIVE visits whether four of them move or sixty; a
+// pruned window (kernels_prune.hip, kernels_home.hip) is thrown away at its first mover.  In between lies where a
+// chain spends its life.  The reference's loop (igmm/crpmm.py:57-88, igmm/pcrpmm.py:93-131) restores the cached
+// statistics verbatim when a visit keeps its component (crpmm.py:82-85): a visit that stays changes nothing, so it
+// need not be on the resolver's sequential chain at all -- IF it can be proven to stay not only under the frozen
+// state but under every state the window can reach.  That proof:
+//
+//   Every change of a component inside a window is a rank-1 term of its augmented scatter matrix
+//   A = [[S, m], [m', k_N]], A += sigma [y; 1][y; 1]'; with c(x, x) = [x; 1]' A^-1 [x; 1] the predictive of x is
+//       not a member:  lp = seat(n) + g(n) - D/2 lc(n) - 1/2 logdet S_N - hv(n) log(k_N / (k_N + 1) (1 + c))
+//       a member    :  lp = seat(n-1) + g(n-1) - D/2 lc(n-1) - 1/2 logdet S_N + (hv(n-1) - 1/2) log(k_N / (k_N - 1) (1 - c))
+//   (gaussian_components.py:228-251 through slot_math.h), logdet S_N = logdet A - log k_N.  Sherman-Morrison:
+//       c_t(x, x) = c_{t-1}(x, x) - sigma_t c_{t-1}(x, y_t)^2 / D_t,   D_t = 1 + sigma_t c_{t-1}(y_t, y_t),
+//       logdet A_t = logdet A_{t-1} + log D_t,
+//   and by Cauchy-Schwarz on the positive definite form c_{t-1}:  c_{t-1}(x, y)^2 <= c_{t-1}(x, x) c_{t-1}(y, y), hence
+//       c_{t-1}(x, x) / (1 + c_{t-1}(y, y)) <= c_t(x, x) <= c_{t-1}(x, x)         (sigma = +1)
+//       c_{t-1}(x, x) <= c_t(x, x) <= c_{t-1}(x, x) / (1 - c_{t-1}(y, y))         (sigma = -1)
+//   i.e. with W_t = sum_{i <= t} |log D_i| (which the window resolver has at hand: it computes every D_i):
+//       | log c_t(x, x) - log c_0(x, x) | <= W_t   and   | logdet A_t - logdet A_0 | <= W_t      for EVERY x.
+//   The resolver ends a window right behind the move that takes a column out of its budget W <= cap, lets its count
+//   drift more than dn(t) = clamp(n0 / 4, 1, kSafeDn) from the frozen one, or opens a component (kernels_gram.hip).
+//   Under that budget, for a visit x whose home h keeps >= 2 members:
+//       home        >= Psi_min(h) - 1/2 logdet0_h - cap/2 + hv1_max(h) log(1 - c_0(x, x) e^cap)          =: lb
+//       other t     <= Phi_max(t) - 1/2 logdet0_t + cap/2 - hv_min(t) log(1 + c_lb,t(x) e^-cap),
+//                      c_lb,t = |mu_t - x|^2 / Lambda_t + 1 / k_N0 from the triangle bound of the pruning kernel
+//                      against the FROZEN centres (tabulated per home over the distance to the home's mean: ftabR)
+//       new table   =  log alpha + log_prior[i]                                                         (exact)
+//   (Phi / Psi: the count-dependent constants, extremised over the counts the budget allows.)  With R = the total
+//   weight of everything but the home relative to lb, the reference's draw (utils/utils.py:7-20: u -= p_j in label
+//   order) returns the home for every u in [R, 1 - R]: the labels in front of it subtract at most R, the home's own
+//   probability is at least 1 - R.  Such a visit is SAFE: it stays whatever the listed visits do.
+//
+// A step = proof pass over the next L visits (bucket sort + home_kernel in safe mode: one exact quadratic form per
+// visit, the same kernel that decides a chain at rest) -> the first 64 visits that are not SAFE, in visiting order
+// (safe_compact_kernel) -> the frozen-factor kernels on exactly those rows.  L follows the density of unproven visits.
+#include "score_common.h"
+#include "slot_math.h"
+#include "wave_ops.h"
+
+// One thread: the open window becomes the stretch of the next proof pass (first step of a batch; later ones are
+// opened by the resolver that closes the window before).
+__global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
+    Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode == MODE_DONE) return;
+    for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;      // (the bucket sort counts from zero)
+    if (threadIdx.x == 0) safe_open_window(d, c);
+}
+
+// Robust per-label constants (rtab[label][8]) for the frozen state:
+//   0 ub0 = Phi_max - logdet0/2 + cap/2    1 hv_min    2 1/Lambda    3 1/k_N0
+//   4 lb0 = Psi_min - logdet0/2 - cap/2    5 hv1_max   6 1: the label keeps >= 2 members whatever the window does
+//   7 dn: how far the resolver lets the label's count drift inside a window (negative: a small label, upwards only)
+// row nslots - 1: 0 e^-cap, 1 e^cap
+__global__ __launch_bounds__(64) void safe_rtab_kernel(Dev d) {
+    const Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
+    const int K = c->job.K;
+    const double Dd = (double)d.D, cap = safe_cap_now(d, c);
+    const int a = blockIdx.x, lane = threadIdx.x;
+    if (a < K) {
+        // one wavefront per label, lane = one of the counts the window may take it to.  A SMALL label (fewer than
+        // kSafeSmall members) proves nothing for its own members and asks nothing of the removals it takes: its count may
+        // fall to 1, its scatter matrix never falls below the prior's (logdet S_N >= logdet S_0), and only the points
+        // that JOIN it count against its budget (they alone can lower c(x, x)).
+        const int s = d.perm[a];
+        const int n0 = d.n[s];
+        const bool small = n0 < kSafeSmall;
+        const double kN0 = d.k0 + (double)n0, L0 = small ? d.sc[d.K_max].logdetC : d.sc[s].logdetC;
+        int dn = n0 / 4;
+        dn = dn < 1 ? 1 : (dn > kSafeDn ? kSafeDn : dn);
+        const int n = small ? 1 + lane : n0 - dn + lane;
+        double phi = -INFINITY, psi = INFINITY, hvmin = INFINITY, hv1max = 0.0;
+        if (n >= 1 && n <= n0 + dn) {
+            const SlotTab t = load_slot_tab(d, n);
+            const double kN = d.k0 + (double)n;
+            const long long v = d.v0 + n - d.D + 1;
+            const double hv = 0.5 * (double)(v + d.D);
+            const double lk = small ? 0.0 : -0.5 * log(kN0 / kN);
+            phi = t.seat + t.g - 0.5 * Dd * t.lc + lk + hv * log((kN + 1.0) / kN);
+            hvmin = hv;
+            if (n >= 2) {
+                hv1max = 0.5 * (double)(v - 1 + d.D) - 0.5;
+                psi = t.seat1 + t.g1 - 0.5 * Dd * t.lc1 + lk + hv1max * log(kN / (kN - 1.0));
+            }
+        }
+        phi = wv_max(phi); psi = -wv_max(-psi); hvmin = -wv_max(-hvmin); hv1max = wv_max(hv1max);
+        if (lane == 0) {
+            double *g = d.rtab + (long long)a * 8;
+            g[0] = phi - 0.5 * L0 + (small ? 0.0 : 0.5 * cap) + 1e-9 * fabs(phi - 0.5 * L0);
+            g[1] = hvmin;
+            g[2] = d.sc[s].inv_lam;
+            g[3] = 1.0 / kN0;
+            g[4] = psi - 0.5 * L0 - 0.5 * cap - 1e-9 * fabs(psi - 0.5 * L0);
+            g[5] = hv1max;
+            g[6] = (!small && n0 - dn >= 2) ? 1.0 : 0.0;
+            g[7] = small ? -(double)dn : (double)dn;          // (negative: a small label -- removals are free)
+            // the bound constants of the pruning kernel (pr_const, written by prune_tables_kernel and already consumed by
+            // prune_ftable_kernel): their robust twins -- ub <= ub0 - hv_min log(1 + |mu - x|^2 e^-cap / Lambda)
+            double *pc = d.pr_const + (long long)(a >> 4) * 128 + (a & 15);
+            pc[0] = g[0];
+            pc[16] = hvmin;
+            pc[32] = d.sc[s].inv_lam * (exp(-cap) * (1.0 - 1e-12));
+        }
+    }
+    if (a == 0 && lane == 0) {
+        double *g = d.rtab + (long long)(d.nslots - 1) * 8;
+        g[0] = exp(-cap) * (1.0 - 1e-12);
+        g[1] = exp(cap) * (1.0 + 1e-12);
+    }
+}
+
+// log(1 + x) from BELOW in single precision: the bounds carry explicit slack for the 1e-6 relative error of the
+// hardware logarithm and the rounding of 1 + x (bounds, not scores: a nat in a thousand does not matter, the
+// 100-instruction double logarithm per (home, label, radius) did -- 120 us per table)
+__device__ __forceinline__ double log1p_below(double x) {
+    const float L = __logf(1.0f + (float)x);
+    const double v = (double)L * (1.0 - 2e-4) - 3e-7;
+    return v > 0.0 ? v : 0.0;
+}
+// exp(x) from ABOVE in single precision, for x <= 0.7 or so (weights relative to a lower bound of the home's)
+__device__ __forceinline__ double exp_above(double x) {
+    if (x < -80.0) return 1.9e-35;
+    return (double)__expf((float)x + 1e-5f) * (1.0 + 1e-5) + 1e-37;
+}
+
+// ftabR[a][j]: upper bound, valid under the budget, of the log of the TOTAL weight of the labels t != a for a visit
+// whose home is a and whose distance to a's (frozen) mean is at most j / finv[a] -- the robust twin of
+// prune_ftable_kernel (same radii, same centre distances, built right behind it).  The labels' constants are staged
+// in LDS once per workgroup.
+__global__ __launch_bounds__(64) void safe_ftab_kernel(Dev d) {
+    extern __shared__ double lt[];                        // [K][4]: ub0, hv_min, e^-cap / Lambda, e^-cap / k_N0
+    const Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
+    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
+    if (a >= K) return;
+    const double emcap = d.rtab[(long long)(d.nslots - 1) * 8 + 0];
+    for (int t = j; t < K; t += 64) {
+        const double *__restrict__ g = d.rtab + (long long)t * 8;
+        lt[4 * t] = g[0]; lt[4 * t + 1] = g[1]; lt[4 * t + 2] = g[2] * emcap; lt[4 * t + 3] = g[3] * emcap;
+    }
+    double *dcs = lt + 4 * K;                             // centre distances from a
+    const double *__restrict__ dc = d.pr_dcc + (long long)a * d.nslots;
+    for (int t = j; t < K; t += 64) dcs[t] = dc[t] * (1.0 - 1e-9);
+    __syncthreads();
+    const double finv = d.finv[a];
+    const double step = finv > 0.0 ? 1.0 / finv : 0.0;
+    const double rj = (double)j * step * (1.0 + 1e-9);
+    auto ub = [&](int t) {
+        double dl = dcs[t] - rj;
+        dl = dl > 0.0 ? dl : 0.0;
+        return lt[4 * t] - lt[4 * t + 1] * log1p_below(dl * dl * lt[4 * t + 2] + lt[4 * t + 3]);
+    };
+    double f = -INFINITY;
+    for (int t = 0; t < K; ++t)
+        if (t != a) f = fmax(f, ub(t));
+    // log of the sum: the labels within 45 nats of the largest bound are added up, the rest (each below e^-45 of it)
+    // are covered by K e^-45
+    double sum = (double)K * 2.9e-20;
+    for (int t = 0; t < K; ++t) {
+        if (t == a) continue;
+        const double v = ub(t);
+        if (v > f - 45.0) sum += exp_above(v - f);
+    }
+    f += log(sum) * (1.0 + 1e-12) + 1e-12;
+    d.ftabR[(long long)a * 64 + j] = (K > 1 && finv > 0.0) ? f : (K > 1 ? INFINITY : -INFINITY);
+}
+
+// The first kGramRows visits of the stretch [win_base, win_hi) that the proof pass did not mark SAFE, in visiting
+// order (cert[row] == 1: SAFE), and where the stretch they vouch for ends: at the (kGramRows + 1)-th such visit, or at
+// win_hi.  One workgroup: every thread counts a contiguous run, one scan, the threads in front of the cut emit.
+__global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
+    __shared__ int wsum[16];
+    Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    const long long base = c->job.win_base;
+    const int nrows = (int)(c->job.win_hi - base);
+    const int per = ((nrows + 1023) / 1024 + 15) & ~15;             // (16-byte pieces)
+    const int lo = threadIdx.x * per, hi = lo + per < nrows ? lo + per : nrows;
+    int cnt = 0;
+    for (int r = lo; r < hi; r += 16) {
+        if (r + 16 <= hi) {
+            const uint4 v = *(const uint4 *)(d.cert + r);
+            // bytes are 0 or 1: the unproven ones are the zero bytes
+            cnt += 16 - (__popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u));
+        } else {
+            for (int q = r; q < hi; ++q) cnt += d.cert[q] ? 0 : 1;
+        }
+    }
+    int incl = cnt;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    int rank = off + incl - cnt;                                    // unproven visits in front of this thread's run
+    for (int b = threadIdx.x; b < d.nslots + 2; b += 1024) d.bucket_bins[b] = 0;      // (left at zero for the next sort)
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < 16; ++k) total += wsum[k];
+        c->gl_n = total < kGramRows ? total : kGramRows;
+        if (total <= kGramRows) c->gl_end = base + nrows;
+        c->safe_scanned += nrows;
+        // the next proof pass: as far as it takes to find kGramRows unproven visits (and a few to spare) at the density
+        // seen here; the resolver shortens it again if the budget keeps ending windows early
+        long long L = total > 0 ? (long long)nrows * (kGramRows + 16) / total : 2ll * nrows;
+        if (L > 4ll * nrows) L = 4ll * nrows;
+        if (L < 256) L = 256;
+        if (L > (1ll << 22)) L = 1ll << 22;
+        c->safe_L = (int)L;
+        c->n_resid = 0;                 // (the residual list of this proof pass has been worked through)
+        c->tables_valid = 1;
+        c->safe_epoch_built = c->state_epoch;
+        c->safe_cap_built = safe_cap_now(d, c);
+    }
+    if (cnt > 0 && rank <= kGramRows) {
+        for (int r = lo; r < hi && rank <= kGramRows; ++r) {
+            if (d.cert[r]) continue;
+            if (rank < kGramRows) d.glist[rank] = base + r;
+            else c->gl_end = base + r;                                // the first visit the list has no room for
+            ++rank;
+        }
+    }
+}
+
+// The residual list of the proof pass (visits home_kernel's table bound could not prove): every label the pruning
+// kernel could not exclude under the budget has its exact frozen quadratic form in the block-sparse q lines.  Four
+// threads per visit (the mask words dealt round robin): robust upper bounds of the kept labels from their exact c_0,
+// the home from below, the excluded labels below e^-80 of max(home, new table) each.
+__global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
+    Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    const long long nrows = c->n_resid;
+    const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int part = threadIdx.x & 3;
+    if (k >= nrows) return;                               // (whole quads leave together)
+    const int K = c->job.K;
+    const int wrow = d.wpermR[k];
+    const WRec rec = d.wrecR[k];
+    const long long b = k >> 4;
+    const unsigned long long *__restrict__ mask = d.keep64 + b * d.keep_stride;
+    const double *__restrict__ qline = d.q + (b * (long long)d.nslots) * 16 + (k & 15);
+    const double *__restrict__ gg = d.rtab + (long long)(d.nslots - 1) * 8;
+    const double emcap = gg[0], ecap = gg[1];
+    const int a = rec.home_label;
+    bool ok = false;
+    double lb = 0.0, R = 0.0;
+    if (rec.home >= 0 && a >= 0 && a < K && ((mask[a >> 6] >> (a & 63)) & 1ull)) {
+        const double *__restrict__ rh = d.rtab + (long long)a * 8;
+        const double chi = (qline[(long long)a * 16] + rh[3]) * ecap;
+        if (rh[6] > 0.5 && chi < 1.0) {
+            ok = true;
+            lb = rh[4] + rh[5] * log(1.0 - chi);
+            const int nw = (K + 63) >> 6;
+            for (int wi = part; wi < nw; wi += 4) {
+                unsigned long long m = mask[wi];
+                if (wi == nw - 1 && (K & 63)) m &= (1ull << (K & 63)) - 1ull;
+                while (m) {
+                    const int t = wi * 64 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (t == a) continue;
+                    const double *__restrict__ rt = d.rtab + (long long)t * 8;
+                    const double qv = qline[(long long)t * 16];
+                    const double clb = ((qv > 0.0 ? qv * (1.0 - 1e-9) : 0.0) + rt[3]) * emcap;
+                    R += exp_above(rt[0] - rt[1] * log1p_below(clb) - lb);
+                }
+            }
+        }
+    }
+    R += __shfl_xor(R, 1);
+    R += __shfl_xor(R, 2);
+    if (part != 0 || !ok) return;
+    const double mstar = fmax(lb, rec.mlb0);
+    R += exp(rec.mlb0 - lb) + (double)K * exp(mstar - 80.0 - lb);
+    R *= 1.0 + 1e-6;
+    const double u = d.u[c->job.win_base + wrow];
+    if (R < 0.25 && u >= R + 1e-12 && u <= 1.0 - R - 1e-12) d.cert[wrow] = 1;
+}
+
+void launch_safe_open(const Dev &d, hipStream_t st) {
+    hipLaunchKernelGGL(safe_open_kernel, dim3(1), dim3(256), 0, st, d);
+}
+
+// One safe-stay step.  The Dev of a safe batch has prune_enabled = 2, use_certify = 0, use_home = 1, safe_mode = 1.
+bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    launch_prune_tables(d, st);                                          // centre distances, radii (exit while valid)
+    hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(safe_ftab_kernel, dim3(d.nslots), dim3(64), d.nslots * 5 * (int)sizeof(double), st, d);
+    launch_bucket_rows(d, max_rows, st);                                  // the stretch's visits grouped by home
+    launch_home(d, max_rows, st);                                         // proof pass: cert[row] = SAFE
+    launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, max_rows, st);   // what its table bound left open: exact forms
+    hipLaunchKernelGGL(safe_choice_kernel, dim3((unsigned)((max_rows + 63) / 64)), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(safe_compact_kernel, dim3(1), dim3(1024), 0, st, d);
+    return launch_gram_core(d, resolve_lds, st, ev0, ev1);
+}

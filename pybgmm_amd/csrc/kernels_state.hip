@@ -326,6 +326,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
         c->n_resid = 0; c->home_in = 0; c->home_out = 0;
         c->n_pairs_exact = 0; c->gram_rows_total = 0; c->gram_windows = 0; c->gram_ntouched = 0; c->gram_nmoves = 0;
+        c->safe_windows = 0; c->safe_scanned = 0; c->safe_rows = 0; c->safe_cuts = 0;
         if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
@@ -385,6 +386,20 @@ __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
             for (int l = 0; l < D; ++l) { const double t = pb[l] - mua[l]; acc = fma(t, t, acc); }
             d.pr_dcc[(long long)a * d.nslots + b] = sqrt(acc);
         }
+        // the label's own scale: root mean square distance of its members to its mean, sqrt(tr S_N / n) -- what the
+        // radius grid of its bound table is sized by (prune_ftable_kernel)
+        if (threadIdx.x < 64) {
+            const int sa = d.perm[a], na = d.n[sa];
+            double tr = 0.0;
+            if (d.cov_type != COV_FIXED && na >= 1) {
+                const double kN = d.k0 + (double)na;
+                const long long DD = d.cov_type == COV_FULL ? (long long)D * D : (long long)D, st = d.cov_type == COV_FULL ? D + 1 : 1;
+                const double *__restrict__ Sa = d.S + (long long)sa * DD;
+                for (int l = threadIdx.x; l < D; l += 64) tr += Sa[(long long)l * st] - kN * mua[l] * mua[l];
+            }
+            for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+            if (threadIdx.x == 0) d.pr_rms[a] = (tr > 0.0 && na >= 1) ? sqrt(tr / (double)na) : 0.0;
+        }
         return;
     }
     const int K = c->job.K, G = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
@@ -429,7 +444,11 @@ __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
     for (int t = 0; t < K; ++t)
         if (t != a) dmin = fmin(dmin, dc[t]);
     const bool fixed = d.cov_type == COV_FIXED;
-    const double step = K > 1 ? 0.5 * dmin / 63.0 : 1.0;
+    // Radii: up to twice the label's own root mean square radius -- where its members are -- when that is known,
+    // whatever lies nearer than that (a small component inside a large one has its centre well inside the other's
+    // members: the bound then takes it at distance 0, which is right); else half the distance to the nearest centre.
+    const double rms = d.pr_rms[a];
+    const double step = K > 1 ? (rms > 0.0 ? 2.0 * rms : 0.5 * dmin) / 63.0 : 1.0;
     const double rj = (double)j * step * (1.0 + 1e-9);
     double f = -INFINITY;
     for (int t = 0; t < K; ++t) {

@@ -343,6 +343,24 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     set_chunks(d, j);
 }
 
+// Safe-stay windows (kernels_safe.hip): the open window becomes the stretch the next proof pass examines.
+__device__ inline void safe_open_window(const Dev &d, Ctrl *c) {
+    Job &j = c->job;
+    if (j.mode == MODE_DONE) return;
+    if (c->safe_L < 256) c->safe_L = 256;
+    long long w = c->safe_L;
+    if (w > d.batch_rows) w = d.batch_rows;
+    long long hi = j.pos + w;
+    if (hi > c->n_visits) hi = c->n_visits;
+    j.win_base = j.pos;
+    j.win_hi = hi;
+    j.mode = MODE_FRESH;
+    j.n_dirty = 0;
+    j.prune = 1;
+    c->skip_sort = 0;
+    c->first_mover = kNoMover;
+    set_chunks(d, j);
+}
 
 // Running mean distance between movers.  A run far below the mean (the chain has just been
 // disturbed: the mean still remembers the quiet stretch before) pulls it down fast -- every mover
