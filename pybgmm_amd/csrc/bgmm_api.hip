@@ -110,10 +110,14 @@ struct bgmm_ctx {
 // Mean distance between movers below which the frozen-factor windows take over from the per-mover
 // kernel chain: a window costs ~60 us plus ~1.5 us per mover and covers 64 visits, the chain ~190 us per mover.
 constexpr double kGramRun = 192.0;
-// Safe-stay windows (kernels_safe.hip) cover the regime in between: from one mover in kSafeRun visits up to every
-// fourth visit moving (beyond that the proof pass proves too little to pay: plain frozen-factor windows).
+// Safe-stay windows (kernels_safe.hip) cover the regime in between: from one mover in kSafeRun visits up to one in
+// sixteen.  A safe-stay window costs about three plain ones (the proof pass in front of it) and walks the visits it could
+// not prove -- two to six per mover where clusters overlap -- so beyond that rate, or once a batch of them has walked
+// more than every fourth visit, plain frozen-factor windows are cheaper (measured at C4's shape: 1.6 % movers 1.2 s per
+// sweep against 3.0 s; 11.6 % movers 5.6 s against 3.0 s).
 constexpr double kSafeRun = 65536.0;
-constexpr double kSafeDenseRate = 0.25;
+constexpr double kSafeDenseRate = 0.0625;
+constexpr double kSafeWalkShare = 0.25;
 
 #define CK(ctx, call)                                                                       \
     do {                                                                                    \
@@ -797,7 +801,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             }
             lean = false;
             first_batch = false;
-            const long long w0 = hc.safe_windows, mv0 = hc.n_moves;
+            const long long w0 = hc.safe_windows, mv0 = hc.n_moves, rows0 = hc.safe_rows;
             const auto t_batch0 = std::chrono::steady_clock::now();
             launch_safe_open(d, st);
             for (int t = 0; t < (int)Tg; ++t)
@@ -824,6 +828,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
                 const double dscale = d.Dp > 64 ? (double)d.Dp / 64.0 : 1.0;
                 const double rate_chain = 1.0 / (mrate * 0.2 * dscale + 3e-4);
                 if (mrate < 2e-3 && visits / ms < 0.6 * rate_chain) { safe_skip = true; c->safe_rest = 1; }
+                if ((double)(h.safe_rows - rows0) > kSafeWalkShare * visits) safe_skip = true;      // (too little proven: plain windows)
             }
             pos = h.job.pos;
             win = h.win_size > 0 ? h.win_size : win;

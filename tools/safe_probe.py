@@ -1,6 +1,7 @@
 """Safe-stay windows (kernels_safe.hip): parity against the C oracle and against the other mover paths, then timing.
     python tools/safe_probe.py check            small problems, forced safe-stay windows vs the C oracle
     python tools/safe_probe.py flip N D K [resolver_mode] [n_sweeps] [sep]    a chain at the truth with N/500 labels flipped
+    python tools/safe_probe.py true N D K [resolver_mode] [n_sweeps] [sep]    a chain at the truth (sep < 1: overlapping clusters, movers at equilibrium)
     python tools/safe_probe.py rand N D K [resolver_mode] [n_sweeps] [sep] [pcrp]   from the reference's "rand" initialisation
 """
 import os, sys, time
@@ -16,6 +17,8 @@ def run(N, D, K, init, resolver, n_sweeps, sep=4.0, pcrp=False, oracle=False, se
     rs = np.random.RandomState(seed)
     if init == "rand":
         z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    elif init == "true":
+        z0 = zt.copy()
     else:
         z0 = zt.copy()
         flip = rs.choice(N, size=max(N // 500, 1), replace=False)
