@@ -103,6 +103,64 @@ def cpu_baseline(D, K, seed, budget_visits, cov="full"):
     return dt / budget_visits, n_cpu, t_init, int(o.lik_evals.value)
 
 
+def cpu_baseline_numpy(D, K, seed, visits):
+    """the numpy restatement of the reference (oracle/gibbs_numpy.py: the reference's own numpy / scipy
+    calls -- slogdet + inv from scratch per update, einsum contraction, scipy logsumexp -- bit-identical floats) timed
+    on this box's host cores, on a small twin of the workload (per-visit cost does not depend on N)."""
+    from oracle import gibbs_numpy
+    from pybgmm_amd.utils import gendata
+    n_cpu = 4 * K
+    X, z_true = gendata.synth_mixture(n_cpu, D, K, seed)
+    m_0, k_0, v_0, S_0 = prior_for("full", D)
+    o = gibbs_numpy.NumpyGibbsOracle(X, m_0, k_0, v_0, S_0, 1.0, z_true, 4 * K)
+    u = np.random.RandomState(seed).random_sample(n_cpu)
+    visits = min(visits, n_cpu)
+    t0 = time.time()
+    for i in range(visits):
+        o.visit(i, u[i])
+    return (time.time() - t0) / visits, n_cpu
+
+
+def steady_moving_leg(args, local_rank):
+    """The regime a chain lives in when its clusters overlap: the workload's shape with the centres
+    drawn at `--moving-sep` times the scale of the at-rest data set, so that of the order of 1 % of the visits move at
+    equilibrium.  Chain started at the generating labels, three sweeps to settle, then five timed ones -- uniforms
+    generated inside the timed region as in the headline."""
+    import random as _random
+    from pybgmm_amd.utils import gendata
+    N, D, K, model = WORKLOADS[args.workload]
+    X2, zt = gendata.synth_mixture(N, D, K, seed=args.seed + 5, mu_scale=args.moving_sep)
+    ctx = make_context(args, X2, zt, local_rank, "certified")          # the library's default configuration
+    rs = np.random.RandomState(4000 + args.seed)
+    _, key_t, _ = _random.Random(4000 + args.seed).getstate()
+    key, pos = np.asarray(key_t[:-1], dtype=np.uint32), int(key_t[-1])
+    sweeps = []
+    for it in range(8):
+        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
+        power = 1.01 if (model == "PCRPMM" and it > 0) else None
+        ctx.synchronize()
+        t0 = time.time()
+        key, pos = ctx.stage_mt19937(key, pos, order)
+        ctx.sweep_staged(power)
+        ctx.synchronize()
+        dt = time.time() - t0
+        st, ss, ps = ctx.sweep_stats(), ctx.safe_stats(), ctx.path_stats()
+        sweeps.append({"seconds": round(dt, 4), "moves": st["moves"], "K": ctx.K, "safe_stay_windows": ss["windows"],
+                       "visits_examined_by_proof_pass": ss["visits_examined"], "unproven_visits_walked": ss["unproven_walked"],
+                       "windows_ended_by_budget": ss["budget_cuts"], "budget": round(ss["budget"], 4),
+                       "plain_frozen_factor_windows": ps["frozen_windows"] - ss["windows"]})
+    ctx.close()
+    timed = sweeps[3:]
+    t = sum(x["seconds"] for x in timed)
+    mv = sum(x["moves"] for x in timed)
+    return {"workload": "%s shape, centres at mu_scale = %.2f (at-rest data: 4.0): clusters overlap" % (args.workload, args.moving_sep),
+            "sweeps_per_s": round(len(timed) / t, 3), "ms_per_sweep": round(1e3 * t / len(timed), 2),
+            "moves_per_sweep": round(mv / len(timed), 1), "movers_fraction": round(mv / len(timed) / N, 5),
+            "us_per_move": round(1e6 * t / max(mv, 1), 2),
+            "unproven_visits_walked_per_move": round(sum(x["unproven_visits_walked"] for x in timed) / max(mv, 1), 2),
+            "sweeps": sweeps}
+
+
 def make_context(args, X, z0, local_rank, mode):
     from pybgmm_amd import _lib
     from pybgmm_amd.gaussian.gaussian_components import reference_tables
@@ -268,8 +326,8 @@ def torchrun_argv(gpus, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=3000, help="timed sweeps (the default keeps the timed region above 0.5 s at C4)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="evaluated", choices=sorted(MODES))
     ap.add_argument("--init", default="true", choices=["true", "rand"])
@@ -283,6 +341,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-burnin", action="store_true")
+    ap.add_argument("--no-moving", action="store_true", help="skip the steady_moving leg (overlapping clusters)")
+    ap.add_argument("--moving-sep", type=float, default=0.55, help="mu_scale of the steady_moving leg's data set")
+    ap.add_argument("--numpy-visits", type=int, default=400, help="visits of the numpy-restatement CPU baseline (0 = skip)")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
@@ -319,23 +380,22 @@ def main():
 
     N, D, K, model = WORKLOADS[args.workload]
     X, z_true = gendata.synth_mixture(N, D, K, seed=args.seed)          # replicated data set
-    n_sweeps = args.warmup + args.steps
-    # chain c: its own uniform (and permutation) streams, seeds seed + c
+    # chain c: its own generators, seeds seed + c.  The per-visit uniforms are the continuation of the chain's
+    # random.Random -- produced ON THE DEVICE from its MT19937 state (bgmm_stage_mt19937: bit-identical to N calls of
+    # random.random(), the state handed back), which is what CRPMM.collapsed_gibbs_sampler does every sweep; a pCRP sweep
+    # also draws its permutation on the host and uploads it.  Both are INSIDE the timed region (t_sweep = the
+    # sweep's inputs + kernels, the `sample_time` of gmm.py:76).
+    import random as _random
+    chain_rng = _random.Random(1000 + args.seed + rank)
     rs = np.random.RandomState(1000 + args.seed + rank)
-    u_all = rs.random_sample((n_sweeps, N))
-    order_all = None
-    power = None
-    if model == "PCRPMM":
-        order_all = np.stack([rs.permutation(N) for _ in range(n_sweeps)]).astype(np.int64)
-        power = 1.01
+    _, key_t, _ = chain_rng.getstate()
+    mt_key, mt_pos = np.asarray(key_t[:-1], dtype=np.uint32), int(key_t[-1])
+    power = 1.01 if model == "PCRPMM" else None
     z0 = z_true if args.init == "true" else np.unique(rs.randint(0, K, N), return_inverse=True)[1]
 
     t0 = time.time()
     ctx = make_context(args, X, z0, local_rank, args.mode)
     t_setup = time.time() - t0
-    t0 = time.time()
-    ctx.upload_streams(u_all, order_all)
-    t_h2d = time.time() - t0
 
     def barrier():
         if dist is not None:
@@ -347,19 +407,49 @@ def main():
         # pcrpmm.py:105: powered weights iff i_iter > power_burnin (= 0): sweep 0 is plain CRP
         return power if (power is not None and it > 0) else None
 
+    def one_sweep(it):
+        nonlocal mt_key, mt_pos
+        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
+        mt_key, mt_pos = ctx.stage_mt19937(mt_key, mt_pos, order)
+        ctx.sweep_staged(sweep_power(it))
+
     for it in range(args.warmup):
-        ctx.sweep_resident(it, sweep_power(it))
+        one_sweep(it)
     barrier()
     t0 = time.time()
     decided = executed = moves = 0
-    for it in range(args.warmup, n_sweeps):
-        ctx.sweep_resident(it, sweep_power(it))
+    chunk_marks = []
+    for it in range(args.warmup, args.warmup + args.steps):
+        one_sweep(it)
         st = ctx.sweep_stats()
         decided += st["lik_evals"]
         executed += ctx.path_stats()["pairs_executed"]
         moves += st["moves"]
+        if (it - args.warmup + 1) % 250 == 0:
+            chunk_marks.append(time.time())           # (every call above ends with a stream sync: host time is device time)
     barrier()
     elapsed = time.time() - t0
+    chunk_rates = [round(250.0 / (b - a), 1) for a, b in zip([t0] + chunk_marks[:-1], chunk_marks)]
+    # the same chain with its inputs already resident (8 sweeps' worth of uniforms / permutations uploaded ahead and
+    # cycled through): what the sweep kernels alone sustain -- reported in `extra`, never the headline
+    n_res = 8
+    u_res = rs.random_sample((n_res, N))
+    order_res = np.stack([rs.permutation(N) for _ in range(n_res)]).astype(np.int64) if model == "PCRPMM" else None
+    t1 = time.time()
+    ctx.upload_streams(u_res, order_res)
+    t_h2d = time.time() - t1
+    n_sweeps = n_res
+    resident_rate = None
+    if moves == 0:
+        reps = max(50, min(args.steps, 400))
+        for it in range(8):
+            ctx.sweep_resident(it % n_res, power)
+        barrier()
+        t1 = time.time()
+        for it in range(reps):
+            ctx.sweep_resident(it % n_res, power)
+        barrier()
+        resident_rate = reps / (time.time() - t1)
     per_rank_rate = [round(args.steps / elapsed, 3)]
     if dist is not None:
         mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -388,9 +478,9 @@ def main():
         """One extra sweep in `mode` with every launch of its dominant likelihood kernel bracketed by HIP
         events on the library's stream."""
         set_mode(mode)
-        ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))          # settle the window policy
+        ctx.sweep_resident(n_sweeps - 1, power)          # settle the window policy
         ctx.set_kernel_timing(True)
-        ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+        ctx.sweep_resident(n_sweeps - 1, power)
         n_launch, ms = ctx.kernel_timing()
         st, ps, pa = ctx.sweep_stats(), ctx.prune_stats(), ctx.path_stats()
         ctx.set_kernel_timing(False)
@@ -459,15 +549,15 @@ def main():
     if single and not args.no_kernel_timing and moves_total == 0:
         for mode, reps in (("evaluated", 5), ("certified", 20), ("full", 3)):
             if mode == args.mode:
-                rates[mode] = round(args.steps / elapsed, 2)
+                rates[mode] = round(resident_rate, 2) if resident_rate else None
                 continue
             set_mode(mode)
             for _ in range(3):
-                ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+                ctx.sweep_resident(n_sweeps - 1, power)
             barrier()
             t0 = time.time()
             for _ in range(reps):
-                ctx.sweep_resident(n_sweeps - 1, sweep_power(n_sweeps - 1))
+                ctx.sweep_resident(n_sweeps - 1, power)
             barrier()
             rates[mode] = round(reps / (time.time() - t0), 2)
             if mode == "full" or (mode == "evaluated" and args.mode == "certified"):
@@ -498,6 +588,10 @@ def main():
     if single and not args.no_burnin and args.cov == "full":
         burnin = burnin_leg(args, X, local_rank, K, args.seed)
 
+    moving = None
+    if single and not args.no_moving and args.cov == "full" and D >= 12:
+        moving = steady_moving_leg(args, local_rank)
+
     cpu = None
     if single and args.cpu_visits > 0:
         per_visit, n_cpu, t_init, cpu_lik = cpu_baseline(D, K, args.seed + 7, args.cpu_visits, args.cov)
@@ -509,6 +603,14 @@ def main():
                "us_per_visit": round(per_visit * 1e6, 2),
                "lik_evals_per_s": round(cpu_lik / (per_visit * args.cpu_visits), 1),
                "reference_python_us_per_visit_survey_container": REFERENCE_US_PER_VISIT.get(args.workload)}
+        if args.numpy_visits > 0 and args.cov == "full":
+            npv, n_np = cpu_baseline_numpy(D, K, args.seed + 7, args.numpy_visits)
+            cpu["numpy_restatement"] = {
+                "kind": "numpy-restatement", "value": round(1.0 / (npv * N), 8), "unit": "sweeps/s", "cores": 1,
+                "us_per_visit": round(npv * 1e6, 2),
+                "sample": "%d visits on a N=%d twin, oracle/gibbs_numpy.py: the reference's numpy / scipy calls (slogdet + "
+                          "inv from scratch per update, einsum, logsumexp), floats bit-identical to the reference's" % (
+                              min(args.numpy_visits, n_np), n_np)}
 
     if rank == 0:
         sweeps_total = args.steps * n_gpus
@@ -541,14 +643,22 @@ def main():
                                      "exact bounds decided without executing them -- only mode `full` executes them all)"},
             "roofline": roofline,
             "burnin": burnin,
+            "steady_moving": moving,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
                       "K_final": K_final, "log_marg_rank0": log_marg,
                       "last_sweep": last_stats, "setup_s": round(t_setup, 3),
-                      "h2d_streams_s": round(t_h2d, 4),
-                      "pcie_inclusive_sweeps_per_s": round(
-                          sweeps_total / (elapsed + t_h2d * args.steps / n_sweeps), 4),
-                      "sweeps_per_s_by_mode": rates or None,
+                      "value_is": "sweeps/s with every sweep's uniforms generated inside the timed region (the caller's MT19937 "
+                                  "continued on the device, bgmm_stage_mt19937) and, for pCRP workloads, its permutation drawn on "
+                                  "the host and uploaded -- SURVEY 8(d)'s t_sweep",
+                      "timed_region_s": round(elapsed, 3),
+                      "sweeps_per_s_per_250_sweeps": {"min": min(chunk_rates), "max": max(chunk_rates),
+                                                      "median": sorted(chunk_rates)[len(chunk_rates) // 2]} if chunk_rates else None,
+                      "resident_inputs_sweeps_per_s": round(resident_rate, 2) if resident_rate else None,
+                      "h2d_of_8_sweeps_of_inputs_s": round(t_h2d, 4),
+                      "host_uniforms_uploaded_per_sweep_sweeps_per_s": round(
+                          1.0 / (1.0 / resident_rate + t_h2d / n_res), 2) if resident_rate else None,
+                      "sweeps_per_s_by_mode_resident_inputs": rates or None,
                       "roofline_other_modes": extra_rooflines or None,
                       "label_gather_s": round(t_gather, 4),
                       "label_gather_c_abi_s": round(t_gather_abi, 4),
