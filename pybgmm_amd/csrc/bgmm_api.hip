@@ -111,12 +111,12 @@ struct bgmm_ctx {
 // kernel chain: a window costs ~60 us plus ~1.5 us per mover and covers 64 visits, the chain ~190 us per mover.
 constexpr double kGramRun = 192.0;
 // Safe-stay windows (kernels_safe.hip) cover the regime in between: from one mover in kSafeRun visits up to one in
-// sixteen.  A safe-stay window costs about three plain ones (the proof pass in front of it) and walks the visits it could
-// not prove -- two to six per mover where clusters overlap -- so beyond that rate, or once a batch of them has walked
-// more than every fourth visit, plain frozen-factor windows are cheaper (measured at C4's shape: 1.6 % movers 1.2 s per
-// sweep against 3.0 s; 11.6 % movers 5.6 s against 3.0 s).
+// four.  A safe-stay window costs three to four plain ones (the proof pass in front of it) and walks the visits it
+// could not prove -- one per mover where clusters are apart, two to seven where they overlap -- so what decides is the
+// share of visits it has to walk, measured batch by batch: above a quarter the rest of the sweep goes to plain
+// frozen-factor windows (C4's shape: 1.6 % movers 1.2 s per sweep against 3.0 s; 11.6 % movers 5.6 s against 3.0 s).
 constexpr double kSafeRun = 65536.0;
-constexpr double kSafeDenseRate = 0.0625;
+constexpr double kSafeDenseRate = 0.25;
 constexpr double kSafeWalkShare = 0.25;
 
 #define CK(ctx, call)                                                                       \
@@ -302,7 +302,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.ftab, (size_t)d.nslots * 64);
         DALLOC(c, d.finv, (size_t)d.nslots);
     }
-    DALLOC(c, d.glist, (size_t)kGramRows);
+    DALLOC(c, d.glist, (size_t)kSafeList + 1);
+    DALLOC(c, d.ep_state, ns);
     DALLOC(c, d.rtab, ns * 8);
     DALLOC(c, d.ftabR, ns * 64);
     d.safe_mode = 0; d.safe_cap = 0.0;
@@ -774,7 +775,12 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             const bool safe_ok = c->resolver_mode != 3 && c->resolver_mode != 5 && c->kind == KERNEL_MFMA &&
                                  c->prune_mode != 1 && !safe_skip;
             const bool very_dense = recent_rate > kSafeDenseRate || hc.ema_run < 1.0 / kSafeDenseRate;
-            const bool moderate = hc.ema_run < kSafeRun || recent_rate * kSafeRun > 1.0;
+            // (a stretch of kSafeRun visits without a mover behind us: the chain has come to rest -- the pruned windows take
+            // over, whose first pass also leaves the per-point caches the certificates of the next sweep are made from)
+            // -- and so do they after a sweep in which nothing moved (the control block on the host still carries that
+            // sweep's running mean: sweep_begin resets it on the device)
+            const bool quiet = (double)(pos - hc.last_mover) > kSafeRun || (first_batch && c->moves_prev == 0);
+            const bool moderate = (hc.ema_run < kSafeRun || recent_rate * kSafeRun > 1.0) && !quiet;
             const bool want_safe = c->resolver_mode == 4 || (safe_ok && moderate && !very_dense);
             if (want_safe && !safe_skip) use_safe = ensure_gram(c, hc.job.K);
             const bool dense = c->resolver_mode == 3 || hc.ema_run < kGramRun || recent_rate * kGramRun > 1.0;
@@ -789,6 +795,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             long long Tg = (long long)std::ceil((double)remaining / vpw) + 1;
             if (first_batch && Tg > 8) Tg = 8;
             if (Tg > 256) Tg = 256;
+            if (recent_rate == 0.0 && Tg > 4) Tg = 4;         // (nothing has moved lately: look again soon, the chain may be at rest)
             if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
             d.safe_mode = 1; d.lean_step = 0; d.publish = 0; d.prune_enabled = 2; d.use_certify = 0; d.use_home = 1;
             d.safe_cap = c->safe_cap_user;

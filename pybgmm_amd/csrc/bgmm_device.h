@@ -54,6 +54,7 @@ static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a windo
 // safe-stay windows: how far a column's count may drift from its frozen value inside one window (the bounds of
 // the proof pass hold for every count in that range)
 static constexpr int kSafeDn = 16;
+static constexpr int kSafeList = 4096;   // unproven visits a proof pass lists (a stretch ends at the next one)
 static constexpr int kSafeSmall = 8;     // labels with fewer members prove nothing for them (their bounds: kernels_safe.hip)
 
 // Per-slot scalar constants.  (Diagonal covariance uses A = D*(lgamma terms) - 0.5 log prod var,
@@ -133,7 +134,13 @@ struct Ctrl {
     unsigned long long n_pairs_exact;   // (visit, component) pairs whose quadratic form was executed this sweep
     long long gram_rows_total, gram_windows;   // rows consumed by / number of frozen-factor windows this sweep
     // safe-stay windows (kernels_safe.hip): frozen-factor windows over the visits that cannot be PROVEN to stay
-    int gl_n;              // rows on the list of the open window (<= kGramRows)
+    int gl_n;              // rows of the open window (<= kGramRows): glist[gl_off .. gl_off + gl_n)
+    int gl_off, gl_total;  // first listed visit not yet walked / listed visits of the stretch (<= kSafeList)
+    int safe_epoch_valid;  // the stretch's proofs still stand: no proof pass in front of the next window.  They lapse when a
+                           // component leaves its budget (cumulative over the stretch's windows: Dev::ep_state), drifts too far
+                           // from the count it had at the proof pass, or is opened; at the end of the stretch; with a new sweep
+    int safe_epoch_pad;
+    long long gl_stretch_end, safe_epoch_pos0;   // the stretch the proof pass vouched for ends here / began here
     int safe_L;            // visits the next proof pass looks at (adapts to the density of unproven visits)
     long long gl_end;      // the window reaches up to (not including) this visit: everything before it that is not listed stays
     double safe_cap;       // the budget per component and window; follows the chain (gram_resolve_kernel) unless Dev::safe_cap pins it
@@ -184,6 +191,13 @@ struct PCache {
 struct PCacheExact {
     long long epoch;
     double log_alt;
+};
+
+// Safe-stay windows: what a component has used of its budget since the last proof pass, and the counts between which
+// that pass's proofs hold (kernels_safe.hip); per slot in global memory between windows, per column in LDS inside one.
+struct SafeCol {
+    float w;               // sum of |log |D_t|| (rounded up)
+    short lo, hi;          // members it may still lose / gain (32767: no limit)
 };
 
 struct Dev {
@@ -274,7 +288,8 @@ struct Dev {
                                  // frozen-factor kernels take their rows from glist)
     double safe_cap;             // > 0: pins the budget per column and window (sum of |log |D_t|| over the rank-1 terms it
                                  // takes); 0: Ctrl::safe_cap, which follows the chain
-    long long *glist;            // [kGramRows] visit positions of the window's rows, ascending
+    long long *glist;            // [kSafeList + 1] visit positions of the stretch's unproven visits, ascending
+    struct SafeCol *ep_state;    // [nslots] per SLOT, since the proof pass: budget used, the counts the proofs allow
     double *rtab;                // [nslots][8] per label of the frozen state: robust constants (kernels_safe.hip)
     double *ftabR;               // [nslots][64] per home label: robust upper bound of every other label's score
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of

@@ -40,6 +40,18 @@ typedef LDS_AS int *lds_i32;
 
 static constexpr int GR = kGramRows;
 
+__device__ __forceinline__ long long safecol_pack(const SafeCol &e) {
+    return (long long)(((unsigned long long)__float_as_uint(e.w)) | ((unsigned long long)(unsigned short)e.lo << 32) |
+                       ((unsigned long long)(unsigned short)e.hi << 48));
+}
+__device__ __forceinline__ SafeCol safecol_unpack(long long v) {
+    SafeCol e;
+    e.w = __uint_as_float((unsigned)((unsigned long long)v & 0xffffffffull));
+    e.lo = (short)(((unsigned long long)v >> 32) & 0xffffull);
+    e.hi = (short)(((unsigned long long)v >> 48) & 0xffffull);
+    return e;
+}
+
 // The window's rows: the next GR visits, or -- safe-stay windows (kernels_safe.hip) -- the listed ones: the visits of
 // [job.pos, gl_end) that the proof pass could not prove to stay; every visit in between stays whatever the listed ones do.
 __device__ __forceinline__ int gram_nrows(const Dev &d, const Ctrl *c) {
@@ -48,7 +60,7 @@ __device__ __forceinline__ int gram_nrows(const Dev &d, const Ctrl *c) {
     return left < GR ? (int)left : GR;
 }
 __device__ __forceinline__ long long gram_pos(const Dev &d, long long pos0, int row) {
-    return d.safe_mode ? d.glist[row] : pos0 + row;
+    return d.safe_mode ? d.glist[d.ctrl->gl_off + row] : pos0 + row;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,7 +265,7 @@ struct GramPlan {
     static constexpr unsigned oRowM = oWv + T * GR * 8;           // rowM[64]
     static constexpr unsigned oInvD = oRowM + GR * 8;             // termInvD[T]
     static constexpr unsigned oRcf = oInvD + T * 8;               // colRCF[KC]
-    static constexpr unsigned oColW = oRcf + KC * 8;              // colW[KC]: sum of |log |D_t|| over the column's terms (its budget)
+    static constexpr unsigned oColW = oRcf + KC * 8;              // colE[KC] (SafeCol): budget used since the proof pass, counts allowed
     static constexpr unsigned oMvI = oColW + KC * 8;              // move log: data index [64]
     static constexpr unsigned oRowHome = oMvI + GR * 8;           // [64]
     static constexpr unsigned oRowHcol = oRowHome + GR * 4;       // [64]
@@ -312,7 +324,8 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     LDS_AS unsigned char *const lb = (LDS_AS unsigned char *)lds_raw;
     LDS_AS GramShared &S = *(LDS_AS GramShared *)lb;
     const lds_f64 etT = (lds_f64)(lb + P::oEt), wvv = (lds_f64)(lb + P::oWv), rowM = (lds_f64)(lb + P::oRowM),
-                  termInvD = (lds_f64)(lb + P::oInvD), colRCF = (lds_f64)(lb + P::oRcf), colW = (lds_f64)(lb + P::oColW);
+                  termInvD = (lds_f64)(lb + P::oInvD), colRCF = (lds_f64)(lb + P::oRcf);
+    const lds_i64 colE = (lds_i64)(lb + P::oColW);             // SafeCol, packed (safecol_pack / safecol_unpack)
     const lds_i64 mvI = (lds_i64)(lb + P::oMvI);
     const lds_i32 rowhome = (lds_i32)(lb + P::oRowHome), rowhcol = (lds_i32)(lb + P::oRowHcol),
                   mvSub = (lds_i32)(lb + P::oMv), mvAdd = mvSub + GR, mvInit = mvAdd + GR,
@@ -380,7 +393,11 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         colLast[j] = -1;
         colBase[j] = j <= K0 ? j : K0;
         colRCF[j] = 1.0;
-        colW[j] = 0.0;
+        {
+            SafeCol e; e.w = 0.0f; e.lo = 0; e.hi = 0;                      // (a column opened inside the window: no allowance)
+            if (d.safe_mode && j < K0 && s >= 0) e = d.ep_state[s];
+            colE[j] = safecol_pack(e);
+        }
         if (j < K0) {
             const int n = d.n[s];
             colSlot[j] = s;
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                                 const int t = permL[Kn];
                                 dcol = nc++;
                                 colSlot[dcol] = t; colN[dcol] = 0; colBase[dcol] = cprior;
-                                colN0[dcol] = 0; colRCF[dcol] = 1.0; colW[dcol] = 0.0;
+                                colN0[dcol] = 0; colRCF[dcol] = 1.0; colE[dcol] = 0ll;
                                 colLast[dcol] = -1;
                                 colLab[dcol] = Kn; labCol[Kn] = dcol;
                                 d.label_of_slot[t] = Kn;
@@ -776,17 +793,16 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     // the budget (kernels_safe.hip): |log c_t(y, y) - log c_0(y, y)| <= sum |log |D_i||  for every y.
                     // A column that leaves its budget (or drifts kSafeDn members from its frozen count) ends the window
                     // right behind this move -- and so does a component OPENED by it: the proofs are about the frozen labels.
-                    const double dn_tab = cl < K0 ? d.rtab[(long long)cl * 8 + 7] : 0.0;
-                    const bool small_col = dn_tab < 0.0;                         // (a small label: what leaves it is free)
+                    SafeCol e = safecol_unpack(colE[cl]);
+                    const bool small_col = e.lo == 32767;                        // (a small label: what leaves it is free)
                     const double wterm = fabs(log(fabs(Dt)));
-                    const double wsum = colW[cl] + ((small_col && sg < 0) ? 0.0 : wterm);
-                    colW[cl] = wsum;
+                    if (!(small_col && sg < 0)) e.w = (float)((double)e.w + wterm) * 1.000001f;     // (rounded up)
+                    colE[cl] = safecol_pack(e);
                     S.wsum2[wave - 1] += wterm;                                  // (waves 1 and 2 each keep their own)
                     S.wterms2[wave - 1] += 1;
                     const int dn = n_new - colN0[cl];
-                    const int dn_cap = (int)fabs(dn_tab);
-                    if (wsum > S.cap) S.cut = 1;                                 // (out of budget: the budget follows, below)
-                    else if (cl >= K0 || dn > dn_cap || (!small_col && dn < -dn_cap)) S.cut = 2;
+                    if ((double)e.w > S.cap) S.cut = 1;                          // (out of budget: the budget follows, below)
+                    else if (cl >= K0 || dn > (int)e.hi || -dn > (int)e.lo) S.cut = 2;
                 }
             }
             if (wave == 1 && r + 1 < nrows) {
@@ -823,8 +839,8 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     // the proof pass vouched for.
     long long next_pos = pos0 + consumed;
     if (d.safe_mode) {
-        if (S.event == GEV_MOVE) next_pos = d.glist[S.cur] + 1;
-        else if (S.event == GEV_CUT) next_pos = d.glist[S.cur];
+        if (S.event == GEV_MOVE) next_pos = d.glist[c->gl_off + S.cur] + 1;
+        else if (S.event == GEV_CUT) next_pos = d.glist[c->gl_off + S.cur];
         else next_pos = c->gl_end;
     }
     for (int k = tid; k < S.nmoves; k += GRT) {
@@ -839,6 +855,14 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         const int s = colSlot[cl], n = colN[cl];
         d.n[s] = n;
         if (n > 0) d.gtouched[atomicAdd(&c->gram_ntouched, 1)] = s;
+        if (d.safe_mode) {
+            // what the label has used of its budget, and what it may still lose / gain, for the stretch's next window
+            SafeCol e = safecol_unpack(colE[cl]);
+            const int dn = n - colN0[cl];
+            if (e.lo != 32767) e.lo = (short)((int)e.lo + dn);
+            if (e.hi != 32767) e.hi = (short)((int)e.hi - dn);
+            d.ep_state[s] = e;
+        }
     }
     if (tid == 0) {
         const Job &j = c->job;
@@ -882,18 +906,27 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     c->safe_adv_sum = 0.0; c->safe_phase_cnt = 0;
                 }
                 if (c->safe_wbar > 0.0) {
+                    // (what a budget costs the proofs: the home's bound gives way by about D / 2 (e^cap - 1) nats -- kept below 30)
+                    const double cap_max = log1p(60.0 / (double)d.D);
                     double cap = c->safe_mult * c->safe_wbar;
-                    cap = cap < 1.0 / 1024.0 ? 1.0 / 1024.0 : (cap > 4.0 ? 4.0 : cap);
+                    cap = cap < 1.0 / 1024.0 ? 1.0 / 1024.0 : (cap > cap_max ? cap_max : cap);
                     // (quantised to a twelfth of an octave: the robust tables are rebuilt only when the budget really moves)
                     c->safe_cap = exp2(rint(log2(cap) * 12.0) / 12.0);
                 }
             }
-            // (the proof pass sized the next stretch from the density of unproven visits it saw; a window the budget ended
-            // early wastes what was examined behind the cut: no further than eight times what this one covered)
-            long long L = c->safe_L;
-            if (S.cut && L > 8 * adv + 64) L = 8 * adv + 64;
-            if (L < 256) L = 256;
-            c->safe_L = (int)L;
+            // the stretch's proofs: they stand while every label stays inside its budget and allowance and no label is opened;
+            // the next stretch is sized by what this one got through (twice that: half of a proof pass wasted at worst)
+            c->gl_off += consumed;
+            if (S.cut != 0 || next_pos >= c->gl_stretch_end || S.err < 0) {
+                c->safe_epoch_valid = 0;
+                long long L = next_pos >= c->gl_stretch_end && S.cut == 0 ? 2ll * (c->gl_stretch_end - c->safe_epoch_pos0)
+                                                                          : 2ll * (next_pos - c->safe_epoch_pos0) + 64;
+                if (L < 1024) L = 1024;
+                if (L > (1ll << 22)) L = 1ll << 22;
+                c->safe_L = (int)L;
+            } else {
+                safe_next_window(d, c);
+            }
         }
         c->ema_run = S.ema_run;
         c->last_mover = S.last_mover;
@@ -912,7 +945,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         } else {
             c->win_size = (int)window_for_rate(c);
             start_window(d, c, next_pos);
-            if (d.safe_mode) safe_open_window(d, c);
+            if (d.safe_mode && !c->safe_epoch_valid) safe_open_window(d, c);
         }
     }
 }

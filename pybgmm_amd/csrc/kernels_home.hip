@@ -107,7 +107,7 @@ template <int NJ, bool WHOLE>
 __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune)) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || (d.safe_mode && c->safe_epoch_valid)) return;
     constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, NJ8 = NJ * 2;
     constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS

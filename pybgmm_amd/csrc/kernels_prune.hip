@@ -677,7 +677,7 @@ template <int NJ, int RB, int MINW, bool WALK>
 __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, const Job *__restrict__ jobp,
                                                                   double *__restrict__ q, long long qstride) {
     const JobView job = load_job(jobp);
-    if (!job_is_pruned(d, job.mode, job.prune)) return;
+    if (!job_is_pruned(d, job.mode, job.prune) || (d.safe_mode && d.ctrl->safe_epoch_valid)) return;
     if constexpr (!WALK) {
         prune_tile<NJ, RB>(d, job, q, blockIdx.x);
     } else {

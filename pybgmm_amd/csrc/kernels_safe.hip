@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode == MODE_DONE) return;
     for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;      // (the bucket sort counts from zero)
-    if (threadIdx.x == 0) safe_open_window(d, c);
+    if (threadIdx.x == 0) { c->safe_epoch_valid = 0; safe_open_window(d, c); }
 }
 
 // Robust per-label constants (rtab[label][8]) for the frozen state:
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
 // row nslots - 1: 0 e^-cap, 1 e^cap
 __global__ __launch_bounds__(64) void safe_rtab_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
-    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
     const int K = c->job.K;
     const double Dd = (double)d.D, cap = safe_cap_now(d, c);
@@ -133,7 +133,7 @@ __device__ __forceinline__ double exp_above(double x) {
 __global__ __launch_bounds__(64) void safe_ftab_kernel(Dev d) {
     extern __shared__ double lt[];                        // [K][4]: ub0, hv_min, e^-cap / Lambda, e^-cap / k_N0
     const Ctrl *c = d.ctrl;
-    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
     const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
     if (a >= K) return;
@@ -169,13 +169,14 @@ __global__ __launch_bounds__(64) void safe_ftab_kernel(Dev d) {
     d.ftabR[(long long)a * 64 + j] = (K > 1 && finv > 0.0) ? f : (K > 1 ? INFINITY : -INFINITY);
 }
 
-// The first kGramRows visits of the stretch [win_base, win_hi) that the proof pass did not mark SAFE, in visiting
-// order (cert[row] == 1: SAFE), and where the stretch they vouch for ends: at the (kGramRows + 1)-th such visit, or at
-// win_hi.  One workgroup: every thread counts a contiguous run, one scan, the threads in front of the cut emit.
+// The visits of the stretch [win_base, win_hi) that the proof pass did not mark SAFE (cert[row] == 1: SAFE), in
+// visiting order -- at most kSafeList of them: the stretch ends at the next one -- and the start of an epoch: every
+// label's budget account opened (Dev::ep_state), the first window's rows set.  One workgroup: every thread counts a
+// contiguous run, one scan, the threads in front of the cut emit.
 __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
     __shared__ int wsum[16];
     Ctrl *c = d.ctrl;
-    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int per = ((nrows + 1023) / 1024 + 15) & ~15;             // (16-byte pieces)
@@ -199,31 +200,42 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
     for (int k = 0; k < w; ++k) off += wsum[k];
     int rank = off + incl - cnt;                                    // unproven visits in front of this thread's run
     for (int b = threadIdx.x; b < d.nslots + 2; b += 1024) d.bucket_bins[b] = 0;      // (left at zero for the next sort)
+    // every label's account for this stretch: nothing used, the counts the robust tables were built for
+    const int K = c->job.K;
+    for (int a = threadIdx.x; a < K; a += 1024) {
+        const double dn_tab = d.rtab[(long long)a * 8 + 7];
+        SafeCol e;
+        e.w = 0.0f;
+        e.hi = (short)(int)fabs(dn_tab);
+        e.lo = dn_tab < 0.0 ? (short)32767 : e.hi;
+        d.ep_state[d.perm[a]] = e;
+    }
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wsum[k];
     if (threadIdx.x == 0) {
-        int total = 0;
-        for (int k = 0; k < 16; ++k) total += wsum[k];
-        c->gl_n = total < kGramRows ? total : kGramRows;
-        if (total <= kGramRows) c->gl_end = base + nrows;
+        c->gl_total = total < kSafeList ? total : kSafeList;
+        if (total <= kSafeList) c->gl_stretch_end = base + nrows;
+        c->gl_off = 0;
+        c->safe_epoch_pos0 = base;
         c->safe_scanned += nrows;
-        // the next proof pass: as far as it takes to find kGramRows unproven visits (and a few to spare) at the density
-        // seen here; the resolver shortens it again if the budget keeps ending windows early
-        long long L = total > 0 ? (long long)nrows * (kGramRows + 16) / total : 2ll * nrows;
-        if (L > 4ll * nrows) L = 4ll * nrows;
-        if (L < 256) L = 256;
-        if (L > (1ll << 22)) L = 1ll << 22;
-        c->safe_L = (int)L;
         c->n_resid = 0;                 // (the residual list of this proof pass has been worked through)
         c->tables_valid = 1;
         c->safe_epoch_built = c->state_epoch;
         c->safe_cap_built = safe_cap_now(d, c);
     }
-    if (cnt > 0 && rank <= kGramRows) {
-        for (int r = lo; r < hi && rank <= kGramRows; ++r) {
+    if (cnt > 0 && rank <= kSafeList) {
+        for (int r = lo; r < hi && rank <= kSafeList; ++r) {
             if (d.cert[r]) continue;
-            if (rank < kGramRows) d.glist[rank] = base + r;
-            else c->gl_end = base + r;                                // the first visit the list has no room for
+            if (rank < kSafeList) d.glist[rank] = base + r;
+            else c->gl_stretch_end = base + r;                        // the first visit the list has no room for
             ++rank;
         }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c->safe_epoch_valid = 1;
+        safe_next_window(d, c);
     }
 }
 
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
 // the home from below, the excluded labels below e^-80 of max(home, new table) each.
 __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
     Ctrl *c = d.ctrl;
-    if (c->error != 0 || c->job.mode != MODE_FRESH) return;
+    if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long nrows = c->n_resid;
     const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int part = threadIdx.x & 3;

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         c->n_resid = 0; c->home_in = 0; c->home_out = 0;
         c->n_pairs_exact = 0; c->gram_rows_total = 0; c->gram_windows = 0; c->gram_ntouched = 0; c->gram_nmoves = 0;
         c->safe_windows = 0; c->safe_scanned = 0; c->safe_rows = 0; c->safe_cuts = 0;
+        c->safe_epoch_valid = 0;        // (new uniforms, maybe a new visiting order: the proofs were about the old ones)
         if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)
         c->last_mover = -1;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     extern __shared__ int bins[];
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort || (d.safe_mode && c->safe_epoch_valid)) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
 // the rest: one label a each, its centre-to-centre distances.
 __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid || (d.safe_mode && c->safe_epoch_valid)) return;
     const int n_tab_blocks = ((d.nslots + 15) / 16 + 15) / 16;
     if ((int)blockIdx.x >= n_tab_blocks) {
         __shared__ double mua[BGMM_MAX_D];
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
 // in j.  Runs after prune_tables_kernel (same validity flag, set by apply_kernel afterwards).
 __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid || (d.safe_mode && c->safe_epoch_valid)) return;
     const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
     if (a >= K) return;
     const double *__restrict__ dc = d.pr_dcc + (long long)a * d.nslots;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
 __global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
     __shared__ int wsum_[16];
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort || (d.safe_mode && c->safe_epoch_valid)) return;
     const int nb = d.nslots + 1;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     extern __shared__ int lds[];                  // [nb] local counts, then [nb] reserved bases
     const Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort || (d.safe_mode && c->safe_epoch_valid)) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;

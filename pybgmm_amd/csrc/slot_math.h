@@ -362,6 +362,14 @@ __device__ inline void safe_open_window(const Dev &d, Ctrl *c) {
     set_chunks(d, j);
 }
 
+// The next window of a stretch whose proofs stand: the next kGramRows listed visits.
+__device__ inline void safe_next_window(const Dev &d, Ctrl *c) {
+    const int off = c->gl_off, total = c->gl_total;
+    const int n = total - off < kGramRows ? total - off : kGramRows;
+    c->gl_n = n > 0 ? n : 0;
+    c->gl_end = off + kGramRows < total ? d.glist[off + kGramRows] : c->gl_stretch_end;
+}
+
 // Running mean distance between movers.  A run far below the mean (the chain has just been
 // disturbed: the mean still remembers the quiet stretch before) pulls it down fast -- every mover
 // that arrives while the windows are still sized for the old mean throws a whole window away.

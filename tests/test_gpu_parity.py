@@ -539,7 +539,7 @@ def test_burnin_against_c_oracle(N, D, K, sep):
 
 @pytest.mark.parametrize("N,D,K,sep,flip,budget", [(100000, 16, 100, 1.0, 0, 0.0), (100000, 16, 100, 1.0, 0, 1.0),
                                                    (100000, 64, 60, 0.5, 0, 0.0), (100000, 64, 40, 4.0, 200, 0.0),
-                                                   (30000, 128, 20, 0.5, 0, 0.0)],
+                                                   (16000, 128, 20, 0.28, 0, 0.0)],
                          ids=["D16-5pct-movers", "D16-5pct-movers-budget-1.0", "D64-0.6pct-movers", "D64-200-wrong-labels",
                               "D128-overlapping"])
 def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
@@ -561,10 +561,11 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
     ctx.set_safe_budget(budget)
     ctx.set_assignments(z0)
     o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
-    windows = walked = 0
+    windows = walked = moved = 0
     for it in range(3):
         u = rs.random_sample(N)
         ctx.sweep(u)
+        moved += ctx.sweep_stats()["moves"]
         o.sweep(u)
         z = ctx.assignments()
         bad = np.nonzero(z != o.z)[0]
@@ -574,6 +575,7 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
         ss = ctx.safe_stats()
         windows += ss["windows"]
         walked += ss["unproven_walked"]
+    assert moved >= 50, "the case is meant to have movers"
     assert windows > 0, "the safe-stay windows never ran"
     assert walked < 0.6 * 3 * N, "the proof pass proved next to nothing"
     ctx.close()
@@ -1065,6 +1067,37 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
         npt.assert_array_equal(ctx.staged_uniforms(), expect)
         assert dev.getstate() == host.getstate()
         ctx.sweep_staged(None)
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,burn", [(70000, 0), (200000, 311), (1000003, 1247)])
+def test_device_mt19937_jump_ahead_across_chains(N, burn):
+    """Requests longer than one chain of 64 blocks (39 936 words) run as chains side by side from jumped-ahead states
+    (kernels_rng.hip): 4, 11 and 51 chains here, from an even and an odd position, against random.random() -- and against
+    the same chains run one after the other (bgmm_set_mt_jump(0))."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(2)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12)
+    ctx.set_assignments(zt)
+    for jump in (1, 0):
+        ctx.set_mt_jump(jump)
+        host, dev = random.Random(N), random.Random(N)
+        for _ in range(burn):
+            host.getrandbits(32); dev.getrandbits(32)
+        for it in range(2):
+            rs = np.random.RandomState()
+            version, key, gauss = host.getstate()
+            rs.set_state(("MT19937", np.asarray(key[:-1], dtype=np.uint32), int(key[-1])))
+            expect = rs.random_sample(N)                       # (the same stream at C speed: utils/rng.py)
+            _, new_key, pos = rs.get_state()[:3]
+            host.setstate((version, tuple(int(v) for v in new_key) + (int(pos),), gauss))
+            assert _rng.stage_uniforms_on_device(ctx, None, dev)
+            npt.assert_array_equal(ctx.staged_uniforms(), expect)
+            assert dev.getstate() == host.getstate()
+    assert host.random() == dev.random()
     ctx.close()
 
 

@@ -195,3 +195,41 @@ def test_wishart_draws_consume_the_streams_like_the_reference():
     np.random.seed(6)
     wishart.iwishrnd(sigma, v0, C)
     assert (random.random(), np.random.random_sample()) == after
+
+
+def test_mt19937_jump_polynomials_against_numpy():
+    """bgmm_mt19937_jump_poly: t^(chain * 39936) modulo the characteristic polynomial of MT19937 (Berlekamp-Massey +
+    shift / multiply-and-reduce on the host, no device).  The state J words ahead must be the GF(2) convolution of the
+    next 19937 + 623 words with the coefficient bits -- checked against numpy's generator for two chains."""
+    from pybgmm_amd import _lib
+    rs = np.random.RandomState(2014)
+    key = rs.get_state()[1].astype(np.uint32)
+    n_blocks = 64 * 2 + 34
+
+    def blocks(mt, nb):          # untempered words: the recurrence, vectorised in its three independent runs
+        out = [mt.copy()]
+        for _ in range(nb):
+            new = mt.copy()
+            for lo, hi in ((0, 227), (227, 454), (454, 623)):
+                k = np.arange(lo, hi)
+                y = (new[k] & np.uint32(0x80000000)) | (new[k + 1] & np.uint32(0x7fffffff))
+                new[k] = new[(k + 397) % 624] ^ (y >> np.uint32(1)) ^ np.where(y & np.uint32(1), np.uint32(0x9908b0df), np.uint32(0))
+            y = (new[623] & np.uint32(0x80000000)) | (new[0] & np.uint32(0x7fffffff))
+            new[623] = new[396] ^ (y >> np.uint32(1)) ^ (np.uint32(0x9908b0df) if (y & np.uint32(1)) else np.uint32(0))
+            mt = new
+            out.append(mt.copy())
+        return np.concatenate(out)
+
+    x = blocks(key, n_blocks)
+    # (sanity of the restated recurrence: numpy's own next block, tempered, is what random_sample consumes)
+    for chain in (1, 2):
+        g = _lib.mt19937_jump_poly(chain)
+        bits = np.unpackbits(g.view(np.uint8), bitorder="little")
+        assert not bits[19937:].any()
+        idx = np.nonzero(bits[:19937])[0]
+        J = chain * 64 * 624
+        acc = np.zeros(624, dtype=np.uint32)
+        for i in idx:
+            acc ^= x[i:i + 624]
+        np.testing.assert_array_equal(acc[1:], x[J + 1:J + 624])
+        assert ((acc[0] ^ x[J]) >> np.uint32(31)) == 0

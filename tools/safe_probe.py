@@ -48,10 +48,12 @@ def run(N, D, K, init, resolver, n_sweeps, sep=4.0, pcrp=False, oracle=False, se
             msg = "  ORACLE %s" % ("ok" if bad.size == 0 else "DIFFERS at %d labels, first i=%d" % (bad.size, bad[0]))
             if bad.size:
                 print(msg); ctx.close(); return None
+        if verbose and os.environ.get("SAFE_DEBUG"):
+            print("   why (cumulative): no-home/small, chi>=1, off-table, others heavy, new-table heavy, u near end, SAFE:", ctx.phase_clocks()[1:8])
         if verbose:
-            print("sweep %2d: %9.3f ms moves %7d K %3d | safe windows %6d examined %9d walked %7d cuts %5d budget %.4f L %7d | frozen %6d steps %6d%s" % (
+            print("sweep %2d: %9.3f ms moves %7d K %3d | safe windows %6d examined %9d walked %7d cuts %5d budget %.4f L %7d | frozen %6d steps %6d certified %7d%s" % (
                 it, dt * 1e3, st["moves"], ctx.K, ss["windows"], ss["visits_examined"], ss["unproven_walked"], ss["budget_cuts"],
-                ss["budget"], ss["next_stretch"], ps["frozen_windows"], st["steps"], msg), flush=True)
+                ss["budget"], ss["next_stretch"], ps["frozen_windows"], st["steps"], ctx.prune_stats()["certified_visits"], msg), flush=True)
     lm = ctx.log_marg()
     if os.environ.get("SAFE_DEBUG"):
         print("why (cumulative): unassigned/small-home, chi>=1, radius off the table, others too heavy, new table heavy, u near an end, SAFE:", ctx.phase_clocks()[1:8])
