@@ -159,6 +159,21 @@ BGMM_API int bgmm_set_stats(bgmm_ctx *ctx, int32_t k, const double *m, const dou
 /* `components.assignments[i] = k` (igmm/crpmm.py:85): the label of point i alone, no statistics touched
  * (k = -1: unassigned).  With bgmm_set_stats it completes the reference's cache / del_item / restore idiom. */
 BGMM_API int bgmm_set_label(bgmm_ctx *ctx, int64_t i, int32_t k);
+/* The raw sufficient statistics of component k as the library keeps them -- what bgmm_set_stats takes back bit for bit
+ * (checkpoint / resume): m[D] and S: D x D (full), D (diag), or for fixed-variance components
+ * [precision_N[D] ; sum of x^2[D]] (the reference's class keeps no second moment: gaussian_components_fixedvar.py:75-90;
+ * this library's log marginal needs it, so bgmm_set_stats takes 2 D values there). */
+BGMM_API int bgmm_get_raw_stats(bgmm_ctx *ctx, int32_t k, double *m_out, double *S_out);
+/* GaussianComponents.del_component(k) (gaussian_components.py:188-205) as a call of its own: label k is deleted by the
+ * reference's swap with the last label.  The reference only ever calls it on a component that has just lost its last
+ * member (:179-181); called on a component that still has members it would leave them labelled k -- i.e. silently
+ * re-homed into what was the last component, whose statistics do not know them.  Here those members become unassigned
+ * (-1) instead, so that counts, statistics and labels stay consistent. */
+BGMM_API int bgmm_del_component(bgmm_ctx *ctx, int32_t k);
+/* The `n_visits` of SURVEY.md 8b's bgmm_sweep: the NEXT sweep call (bgmm_sweep, bgmm_sweep_staged, bgmm_sweep_resident)
+ * stops after the first n_visits visits of its order (0 or N: a whole sweep); later calls are whole sweeps again.  The
+ * staged uniforms / order are indexed by visit as always: a following call that should continue needs its own inputs. */
+BGMM_API int bgmm_set_sweep_visits(bgmm_ctx *ctx, int64_t n_visits);
 
 /*
  * Per-sweep clustering metrics of the record dict (gmm/gmm.py:85-104), SURVEY.md 8f rank 2.

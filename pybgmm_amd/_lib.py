@@ -50,6 +50,9 @@ SIGNATURES = {
     "bgmm_del_item": (ctypes.c_int, [_vp, ctypes.c_int64]),
     "bgmm_set_stats": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int64]),
     "bgmm_set_label": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32]),
+    "bgmm_get_raw_stats": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
+    "bgmm_del_component": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_set_sweep_visits": (ctypes.c_int, [_vp, ctypes.c_int64]),
     "bgmm_contingency": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, _vp]),
     "bgmm_cluster_dispersion": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_sweep_stats": (ctypes.c_int, [_vp, _vp]),
@@ -271,11 +274,26 @@ class Context(object):
     def del_item(self, i):
         self._ck(self.L.bgmm_del_item(self.h, int(i)))
 
+    def _raw_shape(self):
+        return {"full": (self.D, self.D), "diag": (self.D,), "fixed": (2 * self.D,)}[self.cov_type]
+
     def set_stats(self, k, m, S, count):
         m = np.ascontiguousarray(m, dtype=np.float64)
         S = np.ascontiguousarray(S, dtype=np.float64)
-        assert m.shape == (self.D,) and S.shape == ((self.D,) if self.diag else (self.D, self.D))
+        assert m.shape == (self.D,) and S.shape == self._raw_shape()
         self._ck(self.L.bgmm_set_stats(self.h, int(k), _ptr(m), _ptr(S), int(count)))
+
+    def raw_stats(self, k):
+        """(m[D], S) of component k exactly as stored: what ``set_stats`` takes back bit for bit."""
+        m, S = np.empty(self.D), np.empty(self._raw_shape())
+        self._ck(self.L.bgmm_get_raw_stats(self.h, int(k), _ptr(m), _ptr(S)))
+        return m, S
+
+    def del_component(self, k):
+        self._ck(self.L.bgmm_del_component(self.h, int(k)))
+
+    def set_sweep_visits(self, n_visits):
+        self._ck(self.L.bgmm_set_sweep_visits(self.h, int(n_visits)))
 
     def set_label(self, i, k):
         self._ck(self.L.bgmm_set_label(self.h, int(i), int(k)))

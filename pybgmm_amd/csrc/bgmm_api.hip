@@ -29,6 +29,8 @@ void launch_contingency(const Dev &d, const long long *true_idx, int K_true, uns
 void launch_dispersion(const Dev &d, double *out, hipStream_t st);
 void launch_set_stats(const Dev &d, int label, const double *m_in, const double *S_in, int count, hipStream_t st);
 void launch_set_label(const Dev &d, long long i, int label, hipStream_t st);
+void launch_raw_stats(const Dev &d, int label, double *m_out, double *S_out, hipStream_t st);
+void launch_del_component(const Dev &d, int label, hipStream_t st);
 void launch_init_labels(const Dev &d, const long long *z_in, int K_init, hipStream_t st);
 void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, double *logdet_out,
                          double *inv_out, hipStream_t st);
@@ -96,6 +98,7 @@ struct bgmm_ctx {
     bool gram_off = false;           // this context cannot use them (their buffers failed to allocate three times)
     int gram_alloc_fail = 0;
     bool tables_robust = false;      // the pruning tables on the device carry a safe-stay batch's robust constants
+    long long next_sweep_visits = 0; // bgmm_set_sweep_visits: the next sweep stops after this many visits (0: a whole sweep)
     int safe_rest = 0;               // sweeps to go without safe-stay windows: a batch of them covered fewer visits per
                                      // millisecond than the per-mover kernel chain is known to (they are tried again a sweep later)
     // safe-stay windows (kernels_safe.hip)
@@ -677,6 +680,9 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
     d.u = c->cur_u;
     d.order = c->cur_order;
+    d.sweep_visits = c->next_sweep_visits;
+    const bool partial = d.sweep_visits > 0 && d.sweep_visits < d.N;
+    c->next_sweep_visits = 0;
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
@@ -685,7 +691,8 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     // cold caches for hopeless data twice and was dropped)
     const bool use_certify = use_prune && c->prune_mode != 3;
     d.use_certify = use_certify ? 1 : 0;
-    bool lean = use_certify && c->lean_ok && c->prune_mode != 2;
+    // (a lean step looks at the whole sweep in storage order: not for a sweep that stops early)
+    bool lean = use_certify && c->lean_ok && c->prune_mode != 2 && !partial;
     hipStream_t st = c->stream;
     d.seat_dirty = 0;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
@@ -731,7 +738,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     // Lower bound on the steps still needed: one per remaining window.  On top of that,
     // one step per expected mover, estimated from the rate observed so far in this sweep
     // (first chunk: from the previous sweep).
-    const long long N = d.N;
+    const long long N = partial ? d.sweep_visits : d.N;
     long long pos = 0;
     int win = c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows;
     double rate = c->last_move_rate;
@@ -1000,7 +1007,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     else if (h.home_in > 0) c->home_pass = 2 * h.home_out < h.home_in;
     else if (!c->home_pass && (++c->home_retry & 63) == 0) c->home_pass = true;
     c->moves_prev = h.n_moves;
-    c->lean_ok = use_certify && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
+    c->lean_ok = use_certify && !partial && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
     return check_device_error(c);
 }
 
@@ -1197,13 +1204,12 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
 extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const double *S, int64_t count) {
     if (!c || !m || !S) return BGMM_EINVAL;
     CK(c, hipSetDevice(c->device));
-    if (c->d.cov_type == COV_FIXED) return fail(c, BGMM_EUNSUPPORTED, "bgmm_set_stats: not offered for fixed-variance components");
     int rc = fetch_ctrl(c);
     if (rc) return rc;
     if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
     if (count < 1 || count > c->d.N) return fail(c, BGMM_EINVAL, "count must be in 1 .. N");
     const int D = c->d.D;
-    const size_t DD = c->d.cov_type == COV_FULL ? (size_t)D * D : (size_t)D;
+    const size_t DD = c->d.cov_type == COV_FULL ? (size_t)D * D : (c->d.cov_type == COV_FIXED ? (size_t)2 * D : (size_t)D);
     double *dm = nullptr;
     CK(c, hipMalloc((void **)&dm, sizeof(double) * (D + DD)));
     hipError_t e = hipMemcpyAsync(dm, m, sizeof(double) * D, hipMemcpyHostToDevice, c->stream);
@@ -1225,6 +1231,46 @@ extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const dou
     c->moves_prev = -1;
     c->lean_ok = false;
     return rc;
+}
+
+extern "C" int bgmm_get_raw_stats(bgmm_ctx *c, int32_t k, double *m_out, double *S_out) {
+    if (!c || !m_out || !S_out) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
+    const int D = c->d.D;
+    const size_t DD = c->d.cov_type == COV_FULL ? (size_t)D * D : (c->d.cov_type == COV_FIXED ? (size_t)2 * D : (size_t)D);
+    double *dm = nullptr;
+    CK(c, hipMalloc((void **)&dm, sizeof(double) * (D + DD)));
+    launch_raw_stats(c->d, k, dm, dm + D, c->stream);
+    hipError_t e = hipMemcpyAsync(m_out, dm, sizeof(double) * D, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(S_out, dm + D, sizeof(double) * DD, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dm);
+    CK(c, e);
+    return 0;
+}
+
+extern "C" int bgmm_del_component(bgmm_ctx *c, int32_t k) {
+    if (!c) return BGMM_EINVAL;
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    if (k < 0 || k >= c->ctrl_host->job.K) return fail(c, BGMM_EINVAL, "component index out of range");
+    launch_del_component(c->d, k, c->stream);
+    CK(c, hipGetLastError());
+    CK(c, hipStreamSynchronize(c->stream));
+    c->moves_prev = -1;
+    c->lean_ok = false;
+    return 0;
+}
+
+extern "C" int bgmm_set_sweep_visits(bgmm_ctx *c, int64_t n_visits) {
+    if (!c) return BGMM_EINVAL;
+    if (n_visits < 0 || n_visits > c->d.N) return fail(c, BGMM_EINVAL, "n_visits must be in 0 .. N");
+    c->next_sweep_visits = n_visits;
+    return 0;
 }
 
 extern "C" int bgmm_set_label(bgmm_ctx *c, int64_t i, int32_t k) {

@@ -266,6 +266,7 @@ struct Dev {
     int use_home;                // 1: home_kernel runs in front of the pruning kernel, which then works on the residual list
     const double *u;
     const long long *order;      // may be null (identity)
+    long long sweep_visits;      // visits of the sweep being queued (0 or N: all of them; bgmm_set_sweep_visits)
     int use_power;
     double power;
     int batch_rows;              // rows the launches of this batch of steps are sized for: no window

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
     int K = c->job.K;
     if (K + 1 > cap) return;                           // the open window goes to the windowed kernels
     int K_hi = K < d.K_max ? K : K - 1;                // Lslot / Lver are valid for indices <= K_hi
-    const long long N = d.N;
+    const long long N = c->n_visits;                  // (d.N, or fewer: bgmm_set_sweep_visits)
     for (int j = tid; j <= K_hi; j += NT) {
         const int s = d.perm[j];
         Lslot[j] = s;

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         // started with -- the mover-free stretch inside one sweep cannot say more than N)
         if (c->n_visits > 0 && c->n_moves == 0 && c->ema_run < 4.0 * (double)c->win_cap)
             c->ema_run = 4.0 * (double)c->win_cap;
-        c->n_visits = d.N;
+        c->n_visits = d.sweep_visits > 0 && d.sweep_visits < d.N ? d.sweep_visits : d.N;
         c->first_mover = kNoMover;
         c->n_refresh = 0;
         c->skip_apply = 0;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(TPB) void set_stats_kernel(Dev d, int label, const 
                                                         const double *__restrict__ S_in, int count) {
     Ctrl *c = d.ctrl;
     const int s = d.perm[label], D = d.D;
-    const int DD = d.cov_type == COV_FULL ? D * D : D;
+    const int DD = d.cov_type == COV_FULL ? D * D : (d.cov_type == COV_FIXED ? 2 * D : D);
     for (int a = threadIdx.x; a < D; a += TPB) d.m[(long long)s * D + a] = m_in[a];
     for (int e = threadIdx.x; e < DD; e += TPB) d.S[(long long)s * DD + e] = S_in[e];
     if (threadIdx.x == 0) {
@@ -890,6 +890,38 @@ __global__ __launch_bounds__(TPB) void set_stats_kernel(Dev d, int label, const 
         c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1;
         c->n_refresh = 1; c->refresh[0] = s; c->refresh_kind[0] = REFRESH_SCRATCH;
     }
+}
+
+// The raw statistics blocks of one label, as they sit in HBM (m[D]; S: D x D, D, or -- fixed variance -- [precision_N, sum x^2])
+__global__ __launch_bounds__(TPB) void raw_stats_kernel(Dev d, int label, double *__restrict__ m_out, double *__restrict__ S_out) {
+    const int s = d.perm[label], D = d.D;
+    const int DD = d.cov_type == COV_FULL ? D * D : (d.cov_type == COV_FIXED ? 2 * D : D);
+    for (int a = threadIdx.x; a < D; a += TPB) m_out[a] = d.m[(long long)s * D + a];
+    for (int e = threadIdx.x; e < DD; e += TPB) S_out[e] = d.S[(long long)s * DD + e];
+}
+void launch_raw_stats(const Dev &d, int label, double *m_out, double *S_out, hipStream_t st) {
+    hipLaunchKernelGGL(raw_stats_kernel, dim3(1), dim3(TPB), 0, st, d, label, m_out, S_out);
+}
+
+// del_component (gaussian_components.py:188-205) as a call of its own: whoever still sits in the component becomes
+// unassigned, then the swap-with-last delete of its label
+__global__ __launch_bounds__(256) void del_component_members_kernel(Dev d, int label) {
+    const int s = d.perm[label];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.N; i += (long long)gridDim.x * 256)
+        if (d.z[i] == s) d.z[i] = -1;
+}
+__global__ void del_component_label_kernel(Dev d, int lab) {
+    Ctrl *c = d.ctrl;
+    const int h = d.perm[lab], last = c->job.K - 1, s_last = d.perm[last];
+    d.n[h] = 0;
+    d.perm[lab] = s_last; d.label_of_slot[s_last] = lab;
+    d.perm[last] = h; d.label_of_slot[h] = last;
+    c->job.K = last;
+    c->tables_valid = 0; c->wsort_valid = 0; c->state_epoch += 1; c->n_refresh = 0;
+}
+void launch_del_component(const Dev &d, int label, hipStream_t st) {
+    hipLaunchKernelGGL(del_component_members_kernel, dim3(1024), dim3(256), 0, st, d, label);
+    hipLaunchKernelGGL(del_component_label_kernel, dim3(1), dim3(1), 0, st, d, label);
 }
 
 __global__ void set_label_kernel(Dev d, long long i, int label) {

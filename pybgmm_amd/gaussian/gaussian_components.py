@@ -125,6 +125,12 @@ class GaussianComponents(object):
         """Remove data vector ``X[i]`` from its component."""
         self._ctx.del_item(i)
 
+    def del_component(self, k):
+        """Remove component ``k`` (gaussian_components.py:188-205: the last label takes its place).  The reference only
+        calls this on a component that has just lost its last member; members it still has become unassigned (-1)
+        here -- the reference would leave them labelled ``k``, i.e. in the component that moved in (include/bgmm.h)."""
+        self._ctx.del_component(k)
+
     def cache_component_stats(self, k):
         m, S, ld, iv = self._ctx.stats(True)
         return (m[k].copy(), S[k].copy(), ld[k], iv[k].copy(), int(self._ctx.counts()[k]))

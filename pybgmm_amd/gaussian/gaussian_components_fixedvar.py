@@ -77,7 +77,14 @@ class GaussianComponentsFixedVar(GaussianComponents):
     del _no
 
     def cache_component_stats(self, k):
+        """The reference's five statistics of component ``k`` (gaussian_components_fixedvar.py:124-134).  The library also
+        keeps the sum of squares of the members (its log marginal needs it; the reference recomputes from X): it is
+        remembered here, so that ``restore_component_from_stats`` puts back exactly what was there."""
         m, pN, lpp, pp = self._ctx.stats(True)
+        raw_m, raw_S = self._ctx.raw_stats(k)
+        if not hasattr(self, "_raw_cache"):
+            self._raw_cache = {}
+        self._raw_cache[int(k)] = (raw_m, raw_S)
         return (m[k].copy(), pN[k].copy(), lpp[k], pp[k].copy(), int(self._ctx.counts()[k]))
 
     def map(self, k):
@@ -86,8 +93,20 @@ class GaussianComponentsFixedVar(GaussianComponents):
     def map_all(self):
         raise NotImplementedError("the reference's fixed-variance class has no map()")
 
-    def restore_component_from_stats(self, *args, **kwargs):
-        raise NotImplementedError("bgmm_set_stats is not offered for fixed-variance components")
+    def restore_component_from_stats(self, k, mu_N_numerator, precision_N, log_prod_precision_pred, precision_pred, count):
+        """Restore component ``k`` (gaussian_components_fixedvar.py:136-144): numerators, precisions and the count are
+        written to the GPU as given, the predictive's constants rebuilt there.  The members' sum of squares comes from
+        the matching ``cache_component_stats`` call when there was one (the cache / del_item / restore idiom of the
+        sampler loop), else from the points currently labelled ``k``."""
+        mu = np.ascontiguousarray(mu_N_numerator, dtype=np.float64)
+        pN = np.ascontiguousarray(precision_N, dtype=np.float64)
+        cached = getattr(self, "_raw_cache", {}).get(int(k))
+        if cached is not None and np.array_equal(cached[0], mu) and np.array_equal(cached[1][:self.D], pN):
+            sumsq = cached[1][self.D:]
+        else:
+            members = self._ctx.assignments() == k
+            sumsq = np.square(self.X[members]).sum(axis=0) if members.any() else np.zeros(self.D)
+        self._ctx.set_stats(k, mu, np.concatenate([pN, sumsq]), count)
 
     def rand_k(self, k, rng=None, nprng=None):
         """A random mean vector from the posterior product of normals of component ``k``

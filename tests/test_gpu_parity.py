@@ -1347,7 +1347,7 @@ def test_distribution_dict_rand_k_and_streams_match_reference(case):
     npt.assert_array_equal(np.random.random_sample(4), g["after_numpy"])
 
 
-@pytest.mark.parametrize("cov", ["full", "diag"])
+@pytest.mark.parametrize("cov", ["full", "diag", "fixed"])
 def test_cache_del_restore_is_the_reference_idiom(cov):
     """igmm/crpmm.py:60-65, 82-85: cache_component_stats, del_item, restore_component_from_stats,
     assignments[i] = k_old -- afterwards the state is what it was (statistics bit-identical), and a sweep
@@ -1360,8 +1360,12 @@ def test_cache_del_restore_is_the_reference_idiom(cov):
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     if cov == "diag":
         S_0 = np.ascontiguousarray(np.diag(S_0))
-    cls = GaussianComponents if cov == "full" else GaussianComponentsDiag
-    comps = [cls(X, NIW(m_0, k_0, v_0, S_0), zt.copy(), 16) for _ in range(2)]
+    if cov == "fixed":
+        from pybgmm_amd.gaussian.gaussian_components_fixedvar import FixedVarPrior, GaussianComponentsFixedVar
+        comps = [GaussianComponentsFixedVar(X, FixedVarPrior(0.49, np.zeros(D), 16.0), zt.copy(), 16) for _ in range(2)]
+    else:
+        cls = GaussianComponents if cov == "full" else GaussianComponentsDiag
+        comps = [cls(X, NIW(m_0, k_0, v_0, S_0), zt.copy(), 16) for _ in range(2)]
     a = comps[0]
     for i in (3, 250, 599):
         k_old = int(a.assignments[i])
@@ -1375,12 +1379,94 @@ def test_cache_del_restore_is_the_reference_idiom(cov):
     for x, y in zip(a._ctx.stats(True)[2:], comps[1]._ctx.stats(True)[2:]):
         npt.assert_allclose(x, y, rtol=1e-10, atol=1e-12)
     npt.assert_array_equal(a.counts, comps[1].counts)
+    for k in range(a.K):                                   # (fixed variance: the sum of squares behind the log marginal too)
+        for x, y in zip(a._ctx.raw_stats(k), comps[1]._ctx.raw_stats(k)):
+            npt.assert_array_equal(x, y)
+    assert a._ctx.log_marg() == comps[1]._ctx.log_marg()
     u = np.random.RandomState(5).random_sample(N)
     for c in comps:
         c._ctx.sweep(u)
     npt.assert_array_equal(comps[0].assignments, comps[1].assignments)
     for c in comps:
         c._ctx.close()
+
+
+def test_del_component_is_the_swap_with_last():
+    """GaussianComponents.del_component(k) (gaussian_components.py:188-205): the last label takes k's place -- statistics,
+    count and members; K shrinks by one.  Members the deleted component still had become unassigned (include/bgmm.h)."""
+    from pybgmm_amd.gaussian.gaussian_components import GaussianComponents
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    N, D, K = 500, 3, 5
+    X, zt = gendata.synth_mixture(N, D, K, seed=5, mu_scale=3.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    a = GaussianComponents(X, NIW(m_0, k_0, v_0, S_0), zt.copy(), 16)
+    m0, S0 = a._ctx.stats(False)[:2]
+    c0 = a.counts.copy()
+    z0 = a.assignments.copy()
+    a.del_component(1)
+    assert a.K == K - 1
+    z1 = a.assignments
+    npt.assert_array_equal(z1[z0 == 1], -1)                       # its members: unassigned
+    npt.assert_array_equal(z1[z0 == K - 1], 1)                    # the last label moved into its place
+    for k in (0, 2, 3):
+        npt.assert_array_equal(z1[z0 == k], k)
+    m1, S1 = a._ctx.stats(False)[:2]
+    npt.assert_array_equal(m1[1], m0[K - 1]); npt.assert_array_equal(S1[1], S0[K - 1])
+    npt.assert_array_equal(a.counts[:K - 1], [c0[0], c0[K - 1], c0[2], c0[3]])
+    # the unassigned points are seated again by a sweep (they never "stay"): a consistent state afterwards
+    a._ctx.sweep(np.random.RandomState(1).random_sample(N))
+    assert (a.assignments >= 0).all() and int(a.counts.sum()) == N
+    a.del_component(a.K - 1)                                      # deleting the last label: nothing to swap
+    assert int(a.counts.sum()) == N - int((a.assignments < 0).sum())
+    a._ctx.close()
+
+
+@pytest.mark.parametrize("D,pcrp", [(16, True), (3, False), (64, False)])
+def test_partial_sweep_and_resume(D, pcrp):
+    """(i) bgmm_set_sweep_visits: a sweep that stops after n visits equals the C oracle's partial sweep (SURVEY 8b's
+    n_visits).  (ii) Checkpoint / resume: labels + raw statistics + counts put into a NEW context
+    (bgmm_set_assignments, then bgmm_set_stats per component) continue the chain identically, statistics bit-equal."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, K = 20000, 12
+    X, zt = gendata.synth_mixture(N, D, K, seed=9 + D, mu_scale=0.9 if D >= 16 else 2.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D)
+    z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    us = rs.random_sample((5, N))
+    orders = [rs.permutation(N).astype(np.int64) if pcrp else None for _ in range(5)]
+    pw = lambda it: 1.01 if (pcrp and it > 0) else None
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(z0)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+    ctx.sweep(us[0], orders[0], pw(0)); o.sweep(us[0], orders[0], pw(0))
+    for n_vis in (1, 777, N // 2):                               # partial sweeps, each from the state the last one left
+        ctx.set_sweep_visits(n_vis)
+        ctx.sweep(us[1], orders[1], pw(1))
+        o.sweep(us[1], orders[1], pw(1), n_visits=n_vis)
+        npt.assert_array_equal(ctx.assignments(), o.z)
+    ctx.sweep(us[2], orders[2], pw(2)); o.sweep(us[2], orders[2], pw(2))      # (and whole sweeps again afterwards)
+    npt.assert_array_equal(ctx.assignments(), o.z)
+    # ---- checkpoint
+    z_ck, cnt_ck = ctx.assignments(), ctx.counts()
+    raw = [ctx.raw_stats(k) for k in range(ctx.K)]
+    # ---- resume in a new context
+    ctx2 = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx2.set_assignments(z_ck)
+    for k, (m, S) in enumerate(raw):
+        ctx2.set_stats(k, m, S, int(cnt_ck[k]))
+    for it in (3, 4):
+        for c in (ctx, ctx2):
+            c.sweep(us[it], orders[it], pw(it))
+        npt.assert_array_equal(ctx2.assignments(), ctx.assignments())
+        npt.assert_array_equal(ctx2.counts(), ctx.counts())
+    for k in range(ctx.K):
+        for x, y in zip(ctx2.raw_stats(k), ctx.raw_stats(k)):
+            npt.assert_array_equal(x, y)
+    assert abs(ctx2.log_marg() - ctx.log_marg()) <= 1e-10 * abs(ctx.log_marg())
+    ctx.close(); ctx2.close()
 
 
 @pytest.mark.parametrize("model", ["CRPMM", "PCRPMM"])
