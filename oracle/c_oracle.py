@@ -45,6 +45,8 @@ def lib():
         L.go_get_log_prior.argtypes = [ctypes.c_void_p, _f64p]
         L.go_get_stats.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
         L.go_log_post_pred.argtypes = [ctypes.c_void_p, ctypes.c_int64, _f64p]
+        L.go_probe_visit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _f64p]
+        L.go_probe_visit.restype = ctypes.c_int64
         _lib = L
     return _lib
 
@@ -133,6 +135,12 @@ class COracle(object):
         out = np.empty(self.K, dtype=np.float64)
         lib().go_log_post_pred(self.h, int(i), out)
         return out
+
+    def probe_visit(self, i, power=None):
+        """log_prob_z of the next visit of point i (K + 1 values, the new table last).  Destructive: i stays unseated."""
+        out = np.empty(self.K + 1, dtype=np.float64)
+        K = lib().go_probe_visit(self.h, int(i), 0 if power is None else 1, 1.0 if power is None else float(power), out)
+        return out[:K + 1]
 
 
 def run_chain(g, n_iter=None, scipy_tables=True):

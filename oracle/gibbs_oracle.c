@@ -444,6 +444,29 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
     return 0;
 }
 
+/* Diagnostic for the parity harness ("report the CDF margin at first divergence"): the log_prob_z vector
+ * the NEXT visit of point i would normalise (crpmm.py:60-76 / pcrpmm.py:96-118) -- point i unseated, every label scored with
+ * its seating weight, the new table last.  DESTRUCTIVE: i stays unseated (z[i] = -1, an emptied component dropped), so
+ * the oracle is good for nothing else afterwards.  Returns K after the removal; out holds K + 1 values. */
+int64_t go_probe_visit(void *h, int64_t i, int use_power, double power, double *out) {
+    go_t *g = (go_t *)h;
+    int64_t D = g->D;
+    unseat(g, i);
+    int64_t K = g->K;
+    const double *x = g->X + i * D;
+    for (int64_t k = 0; k < K; ++k) {
+        double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
+        int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
+        if (g->diag == 2) {
+            for (int64_t a = 0; a < D; ++a) g->tmp[a] = g->m[k * D + a] / g->S[k * D + a];
+            out[k] = w + student_t(g, x, g->tmp, 1.0, g->logdet[k], g->inv + k * D, 0, g->delta);
+        } else
+        out[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k], g->inv + k * g->SD, nu, g->delta);
+    }
+    out[K] = log(g->alpha) + g->log_prior[i];
+    return K;
+}
+
 double go_log_marg(void *h) {
     go_t *g = (go_t *)h;
     int64_t D = g->D, K = g->K;

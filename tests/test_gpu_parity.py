@@ -127,8 +127,11 @@ def test_every_window_pruned(case, home):
     (12000, 40, 30, 4.0, "D = 40: padded columns in the rows' 16-byte pieces (home_kernel's general loads)"),
     (9000, 32, 25, 4.0, "D = 32: four tiles in flight per wavefront"),
 ])
-@pytest.mark.parametrize("home", [1, 2], ids=["home-pass", "no-home-pass"])
-def test_every_window_pruned_against_c_oracle(N, D, K, sep, label, home):
+@pytest.mark.parametrize("home,prune", [(1, 2), (2, 2), (0, 3)], ids=["home-pass", "no-home-pass", "benchmarked-mode"])
+def test_every_window_pruned_against_c_oracle(N, D, K, sep, label, home, prune):
+    """prune_mode 2 = every window through the pruned kernels (with / without the home pass in front); prune_mode 3 = the
+    mode bench.py times (`evaluated`: the schedule of the default configuration with certified stays off)."""
+    from divergence import assert_same_labels, first_divergence
     from oracle import c_oracle
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
@@ -142,16 +145,23 @@ def test_every_window_pruned_against_c_oracle(N, D, K, sep, label, home):
     K_max = min(N, 2 * K + 64)
     o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max)
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, tables=reference_tables(v_0, N))
-    ctx.set_tuning(kernel_kind=2, prune_mode=2)
+    ctx.set_tuning(kernel_kind=2, prune_mode=prune)
     ctx.set_home_pass(home)
     ctx.set_assignments(z0)
+
+    def fresh_ctx():
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, tables=reference_tables(v_0, N))
+        c.set_tuning(kernel_kind=2, prune_mode=prune)
+        c.set_home_pass(home)
+        c.set_assignments(z0)
+        return c
+    orders, powers = [None, order], [None, 1.03]
     for it in range(2):
-        power = 1.03 if it == 1 else None
-        o.sweep(us[it], order if it == 1 else None, power)
-        ctx.sweep(us[it], order if it == 1 else None, power)
-        z = ctx.assignments()
-        bad = np.nonzero(z != o.z)[0]
-        assert bad.size == 0, "%s: sweep %d: %d labels differ, first at i=%d" % (label, it, bad.size, bad[0])
+        power = powers[it]
+        o.sweep(us[it], orders[it], power)
+        ctx.sweep(us[it], orders[it], power)
+        assert_same_labels(ctx.assignments(), o.z, "%s: sweep %d" % (label, it), lambda: first_divergence(
+            fresh_ctx, lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max), us, orders, powers, it))
         lo = o.log_marg()
         assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
     ctx.close()
@@ -444,7 +454,9 @@ def test_full_size_properties(N, D, K, pcrp):
     flip = rs.choice(N, size=2000, replace=False)
     z0[flip] = rs.randint(0, K, size=flip.size)
     results = []
-    for kind, window, prune in ((0, 0, 0), (1 if D >= 24 else 2, 2048, 1)):
+    # default configuration / every pair evaluated in small windows / the benchmarked mode (bench.py's `evaluated`:
+    # prune_mode 3 = pruned windows with certified stays off, every visit's row read and scored every sweep)
+    for kind, window, prune in ((0, 0, 0), (1 if D >= 24 else 2, 2048, 1), (0, 0, 3)):
         ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
         ctx.set_tuning(max_window=window, kernel_kind=kind, prune_mode=prune)
         ctx.set_assignments(z0)
@@ -458,21 +470,25 @@ def test_full_size_properties(N, D, K, pcrp):
         c = ctx.counts()
         lm = ctx.log_marg()
         results.append((z, c, lm, moves))
-        if kind == 0 and D >= 64:           # (C3's clusters are too close for certificates at the 2^-53 level)
+        if kind == 0 and prune == 0 and D >= 64:   # (C3's clusters are too close for certificates at the 2^-53 level)
             assert certified > 0
+        if prune == 3:
+            assert certified == 0
         assert c.sum() == N and z.min() >= 0 and z.max() == len(c) - 1
         npt.assert_array_equal(np.bincount(z, minlength=len(c)), c)
-        if kind == 0:
+        if kind == 0 and prune == 0:
             # incremental statistics agree with a from-scratch rebuild of the same labelling
             ctx2 = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, tables=tabs)
             ctx2.set_assignments(z)
             assert abs(ctx2.log_marg() - lm) <= 1e-9 * abs(lm)
             ctx2.close()
         ctx.close()
-    (za, ca, lma, mva), (zb, cb, lmb, mvb) = results
-    npt.assert_array_equal(za, zb)      # kernel kind and window size do not change the chain
-    assert mva == mvb and mva > 0
-    assert abs(lma - lmb) <= 1e-9 * abs(lma)
+    za, ca, lma, mva = results[0]
+    assert mva > 0
+    for zb, cb, lmb, mvb in results[1:]:
+        npt.assert_array_equal(za, zb)      # kernel kind, window size and pruning mode do not change the chain
+        assert mva == mvb
+        assert abs(lma - lmb) <= 1e-9 * abs(lma)
 
 
 @pytest.mark.parametrize("N,D,K,pcrp", [(1000000, 64, 200, False), (1000000, 16, 100, True)], ids=["C4-rand", "C3-rand"])
@@ -577,8 +593,101 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
         walked += ss["unproven_walked"]
     assert moved >= 50, "the case is meant to have movers"
     assert windows > 0, "the safe-stay windows never ran"
-    assert walked < 0.6 * 3 * N, "the proof pass proved next to nothing"
+    # (how much the proof pass leaves on the resolver's chain: under half at D <= 64; D = 128 clusters at mu_scale 0.28 sit
+    # a few nats apart and most visits really are undecided -- 73 % walked, measured -- so that case only asks for "some")
+    assert walked < (0.6 if D <= 64 else 0.9) * 3 * N, "the proof pass proved next to nothing"
     ctx.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 25000), (40000, 128, 40, 400, 0)],
+                         ids=["D64-K200-2000-wrong-labels", "D128-K40-400-wrong-labels"])
+def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
+    """the largest problems the C port of the reference finishes in about a minute per sweep, at
+    BASELINE's D and K, the truth with wrong labels sprinkled in (the sweep repairs them: movers one per ~50 visits, then
+    a chain at rest).  The default configuration AND the mode bench.py times (prune_mode 3) against ONE oracle run --
+    a whole sweep, then `tail` visits of a second one (the hand-back to the at-rest path) -- labels identical after
+    each; a mismatch reports the CDF margin at the first diverging visit.  The oracle costs 0.4 - 1.2 ms per visit at
+    D = 64, K = 200 (1.2 - 3.5 at D = 128, K = 40): about a minute per case on the GPU box's host."""
+    from divergence import assert_same_labels, first_divergence
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=31 + D)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D + K)
+    z0 = zt.copy()
+    idx = rs.choice(N, size=flip, replace=False)
+    z0[idx] = rs.randint(0, K, size=flip)
+    n_sw = 2 if tail else 1
+    us = rs.random_sample((n_sw, N))
+    orders, powers = [None] * n_sw, [None] * n_sw
+    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 2 * K, scipy_tables=False)
+
+    def mk_ctx(prune):
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 2 * K)
+        c.set_tuning(prune_mode=prune)
+        c.set_assignments(z0)
+        return c
+    o = mk_oracle()
+    ctxs = {prune: mk_ctx(prune) for prune in (0, 3)}
+    moved = 0
+    for it in range(n_sw):
+        n_vis = N if it == 0 else tail
+        o.sweep(us[it], n_visits=n_vis)
+        zo, lo = o.z, o.log_marg()
+        for prune, ctx in ctxs.items():
+            ctx.set_sweep_visits(n_vis)
+            ctx.sweep(us[it])
+            assert_same_labels(ctx.assignments(), zo, "prune_mode %d, sweep %d" % (prune, it),
+                               lambda: first_divergence(lambda: mk_ctx(prune), mk_oracle, us, orders, powers, it))
+            assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        moved += ctxs[3].sweep_stats()["moves"]
+    assert moved >= flip // 2, "the case is meant to repair its wrong labels"
+    assert ctxs[3].prune_stats()["certified_visits"] == 0
+    for ctx in ctxs.values():
+        ctx.close()
+
+
+def test_first_divergence_diagnostic_finds_a_planted_divergence():
+    """VERDICT r2 #8(iii) / SURVEY 7.3.2: the diagnostic itself.  The device is handed a uniform stream that differs from
+    the oracle's at ONE visit (moved across a CDF boundary of that visit), so the chains part exactly there; the
+    diagnostic must name the visit, rebuild both CDFs to rounding level and call it "not a tie"."""
+    from divergence import _cdf, first_divergence
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 6000, 16, 8
+    X, zt = gendata.synth_mixture(N, D, K, seed=5, mu_scale=0.8)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(0)
+    us = rs.random_sample((2, N))
+    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K, scipy_tables=False)
+
+    def mk_ctx():
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        c.set_assignments(zt)
+        return c
+    # a visit of sweep 1 whose draw can be flipped: run the oracle up to it, look at its CDF
+    p = 3210
+    o = mk_oracle()
+    o.sweep(us[0])
+    o.sweep(us[1], n_visits=p)
+    prob, cdf = _cdf(o.probe_visit(p))
+    j = int(np.argmax(prob))                          # the likeliest label and a uniform that picks another one
+    us_dev = us.copy()
+    lo_edge = cdf[j] - prob[j]
+    inside = lo_edge + 0.5 * prob[j]
+    outside = cdf[j] + 0.5 * (1.0 - cdf[j]) if cdf[j] < 1.0 - 1e-9 else 0.5 * lo_edge
+    us[1][p], us_dev[1][p] = inside, outside
+    rep = first_divergence(mk_ctx, mk_oracle, us, [None, None], [None, None], 1, us_dev=us_dev)
+    assert rep["visit"] == p and rep["point"] == p, rep["text"]
+    assert rep["oracle_draw"] == j and rep["device_draw"] != j, rep["text"]
+    assert rep["max_abs_dlogp"] < 1e-9 and rep["max_abs_dcdf"] < 1e-11, rep["text"]     # (both sides' scores agree)
+    assert rep["verdict"].startswith("NOT a tie"), rep["text"]
+    # and with equal streams there is nothing to report
+    rep = first_divergence(mk_ctx, mk_oracle, us, [None, None], [None, None], 1)
+    assert rep["visit"] is None
 
 
 def test_full_size_safe_stay_windows_equal_the_other_mover_paths():

@@ -40,3 +40,19 @@ def test_component_kats():
     X = np.array([[1.2, 0.9], [-0.1, 0.8], [0.5, 0.4]])
     o = c_oracle.COracle(X, np.zeros(2), 2., 5, 5. * np.eye(2), 1.0, [0, 0, -1], 3)
     npt.assert_almost_equal(o.log_post_pred(2)[0], -2.07325364088)
+
+
+def test_probe_visit_reproduces_the_references_first_visit_probabilities():
+    """go_probe_visit (the first-divergence diagnostic's oracle side, tests/divergence.py) against prob_z of the very
+    first visit as the reference computed it (the fixtures' probes), and the diagnostic's CDF / draw helpers against
+    the label the reference drew there."""
+    from divergence import _cdf, _draw
+    for case in ("kat1_igmm_2d", "c3twin_pcrpmm_16d", "one_by_one_50", "each_in_own_50"):
+        g = Golden(case)
+        p_ref, u, k = g.probes()[0]
+        i = 0 if g.sweep_order(0) is None else int(g.sweep_order(0)[0])
+        o = c_oracle.COracle(g.X, g.m_0, g.k_0, g.v_0, g.S_0, g.alpha, g.z_init, g.K_max, cov_type=g.cov_type)
+        lp = o.probe_visit(i, g.sweep_power(0))
+        p, _ = _cdf(lp)
+        npt.assert_allclose(p, p_ref, rtol=1e-10, atol=1e-14)
+        assert _draw(p, u) == k

@@ -1,0 +1,254 @@
+"""
+Development probes of the HIP path, one script (run on a GPU box, e.g. through gpurun).
+
+    python tools/probe.py chain N D K [options]     per-sweep cost of a chain and what each layer did
+        --init true|rand|flip|own   the truth / the reference's "rand" start / the truth with N/500 (or --flip n) wrong
+                                    labels / each point in its own component                      (default true)
+        --sweeps n                  (default 6)          --sep s      mu_scale of the data (default 4.0; < 1: overlapping)
+        --pcrp                      a fresh permutation per sweep, powered weights from the second sweep on
+        --cov full|diag|fixed       --prune m  --resolver m  --home m  --kernel m  --window w     set_tuning / set_home_pass
+        --budget b                  set_safe_budget          --seq-plan k   set_seq_plan
+        --oracle                    every sweep compared with the C port of the reference (labels, log marginal)
+        --timing                    HIP-event time of the dominant likelihood launches of the LAST sweep
+        --prof                      load libbgmm_hip_prof.so (tools/build_prof.sh / build_prof_seq.sh): per-phase shader
+                                    clocks of home_kernel / sweep_seq_kernel / the resolver
+    python tools/probe.py safe-check                forced safe-stay windows against the C oracle on six small problems
+    python tools/probe.py classes N D K [--profile] end-to-end cost of the user-facing classes (RNG, sweep, record dict)
+    python tools/probe.py chains D G [N K]          G chains of one shape side by side on one device (ChainGroup) vs one
+    python tools/probe.py gather                    torch index_select of C4's rows: what a random row gather costs
+
+Replaces the round-1/2 scripts burnin_probe, c3_probe, cert_probe, gram_probe, home_probe, prune_probe,
+recovery_probe, safe_probe, seq_probe, class_api_probe, class_api_profile, gather_probe.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def prior_for(cov, D):
+    from pybgmm_amd.utils import gendata
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    if cov == "diag":
+        S_0 = np.ascontiguousarray(np.diag(S_0))
+    elif cov == "fixed":
+        m_0, k_0, v_0 = np.zeros(D), 1.0, 1
+        S_0 = np.concatenate([np.full(D, 0.49), np.full(D, 16.0)])
+    return m_0, k_0, v_0, S_0
+
+
+def start_labels(init, zt, K, rs, flip=0):
+    N = len(zt)
+    if init == "rand":
+        return np.unique(rs.randint(0, K, N), return_inverse=True)[1]
+    if init == "own":
+        return np.arange(N)
+    z0 = zt.copy()
+    if init == "flip":
+        idx = rs.choice(N, size=flip or max(N // 500, 1), replace=False)
+        z0[idx] = rs.randint(0, K, size=idx.size)
+    return z0
+
+
+def chain(a, quiet=False):
+    if a.prof:
+        from pybgmm_amd import _build
+        _build.LIB = os.path.join(os.path.dirname(_build.LIB), "libbgmm_hip_prof.so")
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = a.N, a.D, a.K
+    X, zt = gendata.synth_mixture(N, D, K, seed=a.seed, mu_scale=a.sep)
+    m_0, k_0, v_0, S_0 = prior_for(a.cov, D)
+    rs = np.random.RandomState(a.seed)
+    z0 = start_labels(a.init, zt, K, rs, a.flip)
+    K_max = max(4 * K, N if a.init == "own" else 0)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, cov_type=a.cov)
+    ctx.set_tuning(max_window=a.window, kernel_kind=a.kernel, resolver_mode=a.resolver, prune_mode=a.prune)
+    ctx.set_home_pass(a.home)
+    if a.budget:
+        ctx.set_safe_budget(a.budget)
+    if a.seq_plan:
+        ctx.set_seq_plan(a.seq_plan)
+    ctx.set_assignments(z0)
+    o = None
+    if a.oracle:
+        from oracle import c_oracle
+        o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max, scipy_tables=False, cov_type=a.cov)
+    ok = True
+    pc0 = np.array(ctx.phase_clocks())
+    for it in range(a.sweeps):
+        u = rs.random_sample(N)
+        order = rs.permutation(N).astype(np.int64) if a.pcrp else None
+        power = 1.01 if (a.pcrp and it > 0) else None
+        last = it == a.sweeps - 1
+        if last:
+            pc0 = np.array(ctx.phase_clocks())
+            if a.timing:
+                ctx.set_kernel_timing(True)
+        ctx.stage(u, order); ctx.synchronize()
+        t0 = time.time(); ctx.sweep_staged(power); ctx.synchronize(); dt = time.time() - t0
+        st, ss, ps, pr = ctx.sweep_stats(), ctx.safe_stats(), ctx.path_stats(), ctx.prune_stats()
+        msg = ""
+        if o is not None:
+            o.sweep(u, order, power)
+            bad = np.nonzero(ctx.assignments() != o.z)[0]
+            lm, lo = ctx.log_marg(), o.log_marg()
+            msg = "  ORACLE %s, log_marg rel %.1e" % ("ok" if bad.size == 0 else "DIFFERS at %d labels, first i=%d" % (bad.size, bad[0]),
+                                                      abs(lm - lo) / abs(lo))
+            ok = ok and bad.size == 0
+        if not quiet:
+            print("sweep %2d: %9.3f ms moves %7d (%.2f us/move) K %3d | windows %6d steps %6d | safe windows %6d examined %9d walked %7d "
+                  "cuts %5d L %7d | frozen %6d (%7d visits) | certified %7d home-decided %8d bounded blocks %9d kept %8d%s" % (
+                      it, dt * 1e3, st["moves"], dt * 1e6 / max(st["moves"], 1), ctx.K, st["windows"], st["steps"], ss["windows"],
+                      ss["visits_examined"], ss["unproven_walked"], ss["budget_cuts"], ss["next_stretch"], ps["frozen_windows"],
+                      ps["frozen_window_visits"], pr["certified_visits"], ps.get("home_decided", 0), pr["bound_blocks"],
+                      pr["kept_blocks"], msg), flush=True)
+        if not ok:
+            break
+    if a.timing:
+        n, ms = ctx.kernel_timing()
+        print("last sweep: %d timed launches, avg %.4f ms" % (n, ms / max(n, 1)))
+    pc = np.array(ctx.phase_clocks()) - pc0
+    if a.prof and pc[15] > 0 and D >= 12:            # home_kernel's clocks (-DBGMM_HOME_PROF)
+        names = ["wait+stage", "issue", "frags", "mfma+reduce", "tail", "records", "blockhead", "switch"]
+        tot = float(pc[:8].sum())
+        for k in range(8):
+            print("  %-12s %8.0f cycles per tile-wave  %5.1f %%" % (names[k], pc[k] / (N / 16.0), 100.0 * pc[k] / tot))
+    elif a.prof and D <= 4:                          # sweep_seq_kernel's clocks (-DBGMM_SEQ_PROF)
+        names = ["ring read", "home lookup", "evaluate", "stats", "commit", "rebuild", "barrier 1", "barrier 2"]
+        tot = float(pc[:8].sum())
+        for k in range(8):
+            print("   %-12s %6.1f %%   %9.0f cycles per wave and 1000 visits" % (names[k], 100.0 * pc[k] / max(tot, 1), pc[k] / 8.0 / N * 1000))
+    elif a.prof and any(pc):                         # the resolver's clocks
+        w = max(pc[8], 1)
+        print("resolver ticks per window: prologue %.0f  draws %.0f  bookkeeping %.0f  update(home) %.0f  update(dest) %.0f  | windows %d" % (
+            pc[0] / w, pc[1] / w, pc[2] / w, pc[3] / w, pc[4] / w, pc[8]))
+    ctx.close()
+    return ok
+
+
+def safe_check():
+    ok = True
+    for (N, D, K, init, sep, pcrp) in [(3000, 16, 12, "rand", 4.0, False), (20000, 16, 40, "flip", 1.6, False),
+                                       (20000, 64, 20, "flip", 4.0, False), (8000, 32, 30, "rand", 1.2, True),
+                                       (30000, 16, 60, "rand", 1.0, False), (6000, 128, 10, "flip", 4.0, False)]:
+        for budget in (0.0, 1.0 / 64, 2.0):
+            print("== N %d D %d K %d %s sep %.1f pcrp %d forced safe-stay windows, budget %s" % (N, D, K, init, sep, pcrp, budget or "auto"), flush=True)
+            a = parser().parse_args(["chain", str(N), str(D), str(K), "--init", init, "--sep", str(sep), "--resolver", "4",
+                                     "--sweeps", "3", "--oracle", "--budget", str(budget), "--seed", "11"] + (["--pcrp"] if pcrp else []))
+            ok = chain(a, quiet=True) and ok
+    print("CHECK", "OK" if ok else "FAILED")
+    return ok
+
+
+def classes(a):
+    import cProfile
+    import pstats
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(a.N, a.D, a.K, seed=1)
+    random.seed(1); np.random.seed(1)
+    mm = CRPMM(X, NIW(*gendata.demo_prior_params(a.D)), 1.0, None, assignments=zt, K_max=4 * a.K)
+    mm.collapsed_gibbs_sampler(2, zt, num_saved=0)
+    for metrics in (True, False):
+        mm.record_metrics = metrics
+        t = time.time()
+        rec, _ = mm.collapsed_gibbs_sampler(5, zt, num_saved=0)
+        dt = (time.time() - t) / 5
+        print("record_metrics=%s: %.2f ms per sweep wall (sample_time %.3f ms), nmi %.4f K %d" % (
+            metrics, dt * 1e3, 1e3 * np.mean(rec["sample_time"]), rec["nmi"][-1], rec["components"][-1]))
+    if a.profile:
+        pr = cProfile.Profile(); pr.enable()
+        mm.collapsed_gibbs_sampler(10, zt, num_saved=0)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+
+def chains(a):
+    from pybgmm_amd import _lib
+    from pybgmm_amd.chains import ChainGroup
+    from pybgmm_amd.utils import gendata
+    N, D, K, G = a.N, a.D, a.K, a.G
+    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    for g in (1, G):
+        grp = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, 8 * K, n_chains=g, seed=1)
+        grp.set_assignments([zt] * g)
+        grp.sweep(); grp.sweep()
+        t0 = time.time()
+        n = 5
+        for _ in range(n):
+            grp.sweep()
+        dt = (time.time() - t0) / n
+        print("%3d chains: %.2f ms per round of sweeps, %.1f sweeps/s aggregate" % (g, dt * 1e3, g / dt))
+        grp.close()
+
+
+def gather():
+    import torch
+    N, D = 1000000, 64
+    x = torch.randn(N, D, dtype=torch.float64, device="cuda")
+    for name, idx in (("random", torch.randperm(N, device="cuda")), ("identity", torch.arange(N, device="cuda"))):
+        for _ in range(3):
+            x.index_select(0, idx)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(20):
+            x.index_select(0, idx)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / 20
+        print(name, "%.1f us" % (dt * 1e6), "read+write %.2f TB/s" % (2 * N * D * 8 / dt / 1e12))
+
+
+def parser():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    c = sub.add_parser("chain")
+    for n in ("N", "D", "K"):
+        c.add_argument(n, type=int)
+    c.add_argument("--init", default="true", choices=["true", "rand", "flip", "own"])
+    c.add_argument("--flip", type=int, default=0)
+    c.add_argument("--sweeps", type=int, default=6)
+    c.add_argument("--sep", type=float, default=4.0)
+    c.add_argument("--pcrp", action="store_true")
+    c.add_argument("--cov", default="full", choices=["full", "diag", "fixed"])
+    for n in ("prune", "resolver", "home", "kernel", "window", "seq-plan"):
+        c.add_argument("--" + n, type=int, default=0)
+    c.add_argument("--budget", type=float, default=0.0)
+    c.add_argument("--seed", type=int, default=11)
+    c.add_argument("--oracle", action="store_true")
+    c.add_argument("--timing", action="store_true")
+    c.add_argument("--prof", action="store_true")
+    sub.add_parser("safe-check")
+    k = sub.add_parser("classes")
+    for n in ("N", "D", "K"):
+        k.add_argument(n, type=int)
+    k.add_argument("--profile", action="store_true")
+    g = sub.add_parser("chains")
+    g.add_argument("D", type=int)
+    g.add_argument("G", type=int)
+    g.add_argument("N", type=int, nargs="?", default=100000)
+    g.add_argument("K", type=int, nargs="?", default=20)
+    sub.add_parser("gather")
+    return ap
+
+
+if __name__ == "__main__":
+    args = parser().parse_args()
+    if args.cmd == "chain":
+        sys.exit(0 if chain(args) else 1)
+    elif args.cmd == "safe-check":
+        sys.exit(0 if safe_check() else 1)
+    elif args.cmd == "classes":
+        classes(args)
+    elif args.cmd == "chains":
+        chains(args)
+    else:
+        gather()
