@@ -464,6 +464,7 @@ def main():
         decided_total, executed_total, moves_total = (float(v) for v in agg.tolist())
     else:
         decided_total, executed_total, moves_total = float(decided), float(executed), float(moves)
+    mt_ahead, short_steps = ctx.mt_lookahead_stats(), ctx.short_step_stats()   # (of the warm-up and the timed sweeps)
     last_stats = ctx.sweep_stats()
     last_stats.update({"certified_visits": ctx.prune_stats()["certified_visits"],
                        "pairs_executed": ctx.path_stats()["pairs_executed"]})
@@ -649,8 +650,14 @@ def main():
                       "K_final": K_final, "log_marg_rank0": log_marg,
                       "last_sweep": last_stats, "setup_s": round(t_setup, 3),
                       "value_is": "sweeps/s with every sweep's uniforms generated inside the timed region (the caller's MT19937 "
-                                  "continued on the device, bgmm_stage_mt19937) and, for pCRP workloads, its permutation drawn on "
-                                  "the host and uploaded -- SURVEY 8(d)'s t_sweep",
+                                  "continued on the device, bgmm_stage_mt19937: sweep k + 1's are generated on a second stream while "
+                                  "sweep k runs) and, for pCRP workloads, its permutation drawn on the host and uploaded -- SURVEY "
+                                  "8(d)'s t_sweep",
+                      "mt19937_lookahead": dict(mt_ahead, note="stage calls served by the look-ahead (the next sweep's uniforms "
+                                                "generated on a second stream beside the running sweep; taken only when the caller's "
+                                                "generator is exactly where the last call left it) / generated on the spot"),
+                      "short_steps": dict(short_steps, note="sweeps queued as sweep_begin + home_kernel + apply (a chain at rest with "
+                                          "certified stays off) that stood / were refused and redone with the full kernel set"),
                       "timed_region_s": round(elapsed, 3),
                       "sweeps_per_s_per_250_sweeps": {"min": min(chunk_rates), "max": max(chunk_rates),
                                                       "median": sorted(chunk_rates)[len(chunk_rates) // 2]} if chunk_rates else None,

@@ -110,6 +110,18 @@ BGMM_API int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *k
  * coefficients of t^J modulo the generator's characteristic polynomial; the polynomials are built on the host once
  * per process).  0 = run the chains one after the other instead -- same doubles, same final state. */
 BGMM_API int bgmm_set_mt_jump(bgmm_ctx *ctx, int32_t enabled);
+/* Look-ahead (on by default): behind a bgmm_stage_mt19937 request the library generates, on a second stream and beside the
+ * sweep that follows, the uniforms of the NEXT `sweeps` sweeps in one go (one request of sweeps x N doubles: the fixed
+ * cost of a generation -- the chains' jumped-ahead seeds, a dozen launches -- is paid once per batch), and notes the
+ * generator state at every sweep boundary inside it.  A later bgmm_stage_mt19937 call is served from the batch iff the
+ * (key624, pos) it is handed equal, bit for bit, the state at the boundary the batch has reached, i.e. the caller drew
+ * nothing from its generator since the previous call (the sampler loops of crpmm.py:57-88 / pcrpmm.py:93-131 never do);
+ * otherwise the batch is thrown away and the request is generated on the spot as if there had been no look-ahead.  Same
+ * doubles, same states handed back either way; costs two buffers of sweeps x N doubles.  sweeps: -1 = on, depth chosen
+ * from N (about 4e6 doubles per batch, at most 8 sweeps; the default), 0 = off, 1 .. 8 = that many sweeps per batch.
+ * out2 = {requests served by the look-ahead, requests generated on the spot}. */
+BGMM_API int bgmm_set_mt_lookahead(bgmm_ctx *ctx, int32_t sweeps);
+BGMM_API int bgmm_get_mt_lookahead_stats(bgmm_ctx *ctx, int64_t *out2);
 /* The coefficient bits (19 937 of them, bit i = word i / 32, bit i % 32) of t^(chain * 39 936) modulo the characteristic
  * polynomial of MT19937: host arithmetic only, no device needed (what the CPU tests check against numpy's generator). */
 BGMM_API int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624);
@@ -259,8 +271,17 @@ BGMM_API int bgmm_set_seq_plan(bgmm_ctx *ctx, int32_t max_labels);
 
 /* The first pass of a pruned window (home_kernel: visits whose only live candidates are the home component
  * and a new one).  0 = the context decides sweep by sweep from how many visits the pass settled in the last
- * sweep it ran (the default), 1 = always, 2 = never.  It never changes the trajectory. */
+ * sweep it ran (the default), 1 = always, 2 = never; 3 = always, and with certified stays off every sweep first tries a
+ * short step (below) whether or not the last sweep suggests it will stand -- for the tests of its refusal.  It never
+ * changes the trajectory. */
 BGMM_API int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
+/* Sweeps with certified stays off (prune_mode 3, what bench.py times) on a chain at rest: when the previous sweep was one
+ * pruned window, moved nothing and home_kernel decided every visit on its own, the next sweep queues a SHORT step --
+ * home_kernel between sweep_begin and apply, none of the table / bucket / pruning / draw launches that would find nothing
+ * to do.  apply_kernel lets it stand only if nothing moved, nothing was left on the residual list and the tables and the
+ * sort it relied on were still valid; otherwise the same window is queued again with the full kernel set.
+ * out2 = {short steps that stood, short steps refused} over the life of the context. */
+BGMM_API int bgmm_get_short_step_stats(bgmm_ctx *ctx, int64_t *out2);
 
 /* Blocks until all work queued on the context's stream has finished. */
 BGMM_API int bgmm_synchronize(bgmm_ctx *ctx);

@@ -33,6 +33,9 @@ SIGNATURES = {
     "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
     "bgmm_stage_mt19937": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "bgmm_set_mt_jump": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_get_short_step_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_set_mt_lookahead": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_get_mt_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
     "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
@@ -201,6 +204,21 @@ class Context(object):
 
     def set_mt_jump(self, on=True):
         self._ck(self.L.bgmm_set_mt_jump(self.h, 1 if on else 0))
+
+    def short_step_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._ck(self.L.bgmm_get_short_step_stats(self.h, _ptr(out)))
+        return {"stood": int(out[0]), "refused": int(out[1])}
+
+    def set_mt_lookahead(self, sweeps=-1):
+        """-1 / True: on, depth chosen from N; 0 / False: off; 1 .. 8: that many sweeps per look-ahead batch."""
+        sweeps = -1 if sweeps is True else (0 if sweeps is False else int(sweeps))
+        self._ck(self.L.bgmm_set_mt_lookahead(self.h, sweeps))
+
+    def mt_lookahead_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._ck(self.L.bgmm_get_mt_lookahead_stats(self.h, _ptr(out)))
+        return {"hits": int(out[0]), "misses": int(out[1])}
 
     def staged_uniforms(self):
         u = np.empty(self.N, dtype=np.float64)

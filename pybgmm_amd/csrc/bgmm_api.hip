@@ -13,6 +13,7 @@
 #include "../../include/bgmm.h"
 #include "bgmm_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <dlfcn.h>
@@ -79,6 +80,9 @@ struct bgmm_ctx {
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
+    long long short_stood = 0, short_refused = 0;   // short steps over the life of the context (bgmm_get_short_step_stats)
+    bool short_ok = false;           // the previous sweep (certified stays off) was ONE pruned window, moved nothing and
+                                     // home_kernel decided every visit: the next one tries a short step (Dev::short_step)
     long long moves_prev = -1;       // moves of the previous sweep (-1: none yet / state set from outside)
     long long *true_dev = nullptr;   // bgmm_contingency: the reference labelling, kept between calls
     unsigned long long *table_dev = nullptr;
@@ -87,6 +91,24 @@ struct bgmm_ctx {
     unsigned *mt_coef = nullptr, *mt_seeds = nullptr;   // jump polynomials / seeds of the chains of a long request
     int mt_chains = 0;
     bool mt_jump_on = true;          // bgmm_set_mt_jump: false = the chains run one after the other (the r02 route, for comparison)
+    // Look-ahead of the caller's stream (bgmm_set_mt_lookahead): the uniforms of the next `depth` sweeps are generated in one
+    // request on a second stream, beside the running sweep, into one of two batch buffers; a bgmm_stage_mt19937 call is
+    // served from the batch iff the state it is handed is bit for bit the state at that sweep boundary of the batch --
+    // i.e. the caller drew nothing in between.  While the last sweep of a batch is served the next batch is started.
+    bool mt_ahead_on = true;
+    int mt_depth = 0;                // sweeps per batch (0: chosen from N at first use)
+    hipStream_t mt_stream = nullptr;
+    struct MtBatch {
+        bool launched = false, synced = false;
+        int next = 0;                // sweep of the batch the next hit serves
+        int pos_in = 0;
+        hipEvent_t done = nullptr;
+        double *u = nullptr;         // [depth][N]
+        unsigned *host = nullptr;    // pinned: [start key 624 | state behind sweep j: depth x 624 | their positions depth | zero flags depth]
+    } mt_b[2];
+    int mt_cur = -1;                 // batch being served
+    unsigned *mt_words_ahead = nullptr;   // device scratch of a batch generation (layout in mt_launch_batch)
+    long long mt_ahead_hits = 0, mt_ahead_misses = 0;
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     std::vector<char> res_perm;      // per resident sweep: its order is a permutation (or absent)
@@ -107,7 +129,7 @@ struct bgmm_ctx {
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
     bool home_pass = true;           // home_kernel in front of the pruning kernel (kernels_home.hip)
     int home_retry = 0;
-    int home_mode = 0;               // bgmm_set_home_pass: 0 auto, 1 always, 2 never
+    int home_mode = 0;               // bgmm_set_home_pass: 0 auto, 1 always, 2 never, 3 always + a short step tried in every sweep
 };
 
 // Mean distance between movers below which the frozen-factor windows take over from the per-mover
@@ -204,6 +226,13 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->mt_stream) { (void)hipStreamSynchronize(c->mt_stream); (void)hipStreamDestroy(c->mt_stream); }
+    for (auto &b : c->mt_b) {
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.u) (void)hipFree(b.u);
+        if (b.host) (void)hipHostFree(b.host);
+    }
+    if (c->mt_words_ahead) (void)hipFree(c->mt_words_ahead);
     if (c->mt_words) (void)hipFree(c->mt_words);
     if (c->mt_coef) (void)hipFree(c->mt_coef);
     if (c->mt_seeds) (void)hipFree(c->mt_seeds);
@@ -501,7 +530,7 @@ extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
         rc = check_device_error(c);
     } while (0);
     (void)hipFree(dz); (void)hipFree(doff); (void)hipFree(dmem);
-    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->lean_ok = false; }
+    if (rc == 0) { c->assigned = true; c->moves_prev = -1; c->lean_ok = false; c->short_ok = false; }
     return rc;
 }
 
@@ -541,50 +570,198 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     return 0;
 }
 
+// jump polynomials / chain seeds for requests of up to `chains` chains (grown on demand, never while a generation runs)
+static int mt_ensure_tables(bgmm_ctx *c, int chains) {
+    if (chains < 2 || c->mt_chains >= chains) return 0;
+    std::vector<unsigned> coef;
+    const bool have = mt19937_jump_coefficients(chains, coef);
+    if (c->mt_coef) { (void)hipFree(c->mt_coef); c->mt_coef = nullptr; }
+    if (c->mt_seeds) { (void)hipFree(c->mt_seeds); c->mt_seeds = nullptr; }
+    CK(c, hipMalloc((void **)&c->mt_seeds, sizeof(unsigned) * 624 * (size_t)(chains + 1)));
+    if (have) {
+        CK(c, hipMalloc((void **)&c->mt_coef, sizeof(unsigned) * coef.size()));
+        CK(c, hipMemcpy(c->mt_coef, coef.data(), sizeof(unsigned) * coef.size(), hipMemcpyHostToDevice));
+    }
+    c->mt_chains = chains;
+    return 0;
+}
+
+static int mt_depth_for(long long N) {
+    if (N < 4096) return 1;                       // (sweep boundaries must lie behind the request's first block)
+    long long m = 4000000 / N;
+    if (m < 1) m = 1;
+    if (m > kMtMaxMids) m = kMtMaxMids;
+    return (int)m;
+}
+
+// Starts the generation of batch `bi`: `depth` sweeps' uniforms from the generator state (key, pos), on the second stream.
+static int mt_launch_batch(bgmm_ctx *c, int bi, const uint32_t *key, int pos) {
+    const size_t N = (size_t)c->d.N, raw_n = (size_t)mt19937_raw_words();
+    const int M = c->mt_depth;
+    bgmm_ctx::MtBatch &B = c->mt_b[bi];
+    const size_t host_words = 624 + (size_t)M * 624 + 2 * (size_t)M + 16;
+    if (!c->mt_stream) CK(c, hipStreamCreateWithFlags(&c->mt_stream, hipStreamNonBlocking));
+    if (!B.done) CK(c, hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
+    if (!B.u) CK(c, hipMalloc((void **)&B.u, sizeof(double) * N * (size_t)M + 64));
+    if (!B.host) CK(c, hipHostMalloc((void **)&B.host, sizeof(unsigned) * host_words, hipHostMallocDefault));
+    // device scratch: [key in 624 | state behind sweep j: M x 624 | positions M | zero flags M | pad to 16 | spare key 624 |
+    //                  spare position 16 | raw | 2 M N tempered words]
+    const size_t head = 624 + (size_t)M * 624 + 2 * (size_t)M + 16;
+    if (!c->mt_words_ahead)
+        CK(c, hipMalloc((void **)&c->mt_words_ahead, sizeof(unsigned) * (head + 640 + raw_n + 2 * N * (size_t)M)));
+    unsigned *dkey = c->mt_words_ahead, *dmid = dkey + 624;
+    int *dposmid = (int *)(dmid + (size_t)M * 624), *dflags = dposmid + M;
+    unsigned *dspare = c->mt_words_ahead + head, *draw = dspare + 640, *dwords = draw + raw_n;
+    int *dspare_pos = (int *)(dspare + 624);
+    memcpy(B.host, key, sizeof(unsigned) * 624);
+    memset(B.host + 624 + (size_t)M * 624, 0, sizeof(unsigned) * 2 * (size_t)M);
+    B.pos_in = pos;
+    hipStream_t as = c->mt_stream;
+    CK(c, hipMemcpyAsync(dkey, B.host, sizeof(unsigned) * 624, hipMemcpyHostToDevice, as));
+    CK(c, hipMemsetAsync(dposmid, 0, sizeof(int) * 2 * (size_t)M, as));
+    const int chains = mt19937_chains_for(pos, (long long)(N * (size_t)M));
+    launch_mt19937(dkey, pos, M == 1 ? dmid : dspare, M == 1 ? dposmid : dspare_pos, dwords, B.u, (long long)(N * (size_t)M), dflags,
+                   (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, draw, c->mt_seeds, as,
+                   M, M > 1 ? dmid : nullptr, M > 1 ? dposmid : nullptr);
+    CK(c, hipGetLastError());
+    CK(c, hipMemcpyAsync(B.host + 624, dmid, sizeof(unsigned) * ((size_t)M * 624 + 2 * (size_t)M), hipMemcpyDeviceToHost, as));
+    CK(c, hipEventRecord(B.done, as));
+    B.launched = true; B.synced = false; B.next = 0;
+    return 0;
+}
+
+static int mt_wait_batches(bgmm_ctx *c) {
+    for (auto &b : c->mt_b)
+        if (b.launched && !b.synced) { CK(c, hipEventSynchronize(b.done)); b.synced = true; }
+    return 0;
+}
+
 extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *key624, int32_t *pos) {
     if (!c || !key624 || !pos) return BGMM_EINVAL;
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
     CK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->d.N;
-    // device scratch: [key in 624 | key out 624 | pos out, zero flag, pad 16 | raw | 2 N tempered words], and -- requests of
-    // more than one chain -- the jump polynomials' coefficient words and the chains' seeds
+    // device scratch of a request served on the spot: [key in 624 | key out 624 | pos out, zero flag, pad 16 | raw | 2 N
+    // tempered words], and -- requests of more than one chain -- the jump polynomials' coefficient words and the chains'
+    // seeds.  The seeds are shared with the look-ahead: one generation at a time.
     const size_t raw_n = (size_t)mt19937_raw_words();
     if (!c->mt_words) CK(c, hipMalloc((void **)&c->mt_words, sizeof(unsigned) * (1264 + raw_n + 2 * N)));
     unsigned *dkey = c->mt_words, *dkey_out = c->mt_words + 624, *draw = c->mt_words + 1264, *dwords = draw + raw_n;
     int *dpos = (int *)(c->mt_words + 1248), *dflag = (int *)(c->mt_words + 1249);
-    const int chains_max = mt19937_chains_for(624, (long long)N);
-    if (chains_max >= 2 && c->mt_chains < chains_max) {
-        std::vector<unsigned> coef;
-        const bool have = mt19937_jump_coefficients(chains_max, coef);
-        if (c->mt_coef) { (void)hipFree(c->mt_coef); c->mt_coef = nullptr; }
-        if (c->mt_seeds) { (void)hipFree(c->mt_seeds); c->mt_seeds = nullptr; }
-        CK(c, hipMalloc((void **)&c->mt_seeds, sizeof(unsigned) * 624 * (size_t)(chains_max + 1)));
-        if (have) {
-            CK(c, hipMalloc((void **)&c->mt_coef, sizeof(unsigned) * coef.size()));
-            CK(c, hipMemcpy(c->mt_coef, coef.data(), sizeof(unsigned) * coef.size(), hipMemcpyHostToDevice));
+    if (c->mt_depth == 0) c->mt_depth = mt_depth_for((long long)N);
+    const int M = c->mt_ahead_on ? c->mt_depth : 1;
+    {
+        const int chains_max = mt19937_chains_for(624, (long long)(N * (size_t)M));
+        if (chains_max > c->mt_chains) {
+            int rc = mt_wait_batches(c);
+            if (rc) return rc;
+            rc = mt_ensure_tables(c, chains_max);
+            if (rc) return rc;
         }
-        c->mt_chains = chains_max;
     }
-    int host_tail[2] = {0, 0};
-    CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
-    CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
+    // a batch that has been served to its end: the one started while its last sweep was being served takes over
+    if (c->mt_cur >= 0 && c->mt_b[c->mt_cur].launched && c->mt_b[c->mt_cur].next >= c->mt_depth) {
+        c->mt_b[c->mt_cur].launched = false;
+        c->mt_cur ^= 1;
+    }
+    bool hit = false;
+    bgmm_ctx::MtBatch *B = c->mt_cur >= 0 ? &c->mt_b[c->mt_cur] : nullptr;
+    if (B && B->launched && c->mt_ahead_on) {
+        if (!B->synced) { CK(c, hipEventSynchronize(B->done)); B->synced = true; }
+        const int Md = c->mt_depth, j = B->next;
+        const unsigned *exp_key = j == 0 ? B->host : B->host + 624 + (size_t)(j - 1) * 624;
+        const int exp_pos = j == 0 ? B->pos_in : (int)B->host[624 + (size_t)Md * 624 + (size_t)(j - 1)];
+        hit = *pos == exp_pos && memcmp(key624, exp_key, sizeof(unsigned) * 624) == 0;
+        if (hit) {
+            c->cur_u = B->u + (size_t)j * N;
+            memcpy(key624, B->host + 624 + (size_t)j * 624, sizeof(unsigned) * 624);
+            *pos = (int32_t)B->host[624 + (size_t)Md * 624 + (size_t)j];
+            c->cur_zero_u = B->host[624 + (size_t)Md * 624 + (size_t)Md + (size_t)j] != 0;
+            B->next = j + 1;
+            c->mt_ahead_hits += 1;
+        }
+    }
+    if (!hit) {
+        // not foreseen (the first request, or the caller drew from its generator in between): generated on the spot, and
+        // whatever the look-ahead holds is of no use any more
+        int rc = mt_wait_batches(c);
+        if (rc) return rc;
+        c->mt_b[0].launched = c->mt_b[1].launched = false;
+        c->mt_cur = -1;
+        int host_tail[2] = {0, 0};
+        CK(c, hipMemcpyAsync(dkey, key624, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream));
+        CK(c, hipMemcpyAsync(dpos, host_tail, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
+        const int chains = mt19937_chains_for(*pos, (long long)N);
+        launch_mt19937(dkey, *pos, dkey_out, dpos, dwords, c->d_u, (long long)N, dflag,
+                       (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, draw, c->mt_seeds, c->stream);
+        CK(c, hipGetLastError());
+        CK(c, hipMemcpyAsync(key624, dkey_out, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, c->stream));
+        CK(c, hipMemcpyAsync(host_tail, dpos, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+        CK(c, hipStreamSynchronize(c->stream));
+        *pos = host_tail[0];
+        c->cur_zero_u = host_tail[1] != 0;
+        c->cur_u = c->d_u;
+        c->mt_ahead_misses += 1;
+    }
     c->have_order = order != nullptr;
     const int okind = order ? classify_order(order, (long long)N) : 1;
     if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
     c->order_is_perm = okind == 1;
-    if (order)
+    if (order) {
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
-    const int chains = mt19937_chains_for(*pos, (long long)N);
-    launch_mt19937(dkey, *pos, dkey_out, dpos, dwords, c->d_u, (long long)N, dflag,
-                   (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, draw, c->mt_seeds, c->stream);
-    CK(c, hipGetLastError());
-    CK(c, hipMemcpyAsync(key624, dkey_out, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipMemcpyAsync(host_tail, dpos, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipStreamSynchronize(c->stream));
-    *pos = host_tail[0];
-    c->cur_zero_u = host_tail[1] != 0;
-    c->cur_u = c->d_u;
+        CK(c, hipStreamSynchronize(c->stream));
+    }
     c->cur_order = order ? c->d_order : nullptr;
+    if (c->mt_ahead_on) {
+        // what comes behind: after a request served on the spot, a fresh batch from the state just handed back; towards the
+        // end of a batch, the batch behind it (its generation runs beside the sweeps queued meanwhile)
+        if (!hit) {
+            int rc = mt_launch_batch(c, 0, key624, *pos);
+            if (rc) return rc;
+            c->mt_cur = 0;
+        } else if (B->next >= std::max(1, c->mt_depth - 2) && !c->mt_b[c->mt_cur ^ 1].launched) {
+            // (the state behind this batch is known since its generation finished: the next batch is started two sweeps
+            // before it is needed -- under a running sweep a generation takes about two of them)
+            const int Md = c->mt_depth;
+            int rc = mt_launch_batch(c, c->mt_cur ^ 1, B->host + 624 + (size_t)(Md - 1) * 624,
+                                     (int)B->host[624 + (size_t)Md * 624 + (size_t)(Md - 1)]);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int bgmm_get_short_step_stats(bgmm_ctx *c, int64_t *out2) {
+    if (!c || !out2) return BGMM_EINVAL;
+    out2[0] = c->short_stood;
+    out2[1] = c->short_refused;
+    return 0;
+}
+
+extern "C" int bgmm_set_mt_lookahead(bgmm_ctx *c, int32_t sweeps) {
+    if (!c) return BGMM_EINVAL;
+    if (sweeps < -1 || sweeps > kMtMaxMids) return fail(c, BGMM_EINVAL, "look-ahead depth must be -1 (auto), 0 (off) or 1 .. 8 sweeps");
+    CK(c, hipSetDevice(c->device));
+    // (buffers and batches in flight belong to the old depth)
+    int rc = mt_wait_batches(c);
+    if (rc) return rc;
+    for (auto &b : c->mt_b) {
+        b.launched = false;
+        if (b.u) { (void)hipFree(b.u); b.u = nullptr; }
+        if (b.host) { (void)hipHostFree(b.host); b.host = nullptr; }
+    }
+    if (c->mt_words_ahead) { (void)hipFree(c->mt_words_ahead); c->mt_words_ahead = nullptr; }
+    c->mt_cur = -1;
+    c->mt_ahead_on = sweeps != 0;
+    const int auto_depth = mt_depth_for(c->d.N);
+    c->mt_depth = sweeps <= 0 ? auto_depth : (c->d.N < 4096 ? 1 : sweeps);
+    return 0;
+}
+
+extern "C" int bgmm_get_mt_lookahead_stats(bgmm_ctx *c, int64_t *out2) {
+    if (!c || !out2) return BGMM_EINVAL;
+    out2[0] = c->mt_ahead_hits;
+    out2[1] = c->mt_ahead_misses;
     return 0;
 }
 
@@ -693,6 +870,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     d.use_certify = use_certify ? 1 : 0;
     // (a lean step looks at the whole sweep in storage order: not for a sweep that stops early)
     bool lean = use_certify && c->lean_ok && c->prune_mode != 2 && !partial;
+    // (certified stays off -- prune_mode 3 -- and the chain at rest: home_kernel between sweep_begin and apply, nothing else)
+    // (bgmm_set_home_pass(3) tries one in EVERY sweep: the refusal path under test)
+    bool short_step = use_prune && !use_certify && (c->short_ok || c->home_mode == 3) && c->prune_mode != 2 && !partial &&
+                      !c->tables_robust && c->resolver_mode == 0;
     hipStream_t st = c->stream;
     d.seat_dirty = 0;
     if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
@@ -932,8 +1113,11 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         }
         if (pmode != 2) lean = false;
         d.lean_step = lean ? 1 : 0;
-        d.publish = lean ? 1 : 0;
         d.use_home = (d.cov_type == COV_FULL && c->kind == KERNEL_MFMA && c->home_pass) ? 1 : 0;
+        if ((pmode != 2 && !(pmode == 1 && c->home_mode == 3)) || !first_batch || !d.use_home || lean) short_step = false;
+        d.short_step = short_step ? (d.order ? 2 : 1) : 0;
+        d.publish = (lean || short_step) ? 1 : 0;
+        if (short_step) T = 1;        // (one window is the whole sweep; a refused step is queued again in full)
         first_batch = false;
         d.prune_enabled = pmode;
         // (a forced batch cannot fall back to the dense kernels: keep it short while moves are seen)
@@ -942,6 +1126,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             // With pruning on, fresh windows are scored by the pruning kernel and the plain kernel
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
+            if (short_step) {
+                if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
+                if (d.short_step == 2) launch_bucket_rows(d, grid_rows, st);
+                launch_home(d, grid_rows, st);
+                if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
+                launch_apply(d, st);
+                continue;
+            }
             if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
             if (pmode >= 1 && !lean) launch_prune_tables(d, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
@@ -958,7 +1150,7 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             if (!lean) launch_refresh_ctrl(d, st);        // (a lean step moves nothing: apply refuses it otherwise)
         }
         CK(c, hipGetLastError());
-        if (lean) {
+        if (lean || short_step) {
             // (apply_kernel has left the control block in host memory: no copy in the queue)
             CK(c, hipStreamSynchronize(st));
             memcpy(c->ctrl_host, c->ctrl_pub, sizeof(Ctrl));
@@ -977,8 +1169,10 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
             }
         }
         steps_done = h.n_steps;
-        if (h.retry_full) {          // a lean step met something it could not certify: full steps from here on
-            lean = false;
+        if (short_step) { if (h.retry_full) c->short_refused += 1; else c->short_stood += 1; }
+        if (h.retry_full) {          // a lean step met something it could not certify (a short step: a mover, a visit
+            lean = false;            // home_kernel could not decide, stale tables): full steps from here on
+            short_step = false;
             c->ctrl_host->retry_full = 0;
             CK(c, hipMemcpy(&d.ctrl->retry_full, &c->ctrl_host->retry_full, sizeof(int), hipMemcpyHostToDevice));
         }
@@ -1003,11 +1197,13 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->safe_stats[5] = h.safe_L;
     // home_kernel pays while the table bound decides most visits (well separated components); when it had to
     // pass most of them on, the next sweep goes straight to the pruning kernel -- and tries again every 64th sweep
-    if (c->home_mode) c->home_pass = c->home_mode == 1;
+    if (c->home_mode) c->home_pass = c->home_mode != 2;
     else if (h.home_in > 0) c->home_pass = 2 * h.home_out < h.home_in;
     else if (!c->home_pass && (++c->home_retry & 63) == 0) c->home_pass = true;
     c->moves_prev = h.n_moves;
     c->lean_ok = use_certify && !partial && h.n_moves == 0 && h.n_certified == (unsigned long long)N;
+    c->short_ok = use_prune && !use_certify && !partial && h.n_moves == 0 && h.n_steps == 1 && h.n_windows == 1 &&
+                  h.home_in == (long long)N && h.home_out == 0;
     return check_device_error(c);
 }
 
@@ -1198,6 +1394,7 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
     }
     c->assigned = true;
     c->moves_prev = -1;          // (the state changed behind the sweeps' back: the next sweep's caches are cold)
+    c->short_ok = false;
     return rc;
 }
 
@@ -1230,6 +1427,7 @@ extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const dou
     }
     c->moves_prev = -1;
     c->lean_ok = false;
+    c->short_ok = false;
     return rc;
 }
 
@@ -1263,6 +1461,7 @@ extern "C" int bgmm_del_component(bgmm_ctx *c, int32_t k) {
     CK(c, hipStreamSynchronize(c->stream));
     c->moves_prev = -1;
     c->lean_ok = false;
+    c->short_ok = false;
     return 0;
 }
 
@@ -1284,6 +1483,7 @@ extern "C" int bgmm_set_label(bgmm_ctx *c, int64_t i, int32_t k) {
     CK(c, hipStreamSynchronize(c->stream));
     c->moves_prev = -1;
     c->lean_ok = false;
+    c->short_ok = false;
     return 0;
 }
 
@@ -1384,7 +1584,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
 }
 
 extern "C" int bgmm_set_home_pass(bgmm_ctx *c, int32_t mode) {
-    if (!c || mode < 0 || mode > 2) return BGMM_EINVAL;
+    if (!c || mode < 0 || mode > 3) return BGMM_EINVAL;
     c->home_mode = mode;
     c->home_pass = mode != 2;
     return 0;

@@ -239,6 +239,10 @@ struct Dev {
     int use_certify;             // 1: certify_kernel runs in front of the bucket sort (which then skips its rows)
     int lean_step;               // 1: this batch queues certify_kernel WITHOUT the pruning and draw kernels (the
                                  // previous sweep certified every visit); apply_kernel refuses the step otherwise
+    int short_step;              // 1 / 2: this batch queues home_kernel (2: with the bucket sort in front) and apply_kernel only
+                                 // -- no table, pruning or draw kernels: the previous sweep moved nothing and home_kernel decided
+                                 // every visit on its own.  Stands iff the tables and the sort are still valid, nothing is left
+                                 // on the residual list and nobody moves; apply_kernel refuses the step otherwise (retry_full)
     int publish;                 // 1: apply_kernel leaves a copy of the control block in host memory (ctrl_pub), so that
                                  // the host reads the outcome of a lean batch without a device-to-host copy in the queue
     Ctrl *ctrl_pub;              // host-pinned, device-mapped
@@ -368,5 +372,8 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();
 bool mt19937_jump_coefficients(int n_chains, std::vector<unsigned> &out);
+static constexpr int kMtMaxMids = 8;      // sweeps a look-ahead request of the uniform generator may span
+struct MtMids { long long nb[kMtMaxMids]; int pos[kMtMaxMids]; int m; };
 void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos_out, unsigned *words, double *u, long long n,
-                    int *zero_flag, const unsigned *coef_dev, int n_chains, unsigned *raw, unsigned *seeds, hipStream_t st);
+                    int *zero_flag, const unsigned *coef_dev, int n_chains, unsigned *raw, unsigned *seeds, hipStream_t st,
+                    int n_sweeps = 1, unsigned *key_mid = nullptr, int *pos_mid = nullptr);

@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune) || (d.safe_mode && c->safe_epoch_valid)) return;
+    // (a short step queued neither the table kernels nor -- short_step 1 -- the bucket sort: without them there is
+    // nothing sound to do here, and apply_kernel will refuse the step)
+    if (d.short_step && (!c->tables_valid || (d.short_step == 1 && !c->skip_sort))) return;
     constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, NJ8 = NJ * 2;
     constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS

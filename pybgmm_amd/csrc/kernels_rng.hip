@@ -34,14 +34,15 @@ __device__ __forceinline__ unsigned mt_twist(unsigned y0, unsigned y1) {
     return (y >> 1) ^ ((y1 & 1u) ? 0x9908b0dfu : 0u);
 }
 
-__global__ void mt19937_doubles_kernel(const unsigned *__restrict__ words, double *__restrict__ u, long long n,
+// (n_per: doubles per sweep of a request that spans several -- zero_flag[j] tells whether sweep j's hold an exact 0)
+__global__ void mt19937_doubles_kernel(const unsigned *__restrict__ words, double *__restrict__ u, long long n, long long n_per,
                                        int *__restrict__ zero_flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned a = words[2 * i] >> 5, b = words[2 * i + 1] >> 6;
     const double v = ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
     u[i] = v;
-    if (v == 0.0) atomicOr(zero_flag, 1);
+    if (v == 0.0) atomicOr(zero_flag + i / n_per, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -68,10 +69,14 @@ static constexpr int kJumpSplits = 16, kJumpTargets = 4; // coefficient range pe
 // chain `p` of a sweep: seed = block p * kChainBlocks of the stream (key_in for p = 0, a jumped state otherwise);
 // emits the blocks (p kChainBlocks, (p + 1) kChainBlocks] that the request [pos, E) reaches into -- chain 0 also what is
 // left of block 0 -- and, if the request ends in its range, the generator state the caller gets back.
+// `mids`: a request that spans several sweeps (the look-ahead, bgmm_api.hip) also wants the generator state at every
+// sweep boundary inside it: mids.nb[j] / mids.pos[j] = the block that boundary lies in and the position in it; the chain
+// that regenerates that block leaves it in key_mid[j] (blocks >= 1 only: such requests are long).
 __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__restrict__ key_in, const unsigned *__restrict__ seeds,
                                                             int p_first, int pos, long long E, unsigned *__restrict__ words,
                                                             unsigned *__restrict__ raw, unsigned *__restrict__ key_out,
-                                                            int *__restrict__ pos_out, unsigned *__restrict__ seed_next) {
+                                                            int *__restrict__ pos_out, unsigned *__restrict__ seed_next,
+                                                            MtMids mids, unsigned *__restrict__ key_mid, int *__restrict__ pos_mid) {
     __shared__ unsigned blk[2][624];
     const int tid = threadIdx.x;
     const int p = p_first + (int)blockIdx.x;
@@ -120,6 +125,13 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
                 raw[624 * b + l] = nA; raw[624 * b + l + 227] = nB;
                 if (has_c) raw[624 * b + l + 454] = nC;
             }
+            for (int j = 0; j < mids.m; ++j)
+                if (mids.nb[j] == b) {                       // (uniform: a sweep boundary lies in this block)
+                    unsigned *__restrict__ km = key_mid + (long long)j * 624;
+                    km[l] = nA; km[l + 227] = nB;
+                    if (has_c) km[l + 454] = nC;
+                    if (tid == 0) pos_mid[j] = mids.pos[j];
+                }
         }
         cur ^= 1;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (the LDS words only: global stores need not have landed)
@@ -158,7 +170,8 @@ __global__ __launch_bounds__(640) void mt19937_jump_kernel(const unsigned *__res
         for (int b = 0; b < 32; ++b) {
             const unsigned xv = xs[32 * c + b + w];
 #pragma unroll
-            for (int t = 0; t < kJumpTargets; ++t) acc[t] ^= xv & (0u - ((cw[t] >> b) & 1u));
+            for (int t = 0; t < kJumpTargets; ++t)          // acc ^= xv & mask in ONE v_bitop3_b32 (truth table a ^ (b & c)); the
+                acc[t] = __builtin_amdgcn_bitop3_b32(acc[t], xv, 0u - ((cw[t] >> b) & 1u), 0x78);   // mask is scalar (s_bfe_i32)
         }
     }
     if (w < 624) {
@@ -330,23 +343,36 @@ bool mt19937_jump_coefficients(int n_chains, std::vector<unsigned> &out) {
 // doubles.  coef_dev == nullptr (or a single chain): one workgroup walks the whole stream.  Otherwise the first chain
 // emits its blocks and the convolution's input (raw), the jump kernel seeds the other chains (seeds: zeroed here), and
 // they run side by side.  key_out / pos_out: where the advanced state is left (may not alias key_io).
+// n_sweeps > 1: the request is n_sweeps consecutive sweeps of n / n_sweeps doubles each; key_mid [n_sweeps][624] /
+// pos_mid [n_sweeps] receive the generator state behind each of them, zero_flag has n_sweeps entries.
 void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos_out, unsigned *words, double *u, long long n,
-                    int *zero_flag, const unsigned *coef_dev, int n_chains, unsigned *raw, unsigned *seeds, hipStream_t st) {
+                    int *zero_flag, const unsigned *coef_dev, int n_chains, unsigned *raw, unsigned *seeds, hipStream_t st,
+                    int n_sweeps, unsigned *key_mid, int *pos_mid) {
     const long long E = (long long)pos + 2 * n;
+    MtMids mids;
+    mids.m = 0;
+    const long long n_per = n_sweeps > 1 ? n / n_sweeps : n;
+    if (n_sweeps > 1 && key_mid && pos_mid)
+        for (int j = 0; j < n_sweeps && j < kMtMaxMids; ++j) {
+            const long long Ej = (long long)pos + 2 * n_per * (j + 1);
+            mids.nb[j] = (Ej - 1) / 624;
+            mids.pos[j] = (int)(Ej - 624 * mids.nb[j]);
+            mids.m = j + 1;
+        }
     if (!coef_dev || n_chains < 2) {
         // (one chain per launch, in stream order: each leaves the state the next one starts from)
         const int chains = mt19937_chains_for(pos, n);
         for (int p = 0; p < (chains > 1 ? chains : 1); ++p)
             hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, p, pos, E,
-                               words, (unsigned *)nullptr, key_out, pos_out, seeds);
+                               words, (unsigned *)nullptr, key_out, pos_out, seeds, mids, key_mid, pos_mid);
     } else {
         (void)hipMemsetAsync(seeds, 0, sizeof(unsigned) * 624 * (size_t)n_chains, st);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, 0, pos, E, words, raw,
-                           key_out, pos_out, (unsigned *)nullptr);
+                           key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid);
         hipLaunchKernelGGL(mt19937_jump_kernel, dim3(kJumpSplits, (unsigned)((n_chains - 1 + kJumpTargets - 1) / kJumpTargets)),
                            dim3(640), 0, st, raw, coef_dev, n_chains, seeds);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3((unsigned)(n_chains - 1)), dim3(256), 0, st, key_in, (const unsigned *)seeds, 1,
-                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr);
+                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid);
     }
-    hipLaunchKernelGGL(mt19937_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, u, n, zero_flag);
+    hipLaunchKernelGGL(mt19937_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, u, n, n_per, zero_flag);
 }

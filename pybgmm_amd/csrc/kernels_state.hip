@@ -731,6 +731,22 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             return;
         }
     }
+    if (d.short_step && c->job.mode != MODE_DONE) {
+        // only home_kernel (and maybe the bucket sort) ran: the step stands iff that was all the window needed
+        __shared__ int refuse;
+        if (threadIdx.x == 0) {
+            const bool ok = job_is_pruned(d, c->job.mode, c->job.prune) && c->tables_valid &&
+                            (d.short_step == 2 || c->skip_sort) && c->n_resid == 0 && c->first_mover == kNoMover;
+            refuse = ok ? 0 : 1;
+            if (refuse) { c->retry_full = 1; c->n_refresh = 0; c->n_resid = 0; c->first_mover = kNoMover; __threadfence(); }
+        }
+        __syncthreads();
+        if (refuse) {
+            for (int t = 0; t < 4; ++t) d.pr_counts[t * 256 + threadIdx.x] = 0;     // (its counts are discarded)
+            if (d.publish) publish_ctrl_block(d);
+            return;
+        }
+    }
     if (job_is_pruned(d, c->job.mode, c->job.prune) && !c->skip_apply) {
         // fold (and clear) the pruning kernel's spread counters of this window
         __shared__ unsigned long long cnt_red[4 * TPB];

@@ -1210,6 +1210,109 @@ def test_device_mt19937_jump_ahead_across_chains(N, burn):
     ctx.close()
 
 
+@pytest.mark.parametrize("pcrp", [False, True], ids=["crp", "pcrp-fresh-permutation"])
+def test_short_steps_of_the_benchmarked_mode(pcrp):
+    """prune_mode 3 (what bench.py times) on a chain at rest queues short steps: home_kernel between sweep_begin and apply
+    (bgmm_get_short_step_stats).  (i) On well-separated data they must come about by themselves and stand, and a change
+    made through the API must send the next sweep back to the full kernel set.  (ii) On overlapping data -- movers in most
+    sweeps, visits home_kernel cannot decide in all of them -- a short step is FORCED in front of every sweep
+    (bgmm_set_home_pass(3)) wherever the schedule opens with a pruned window: every one of them must be refused and redone
+    in full.  Every sweep of both chains against the C port of the reference."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    power = 1.01 if pcrp else None
+    # (i) N large enough for the host to queue pruned-only batches (four windows' worth of mover-free visits)
+    N, D, K = 20000, 64, 8
+    X, zt = gendata.synth_mixture(N, D, K, seed=13)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(2)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K, scipy_tables=False)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_tuning(prune_mode=3)
+    ctx.set_assignments(zt)
+    stood = []
+    for it in range(7):
+        if it == 3:                                  # a label changed behind the sweeps' back: no short step next
+            j = 4321
+            ctx.del_item(j); ctx.add_item(j, (int(zt[j]) + 1) % K)
+            z_mid = o.z.copy(); z_mid[j] = (int(zt[j]) + 1) % K
+            o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z_mid, 4 * K, scipy_tables=False)
+        u = rs.random_sample(N)
+        order = rs.permutation(N).astype(np.int64) if pcrp else None
+        ctx.sweep(u, order, power)
+        o.sweep(u, order, power)
+        npt.assert_array_equal(ctx.assignments(), o.z, err_msg="sweep %d" % it)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        stood.append(ctx.short_step_stats()["stood"])
+    # sweep 0 in full, 1 and 2 short, 3 (after the API change), 4 (after 3's move: shorter windows) and 5 (the first
+    # whole-sweep window again) in full, 6 short again
+    assert stood == [0, 1, 2, 2, 2, 2, 3] and ctx.short_step_stats()["refused"] == 0, (stood, ctx.short_step_stats())
+    ctx.close()
+    # (ii)
+    N, D, K = 20000, 16, 6
+    X, zt = gendata.synth_mixture(N, D, K, seed=21, mu_scale=1.4)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, zt, 4 * K, scipy_tables=False)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_tuning(prune_mode=3)
+    ctx.set_home_pass(3)
+    ctx.set_assignments(zt)
+    moves = 0
+    for it in range(6):
+        u = rs.random_sample(N)
+        order = rs.permutation(N).astype(np.int64) if pcrp else None
+        ctx.sweep(u, order, power)
+        o.sweep(u, order, power)
+        npt.assert_array_equal(ctx.assignments(), o.z, err_msg="forced short steps, sweep %d" % it)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        moves += ctx.sweep_stats()["moves"]
+    st = ctx.short_step_stats()
+    assert moves > 0, "the case is meant to have movers"
+    # (later sweeps of this chain open with safe-stay / frozen-factor windows, which have no short form: at least the
+    # first sweep's attempt must have been made and refused, and none may ever have stood)
+    assert st["refused"] >= 1 and st["stood"] == 0, st
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,D,depth", [(50000, 16, -1), (300000, 2, 3), (20000, 16, 1), (3000, 16, 4)])
+def test_device_mt19937_lookahead_serves_only_an_untouched_stream(N, D, depth):
+    """bgmm_set_mt_lookahead: the uniforms of the next `depth` sweeps (-1: chosen from N; N < 4096: always one) are generated
+    in one batch beside the running sweep and handed out sweep by sweep iff the caller's generator is exactly where the
+    previous call left it; while a batch's last sweep is served the next batch is started.  A chain with real sweeps between
+    the stage calls, with the caller drawing from its generator before some of them (those requests must NOT be served by
+    the look-ahead), against random.random() value for value, and label for label against the same chain with the
+    look-ahead switched off."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    X, zt = gendata.synth_mixture(N, D, 6, seed=3, mu_scale=1.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    out = []
+    for ahead in (depth, 0):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 48)
+        ctx.set_mt_lookahead(ahead)
+        ctx.set_assignments(zt)
+        host, dev = random.Random(7), random.Random(7)
+        foreign = (2, 9)                                   # sweeps in front of which the caller draws three numbers itself
+        for it in range(12):
+            if it in foreign:
+                assert [host.random() for _ in range(3)] == [dev.random() for _ in range(3)]
+            expect = _rng.take_uniforms(N, host)
+            assert _rng.stage_uniforms_on_device(ctx, None, dev)
+            npt.assert_array_equal(ctx.staged_uniforms(), expect)
+            assert dev.getstate() == host.getstate()
+            ctx.sweep_staged(None)
+        st = ctx.mt_lookahead_stats()
+        assert st == ({"hits": 9, "misses": 3} if ahead else {"hits": 0, "misses": 12}), st
+        out.append((ctx.assignments(), ctx.log_marg()))
+        ctx.close()
+    npt.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
+
+
 @pytest.mark.parametrize("cov", ["diag", "fixed"])
 @pytest.mark.parametrize("N", [1, 3, 64, 65, 700])
 def test_diag_fixed_edge_sizes_and_repeated_orders(cov, N):

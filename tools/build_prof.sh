@@ -1,5 +1,5 @@
 #!/bin/bash
-# libbgmm_hip_prof.so: the library with the phase clocks of home_kernel compiled in (tools/home_probe.py ... prof)
+# libbgmm_hip_prof.so: the library with the phase clocks of home_kernel compiled in (tools/probe.py chain N D K --prune 3 --prof)
 set -e
 cd "$(dirname "$0")/../pybgmm_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# libbgmm_hip_prof.so with the phase clocks of sweep_seq_kernel compiled in (tools/seq_probe.py prof)
+# libbgmm_hip_prof.so with the phase clocks of sweep_seq_kernel compiled in (tools/probe.py chain 100000 2 20 --prof)
 set -e
 cd "$(dirname "$0")/../pybgmm_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"

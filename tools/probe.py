@@ -15,6 +15,9 @@ Development probes of the HIP path, one script (run on a GPU box, e.g. through g
     python tools/probe.py safe-check                forced safe-stay windows against the C oracle on six small problems
     python tools/probe.py classes N D K [--profile] end-to-end cost of the user-facing classes (RNG, sweep, record dict)
     python tools/probe.py chains D G [N K]          G chains of one shape side by side on one device (ChainGroup) vs one
+    python tools/probe.py staged [N D K n]          a chain at rest, certified stays off, every sweep's uniforms continued on
+                                                    the device: us per stage + sweep, the stage call's share, look-ahead hits
+                                                    (under `rocprofv3 --kernel-trace` + tools/timeline.py: the GPU timeline)
     python tools/probe.py gather                    torch index_select of C4's rows: what a random row gather costs
 
 Replaces the round-1/2 scripts burnin_probe, c3_probe, cert_probe, gram_probe, home_probe, prune_probe,
@@ -191,6 +194,30 @@ def chains(a):
         grp.close()
 
 
+def staged(a):
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(a.N, a.D, a.K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(a.D)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * a.K)
+    ctx.set_tuning(prune_mode=3)
+    ctx.set_assignments(zt)
+    _, key_t, _ = random.Random(5).getstate()
+    key, pos = np.asarray(key_t[:-1], dtype=np.uint32), int(key_t[-1])
+    for it in range(20):
+        key, pos = ctx.stage_mt19937(key, pos, None); ctx.sweep_staged(None)
+    ctx.synchronize()
+    t0 = time.time(); ts = 0.0
+    for it in range(a.n):
+        t1 = time.time(); key, pos = ctx.stage_mt19937(key, pos, None); ts += time.time() - t1
+        ctx.sweep_staged(None)
+    ctx.synchronize()
+    print("stage + sweep: %.1f us per sweep, of which the stage call %.1f us" % ((time.time() - t0) / a.n * 1e6, ts / a.n * 1e6),
+          ctx.mt_lookahead_stats(), ctx.short_step_stats())
+    ctx.close()
+
+
 def gather():
     import torch
     N, D = 1000000, 64
@@ -236,6 +263,11 @@ def parser():
     g.add_argument("G", type=int)
     g.add_argument("N", type=int, nargs="?", default=100000)
     g.add_argument("K", type=int, nargs="?", default=20)
+    t = sub.add_parser("staged")
+    t.add_argument("N", type=int, nargs="?", default=1000000)
+    t.add_argument("D", type=int, nargs="?", default=64)
+    t.add_argument("K", type=int, nargs="?", default=200)
+    t.add_argument("n", type=int, nargs="?", default=300)
     sub.add_parser("gather")
     return ap
 
@@ -250,5 +282,7 @@ if __name__ == "__main__":
         classes(args)
     elif args.cmd == "chains":
         chains(args)
+    elif args.cmd == "staged":
+        staged(args)
     else:
         gather()
