@@ -161,6 +161,45 @@ def steady_moving_leg(args, local_rank):
             "sweeps": sweeps}
 
 
+def many_chains_leg(args, X, z0, local_rank, single_rate):
+    """Small dimensions: one sweep is one workgroup's chain of dependent draws, so a single chain leaves 255 of the 256
+    compute units idle.  `--chains` G independent chains of the workload on THIS GPU (chain c: its own generator, seed
+    + c, continued on the device), every round of sweeps one bgmm_group_sweep_staged call: aggregate sweeps/s against the
+    single chain of the headline."""
+    from pybgmm_amd.chains import ChainGroup
+    from pybgmm_amd.utils import gendata
+    N, D, K, model = WORKLOADS[args.workload]
+    G = args.chains
+    m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
+    t0 = time.time()
+    grp = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, max(4 * K, 64), n_chains=G, seed=7000 + args.seed, device=local_rank,
+                     cov_type=args.cov)
+    grp.set_assignments([z0] * G)
+    t_setup = time.time() - t0
+    rs = np.random.RandomState(7000 + args.seed)
+
+    def one_round(it):
+        orders = [rs.permutation(N).astype(np.int64) for _ in range(G)] if model == "PCRPMM" else None
+        grp.sweep(orders, [1.01 if (model == "PCRPMM" and it > 0) else None] * G)
+    for it in range(2):
+        one_round(it)
+    n = 8
+    t0 = time.time()
+    for it in range(2, 2 + n):
+        one_round(it)
+    dt = (time.time() - t0) / n
+    moves = [ctx.sweep_stats()["moves"] for ctx in grp.ctxs]
+    distinct = len({int(ctx.assignments()[:2000].sum()) for ctx in grp.ctxs[:8]})
+    grp.close()
+    return {"chains": G, "ms_per_round": round(1e3 * dt, 2), "aggregate_sweeps_per_s": round(G / dt, 2),
+            "single_chain_sweeps_per_s": round(single_rate, 3), "aggregate_over_single_chain": round(G / dt / single_rate, 1),
+            "moves_last_sweep_min_max": [int(min(moves)), int(max(moves))], "distinct_label_vectors_among_first_8": distinct,
+            "setup_s": round(t_setup, 2),
+            "how": "ChainGroup: G contexts on one device, uniforms from each chain's own MT19937 continued on the device, one "
+                   "bgmm_group_sweep_staged call per round (sweep_begin + sweep_seq for all chains in two launches: one workgroup "
+                   "= one compute unit per chain)"}
+
+
 def make_context(args, X, z0, local_rank, mode):
     from pybgmm_amd import _lib
     from pybgmm_amd.gaussian.gaussian_components import reference_tables
@@ -344,6 +383,8 @@ def main():
     ap.add_argument("--no-moving", action="store_true", help="skip the steady_moving leg (overlapping clusters)")
     ap.add_argument("--moving-sep", type=float, default=0.55, help="mu_scale of the steady_moving leg's data set")
     ap.add_argument("--numpy-visits", type=int, default=400, help="visits of the numpy-restatement CPU baseline (0 = skip)")
+    ap.add_argument("--chains", type=int, default=-1,
+                    help="chains of the many_chains leg, all on this GPU (-1: 256 -- one per compute unit -- for D <= 4, none otherwise; 0: skip)")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
@@ -593,6 +634,12 @@ def main():
     if single and not args.no_moving and args.cov == "full" and D >= 12:
         moving = steady_moving_leg(args, local_rank)
 
+    many = None
+    n_chains = args.chains if args.chains >= 0 else (256 if D <= 4 else 0)
+    if single and n_chains > 1:
+        args.chains = n_chains
+        many = many_chains_leg(args, X, z0, local_rank, args.steps / elapsed)
+
     cpu = None
     if single and args.cpu_visits > 0:
         per_visit, n_cpu, t_init, cpu_lik = cpu_baseline(D, K, args.seed + 7, args.cpu_visits, args.cov)
@@ -645,6 +692,7 @@ def main():
             "roofline": roofline,
             "burnin": burnin,
             "steady_moving": moving,
+            "many_chains": many,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
                       "K_final": K_final, "log_marg_rank0": log_marg,

@@ -96,6 +96,19 @@ BGMM_API int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const 
 BGMM_API int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
 
 /*
+ * Many chains per GPU (SURVEY.md section 5 `chains=`; 8e: chains are replicas, they exchange nothing).  The staged sweeps of
+ * n contexts that live on one device, side by side: what bgmm_sweep_staged(ctxs[i], use_power[i], power[i]) would do for
+ * each, with the same trajectories -- but the chains that can take the one-workgroup sweep of small dimensions (D <= 4, full
+ * covariance, automatic tuning, a permutation as visiting order, labels within the LDS plan) are opened and swept by TWO
+ * launches for all of them, one workgroup and one compute unit per chain, where separate calls pay two launches and a host
+ * round trip per chain and leave 255 of the 256 compute units idle.  Every other chain of the group is swept on its own.
+ * use_power / power may be NULL (plain CRP weights).  rc_out[i] = the status of chain i; returns the first failure, or 0.
+ * Contexts are not thread-safe: the group call is the one host thread working on all of them.
+ */
+BGMM_API int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const int32_t *use_power, const double *power,
+                                     int32_t *rc_out);
+
+/*
  * The sweep's uniforms continued ON THE DEVICE from the caller's Mersenne Twister: replaces the
  * N calls of random.random() (utils/utils.py:13-16) plus the upload.  key624 / pos are the 624 state
  * words and the position of random.getstate()[1]; on return they hold the state N calls of

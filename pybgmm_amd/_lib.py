@@ -39,6 +39,7 @@ SIGNATURES = {
     "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
     "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
+    "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
     "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
     "bgmm_sweep_resident": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     "bgmm_log_marg": (ctypes.c_int, [_vp, _f64]),
@@ -394,6 +395,24 @@ class Context(object):
 
     def synchronize(self):
         self._ck(self.L.bgmm_synchronize(self.h))
+
+
+def group_sweep_staged(ctxs, powers=None):
+    """``bgmm_group_sweep_staged``: the staged sweeps of several contexts of ONE device side by side (small-D chains: one
+    workgroup each, two launches for all).  ``powers[i]``: chain i's pCRP exponent or None.  Raises for the first
+    chain that failed."""
+    n = len(ctxs)
+    L = ctxs[0].L
+    handles = (_vp * n)(*[c.h for c in ctxs])
+    powers = [None] * n if powers is None else list(powers)
+    up = np.array([0 if p is None else 1 for p in powers], dtype=np.int32)
+    pw = np.array([1.0 if p is None else float(p) for p in powers], dtype=np.float64)
+    rcs = np.zeros(n, dtype=np.int32)
+    rc_all = L.bgmm_group_sweep_staged(handles, n, _ptr(up), _ptr(pw), _ptr(rcs))
+    for c, rc in zip(ctxs, rcs):
+        c._ck(int(rc))
+    if rc_all != 0:                     # (refused as a whole: e.g. a context twice in the group)
+        raise BGMMError(rc_all, "; ".join(filter(None, ((L.bgmm_last_error(c.h) or b"").decode() for c in ctxs))) or "group sweep refused")
 
 
 class Comm(object):

@@ -7,8 +7,15 @@ shard; the multi-GPU mode runs G independent chains, chain c on GPU c with seeds
 final labels (int64[N] per chain) and the per-sweep log marginals.  With
 ``torch.distributed`` backend "nccl" that collective is RCCL over xGMI; the CPU
 tests run the identical code over "gloo".
+
+Many chains on ONE GPU (``chains=``): at small dimensions a sweep is one workgroup's chain of
+dependent draws (kernels_seq.hip) and a GPU has 256 compute units.  ``ChainGroup`` keeps G contexts on one device and
+sweeps them side by side through ``bgmm_group_sweep_staged`` (two launches for all of them); ``run_chains_on_device``
+does the same for G model objects (CRPMM / PCRPMM / ADAPCRPMM), each with its own seeded generators, whose sampler
+loops run in lockstep.  Chain c is label for label the chain a solo run with seed ``seed + c`` produces.
 """
 import random
+import threading
 
 import numpy as np
 
@@ -71,3 +78,113 @@ def run_chain(model_cls, X, prior, alpha, n_iter, seed, rank, device_index, true
     record, _ = model.collapsed_gibbs_sampler(n_iter, true_assignments, num_saved=0,
                                               **(sampler_kwargs or {}))
     return model, record
+
+
+class ChainGroup(object):
+    """G chains of one data set on one device at the C-ABI level: contexts, per-chain ``random.Random(seed + c)`` whose
+    streams the device continues (``bgmm_stage_mt19937``), sweeps side by side."""
+
+    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, n_chains, seed=0, device=0, cov_type="full"):
+        from . import _lib
+        self._lib = _lib
+        self.ctxs = [_lib.Context(X, m_0, k_0, v_0, S_0, alpha, K_max, device=device, cov_type=cov_type)
+                     for _ in range(int(n_chains))]
+        self.rngs = [random.Random(seed + c) for c in range(int(n_chains))]
+        self._keys = []
+        for r in self.rngs:
+            _, key, _ = r.getstate()
+            self._keys.append([np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
+
+    def set_assignments(self, zs):
+        for ctx, z in zip(self.ctxs, zs):
+            ctx.set_assignments(z)
+
+    def sweep(self, orders=None, powers=None):
+        """One sweep of every chain: chain c's uniforms are the next N values of its generator."""
+        for c, ctx in enumerate(self.ctxs):
+            key, pos = ctx.stage_mt19937(self._keys[c][0], self._keys[c][1], None if orders is None else orders[c])
+            self._keys[c] = [key, pos]
+        self._lib.group_sweep_staged(self.ctxs, powers)
+
+    def sync_rngs(self):
+        """Writes the generator states the device has reached back into ``self.rngs``."""
+        for r, (key, pos) in zip(self.rngs, self._keys):
+            version, _, gauss = r.getstate()
+            r.setstate((version, tuple(key.tolist()) + (int(pos),), gauss))
+
+    def assignments(self):
+        return np.stack([ctx.assignments() for ctx in self.ctxs])
+
+    def close(self):
+        for ctx in self.ctxs:
+            ctx.close()
+        self.ctxs = []
+
+
+class _Lockstep(object):
+    """Rendezvous of G sampler loops: every chain stages its own sweep inputs, the last one to arrive sweeps the whole
+    group, all of them carry on.  A chain that fails breaks the barrier so that nobody waits for it."""
+
+    def __init__(self, models):
+        from . import _lib
+        self._lib = _lib
+        self.models = list(models)
+        self.powers = [None] * len(self.models)
+        self.error = None
+        self.barrier = threading.Barrier(len(self.models), action=self._sweep_all)
+
+    def _sweep_all(self):
+        try:
+            self._lib.group_sweep_staged([m.components._ctx for m in self.models], self.powers)
+        except Exception as e:          # (raised again in every chain's thread below)
+            self.error = e
+
+    def sweep(self, model, power):
+        self.powers[self.models.index(model)] = power
+        self.barrier.wait()
+        if self.error is not None:
+            raise self.error
+
+    def leave(self):
+        self.barrier.abort()
+
+
+def run_chains_on_device(model_cls, X, prior, alpha, n_chains, n_iter, seed=0, device_index=0, true_assignments=None,
+                         assignments="rand", K=1, K_max=None, covariance_type="full", sampler_kwargs=None):
+    """
+    ``n_chains`` independent chains of ``model_cls`` on ONE GPU, chain c seeded ``seed + c`` (its own ``random.Random``
+    and ``RandomState``: the streams a solo run under ``random.seed(seed + c); np.random.seed(seed + c)`` consumes),
+    their ``collapsed_gibbs_sampler`` loops in lockstep so that every round of sweeps is one group call
+    (``bgmm_group_sweep_staged``).  Returns ``[(model, record_dict), ...]``; ``record_dict["sample_time"]`` of a chain is
+    the time of the ROUND it took part in.  Worth it where a sweep cannot fill the GPU on its own: D <= 4.
+    """
+    models = []
+    for c in range(int(n_chains)):
+        rng, nprng = chain_rngs(seed, c)
+        models.append(model_cls(X, prior, alpha, None, assignments=assignments, K=K, K_max=K_max,
+                                covariance_type=covariance_type, device=device_index, rng=rng, nprng=nprng))
+    step = _Lockstep(models)
+    out = [None] * len(models)
+    errors = []
+
+    def work(c):
+        m = models[c]
+        m._lockstep = step
+        try:
+            rec, _ = m.collapsed_gibbs_sampler(n_iter, true_assignments, num_saved=0, **(sampler_kwargs or {}))
+            out[c] = (m, rec)
+        except threading.BrokenBarrierError:
+            pass                        # (another chain failed: its error is the one reported)
+        except Exception as e:
+            errors.append(e)
+            step.leave()
+        finally:
+            m._lockstep = None
+    threads = [threading.Thread(target=work, args=(c,)) for c in range(len(models))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out

@@ -80,6 +80,9 @@ struct bgmm_ctx {
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
+    int grp_cap = 0;                 // bgmm_group_sweep_staged: the LDS plan phase 1 of sweep_impl chose for the one-workgroup sweep
+    Dev *grp_devs = nullptr;         // device array of the chains' views (owned by the chain that leads a group launch)
+    int grp_devs_cap = 0;
     long long short_stood = 0, short_refused = 0;   // short steps over the life of the context (bgmm_get_short_step_stats)
     bool short_ok = false;           // the previous sweep (certified stays off) was ONE pruned window, moved nothing and
                                      // home_kernel decided every visit: the next one tries a short step (Dev::short_step)
@@ -233,6 +236,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
         if (b.host) (void)hipHostFree(b.host);
     }
     if (c->mt_words_ahead) (void)hipFree(c->mt_words_ahead);
+    if (c->grp_devs) (void)hipFree(c->grp_devs);
     if (c->mt_words) (void)hipFree(c->mt_words);
     if (c->mt_coef) (void)hipFree(c->mt_coef);
     if (c->mt_seeds) (void)hipFree(c->mt_seeds);
@@ -847,19 +851,25 @@ static int ensure_events(bgmm_ctx *c, size_t n) {
     return 0;
 }
 
-extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
+// One sweep.  phase 0: all of it.  Phases 1 and 2 split it for bgmm_group_sweep_staged, which opens the sweeps of several
+// chains and runs their one-workgroup sweeps (kernels_seq.hip) in ONE launch each: phase 1 = everything in front of
+// sweep_begin; returns 1 if the chain can take the one-workgroup sweep (bgmm_ctx::grp_cap = its LDS plan; the caller
+// launches, fills ctrl_host and comes back with phase 2), otherwise carries on as phase 0.  Phase 2 = what follows.
+static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     if (!c) return BGMM_EINVAL;
     if (!c->assigned) return fail(c, BGMM_EINVAL, "bgmm_set_assignments has not been called");
     CK(c, hipSetDevice(c->device));
     Dev &d = c->d;
-    d.use_power = use_power ? 1 : 0;
-    d.power = use_power ? power : 1.0;
-    if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
-    d.u = c->cur_u;
-    d.order = c->cur_order;
-    d.sweep_visits = c->next_sweep_visits;
+    if (phase != 2) {
+        d.use_power = use_power ? 1 : 0;
+        d.power = use_power ? power : 1.0;
+        if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
+        d.u = c->cur_u;
+        d.order = c->cur_order;
+        d.sweep_visits = c->next_sweep_visits;
+        c->next_sweep_visits = 0;
+    }
     const bool partial = d.sweep_visits > 0 && d.sweep_visits < d.N;
-    c->next_sweep_visits = 0;
     resolve_kind(c);
     const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
@@ -875,12 +885,14 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     bool short_step = use_prune && !use_certify && (c->short_ok || c->home_mode == 3) && c->prune_mode != 2 && !partial &&
                       !c->tables_robust && c->resolver_mode == 0;
     hipStream_t st = c->stream;
-    d.seat_dirty = 0;
-    if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
-        d.seat_dirty = 1;
-        launch_build_seat_table(d, c->tabSeat, st);
-        c->seat_use_power = d.use_power;
-        c->seat_power = d.power;
+    if (phase != 2) {
+        d.seat_dirty = 0;
+        if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
+            d.seat_dirty = 1;
+            launch_build_seat_table(d, c->tabSeat, st);
+            c->seat_use_power = d.use_power;
+            c->seat_power = d.power;
+        }
     }
     // Launch grids follow the window scale: sized for twice the device's current window (at least
     // 4096 rows, at most the allocation), never below the window that is already open.
@@ -891,29 +903,41 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
         if (r > c->win_rows) r = c->win_rows;
         return (int)r;
     };
-    d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
-    if (c->moves_prev != 0 && d.cov_type == COV_FULL && use_prune)
-        launch_refresh_stale(d, c->ctrl_host->job.K, st);   // (tight bounds again after a sweep with moves)
-    launch_sweep_begin(d, st);
-    long long steps_done = 0;
-    // Tiny dimensions: one wavefront walks the visits in order with the labels' state in LDS
+    if (phase != 2) {
+        d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
+        if (c->moves_prev != 0 && d.cov_type == COV_FULL && use_prune)
+            launch_refresh_stale(d, c->ctrl_host->job.K, st);   // (tight bounds again after a sweep with moves)
+    }
+    // Tiny dimensions: one workgroup walks the visits in order with the labels' state in LDS
     // (kernels_seq.hip: sweep_seq_kernel).  It leaves the sweep DONE, or -- when the labels outgrow
     // its LDS plan -- a window open at the visit it stopped at, and the loop below carries on.
-    bool seq_ran = false;
-    if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
-        c->order_is_perm) {
+    int seq_plan = 0;                      // labels the one-workgroup sweep would plan LDS for (0: not for this sweep)
+    if (phase == 2) {
+        seq_plan = c->grp_cap;
+    } else if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
+               c->order_is_perm) {
         int cap = 2;
         while (sweep_seq_lds_bytes(d.D, cap + 16) <= 150 * 1024) cap += 16;
         if (c->seq_cap >= 2 && c->seq_cap < cap) cap = c->seq_cap;     // (bgmm_set_seq_plan)
         if (cap > d.K_max + 1) cap = d.K_max + 1;
-        if (c->ctrl_host->job.K + 1 <= cap) {
-            if (!launch_sweep_seq(d, cap, st)) return fail(c, BGMM_EDEVICE, "sequential sweep kernel launch failed");
+        if (c->ctrl_host->job.K + 1 <= cap) seq_plan = cap;
+    }
+    if (phase == 1 && seq_plan > 0) {
+        c->grp_cap = seq_plan;
+        return 1;
+    }
+    if (phase != 2) launch_sweep_begin(d, st);
+    long long steps_done = 0;
+    bool seq_ran = false;
+    if (seq_plan > 0) {
+        if (phase != 2) {
+            if (!launch_sweep_seq(d, seq_plan, st)) return fail(c, BGMM_EDEVICE, "sequential sweep kernel launch failed");
             CK(c, hipGetLastError());
             int rc = fetch_ctrl(c);
             if (rc) return rc;
-            seq_ran = true;
-            steps_done = c->ctrl_host->n_steps;
         }
+        seq_ran = true;
+        steps_done = c->ctrl_host->n_steps;
     }
     // Steps are queued blindly; a step issued after the sweep is DONE is a (cheap) no-op.
     // Lower bound on the steps still needed: one per remaining window.  On top of that,
@@ -1205,6 +1229,84 @@ extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) {
     c->short_ok = use_prune && !use_certify && !partial && h.n_moves == 0 && h.n_steps == 1 && h.n_windows == 1 &&
                   h.home_in == (long long)N && h.home_out == 0;
     return check_device_error(c);
+}
+
+extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) { return sweep_impl(c, use_power, power, 0); }
+
+// Sweeps of several chains that live on ONE device, side by side.  Chains that can take the one-workgroup sweep (D <= 4,
+// full covariance, automatic tuning, labels within the LDS plan) are opened and swept by two launches for all of them
+// -- one workgroup, one compute unit per chain -- instead of two launches and a host round trip each; every other chain
+// is swept on its own as bgmm_sweep_staged would.  Same trajectories as separate calls.
+extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const int32_t *use_power, const double *power,
+                                       int32_t *rc_out) {
+    if (!ctxs || n < 1 || !rc_out) return BGMM_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return BGMM_EINVAL;
+        rc_out[i] = 0;
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctxs[i], BGMM_EINVAL, "a context appears twice in the group");
+    }
+    std::vector<int> deferred;
+    int worst = 0;
+    for (int i = 0; i < n; ++i) {
+        const int up = use_power ? use_power[i] : 0;
+        const int rc = sweep_impl(ctxs[i], up, (up && power) ? power[i] : 1.0, 1);
+        if (rc == 1) deferred.push_back(i);
+        else { rc_out[i] = rc; if (rc < 0 && worst == 0) worst = rc; }
+    }
+    // one pair of launches per (device, D, LDS plan) among the chains that wait
+    std::vector<char> done(deferred.size(), 0);
+    for (size_t a = 0; a < deferred.size(); ++a) {
+        if (done[a]) continue;
+        bgmm_ctx *lead = ctxs[deferred[a]];
+        std::vector<int> grp;
+        for (size_t b = a; b < deferred.size(); ++b) {
+            bgmm_ctx *o = ctxs[deferred[b]];
+            if (!done[b] && o->device == lead->device && o->d.D == lead->d.D && o->grp_cap == lead->grp_cap) {
+                grp.push_back(deferred[b]);
+                done[b] = 1;
+            }
+        }
+        const int m = (int)grp.size();
+        hipError_t e = hipSetDevice(lead->device);
+        if (e == hipSuccess && lead->grp_devs_cap < m) {
+            if (lead->grp_devs) (void)hipFree(lead->grp_devs);
+            lead->grp_devs = nullptr; lead->grp_devs_cap = 0;
+            e = hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m);
+            if (e == hipSuccess) lead->grp_devs_cap = m;
+        }
+        std::vector<Dev> views((size_t)m);
+        for (int k = 0; k < m && e == hipSuccess; ++k) {
+            views[(size_t)k] = ctxs[grp[(size_t)k]]->d;
+            // (what phase 1 queued on the chain's own stream -- a new seating table, stale factors rebuilt -- has to be there)
+            e = hipStreamSynchronize(ctxs[grp[(size_t)k]]->stream);
+        }
+        hipStream_t st = lead->stream;
+        if (e == hipSuccess) e = hipMemcpyAsync(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            launch_sweep_begin(lead->d, st, lead->grp_devs, m);
+            if (!launch_sweep_seq(lead->d, lead->grp_cap, st, lead->grp_devs, m)) e = hipErrorLaunchFailure;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        for (int k = 0; k < m && e == hipSuccess; ++k) {
+            bgmm_ctx *o = ctxs[grp[(size_t)k]];
+            e = hipMemcpyAsync(o->ctrl_host, o->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);      // (views is pageable: the copy above has been staged by now)
+        for (int k = 0; k < m; ++k) {
+            bgmm_ctx *o = ctxs[grp[(size_t)k]];
+            int rc;
+            if (e != hipSuccess) {
+                o->err = std::string("group sweep: ") + hipGetErrorString(e);
+                rc = BGMM_EDEVICE;
+            } else {
+                rc = sweep_impl(o, o->d.use_power, o->d.power, 2);
+            }
+            rc_out[grp[(size_t)k]] = rc;
+            if (rc < 0 && worst == 0) worst = rc;
+        }
+    }
+    return worst;
 }
 
 extern "C" int bgmm_sweep_resident(bgmm_ctx *c, int32_t index, int32_t use_power, double power) {

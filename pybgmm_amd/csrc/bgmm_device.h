@@ -335,10 +335,10 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
                        hipStream_t st);
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st);  // explicit slots
 void launch_refresh_ctrl(const Dev &d, hipStream_t st);                          // ctrl->refresh[]
-bool launch_sweep_seq(const Dev &d, int cap, hipStream_t st);                    // D <= 4: one wave, visit by visit
+bool launch_sweep_seq(const Dev &d, int cap, hipStream_t st, const Dev *group = nullptr, int n_group = 0);                    // D <= 4: one wave, visit by visit
 int sweep_seq_lds_bytes(int D, int cap);
 void launch_refresh_stale(const Dev &d, int K, hipStream_t st);                  // live slots with rank-1 steps
-void launch_sweep_begin(const Dev &d, hipStream_t st);
+void launch_sweep_begin(const Dev &d, hipStream_t st, const Dev *group = nullptr, int n_group = 0);
 void launch_build_tables(const Dev &d, double *tabG, double *tabLogC, hipStream_t st);
 void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st);
 void launch_apply(const Dev &d, hipStream_t st);

@@ -213,7 +213,7 @@ int sweep_seq_lds_bytes(int D, int cap) {
 }
 
 template <int DD>
-__global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int cap) {
+__device__ __forceinline__ void sweep_seq_body(const Dev &d, int cap) {
     using Ly = SeqLayout<DD>;
     constexpr int T = Ly::T, NS = DD + T;               // NS: statistics per label (m, packed S)
     constexpr int NW = kSeqWaves, RING = kSeqRing, NT = 64 * NW;
@@ -625,7 +625,24 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int ca
 #undef PF
 
 template <int DD>
-static hipError_t launch_seq_t(const Dev &d, int cap, int lds, hipStream_t st) {
+__global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_kernel(Dev d, int cap) { sweep_seq_body<DD>(d, cap); }
+
+// Several chains in one launch (bgmm_group_sweep_staged): workgroup b runs the whole sweep of the chain whose device view
+// is group[b] -- every chain's labels in its own workgroup's LDS, one compute unit each.
+template <int DD>
+__global__ __launch_bounds__(64 * kSeqWaves) void sweep_seq_group_kernel(const Dev *__restrict__ group, int cap) {
+    const Dev d = group[blockIdx.x];
+    sweep_seq_body<DD>(d, cap);
+}
+
+template <int DD>
+static hipError_t launch_seq_t(const Dev &d, int cap, int lds, hipStream_t st, const Dev *group, int n_group) {
+    if (group) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_seq_group_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sweep_seq_group_kernel<DD>, dim3((unsigned)n_group), dim3(64 * kSeqWaves), lds, st, group, cap);
+        return hipSuccess;
+    }
     hipError_t e = hipFuncSetAttribute((const void *)sweep_seq_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sweep_seq_kernel<DD>, dim3(1), dim3(64 * kSeqWaves), lds, st, d, cap);
@@ -633,13 +650,14 @@ static hipError_t launch_seq_t(const Dev &d, int cap, int lds, hipStream_t st) {
 }
 
 // cap: labels (plus the next free slot) the LDS plan holds.  Returns false when D is out of range.
-bool launch_sweep_seq(const Dev &d, int cap, hipStream_t st) {
+// group / n_group: device array of the chains' views, one workgroup each (all of dimension d.D, all planned for `cap`).
+bool launch_sweep_seq(const Dev &d, int cap, hipStream_t st, const Dev *group, int n_group) {
     const int lds = sweep_seq_lds_bytes(d.D, cap);
     switch (d.D) {
-        case 1: return launch_seq_t<1>(d, cap, lds, st) == hipSuccess;
-        case 2: return launch_seq_t<2>(d, cap, lds, st) == hipSuccess;
-        case 3: return launch_seq_t<3>(d, cap, lds, st) == hipSuccess;
-        case 4: return launch_seq_t<4>(d, cap, lds, st) == hipSuccess;
+        case 1: return launch_seq_t<1>(d, cap, lds, st, group, n_group) == hipSuccess;
+        case 2: return launch_seq_t<2>(d, cap, lds, st, group, n_group) == hipSuccess;
+        case 3: return launch_seq_t<3>(d, cap, lds, st, group, n_group) == hipSuccess;
+        case 4: return launch_seq_t<4>(d, cap, lds, st, group, n_group) == hipSuccess;
         default: return false;
     }
 }

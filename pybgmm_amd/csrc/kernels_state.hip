@@ -303,7 +303,7 @@ void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st) {
     hipLaunchKernelGGL(build_seat_table_kernel, dim3((unsigned)((d.N + 2 + 255) / 256)), dim3(256), 0, st, d, tabSeat);
 }
 
-__global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
+__device__ __forceinline__ void sweep_begin_body(const Dev &d) {
     Ctrl *c = d.ctrl;
     const int K = c->job.K;
     // seating weights depend on the sweep's exponent (tabSeat was rebuilt by the host if it changed)
@@ -336,6 +336,13 @@ __global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) {
         if (c->error == 0) start_window(d, c, 0);
         else c->job.mode = MODE_DONE;
     }
+}
+
+__global__ __launch_bounds__(TPB) void sweep_begin_kernel(Dev d) { sweep_begin_body(d); }
+// (several chains in one launch: workgroup b opens the sweep of chain group[b] -- bgmm_group_sweep_staged)
+__global__ __launch_bounds__(TPB) void sweep_begin_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.x];
+    sweep_begin_body(d);
 }
 
 // Evaluation order of a pruned window: its visits grouped by home component -- a counting sort
@@ -553,8 +560,9 @@ void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 2 * nb * (int)sizeof(int), st, d);
 }
 
-void launch_sweep_begin(const Dev &d, hipStream_t st) {
-    hipLaunchKernelGGL(sweep_begin_kernel, dim3(1), dim3(TPB), 0, st, d);
+void launch_sweep_begin(const Dev &d, hipStream_t st, const Dev *group, int n_group) {
+    if (group) hipLaunchKernelGGL(sweep_begin_group_kernel, dim3((unsigned)n_group), dim3(TPB), 0, st, group);
+    else hipLaunchKernelGGL(sweep_begin_kernel, dim3(1), dim3(TPB), 0, st, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -730,6 +738,11 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
             if (d.publish) publish_ctrl_block(d);
             return;
         }
+    }
+    if (d.short_step == 2) {
+        // (the bucket sort of this step has left its offsets in the bins, and the draw kernel that clears them for the next
+        // sort was not queued)
+        for (int b = threadIdx.x; b < d.nslots + 2; b += TPB) d.bucket_bins[b] = 0;
     }
     if (d.short_step && c->job.mode != MODE_DONE) {
         // only home_kernel (and maybe the bucket sort) ran: the step stands iff that was all the window needed

@@ -128,7 +128,11 @@ class IGMM(GMM):
     def _sweep(self, order=None, power=None):
         """One device sweep fed from the caller's random streams."""
         ctx = self.components._ctx
-        if _rng.stage_uniforms_on_device(ctx, order, self._rng):     # the caller's stream, continued on the GPU
-            ctx.sweep_staged(power)
+        staged = _rng.stage_uniforms_on_device(ctx, order, self._rng)   # the caller's stream, continued on the GPU
+        if not staged:
+            ctx.stage(_rng.take_uniforms(self.N, self._rng), order)
+        step = getattr(self, "_lockstep", None)
+        if step is not None:            # one of several chains on this device (chains.run_chains_on_device)
+            step.sweep(self, power)
         else:
-            ctx.sweep(_rng.take_uniforms(self.N, self._rng), order, power)
+            ctx.sweep_staged(power)

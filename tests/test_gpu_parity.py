@@ -1714,6 +1714,78 @@ def test_chain_c_equals_a_global_seed_run(model):
     npt.assert_array_equal(np.stack(zs), np.stack([Z[0], zs[1]]))
 
 
+def test_group_sweep_equals_separate_sweeps():
+    """bgmm_group_sweep_staged (many chains per GPU): chains that take the one-workgroup sweep go through ONE pair of
+    launches, the others (here: D = 16, and a D = 2 chain pinned to the windowed kernels) are swept on their own -- every
+    chain label for label what separate bgmm_sweep_staged calls on a twin context give, from the same seeds.  One of the
+    small chains gets a tiny LDS plan, so that its group sweep is handed over to the windowed kernels half way."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    shapes = [(20000, 2, 20, 0), (20000, 2, 20, 0), (9000, 3, 8, 0), (6000, 16, 6, 0), (20000, 2, 20, 1), (20000, 2, 20, 2),
+              (20000, 2, 20, 0)]                             # (N, D, K, variant: 1 = forced VALU kernels, 2 = tiny LDS plan)
+    data = {}
+    for (N, D, K, _) in shapes:
+        if (N, D, K) not in data:
+            data[(N, D, K)] = gendata.synth_mixture(N, D, K, seed=N % 97 + D) + gendata.demo_prior_params(D)
+
+    def build():
+        out = []
+        for c, (N, D, K, var) in enumerate(shapes):
+            X, zt, m_0, k_0, v_0, S_0 = data[(N, D, K)]
+            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12 * K)
+            if var == 1:
+                ctx.set_tuning(kernel_kind=1)
+            if var == 2:
+                ctx.set_seq_plan(K + 3)
+            z0 = np.unique(np.random.RandomState(c).randint(0, K, N), return_inverse=True)[1] if c % 2 else zt
+            ctx.set_assignments(z0)
+            _, key, _ = random.Random(100 + c).getstate()
+            out.append([ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
+        return out
+    grouped, solo = build(), build()
+    rs = np.random.RandomState(9)
+    for it in range(4):
+        orders = [rs.permutation(sh[0]).astype(np.int64) if (it % 2 and c % 3 == 0) else None for c, sh in enumerate(shapes)]
+        powers = [1.02 if (it >= 2 and c % 2 == 0) else None for c in range(len(shapes))]
+        for chains_ in (grouped, solo):
+            for c, ch in enumerate(chains_):
+                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], orders[c])
+        _lib.group_sweep_staged([ch[0] for ch in grouped], powers)
+        for c, ch in enumerate(solo):
+            ch[0].sweep_staged(powers[c])
+        for c in range(len(shapes)):
+            npt.assert_array_equal(grouped[c][0].assignments(), solo[c][0].assignments(), err_msg="sweep %d chain %d" % (it, c))
+            assert grouped[c][0].log_marg() == solo[c][0].log_marg()
+            assert grouped[c][0].sweep_stats() == solo[c][0].sweep_stats()
+    assert not np.array_equal(grouped[0][0].assignments(), grouped[1][0].assignments()), "chains with different seeds must differ"
+    with pytest.raises(_lib.BGMMError):                     # (a context twice in one group)
+        _lib.group_sweep_staged([grouped[0][0], grouped[0][0]])
+    for ch in grouped + solo:
+        ch[0].close()
+
+
+@pytest.mark.parametrize("model", ["CRPMM", "PCRPMM"])
+def test_run_chains_on_device_equals_solo_runs(model):
+    """chains.run_chains_on_device: G model objects on one GPU, their sampler loops in lockstep, every round of sweeps one
+    group call.  Chain c is the chain a solo run with seed s + c gives: labels, K per sweep, log marginals."""
+    from pybgmm_amd import chains
+    from pybgmm_amd.igmm import CRPMM, PCRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    N, D, K, s, n_iter, G = 4000, 2, 6, 11, 4, 5
+    X, zt = gendata.synth_mixture(N, D, K, seed=3, mu_scale=2.0)
+    prior = NIW(*gendata.demo_prior_params(D))
+    runs = chains.run_chains_on_device(cls, X, prior, 1.0, G, n_iter, seed=s, true_assignments=zt, K=K, K_max=80)
+    for c in range(G):
+        m_solo, rec_solo = chains.run_chain(cls, X, prior, 1.0, n_iter, s, c, 0, true_assignments=zt, K=K, K_max=80)
+        npt.assert_array_equal(runs[c][0].components.assignments, m_solo.components.assignments)
+        npt.assert_array_equal(np.array(runs[c][1]["components"]), np.array(rec_solo["components"]))
+        npt.assert_array_equal(np.array(runs[c][1]["log_marg"]), np.array(rec_solo["log_marg"]))
+    assert not np.array_equal(runs[0][0].components.assignments, runs[1][0].components.assignments)
+
+
 def test_label_gather_through_the_c_abi():
     """bgmm_comm_* + bgmm_gather_labels (RCCL all-gather of the final labels).  One GPU here, so a
     communicator of one rank: the gathered stack is the chain's own labelling (unassigned points as -1)."""
