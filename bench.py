@@ -135,11 +135,19 @@ def steady_moving_leg(args, local_rank):
     _, key_t, _ = _random.Random(4000 + args.seed).getstate()
     key, pos = np.asarray(key_t[:-1], dtype=np.uint32), int(key_t[-1])
     sweeps = []
+    st_ = rs.get_state()
+    np_key, np_pos = np.asarray(st_[1], dtype=np.uint32), int(st_[2])
     for it in range(8):
-        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
         power = 1.01 if (model == "PCRPMM" and it > 0) else None
         ctx.synchronize()
         t0 = time.time()
+        order = None
+        if model == "PCRPMM":                 # (the permutation is part of the sweep's time, as in the headline)
+            nxt = ctx.stage_permutation_mt19937(np_key, np_pos)
+            if nxt is None:
+                order = rs.permutation(N).astype(np.int64)
+            else:
+                np_key, np_pos = nxt
         key, pos = ctx.stage_mt19937(key, pos, order)
         ctx.sweep_staged(power)
         ctx.synchronize()
@@ -448,9 +456,24 @@ def main():
         # pcrpmm.py:105: powered weights iff i_iter > power_burnin (= 0): sweep 0 is plain CRP
         return power if (power is not None and it > 0) else None
 
+    np_state = rs.get_state()
+    np_key, np_pos = np.asarray(np_state[1], dtype=np.uint32), int(np_state[2])
+
     def one_sweep(it):
-        nonlocal mt_key, mt_pos
-        order = rs.permutation(N).astype(np.int64) if model == "PCRPMM" else None
+        # what PCRPMM.collapsed_gibbs_sampler does per sweep (pybgmm_amd/igmm/pcrpmm.py): the visiting order is
+        # np.random.permutation(N) from the chain's numpy stream -- drawn on the device (bgmm_stage_permutation_mt19937:
+        # bit-identical, the state handed back), on the host where the library leaves it to the host
+        nonlocal mt_key, mt_pos, np_key, np_pos
+        order = None
+        if model == "PCRPMM":
+            nxt = ctx.stage_permutation_mt19937(np_key, np_pos)
+            if nxt is None:
+                rs.set_state(("MT19937", np_key, np_pos))
+                order = rs.permutation(N).astype(np.int64)
+                st_ = rs.get_state()
+                np_key, np_pos = np.asarray(st_[1], dtype=np.uint32), int(st_[2])
+            else:
+                np_key, np_pos = nxt
         mt_key, mt_pos = ctx.stage_mt19937(mt_key, mt_pos, order)
         ctx.sweep_staged(sweep_power(it))
 
@@ -699,8 +722,8 @@ def main():
                       "last_sweep": last_stats, "setup_s": round(t_setup, 3),
                       "value_is": "sweeps/s with every sweep's uniforms generated inside the timed region (the caller's MT19937 "
                                   "continued on the device, bgmm_stage_mt19937: sweep k + 1's are generated on a second stream while "
-                                  "sweep k runs) and, for pCRP workloads, its permutation drawn on the host and uploaded -- SURVEY "
-                                  "8(d)'s t_sweep",
+                                  "sweep k runs) and, for pCRP workloads, its np.random.permutation(N) drawn on the device as well "
+                                  "(bgmm_stage_permutation_mt19937, bit-identical to numpy's) -- SURVEY 8(d)'s t_sweep",
                       "mt19937_lookahead": dict(mt_ahead, note="stage calls served by the look-ahead (the next sweep's uniforms "
                                                 "generated on a second stream beside the running sweep; taken only when the caller's "
                                                 "generator is exactly where the last call left it) / generated on the spot"),

@@ -139,6 +139,19 @@ BGMM_API int bgmm_get_mt_lookahead_stats(bgmm_ctx *ctx, int64_t *out2);
  * polynomial of MT19937: host arithmetic only, no device needed (what the CPU tests check against numpy's generator). */
 BGMM_API int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624);
 BGMM_API int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
+/*
+ * The visiting order of a pCRP sweep, `np.random.permutation(range(N))` (pcrpmm.py:86-91), drawn ON THE DEVICE from the
+ * caller's legacy numpy generator: key624 / pos are the 624 state words and the position of
+ * np.random.get_state()[1:3] (or a RandomState's); on return they hold the state the call of permutation() would have
+ * left (feed them to set_state() together with the untouched Gaussian cache fields).  The permutation is bit-identical
+ * to numpy's (legacy shuffle: for i = N-1 .. 1, j = random_interval(i) by masked rejection, swap) and becomes the
+ * visiting order of the NEXT sweep: follow with bgmm_stage_mt19937 / bgmm_stage_sweep_inputs with order = NULL (which
+ * then means "the staged one", once) and bgmm_sweep_staged.  N >= 4096; BGMM_EUNSUPPORTED (state untouched) otherwise, or
+ * in the astronomically unlikely case that 2 N + 1248 words do not suffice -- draw it on the host then.
+ * bgmm_get_staged_order: the order the next sweep will use (tests).
+ */
+BGMM_API int bgmm_stage_permutation_mt19937(bgmm_ctx *ctx, uint32_t *key624, int32_t *pos);
+BGMM_API int bgmm_get_staged_order(bgmm_ctx *ctx, int64_t *order_out);
 
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
  * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no

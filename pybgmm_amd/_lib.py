@@ -38,6 +38,8 @@ SIGNATURES = {
     "bgmm_get_mt_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
     "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_stage_permutation_mt19937": (ctypes.c_int, [_vp, _vp, _vp]),
+    "bgmm_get_staged_order": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
     "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
@@ -220,6 +222,24 @@ class Context(object):
         out = np.zeros(2, dtype=np.int64)
         self._ck(self.L.bgmm_get_mt_lookahead_stats(self.h, _ptr(out)))
         return {"hits": int(out[0]), "misses": int(out[1])}
+
+    def stage_permutation_mt19937(self, key624, pos):
+        """``np.random.permutation(N)`` drawn on the device from a legacy numpy MT19937 state as the next sweep's visiting
+        order (``bgmm_stage_permutation_mt19937``).  Returns the advanced ``(key624, pos)``, or None if the library
+        leaves this one to the host (N < 4096)."""
+        key = np.ascontiguousarray(key624, dtype=np.uint32).copy()
+        assert key.shape == (624,)
+        p = ctypes.c_int32(int(pos))
+        rc = self.L.bgmm_stage_permutation_mt19937(self.h, _ptr(key), ctypes.byref(p))
+        if rc == -5:                    # BGMM_EUNSUPPORTED
+            return None
+        self._ck(rc)
+        return key, int(p.value)
+
+    def staged_order(self):
+        o = np.empty(self.N, dtype=np.int64)
+        self._ck(self.L.bgmm_get_staged_order(self.h, _ptr(o)))
+        return o
 
     def staged_uniforms(self):
         u = np.empty(self.N, dtype=np.float64)

@@ -80,6 +80,24 @@ struct bgmm_ctx {
     // with a positive probability), so sweeps whose uniform stream contains an exact zero are run
     // unpruned.
     bool lean_ok = false;            // the previous sweep certified every visit and moved nothing
+    // the visiting order drawn on the device (bgmm_stage_permutation_mt19937, kernels_perm.hip)
+    long long *d_order_ahead = nullptr;   // the look-ahead's permutation (swapped with d_order when it is taken)
+    hipStream_t perm_stream = nullptr;
+    hipEvent_t perm_done = nullptr;
+    bool perm_ahead_valid = false;
+    int perm_ahead_pos_in = 0;
+    long long perm_hits = 0, perm_misses = 0;
+    bool order_staged = false;       // d_order holds a permutation staged for the NEXT sweep: a stage call without an order keeps it
+    unsigned *perm_words = nullptr;  // [key in 624 | key out 624 | pos out 16 | spare key 624 | spare pos 16 | raw | untempered words]
+    unsigned *perm_seeds = nullptr;  // the chains' seeds (its own: the uniforms' look-ahead may be running beside it)
+    long long perm_n_words = 0;
+    int perm_chains = 0;
+    int *perm_ints = nullptr;        // J, pred, ptr [N] each, then changed
+    unsigned *perm_uints = nullptr;  // ks, idx, iota [N] each
+    void *perm_temp = nullptr;
+    size_t perm_temp_bytes = 0;
+    long long *perm_out = nullptr;   // {words consumed, ran out}
+    unsigned *perm_host = nullptr;   // pinned: [key out 624 | pos out | changed | out (2 x 64 bit)]
     int grp_cap = 0;                 // bgmm_group_sweep_staged: the LDS plan phase 1 of sweep_impl chose for the one-workgroup sweep
     Dev *grp_devs = nullptr;         // device array of the chains' views (owned by the chain that leads a group launch)
     int grp_devs_cap = 0;
@@ -237,6 +255,15 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     }
     if (c->mt_words_ahead) (void)hipFree(c->mt_words_ahead);
     if (c->grp_devs) (void)hipFree(c->grp_devs);
+    if (c->perm_stream) { (void)hipStreamSynchronize(c->perm_stream); (void)hipStreamDestroy(c->perm_stream); }
+    if (c->perm_done) (void)hipEventDestroy(c->perm_done);
+    if (c->perm_words) (void)hipFree(c->perm_words);
+    if (c->perm_seeds) (void)hipFree(c->perm_seeds);
+    if (c->perm_ints) (void)hipFree(c->perm_ints);
+    if (c->perm_uints) (void)hipFree(c->perm_uints);
+    if (c->perm_temp) (void)hipFree(c->perm_temp);
+    if (c->perm_out) (void)hipFree(c->perm_out);
+    if (c->perm_host) (void)hipHostFree(c->perm_host);
     if (c->mt_words) (void)hipFree(c->mt_words);
     if (c->mt_coef) (void)hipFree(c->mt_coef);
     if (c->mt_seeds) (void)hipFree(c->mt_seeds);
@@ -562,15 +589,18 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
     c->cur_zero_u = false;
     for (long long i = 0; i < c->d.N; ++i)
         if (u[i] == 0.0) { c->cur_zero_u = true; break; }
-    c->have_order = order != nullptr;
+    const bool keep = !order && c->order_staged;        // (bgmm_stage_permutation_mt19937 has put this sweep's order in place)
+    c->have_order = order != nullptr || keep;
     const int okind = order ? classify_order(order, c->d.N) : 1;
     if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
     c->order_is_perm = okind == 1;
-    if (order)
+    if (order) {
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
+        c->order_staged = false;
+    }
     CK(c, hipStreamSynchronize(c->stream));
     c->cur_u = c->d_u;
-    c->cur_order = order ? c->d_order : nullptr;
+    c->cur_order = (order || keep) ? c->d_order : nullptr;
     return 0;
 }
 
@@ -637,6 +667,7 @@ static int mt_launch_batch(bgmm_ctx *c, int bi, const uint32_t *key, int pos) {
 static int mt_wait_batches(bgmm_ctx *c) {
     for (auto &b : c->mt_b)
         if (b.launched && !b.synced) { CK(c, hipEventSynchronize(b.done)); b.synced = true; }
+    if (c->perm_ahead_valid) CK(c, hipEventSynchronize(c->perm_done));     // (the permutation's look-ahead reads the same tables)
     return 0;
 }
 
@@ -707,15 +738,17 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
         c->cur_u = c->d_u;
         c->mt_ahead_misses += 1;
     }
-    c->have_order = order != nullptr;
+    const bool keep = !order && c->order_staged;        // (bgmm_stage_permutation_mt19937 has put this sweep's order in place)
+    c->have_order = order != nullptr || keep;
     const int okind = order ? classify_order(order, (long long)N) : 1;
     if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
     c->order_is_perm = okind == 1;
     if (order) {
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
         CK(c, hipStreamSynchronize(c->stream));
+        c->order_staged = false;
     }
-    c->cur_order = order ? c->d_order : nullptr;
+    c->cur_order = (order || keep) ? c->d_order : nullptr;
     if (c->mt_ahead_on) {
         // what comes behind: after a request served on the spot, a fresh batch from the state just handed back; towards the
         // end of a batch, the batch behind it (its generation runs beside the sweeps queued meanwhile)
@@ -732,6 +765,165 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
             if (rc) return rc;
         }
     }
+    return 0;
+}
+
+// np.random.permutation(N) from the caller's legacy numpy generator, on the device (kernels_perm.hip).
+struct PermPtrs {
+    unsigned *dkey, *dkey_out, *dspare, *draw, *dwords, *ks, *idx, *iota;
+    int *dpos_out, *dspare_pos, *J, *pred, *ptr, *changed, *flags, *cnt;
+    long long n_words_cap;
+};
+
+static int perm_ensure(bgmm_ctx *c, PermPtrs &P) {
+    const long long N = c->d.N;
+    const size_t raw_n = (size_t)mt19937_raw_words();
+    // words: rejection sampling takes 1.39 words per step on average (at most 2 while the mask's range is nearly all
+    // rejected): 2 N and a block to spare, rounded so that the request ends on a block boundary whatever pos is
+    P.n_words_cap = 624 * ((624 + 2 * N + 1248 + 623) / 624);
+    const size_t head = 624 + 624 + 16 + 624 + 16;
+    if (!c->perm_words) {
+        CK(c, hipMalloc((void **)&c->perm_words, sizeof(unsigned) * (head + raw_n + (size_t)P.n_words_cap)));
+        c->perm_chains = mt19937_chains_for_words(624, P.n_words_cap);
+        CK(c, hipMalloc((void **)&c->perm_seeds, sizeof(unsigned) * 624 * (size_t)(c->perm_chains + 2)));
+        CK(c, hipMalloc((void **)&c->perm_ints, sizeof(int) * (3 * (size_t)N + 64 + 5 * (size_t)perm_segments(P.n_words_cap))));
+        CK(c, hipMalloc((void **)&c->perm_uints, sizeof(unsigned) * (3 * (size_t)N + 16)));
+        c->perm_temp_bytes = perm_sort_temp_bytes((int)N);
+        CK(c, hipMalloc(&c->perm_temp, c->perm_temp_bytes + 256));
+        CK(c, hipMalloc((void **)&c->perm_out, sizeof(long long) * 2));
+        CK(c, hipHostMalloc((void **)&c->perm_host, sizeof(unsigned) * (1280 + (size_t)perm_segments(P.n_words_cap)), hipHostMallocDefault));
+        { int rc = dalloc(c, &c->d_order_ahead, (size_t)N); if (rc) return rc; }      // (freed with the context's other buffers)
+        CK(c, hipStreamCreateWithFlags(&c->perm_stream, hipStreamNonBlocking));
+        CK(c, hipEventCreateWithFlags(&c->perm_done, hipEventDisableTiming));
+        launch_perm_iota((int)N, c->perm_uints + 2 * (size_t)N, c->stream);
+        CK(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->perm_chains > c->mt_chains) {
+        int rc = mt_wait_batches(c);
+        if (rc) return rc;
+        rc = mt_ensure_tables(c, c->perm_chains);
+        if (rc) return rc;
+    }
+    P.dkey = c->perm_words; P.dkey_out = P.dkey + 624; P.dspare = P.dkey + 1264;
+    P.draw = c->perm_words + head; P.dwords = P.draw + raw_n;
+    P.dpos_out = (int *)(P.dkey + 1248); P.dspare_pos = (int *)(P.dspare + 624);
+    P.J = c->perm_ints; P.pred = P.J + N; P.ptr = P.pred + N; P.changed = P.ptr + N; P.flags = P.changed + 4; P.cnt = P.changed + 64;
+    P.ks = c->perm_uints; P.idx = P.ks + N; P.iota = P.idx + N;
+    return 0;
+}
+
+// queues the whole generation on `st`: words, draws, swaps, the state behind them, and the copies of the verdicts into
+// perm_host [key out 624 | pos out | pointer jumping still moved | the write pass ran | - | out (2 x 64 bit)]
+static int perm_queue(bgmm_ctx *c, const PermPtrs &P, const unsigned *key_pinned, int pos, long long *order_dst, hipStream_t st) {
+    const long long N = c->d.N;
+    const long long n_words = 624 * (((long long)pos + 2 * N + 1248 + 623) / 624) - (long long)pos;
+    c->perm_n_words = n_words;
+    CK(c, hipMemcpyAsync(P.dkey, key_pinned, sizeof(unsigned) * 624, hipMemcpyHostToDevice, st));
+    const int chains = mt19937_chains_for_words(pos, n_words);
+    launch_mt19937_raw(P.dkey, pos, P.dwords, n_words, (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, P.draw, c->perm_seeds,
+                       P.dspare, P.dspare_pos, st);
+    if (!launch_permutation(P.dwords, n_words, (int)N, P.dkey, pos, P.J, P.pred, P.ptr, P.cnt, (int *)(c->perm_host + 1280), P.flags, P.ks,
+                            P.idx, P.iota, c->perm_temp, c->perm_temp_bytes, c->perm_out, P.changed, order_dst, P.dkey_out, P.dpos_out, st))
+        return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+    CK(c, hipGetLastError());
+    return 0;
+}
+
+static int perm_queue_verdicts(bgmm_ctx *c, const PermPtrs &P, hipStream_t st) {
+    unsigned *H = c->perm_host;
+    CK(c, hipMemcpyAsync(H, P.dkey_out, sizeof(unsigned) * 624, hipMemcpyDeviceToHost, st));
+    CK(c, hipMemcpyAsync(H + 624, P.dpos_out, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK(c, hipMemcpyAsync(H + 625, P.changed, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK(c, hipMemcpyAsync(H + 626, P.flags + perm_rounds() + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK(c, hipMemcpyAsync(H + 628, c->perm_out, sizeof(long long) * 2, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// after the stream has drained: the rare repairs (draws not settled within the queued rounds, chains of swaps longer than
+// the queued rounds of pointer jumping), then the state numpy would be left in
+static int perm_finish(bgmm_ctx *c, const PermPtrs &P, int pos_in, long long *order_dst, hipStream_t st, uint32_t *key624, int32_t *pos) {
+    const long long N = c->d.N;
+    unsigned *H = c->perm_host;
+    for (int tries = 0;; ++tries) {
+        if (tries > 64) return fail(c, BGMM_EDEVICE, "the permutation's draws did not settle");
+        if (H[626] == 0) {               // the draws had not settled (no write pass yet): more rounds, then the rest again
+            launch_permutation_draw_more(P.dwords, c->perm_n_words, (int)N, P.J, P.cnt, P.flags, c->perm_out, st);
+            if (!launch_permutation_tail(P.dwords, (int)N, P.dkey, pos_in, P.J, P.pred, P.ptr, P.ks, P.idx, P.iota, c->perm_temp,
+                                         c->perm_temp_bytes, c->perm_out, P.changed, order_dst, P.dkey_out, P.dpos_out, st))
+                return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+        } else {
+            long long out[2];
+            memcpy(out, H + 628, sizeof(out));
+            if (out[1] != 0) return fail(c, BGMM_EUNSUPPORTED, "the permutation ran out of random words (draw it on the host)");
+            if (H[625] == 0) break;
+            launch_permutation_more((int)N, P.J, P.pred, P.ptr, P.changed, order_dst, st);    // (chains of swaps longer than 128 links)
+        }
+        int rc = perm_queue_verdicts(c, P, st);
+        if (rc) return rc;
+        CK(c, hipStreamSynchronize(st));
+    }
+    memcpy(key624, H, sizeof(unsigned) * 624);
+    *pos = (int32_t)H[624];
+    return 0;
+}
+
+extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int32_t *pos) {
+    if (!c || !key624 || !pos) return BGMM_EINVAL;
+    if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
+    const long long N = c->d.N;
+    if (N < 4096) return fail(c, BGMM_EUNSUPPORTED, "device permutations are for N >= 4096 (draw it on the host)");
+    CK(c, hipSetDevice(c->device));
+    PermPtrs P;
+    int rc = perm_ensure(c, P);
+    if (rc) return rc;
+    unsigned *key_in_pinned = c->perm_host + 640;                 // [640, 1264): the state a generation starts from
+    // The permutation BEHIND the last one was started when that one was handed out (look-ahead, as for the uniforms): taken
+    // iff the caller's generator is exactly where that call left it.
+    bool hit = false;
+    if (c->perm_ahead_valid) {
+        CK(c, hipEventSynchronize(c->perm_done));
+        c->perm_ahead_valid = false;
+        hit = c->mt_ahead_on && *pos == c->perm_ahead_pos_in && memcmp(key624, key_in_pinned, sizeof(unsigned) * 624) == 0;
+        if (hit) {
+            rc = perm_finish(c, P, c->perm_ahead_pos_in, c->d_order_ahead, c->perm_stream, key624, pos);
+            if (rc) return rc;
+            std::swap(c->d_order, c->d_order_ahead);
+            c->perm_hits += 1;
+        }
+    }
+    if (!hit) {
+        const int pos_in = *pos;
+        memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);
+        rc = perm_queue(c, P, key_in_pinned, pos_in, c->d_order, c->stream);
+        if (rc == 0) rc = perm_queue_verdicts(c, P, c->stream);
+        if (rc) return rc;
+        CK(c, hipStreamSynchronize(c->stream));
+        rc = perm_finish(c, P, pos_in, c->d_order, c->stream, key624, pos);
+        if (rc) return rc;
+        c->perm_misses += 1;
+    }
+    c->order_staged = true;
+    c->order_is_perm = true;
+    c->have_order = true;
+    c->cur_order = c->d_order;
+    if (c->mt_ahead_on) {
+        // the next permutation, from the state just handed back, into the other buffer, beside the sweep about to be queued
+        memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);
+        c->perm_ahead_pos_in = *pos;
+        rc = perm_queue(c, P, key_in_pinned, *pos, c->d_order_ahead, c->perm_stream);
+        if (rc == 0) rc = perm_queue_verdicts(c, P, c->perm_stream);
+        if (rc) return rc;
+        CK(c, hipEventRecord(c->perm_done, c->perm_stream));
+        c->perm_ahead_valid = true;
+    }
+    return 0;
+}
+
+extern "C" int bgmm_get_staged_order(bgmm_ctx *c, int64_t *order_out) {
+    if (!c || !order_out) return BGMM_EINVAL;
+    if (!c->cur_order) return fail(c, BGMM_EINVAL, "no visiting order staged (the next sweep visits 0 .. N-1)");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpy(order_out, c->cur_order, sizeof(long long) * c->d.N, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -764,8 +956,8 @@ extern "C" int bgmm_set_mt_lookahead(bgmm_ctx *c, int32_t sweeps) {
 
 extern "C" int bgmm_get_mt_lookahead_stats(bgmm_ctx *c, int64_t *out2) {
     if (!c || !out2) return BGMM_EINVAL;
-    out2[0] = c->mt_ahead_hits;
-    out2[1] = c->mt_ahead_misses;
+    out2[0] = c->mt_ahead_hits + c->perm_hits;
+    out2[1] = c->mt_ahead_misses + c->perm_misses;
     return 0;
 }
 
@@ -866,6 +1058,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
         d.u = c->cur_u;
         d.order = c->cur_order;
+        c->order_staged = false;            // (a staged permutation serves one sweep)
         d.sweep_visits = c->next_sweep_visits;
         c->next_sweep_visits = 0;
     }

@@ -372,6 +372,23 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();
 bool mt19937_jump_coefficients(int n_chains, std::vector<unsigned> &out);
+void launch_mt19937_raw(const unsigned *key_in, int pos, unsigned *words, long long n_words, const unsigned *coef_dev, int n_chains,
+                        unsigned *raw, unsigned *seeds, unsigned *spare_key, int *spare_pos, hipStream_t st);
+int mt19937_chains_for_words(long long pos, long long n_words);
+// kernels_perm.hip: np.random.permutation(n) from the caller's legacy numpy stream, on the device
+size_t perm_sort_temp_bytes(int n);
+int perm_segments(long long n_avail);
+int perm_rounds();
+bool launch_permutation(const unsigned *raw, long long n_avail, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr,
+                        int *cnt, int *guess_pinned, int *flags, unsigned *ks, unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes,
+                        long long *out, int *changed, long long *order, unsigned *key_out, int *pos_out, hipStream_t st);
+bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr, unsigned *ks,
+                             unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes, long long *out, int *changed, long long *order,
+                             unsigned *key_out, int *pos_out, hipStream_t st);
+void launch_permutation_draw_more(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out,
+                                  hipStream_t st);
+void launch_permutation_more(int n, const int *J, const int *pred, int *ptr, int *changed, long long *order, hipStream_t st);
+void launch_perm_iota(int n, unsigned *iota, hipStream_t st);
 static constexpr int kMtMaxMids = 8;      // sweeps a look-ahead request of the uniform generator may span
 struct MtMids { long long nb[kMtMaxMids]; int pos[kMtMaxMids]; int m; };
 void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos_out, unsigned *words, double *u, long long n,

@@ -1,0 +1,308 @@
+// The visiting order of a pCRP sweep, drawn on the device.
+//
+// PCRPMM.collapsed_gibbs_sampler visits the data in `np.random.permutation(range(N))` (pcrpmm.py:86-91), a fresh one every
+// sweep, drawn from the caller's legacy numpy stream.  On the host that is 9 ms per 1e6 points (17 ms for C5's 2e6) in
+// front of a sweep of 0.5 - 1 ms.  This file produces the SAME permutation from the SAME stream on the GPU, bit for bit,
+// and hands back the generator state numpy would be left in.
+//
+// What numpy does (legacy RandomState.permutation(n) = shuffle(arange(n)), mtrand.pyx / distributions.c):
+//     for i = n-1 down to 1:   j = random_interval(i);   swap(x[i], x[j])
+//     random_interval(max):    mask = smallest 2^k - 1 >= max;   repeat v = next_uint32() & mask until v <= max
+// Two sequential chains -- which 32-bit words step i consumes depends on every rejection before it, and the swaps act on
+// one array -- both restated here in parallel form:
+//
+// 1. DRAWS (perm_draw_kernel).  Inside a wavefront: with c = the number of words accepted so far in a run of 64 words,
+//    word l is accepted iff (w_l & mask) <= i - c_l.  Starting from "every word with (w & mask) <= i is accepted" the wave
+//    iterates acc <- ballot((w & mask) <= i - popcount(acc below me)); the iterates bracket the true set from above and
+//    below in turn and lane l is exact once the lanes below it are, so the fixed point -- usually reached in two or three
+//    rounds, because a word's fate depends on c only when it lies within 64 of the threshold -- is the sequential answer.
+//    A run is cut behind the step that ends a mask's range (i = 2^(k-1)): the words behind it meet the next mask.
+//    Across wavefronts the same idea once more: the stream is cut into segments of 1024 words, one wavefront each, and
+//    the step a segment starts at (n - 1 minus what the segments in front of it accept) is taken from the previous
+//    ROUND's counts; the rounds settle because a segment's count depends only weakly on where it starts.
+//
+// 2. SWAPS.  Position i is final once step i has run, and what it receives is what position J[i] held just before:
+//       final[i] = (J[i] == i) ? V(i) : (pred(i) exists ? V(pred(i)) : J[i])
+//    where V(i) = the value at position i just before step i, pred(i) = the next larger step with the same target as i
+//    (the most recent earlier swap into that position), and V(i) = V(predV(i)) with predV(i) = the smallest step > i whose
+//    target is i (or i itself, untouched, if there is none).  pred / predV fall out of a stable sort of the steps by
+//    target (rocPRIM radix sort), V out of a few rounds of pointer jumping.
+// tests/test_perm_formulation.py holds the same formulation in numpy, checked against np.random on the CPU.
+#include "bgmm_device.h"
+
+#include <cmath>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+__device__ __forceinline__ unsigned perm_temper(unsigned y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+static constexpr int kPermRounds = 40;     // rounds of draws queued at a time (those behind the write pass return at once)
+static constexpr int kPermSeg = 1024;      // words per segment (one wavefront, 4 KB of LDS)
+int perm_segments(long long n_avail) { return (int)((n_avail + kPermSeg - 1) / kPermSeg); }
+int perm_rounds() { return kPermRounds; }
+
+// raw: untempered MT19937 words following the caller's position, n_avail of them, cut into segments of kPermSeg words;
+// one wavefront per segment, its words in LDS.  Round r takes the step a segment starts at from round r - 1's counts
+// (cnt_prev) while it writes its own (cnt_new): segment 0 is exact at once, segment t once those in front of it are, and
+// a segment's count depends only weakly on where it starts (a word's fate changes only if its value lies between the two
+// thresholds), so the rounds settle -- a dozen or two of them, launched blindly; a segment whose start has not changed
+// since it last ran keeps its count without running again.  The round in which no count changed had every segment at its
+// true start; the round behind it writes the targets J[i] (i = 1 .. n-1) -- numpy's -- and out[0] = words consumed,
+// out[1] = 0 (by the segment in which step 1 is served), and the rounds behind that return at once.
+__global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int round,
+                                                        const int *__restrict__ cnt_prev, int *__restrict__ cnt_new,
+                                                        int *__restrict__ seen, int *__restrict__ J,
+                                                        long long *__restrict__ out, int *__restrict__ flags) {
+    __shared__ unsigned ws[4][kPermSeg];
+    // flags[r] = some count changed in round r.  The first round behind a round that changed nothing is the WRITE pass:
+    // every segment runs from its (now true) start once more and leaves its targets in J; the rounds behind it return.
+    const bool settled = round >= 2 && flags[round - 1] == 0;
+    if (settled && round >= 3 && flags[round - 2] == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
+        return;
+    }
+    const bool write_pass = settled;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = (int)blockIdx.x * 4 + wv;
+    const long long seg0 = (long long)t * kPermSeg;
+    if (seg0 >= n_avail) return;
+    const int len = (int)(seg0 + kPermSeg < n_avail ? kPermSeg : n_avail - seg0);
+    // the step this segment starts at
+    long long before = 0;
+    for (int k = lane; k < t; k += 64) before += cnt_prev[k];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    const long long i0l = (long long)(n - 1) - before;
+    const int i0 = i0l > 0 ? (int)i0l : 0;
+    // seen[3 t ..]: the start this segment last ran from, what it accepted then, where it served step 1 (-1: not here).
+    // From the same start it would do exactly the same again: its count and the targets it wrote stand.
+    int *__restrict__ mine_seen = seen + 3 * (long long)t;
+    int accepted = 0, end = -1;
+    if (round >= 2 && !write_pass && mine_seen[0] == i0) {
+        accepted = mine_seen[1];
+        end = mine_seen[2];
+    } else if (i0 >= 1) {
+        unsigned *__restrict__ W = ws[wv];
+        for (int k = lane; k < len; k += 64) W[k] = perm_temper(raw[seg0 + k]);     // (all of the segment's loads in flight together)
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        int i = i0;
+        int p = 0;
+        while (i >= 1 && p < len) {
+            const unsigned mask = 0xffffffffu >> __builtin_clz((unsigned)i);
+            const int lowi = (int)(mask >> 1) + 1;
+            const int a = (p + lane < len) ? (int)(W[p + lane] & mask) : 0x7fffffff;
+            unsigned long long acc = __ballot(a <= i);
+            for (;;) {
+                const int c = __builtin_popcountll(acc & below);
+                const unsigned long long acc2 = __ballot(a <= i - c);
+                if (acc2 == acc) break;
+                acc = acc2;
+            }
+            const int c = __builtin_popcountll(acc & below);
+            const int s = i - c;                                         // the step this word serves, if accepted
+            const bool mine = (acc >> lane) & 1ull;
+            const unsigned long long last = __ballot(mine && s == lowi);   // the step that ends this mask's range
+            const int cut = last ? (int)__builtin_ctzll(last) + 1 : 64;
+            if (write_pass && mine && lane < cut) J[s] = a;
+            const unsigned long long used = cut == 64 ? acc : (acc & (~0ull >> (64 - cut)));
+            const int k = (int)__builtin_popcountll(used);
+            i -= k;
+            accepted += k;
+            p += cut;
+        }
+        if (i < 1) end = p < len ? p : len;              // step 1 has been served: the stream ends here
+    }
+    if (lane == 0) {
+        mine_seen[0] = i0; mine_seen[1] = accepted; mine_seen[2] = end;
+        cnt_new[t] = accepted;
+        if (!write_pass && cnt_prev[t] != accepted) flags[round] = 1;
+        // (exactly one segment sees the last of the n - 1 steps served inside it)
+        if (write_pass && accepted > 0 && before + accepted == (long long)(n - 1) && end >= 0) { out[0] = seg0 + end; out[1] = 0; }
+        if (write_pass && t == 0) flags[kPermRounds + 1] = 1;           // "the targets have been written"
+    }
+}
+
+// flags cleared (flags[0] = 1: "round 0 changed everything"), out = {0, "the words ran out"} until a segment says otherwise
+__global__ void perm_reflag_kernel(int rounds, int *__restrict__ flags, long long *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    for (int r = 0; r <= rounds + 1; ++r) flags[r] = r == 0 ? 1 : 0;      // (flags[rounds + 1]: the write pass has run)
+    out[0] = 0; out[1] = 1;
+}
+
+// The counts round 1 starts from: the EXPECTED progress of the rejection sampling (a word is accepted with probability
+// (i + 1) / 2^k at step i of a mask of k bits), segment by segment -- on the host, a microsecond's worth of arithmetic.
+void perm_guess_host(int T, long long n_avail, int n, int *cnt) {
+    double i = (double)(n - 1);
+    for (int t = 0; t < T; ++t) {
+        const long long seg0 = (long long)t * kPermSeg;
+        double words = (double)(seg0 + kPermSeg < n_avail ? kPermSeg : n_avail - seg0);
+        const double i_in = i;
+        while (words > 0.0 && i >= 1.0) {
+            const unsigned ii = (unsigned)i;
+            const double m = (double)(0xffffffffu >> __builtin_clz(ii)) + 1.0, lowi = 0.5 * m;
+            const double need = m * log((i + 1.0) / lowi);           // words this mask's range still takes (sum of m / (j + 1))
+            if (need <= words) { words -= need; i = lowi - 1.0; }
+            else { i = (i + 1.0) * exp(-words / m) - 1.0; words = 0.0; }
+        }
+        if (i < 0.0) i = 0.0;
+        cnt[t] = (int)(i_in - i + 0.5);
+    }
+}
+
+__global__ void perm_init_kernel(int n, int *__restrict__ pred, int *__restrict__ ptr) {
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= n) return;
+    pred[v] = -1;
+    ptr[v] = v;
+}
+
+// ks / idx: the steps 1 .. n-1 sorted by target (stable: ascending step inside a target), m = n - 1 of them
+__global__ void perm_links_kernel(int m, const unsigned *__restrict__ ks, const unsigned *__restrict__ idx,
+                                  int *__restrict__ pred, int *__restrict__ ptr) {
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (q >= m) return;
+    const unsigned v = ks[q], i = idx[q];
+    const bool next_same = q + 1 < m && ks[q + 1] == v;
+    if (next_same) pred[i] = (int)idx[q + 1];
+    if (q == 0 || ks[q - 1] != v) {
+        const int pv = (i != v) ? (int)i : (next_same ? (int)idx[q + 1] : -1);
+        if (pv >= 0) ptr[v] = pv;
+    }
+}
+
+// in place: every pointer only ever moves towards its root, so a half-updated neighbour is still an ancestor
+__global__ void perm_jump_kernel(int n, int *__restrict__ ptr, int *__restrict__ changed) {
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= n) return;
+    const int p = ptr[v];
+    const int pp = ptr[p];
+    if (pp != p) {
+        ptr[v] = pp;
+        if (changed) *changed = 1;
+    }
+}
+
+__global__ void perm_final_kernel(int n, const int *__restrict__ J, const int *__restrict__ pred, const int *__restrict__ ptr,
+                                  long long *__restrict__ order) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    int val;
+    if (i == 0) {
+        val = ptr[0];
+    } else {
+        const int j = J[i];
+        if (j == i) val = ptr[i];
+        else {
+            const int pr = pred[i];
+            val = pr >= 0 ? ptr[pr] : j;
+        }
+    }
+    order[i] = (long long)val;
+}
+
+// the generator state behind `used` words: block nb = (pos + used - 1) / 624 of the stream and the position in it
+__global__ void perm_state_kernel(const unsigned *__restrict__ key_in, const unsigned *__restrict__ raw, int pos,
+                                  const long long *__restrict__ out, unsigned *__restrict__ key_out, int *__restrict__ pos_out) {
+    const long long used = out[0];
+    const long long g = (long long)pos + used;
+    const long long nb = used > 0 ? (g - 1) / 624 : 0;
+    for (int k = threadIdx.x; k < 624; k += blockDim.x)
+        key_out[k] = nb == 0 ? key_in[k] : raw[624 * nb - pos + k];
+    if (threadIdx.x == 0) pos_out[0] = (int)(g - 624 * nb);
+}
+
+static unsigned perm_key_bits(int n) {
+    unsigned bits = 1;
+    while ((1ll << bits) < (long long)n) ++bits;
+    return bits;
+}
+
+size_t perm_sort_temp_bytes(int n) {
+    size_t bytes = 0;
+    unsigned *nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)(n > 1 ? n - 1 : 1), 0, perm_key_bits(n),
+                                    hipStream_t(nullptr));
+    return bytes;
+}
+
+static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out, int parity,
+                              hipStream_t st) {
+    const int T = perm_segments(n_avail);
+    int *seen = cnt + 2 * (long long)T;              // [3 T]: perm_draw_kernel's memo (round 1 ignores what it holds)
+    hipLaunchKernelGGL(perm_reflag_kernel, dim3(1), dim3(64), 0, st, kPermRounds, flags, out);
+    // (round r reads cnt + ((r + 1 + parity) & 1) * T and writes the other half)
+    for (int r = 1; r <= kPermRounds; ++r)
+        hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, r,
+                           cnt + ((r + 1 + parity) & 1) * T, cnt + ((r + parity) & 1) * T, seen, J, out, flags);
+}
+
+// everything behind the draws: the swaps (sort by target, links, pointer jumping, assembly) and the generator state
+bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr, unsigned *ks,
+                             unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes, long long *out, int *changed, long long *order,
+                             unsigned *key_out, int *pos_out, hipStream_t st) {
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(perm_init_kernel, dim3(g), dim3(256), 0, st, n, pred, ptr);
+    if (n > 1) {
+        // values: the steps 1 .. n-1 (iota[k] = k, filled once by the caller)
+        if (rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)(J + 1), ks, (const unsigned *)(iota + 1), idx, (size_t)(n - 1), 0,
+                                      perm_key_bits(n), st) != hipSuccess)
+            return false;
+        hipLaunchKernelGGL(perm_links_kernel, dim3((unsigned)((n - 1 + 255) / 256)), dim3(256), 0, st, n - 1, ks, idx, pred, ptr);
+        // chains of "who was swapped in here before" are a handful of links long (each link goes to a uniformly later
+        // step): seven rounds of doubling cover 2^7 of them; the eighth only reports whether anything still moved
+        for (int r = 0; r < 7; ++r) hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, (int *)nullptr);
+        (void)hipMemsetAsync(changed, 0, sizeof(int), st);
+        hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, changed);
+    } else {
+        (void)hipMemsetAsync(changed, 0, sizeof(int), st);
+    }
+    hipLaunchKernelGGL(perm_final_kernel, dim3(g), dim3(256), 0, st, n, J, pred, ptr, order);
+    hipLaunchKernelGGL(perm_state_kernel, dim3(1), dim3(256), 0, st, key_in, raw, pos, out, key_out, pos_out);
+    return hipGetLastError() == hipSuccess;
+}
+
+// raw / n_avail: untempered words behind the caller's position.  Scratch (device): J, pred, ptr [n] ints; cnt [5 x
+// perm_segments] ints; flags [perm_rounds + 2] ints (flags[perm_rounds + 1] == 0 afterwards: the draws have not settled --
+// launch_permutation_draw_more, then launch_permutation_tail again); ks, idx, iota [n] unsigned; temp
+// (perm_sort_temp_bytes); out [2] long long; changed [1] int (!= 0 afterwards: launch_permutation_more).  order: the
+// permutation, int64 [n].  guess_pinned: perm_segments ints of pinned host memory.  key_in (device, 624 words) / pos: the state the words start from; key_out / pos_out (device):
+// the state behind the words consumed.
+bool launch_permutation(const unsigned *raw, long long n_avail, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr,
+                        int *cnt, int *guess_pinned, int *flags, unsigned *ks, unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes,
+                        long long *out, int *changed, long long *order, unsigned *key_out, int *pos_out, hipStream_t st) {
+    const int T = perm_segments(n_avail);
+    perm_guess_host(T, n_avail, n, guess_pinned);
+    if (hipMemcpyAsync(cnt, guess_pinned, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess) return false;   // (round 1 reads cnt[0 .. T))
+    queue_draw_rounds(raw, n_avail, n, J, cnt, flags, out, 0, st);
+    return launch_permutation_tail(raw, n, key_in, pos, J, pred, ptr, ks, idx, iota, temp, temp_bytes, out, changed, order, key_out,
+                                   pos_out, st);
+}
+
+// kPermRounds more rounds of draws from the counts the last round left (an even number of rounds: they are back in
+// cnt[0 .. T))
+void launch_permutation_draw_more(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out,
+                                  hipStream_t st) {
+    queue_draw_rounds(raw, n_avail, n, J, cnt, flags, out, 0, st);
+}
+
+// more rounds of pointer jumping + the final assembly again (the rare case `changed` reported)
+void launch_permutation_more(int n, const int *J, const int *pred, int *ptr, int *changed, long long *order, hipStream_t st) {
+    const unsigned g = (unsigned)((n + 255) / 256);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, (int *)nullptr);
+    (void)hipMemsetAsync(changed, 0, sizeof(int), st);
+    hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, changed);
+    hipLaunchKernelGGL(perm_final_kernel, dim3(g), dim3(256), 0, st, n, J, pred, ptr, order);
+}
+
+__global__ void perm_iota_kernel(int n, unsigned *__restrict__ iota) {
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v < n) iota[v] = (unsigned)v;
+}
+void launch_perm_iota(int n, unsigned *iota, hipStream_t st) {
+    hipLaunchKernelGGL(perm_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, iota);
+}

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
                                                             int p_first, int pos, long long E, unsigned *__restrict__ words,
                                                             unsigned *__restrict__ raw, unsigned *__restrict__ key_out,
                                                             int *__restrict__ pos_out, unsigned *__restrict__ seed_next,
-                                                            MtMids mids, unsigned *__restrict__ key_mid, int *__restrict__ pos_mid) {
+                                                            MtMids mids, unsigned *__restrict__ key_mid, int *__restrict__ pos_mid,
+                                                            int untempered) {
     __shared__ unsigned blk[2][624];
     const int tid = threadIdx.x;
     const int p = p_first + (int)blockIdx.x;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
     __syncthreads();
     const long long nb = (E - 1) / 624;                      // the block the request ends in
     if (p == 0) {
-        for (long long k = pos + tid; k < 624 && k < E; k += 256) words[k - pos] = mt_temper(blk[0][k]);
+        for (long long k = pos + tid; k < 624 && k < E; k += 256) words[k - pos] = untempered ? blk[0][k] : mt_temper(blk[0][k]);
         if (raw) for (int k = tid; k < 624; k += 256) raw[k] = blk[0][k];
         if (nb == 0) {
             for (int k = tid; k < 624; k += 256) key_out[k] = blk[0][k];
@@ -118,9 +119,11 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
             nw[l + 227] = nB;
             if (has_c) nw[l + 454] = nC;
             const long long o = 624 * b - pos + l;           // word l of block b in the output stream
-            if (o < n_words) words[o] = mt_temper(nA);
-            if (o + 227 < n_words) words[o + 227] = mt_temper(nB);
-            if (has_c && o + 454 < n_words) words[o + 454] = mt_temper(nC);
+            // (untempered: the words as the state holds them -- the permutation kernels temper on the fly and read the
+            // generator state behind the words they consumed straight out of this array)
+            if (o < n_words) words[o] = untempered ? nA : mt_temper(nA);
+            if (o + 227 < n_words) words[o + 227] = untempered ? nB : mt_temper(nB);
+            if (has_c && o + 454 < n_words) words[o + 454] = untempered ? nC : mt_temper(nC);
             if (raw && b < 33) {
                 raw[624 * b + l] = nA; raw[624 * b + l + 227] = nB;
                 if (has_c) raw[624 * b + l + 454] = nC;
@@ -364,15 +367,47 @@ void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos
         const int chains = mt19937_chains_for(pos, n);
         for (int p = 0; p < (chains > 1 ? chains : 1); ++p)
             hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, p, pos, E,
-                               words, (unsigned *)nullptr, key_out, pos_out, seeds, mids, key_mid, pos_mid);
+                               words, (unsigned *)nullptr, key_out, pos_out, seeds, mids, key_mid, pos_mid, 0);
     } else {
         (void)hipMemsetAsync(seeds, 0, sizeof(unsigned) * 624 * (size_t)n_chains, st);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, 0, pos, E, words, raw,
-                           key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid);
+                           key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0);
         hipLaunchKernelGGL(mt19937_jump_kernel, dim3(kJumpSplits, (unsigned)((n_chains - 1 + kJumpTargets - 1) / kJumpTargets)),
                            dim3(640), 0, st, raw, coef_dev, n_chains, seeds);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3((unsigned)(n_chains - 1)), dim3(256), 0, st, key_in, (const unsigned *)seeds, 1,
-                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid);
+                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0);
     }
     hipLaunchKernelGGL(mt19937_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, u, n, n_per, zero_flag);
+}
+
+// n_words UNTEMPERED words behind (key_in, pos) into `words` (the permutation kernels' input): the same chains, no doubles.
+// spare_key / spare_pos: scratch for the state the chains leave (not used by the caller).
+void launch_mt19937_raw(const unsigned *key_in, int pos, unsigned *words, long long n_words, const unsigned *coef_dev, int n_chains,
+                        unsigned *raw, unsigned *seeds, unsigned *spare_key, int *spare_pos, hipStream_t st) {
+    const long long E = (long long)pos + n_words;
+    MtMids mids;
+    mids.m = 0;
+    if (!coef_dev || n_chains < 2) {
+        const long long nb = E > 0 ? (E - 1) / 624 : 0;
+        const int chains = (int)((nb + kChainBlocks - 1) / kChainBlocks);
+        for (int p = 0; p < (chains > 1 ? chains : 1); ++p)
+            hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, p, pos, E,
+                               words, (unsigned *)nullptr, spare_key, spare_pos, seeds, mids, (unsigned *)nullptr, (int *)nullptr, 1);
+    } else {
+        (void)hipMemsetAsync(seeds, 0, sizeof(unsigned) * 624 * (size_t)n_chains, st);
+        hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, 0, pos, E, words, raw,
+                           spare_key, spare_pos, (unsigned *)nullptr, mids, (unsigned *)nullptr, (int *)nullptr, 1);
+        hipLaunchKernelGGL(mt19937_jump_kernel, dim3(kJumpSplits, (unsigned)((n_chains - 1 + kJumpTargets - 1) / kJumpTargets)),
+                           dim3(640), 0, st, raw, coef_dev, n_chains, seeds);
+        hipLaunchKernelGGL(mt19937_chain_kernel, dim3((unsigned)(n_chains - 1)), dim3(256), 0, st, key_in, (const unsigned *)seeds, 1,
+                           pos, E, words, (unsigned *)nullptr, spare_key, spare_pos, (unsigned *)nullptr, mids, (unsigned *)nullptr,
+                           (int *)nullptr, 1);
+    }
+}
+
+// chains a request of n_words words from position pos is cut into
+int mt19937_chains_for_words(long long pos, long long n_words) {
+    const long long E = pos + n_words;
+    const long long nb = E > 0 ? (E - 1) / 624 : 0;
+    return (int)((nb + kChainBlocks - 1) / kChainBlocks);
 }

@@ -59,7 +59,7 @@ class ADAPCRPMM(IGMM):
                 if adapcrp_power > 1:
                     if i_iter % 20 == 0:
                         logger.info(" Permutate data")
-                    order = _rng.take_permutation(self.N, self._nprng)
+                    order = self._draw_order()
             self._sweep(order=order, power=adapcrp_power if powered else None)
             record_dict = self.update_record_dict(record_dict, i_iter, true_assignments, start_time)
             start_time = time.time()

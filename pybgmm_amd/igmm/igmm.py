@@ -125,9 +125,16 @@ class IGMM(GMM):
         return stats.dirichlet(alpha).rvs(size=1, random_state=self._nprng).flatten()
 
     # ------------------------------------------------------------------ #
+    def _draw_order(self):
+        """``np.random.permutation(range(N))`` from the caller's numpy stream as the next sweep's visiting order: drawn on
+        the device where the library can (``rng.STAGED``), on the host otherwise (the array)."""
+        return _rng.take_permutation_staged(self.components._ctx, self.N, self._nprng)
+
     def _sweep(self, order=None, power=None):
         """One device sweep fed from the caller's random streams."""
         ctx = self.components._ctx
+        if order is _rng.STAGED:        # (drawn on the device and already in place: _draw_order)
+            order = None
         staged = _rng.stage_uniforms_on_device(ctx, order, self._rng)   # the caller's stream, continued on the GPU
         if not staged:
             ctx.stage(_rng.take_uniforms(self.N, self._rng), order)

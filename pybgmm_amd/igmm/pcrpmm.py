@@ -37,7 +37,7 @@ class PCRPMM(IGMM):
             if flag_power and n_power > 1:
                 if i_iter % 20 == 0:
                     logger.info(" Permutate data; " + "Power value: {}".format(n_power))
-                order = _rng.take_permutation(self.N, self._nprng)
+                order = self._draw_order()
             else:
                 order = None
             power = n_power if (flag_power and i_iter > power_burnin) else None

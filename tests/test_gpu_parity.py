@@ -1210,6 +1210,66 @@ def test_device_mt19937_jump_ahead_across_chains(N, burn):
     ctx.close()
 
 
+@pytest.mark.parametrize("N", [4096, 4097, 65536, 100003, 1000000, 2000000])
+def test_device_permutation_equals_numpy(N):
+    """bgmm_stage_permutation_mt19937: np.random.permutation(N) of the pCRP sweep (pcrpmm.py:89) drawn on the device from a
+    legacy numpy state -- the same permutation, the same generator state afterwards; three in a row from a position
+    inside a block, then through the host helper with the GLOBAL np.random stream."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(2)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12)
+    ctx.set_assignments(zt)
+    host = np.random.RandomState(N % 1000)
+    host.random_sample(N % 500 + 7)
+    key, pos = host.get_state()[1].copy(), int(host.get_state()[2])
+    for it in range(3):
+        expect = host.permutation(N)
+        key, pos = ctx.stage_permutation_mt19937(key, pos)
+        got = ctx.staged_order()
+        bad = np.nonzero(got != expect)[0]
+        assert bad.size == 0, "draw %d: %d entries differ, first at %d" % (it, bad.size, bad[0])
+        npt.assert_array_equal(key, host.get_state()[1])
+        assert pos == host.get_state()[2]
+    np.random.seed(5)
+    np.random.standard_normal(3)                     # (a cached Gaussian in the state: must survive the round trip)
+    st = np.random.get_state()
+    expect = np.random.permutation(N)
+    after = np.random.get_state()
+    np.random.set_state(st)
+    assert _rng.take_permutation_staged(ctx, N) is _rng.STAGED
+    npt.assert_array_equal(ctx.staged_order(), expect)
+    now = np.random.get_state()
+    npt.assert_array_equal(now[1], after[1])
+    assert now[2:] == after[2:]
+    ctx.close()
+
+
+def test_device_permutation_drives_the_pcrp_classes():
+    """PCRPMM with the visiting order drawn on the device equals the same run with the order drawn by numpy on the host
+    (N < 4096 is the host's: a twin run with a monkey-patched helper gives the host route at the same N)."""
+    import random
+    from pybgmm_amd.igmm import PCRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata, rng as _rng
+    N, D, K = 6000, 6, 5
+    X, zt = gendata.synth_mixture(N, D, K, seed=3, mu_scale=1.5)
+    prior = NIW(*gendata.demo_prior_params(D))
+    out = []
+    for route in ("device", "host"):
+        random.seed(4); np.random.seed(4)
+        mm = PCRPMM(X, prior, 1.0, None, assignments="rand", K=K, K_max=60)
+        if route == "host":
+            mm._draw_order = lambda mm=mm: _rng.take_permutation(mm.N, mm._nprng)
+        rec, _ = mm.collapsed_gibbs_sampler(4, zt, num_saved=0)
+        out.append((mm.components.assignments.copy(), rec["log_marg"], rec["components"], np.random.get_state()[1].copy(), random.random()))
+    npt.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    npt.assert_array_equal(out[0][3], out[1][3])         # (both global streams end where the host route leaves them)
+    assert out[0][4] == out[1][4]
+
+
 @pytest.mark.parametrize("pcrp", [False, True], ids=["crp", "pcrp-fresh-permutation"])
 def test_short_steps_of_the_benchmarked_mode(pcrp):
     """prune_mode 3 (what bench.py times) on a chain at rest queues short steps: home_kernel between sweep_begin and apply

@@ -18,6 +18,8 @@ Development probes of the HIP path, one script (run on a GPU box, e.g. through g
     python tools/probe.py staged [N D K n]          a chain at rest, certified stays off, every sweep's uniforms continued on
                                                     the device: us per stage + sweep, the stage call's share, look-ahead hits
                                                     (under `rocprofv3 --kernel-trace` + tools/timeline.py: the GPU timeline)
+    python tools/probe.py perm [N ...]              np.random.permutation(N) on the device (bgmm_stage_permutation_mt19937)
+                                                    against numpy on this host: ms per permutation
     python tools/probe.py gather                    torch index_select of C4's rows: what a random row gather costs
 
 Replaces the round-1/2 scripts burnin_probe, c3_probe, cert_probe, gram_probe, home_probe, prune_probe,
@@ -218,6 +220,32 @@ def staged(a):
     ctx.close()
 
 
+def perm(a):
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    for N in a.N or [1000000, 2000000]:
+        X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
+        m_0, k_0, v_0, S_0 = gendata.demo_prior_params(2)
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12)
+        ctx.set_assignments(zt)
+        rs = np.random.RandomState(3)
+        key, pos = rs.get_state()[1].copy(), int(rs.get_state()[2])
+        for ahead in (0, -1):
+            ctx.set_mt_lookahead(ahead)
+            for _ in range(3):
+                key, pos = ctx.stage_permutation_mt19937(key, pos)
+            t0 = time.time()
+            for _ in range(20):
+                key, pos = ctx.stage_permutation_mt19937(key, pos)
+            dt = (time.time() - t0) / 20
+            print("N=%d look-ahead %s: device %.3f ms per permutation" % (N, "on" if ahead else "off", dt * 1e3))
+        t0 = time.time()
+        for _ in range(5):
+            rs.permutation(N)
+        print("N=%d: numpy on this host %.3f ms" % (N, (time.time() - t0) / 5 * 1e3))
+        ctx.close()
+
+
 def gather():
     import torch
     N, D = 1000000, 64
@@ -268,6 +296,8 @@ def parser():
     t.add_argument("D", type=int, nargs="?", default=64)
     t.add_argument("K", type=int, nargs="?", default=200)
     t.add_argument("n", type=int, nargs="?", default=300)
+    pm = sub.add_parser("perm")
+    pm.add_argument("N", type=int, nargs="*")
     sub.add_parser("gather")
     return ap
 
@@ -284,5 +314,7 @@ if __name__ == "__main__":
         chains(args)
     elif args.cmd == "staged":
         staged(args)
+    elif args.cmd == "perm":
+        perm(args)
     else:
         gather()
