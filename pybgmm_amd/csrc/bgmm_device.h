@@ -55,6 +55,7 @@ static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a windo
 // the proof pass hold for every count in that range)
 static constexpr int kSafeDn = 16;
 static constexpr int kSafeList = 4096;   // unproven visits a proof pass lists (a stretch ends at the next one)
+static constexpr int kSafeResidSkip = 64; // a proof pass that leaves at most this many visits to the pruning kernel skips it (they are walked)
 static constexpr int kSafeSmall = 8;     // labels with fewer members prove nothing for them (their bounds: kernels_safe.hip)
 
 // Per-slot scalar constants.  (Diagonal covariance uses A = D*(lgamma terms) - 0.5 log prod var,

@@ -678,6 +678,9 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_prune_kernel(Dev d, cons
                                                                   double *__restrict__ q, long long qstride) {
     const JobView job = load_job(jobp);
     if (!job_is_pruned(d, job.mode, job.prune) || (d.safe_mode && d.ctrl->safe_epoch_valid)) return;
+    // (a proof pass whose table bound left only a window's worth of visits open: the resolver walks them anyway -- this
+    // kernel's fixed cost, ~0.2 ms at K = 200, would buy nothing; safe_choice_kernel makes the same call)
+    if (d.safe_mode && d.ctrl->n_resid <= kSafeResidSkip) return;
     if constexpr (!WALK) {
         prune_tile<NJ, RB>(d, job, q, blockIdx.x);
     } else {

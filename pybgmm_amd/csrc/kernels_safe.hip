@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long nrows = c->n_resid;
+    if (nrows <= kSafeResidSkip) return;                  // (the pruning kernel stood aside: these visits stay unproven)
     const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int part = threadIdx.x & 3;
     if (k >= nrows) return;                               // (whole quads leave together)

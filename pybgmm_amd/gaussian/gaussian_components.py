@@ -205,6 +205,35 @@ class GaussianComponents(object):
         return mu, sigma
 
 
+def log_post_pred_unvectorized(gmm, i):
+    """
+    The cross-check helper of the reference (gaussian_components.py:355-363: ``log_post_pred`` one component at a time,
+    "for testing purposes").  ``log_post_pred`` / ``log_post_pred_k`` here are one kernel's output, so a per-component
+    loop over them would check nothing; this one is independent of the device's predictive: it takes the raw
+    statistics (counts, ``m``, ``S``) from the GPU and evaluates every component's Student-t on the HOST the way the
+    reference's scalar path does -- covariance ``(k_N + 1) / (k_N (v_N - D + 1)) (S - k_N m_N m_N')`` (:319-331),
+    its ``slogdet`` and inverse by LAPACK, the density of ``_multivariate_students_t`` (:334-344).
+    Full-covariance components only (the class the reference defines it for).
+    """
+    assert type(gmm) is GaussianComponents, "defined for full-covariance components, as in the reference"
+    D, prior = gmm.D, gmm.prior
+    counts = gmm._ctx.counts()
+    m, S, _, _ = gmm._ctx.stats(False)
+    x = np.asarray(gmm.X[i], dtype=np.float64)
+    out = np.zeros(len(counts), dtype=np.float64)
+    for k in range(len(counts)):
+        n = int(counts[k])
+        k_N, v_N = prior.k_0 + n, prior.v_0 + n
+        mean = m[k] / k_N
+        dof = v_N - D + 1
+        covar = (k_N + 1.0) / (k_N * dof) * (S[k] - k_N * np.outer(mean, mean))
+        diff = x - mean
+        out[k] = (gammaln((dof + D) / 2.0) - gammaln(dof / 2.0) - D / 2.0 * np.log(dof) - D / 2.0 * np.log(np.pi)
+                  - 0.5 * np.linalg.slogdet(covar)[1]
+                  - (dof + D) / 2.0 * np.log1p(diff.dot(np.linalg.inv(covar)).dot(diff) / dof))
+    return out
+
+
 class GaussianComponentsDiag(GaussianComponents):
     """
     Diagonal-covariance components: the interface of the reference's

@@ -202,6 +202,26 @@ def test_first_visit_probabilities():
     ctx.close()
 
 
+def test_log_post_pred_unvectorized_is_an_independent_check():
+    """gaussian_components.py:355-363 / SURVEY 4.2: the vectorised predictive against the per-component scalar path.  Here
+    the scalar path runs on the host (LAPACK slogdet / inverse of every component's covariance from the downloaded raw
+    statistics), the vectorised one is the device kernel: after two sweeps of a captured chain, for points inside,
+    between and far from the components, the two agree to 1e-9 -- and on the reference's own 2014 known answer."""
+    from pybgmm_amd.gaussian.gaussian_components import GaussianComponents, log_post_pred_unvectorized
+    from pybgmm_amd.prior import NIW
+    g = Golden("crpmm_12d")
+    comp = GaussianComponents(g.X, NIW(g.m_0, g.k_0, g.v_0, g.S_0), assignments=g.z_init, K_max=g.K_max)
+    for it in range(2):
+        comp._ctx.sweep(g.u[it], g.sweep_order(it), g.sweep_power(it))
+    for i in (0, 1, g.N // 2, g.N - 1):
+        npt.assert_allclose(comp.log_post_pred(i), log_post_pred_unvectorized(comp, i), rtol=1e-9, atol=1e-9)
+    # pybgmm/tests/test_gaussian_components.py:104 (expected value)
+    X = np.array([[1.2, 0.9], [-0.1, 0.8], [0.5, 0.4]])
+    comp = GaussianComponents(X, NIW(np.zeros(2), 2., 5, 5. * np.eye(2)), assignments=[0, 0, -1], K_max=3)
+    npt.assert_almost_equal(log_post_pred_unvectorized(comp, 2)[0], -2.07325364088)
+    npt.assert_almost_equal(comp.log_post_pred_k(2, 0), -2.07325364088)
+
+
 # ---- the reference's component known answers (pybgmm/tests/test_gaussian_components.py) ----
 def test_component_known_answers():
     from pybgmm_amd.gaussian import GaussianComponents
