@@ -539,13 +539,22 @@ def main():
         ctx.set_tuning(max_window=args.window, kernel_kind=args.kernel, resolver_mode=args.resolver,
                        prune_mode=MODES[mode])
 
-    def kernel_roofline(mode):
-        """One extra sweep in `mode` with every launch of its dominant likelihood kernel bracketed by HIP
-        events on the library's stream."""
+    def kernel_roofline(mode, live_sweeps=0):
+        """Every launch of the mode's dominant likelihood kernel bracketed by HIP events on the library's stream.
+        live_sweeps > 0 (the benchmarked mode): that many sweeps EXACTLY as the timed region runs them -- inputs staged
+        per sweep, the look-ahead generating the next sweeps' uniforms beside them -- so that the average is the one a
+        kernel trace of this command shows; otherwise one extra sweep with resident inputs."""
         set_mode(mode)
-        ctx.sweep_resident(n_sweeps - 1, power)          # settle the window policy
-        ctx.set_kernel_timing(True)
-        ctx.sweep_resident(n_sweeps - 1, power)
+        if live_sweeps > 0:
+            for it in range(4):
+                one_sweep(args.warmup + args.steps + it)
+            ctx.set_kernel_timing(True)
+            for it in range(live_sweeps):
+                one_sweep(args.warmup + args.steps + 4 + it)
+        else:
+            ctx.sweep_resident(n_sweeps - 1, power)          # settle the window policy
+            ctx.set_kernel_timing(True)
+            ctx.sweep_resident(n_sweeps - 1, power)
         n_launch, ms = ctx.kernel_timing()
         st, ps, pa = ctx.sweep_stats(), ctx.prune_stats(), ctx.path_stats()
         ctx.set_kernel_timing(False)
@@ -553,8 +562,14 @@ def main():
             return None
         name = heavy_kernel_name(args, mode, D)
         visits = float(N)
-        common = {"kernel": name, "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                  "visits_per_launch": round(visits / n_launch, 1), "traffic": None}
+        sweeps_timed = max(live_sweeps, 1)
+        avg_ms = ms / n_launch
+        n_launch = n_launch / float(sweeps_timed)          # launches per sweep (the statistics below are the last sweep's)
+        ms = ms / float(sweeps_timed)
+        common = {"kernel": name, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+                  "visits_per_launch": round(visits / n_launch, 1), "traffic": None,
+                  "timed_over": ("%d sweeps run exactly as the timed region runs them (inputs staged per sweep, the look-ahead "
+                                 "generating beside them)" % live_sweeps) if live_sweeps else "one sweep with resident inputs"}
         if mode == "full":
             pairs = float(pa["pairs_executed"])
             if args.cov != "full":
@@ -598,7 +613,7 @@ def main():
     extra_rooflines = {}
     single = rank == 0 and n_gpus == 1
     if not args.no_kernel_timing:
-        roofline = kernel_roofline(args.mode)
+        roofline = kernel_roofline(args.mode, live_sweeps=200 if moves_total == 0 else 0)
         if single and roofline and not args.no_pmc and args.cov == "full":
             traffic, note = pmc_traffic(args, args.mode,
                                         tuple(roofline.get("kernels_for_traffic") or [heavy_kernel_name(args, args.mode, D)]))

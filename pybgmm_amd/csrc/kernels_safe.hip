@@ -130,21 +130,23 @@ __device__ __forceinline__ double exp_above(double x) {
 // whose home is a and whose distance to a's (frozen) mean is at most j / finv[a] -- the robust twin of
 // prune_ftable_kernel (same radii, same centre distances, built right behind it).  The labels' constants are staged
 // in LDS once per workgroup.
-__global__ __launch_bounds__(64) void safe_ftab_kernel(Dev d) {
-    extern __shared__ double lt[];                        // [K][4]: ub0, hv_min, e^-cap / Lambda, e^-cap / k_N0
+__global__ __launch_bounds__(256) void safe_ftab_kernel(Dev d) {
+    extern __shared__ double lt[];                        // [K][4]: ub0, hv_min, e^-cap / Lambda, e^-cap / k_N0; [K] distances
+    __shared__ double red[4][64];
     const Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
-    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
+    // thread = (radius j, quarter of the labels): the 64 radii of home a, the other labels dealt to four wavefronts
+    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x & 63, part = threadIdx.x >> 6;
     if (a >= K) return;
     const double emcap = d.rtab[(long long)(d.nslots - 1) * 8 + 0];
-    for (int t = j; t < K; t += 64) {
+    for (int t = threadIdx.x; t < K; t += 256) {
         const double *__restrict__ g = d.rtab + (long long)t * 8;
         lt[4 * t] = g[0]; lt[4 * t + 1] = g[1]; lt[4 * t + 2] = g[2] * emcap; lt[4 * t + 3] = g[3] * emcap;
     }
     double *dcs = lt + 4 * K;                             // centre distances from a
     const double *__restrict__ dc = d.pr_dcc + (long long)a * d.nslots;
-    for (int t = j; t < K; t += 64) dcs[t] = dc[t] * (1.0 - 1e-9);
+    for (int t = threadIdx.x; t < K; t += 256) dcs[t] = dc[t] * (1.0 - 1e-9);
     __syncthreads();
     const double finv = d.finv[a];
     const double step = finv > 0.0 ? 1.0 / finv : 0.0;
@@ -155,16 +157,25 @@ __global__ __launch_bounds__(64) void safe_ftab_kernel(Dev d) {
         return lt[4 * t] - lt[4 * t + 1] * log1p_below(dl * dl * lt[4 * t + 2] + lt[4 * t + 3]);
     };
     double f = -INFINITY;
-    for (int t = 0; t < K; ++t)
+    for (int t = part; t < K; t += 4)
         if (t != a) f = fmax(f, ub(t));
+    red[part][j] = f;
+    __syncthreads();
+    f = fmax(fmax(red[0][j], red[1][j]), fmax(red[2][j], red[3][j]));
+    __syncthreads();
     // log of the sum: the labels within 45 nats of the largest bound are added up, the rest (each below e^-45 of it)
-    // are covered by K e^-45
-    double sum = (double)K * 2.9e-20;
-    for (int t = 0; t < K; ++t) {
+    // are covered by K e^-45  (the order of the additions differs from a serial loop's by rounding only, and the
+    // result is an UPPER bound with 1e-12 to spare)
+    double sum = 0.0;
+    for (int t = part; t < K; t += 4) {
         if (t == a) continue;
         const double v = ub(t);
         if (v > f - 45.0) sum += exp_above(v - f);
     }
+    red[part][j] = sum;
+    __syncthreads();
+    if (part != 0) return;
+    sum = (double)K * 2.9e-20 + ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
     f += log(sum) * (1.0 + 1e-12) + 1e-12;
     d.ftabR[(long long)a * 64 + j] = (K > 1 && finv > 0.0) ? f : (K > 1 ? INFINITY : -INFINITY);
 }
@@ -302,7 +313,7 @@ void launch_safe_open(const Dev &d, hipStream_t st) {
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     launch_prune_tables(d, st);                                          // centre distances, radii (exit while valid)
     hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(safe_ftab_kernel, dim3(d.nslots), dim3(64), d.nslots * 5 * (int)sizeof(double), st, d);
+    hipLaunchKernelGGL(safe_ftab_kernel, dim3(d.nslots), dim3(256), d.nslots * 5 * (int)sizeof(double), st, d);
     launch_bucket_rows(d, max_rows, st);                                  // the stretch's visits grouped by home
     launch_home(d, max_rows, st);                                         // proof pass: cert[row] = SAFE
     launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, max_rows, st);   // what its table bound left open: exact forms

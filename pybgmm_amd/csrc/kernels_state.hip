@@ -442,15 +442,18 @@ __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
 // most r_j = j / finv[a]  (triangle inequality through the centre distances, as in the coarse level of
 // score_mfma_prune_kernel); the grid reaches half the distance to a's nearest neighbour.  Increasing
 // in j.  Runs after prune_tables_kernel (same validity flag, set by apply_kernel afterwards).
-__global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
+__global__ __launch_bounds__(256) void prune_ftable_kernel(Dev d) {
+    __shared__ double red[4][64];
     const Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid || (d.safe_mode && c->safe_epoch_valid)) return;
-    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x;
+    // thread = (radius j, quarter of the labels): the other labels are dealt to the four wavefronts, a maximum each
+    const int K = c->job.K, a = blockIdx.x, j = threadIdx.x & 63, part = threadIdx.x >> 6;
     if (a >= K) return;
     const double *__restrict__ dc = d.pr_dcc + (long long)a * d.nslots;
     double dmin = INFINITY;
-    for (int t = 0; t < K; ++t)
+    for (int t = j; t < K; t += 64)
         if (t != a) dmin = fmin(dmin, dc[t]);
+    for (int o = 32; o > 0; o >>= 1) dmin = fmin(dmin, __shfl_xor(dmin, o));
     const bool fixed = d.cov_type == COV_FIXED;
     // Radii: up to twice the label's own root mean square radius -- where its members are -- when that is known,
     // whatever lies nearer than that (a small component inside a large one has its centre well inside the other's
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
     const double step = K > 1 ? (rms > 0.0 ? 2.0 * rms : 0.5 * dmin) / 63.0 : 1.0;
     const double rj = (double)j * step * (1.0 + 1e-9);
     double f = -INFINITY;
-    for (int t = 0; t < K; ++t) {
+    for (int t = part; t < K; t += 4) {
         if (t == a) continue;
         const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
         double dl = dc[t] * (1.0 - 1e-9) - rj;
@@ -472,6 +475,10 @@ __global__ __launch_bounds__(64) void prune_ftable_kernel(Dev d) {
         const double L = 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
         f = fmax(f, g[0] - g[16] * (fixed ? tt : L));
     }
+    red[part][j] = f;
+    __syncthreads();
+    if (part != 0) return;
+    f = fmax(fmax(red[0][j], red[1][j]), fmax(red[2][j], red[3][j]));
     d.ftab[(long long)a * 64 + j] = f;
     if (j == 0) d.finv[a] = (step > 0.0 && step < INFINITY) ? 1.0 / step : 0.0;
 }
@@ -548,7 +555,7 @@ void launch_prune_tables(const Dev &d, hipStream_t st) {
     const unsigned ngrp = (unsigned)((d.nslots + 15) / 16);
     hipLaunchKernelGGL(prune_tables_kernel, dim3((ngrp + 15) / 16 + d.nslots), dim3(1024), 0, st, d);
     // (always together with the tables, also in sweeps that do not certify: one validity flag)
-    hipLaunchKernelGGL(prune_ftable_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(prune_ftable_kernel, dim3(d.nslots), dim3(256), 0, st, d);
 }
 
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st) {
