@@ -614,6 +614,12 @@ def main():
     single = rank == 0 and n_gpus == 1
     if not args.no_kernel_timing:
         roofline = kernel_roofline(args.mode, live_sweeps=200 if moves_total == 0 else 0)
+        if roofline and moves_total == 0:
+            # the same kernel with nothing beside it (inputs resident, no look-ahead generating on the second stream)
+            alone = kernel_roofline(args.mode)
+            if alone:
+                roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone["avg_launch_ms"], "frac": alone.get("frac"),
+                                                "timed_over": alone["timed_over"]}
         if single and roofline and not args.no_pmc and args.cov == "full":
             traffic, note = pmc_traffic(args, args.mode,
                                         tuple(roofline.get("kernels_for_traffic") or [heavy_kernel_name(args, args.mode, D)]))

@@ -138,6 +138,8 @@ BGMM_API int bgmm_get_mt_lookahead_stats(bgmm_ctx *ctx, int64_t *out2);
 /* The coefficient bits (19 937 of them, bit i = word i / 32, bit i % 32) of t^(chain * 39 936) modulo the characteristic
  * polynomial of MT19937: host arithmetic only, no device needed (what the CPU tests check against numpy's generator). */
 BGMM_API int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624);
+/* 624-word blocks per chain (the J of the polynomials above is this many blocks). */
+BGMM_API int bgmm_mt19937_chain_blocks(void);
 BGMM_API int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
 /*
  * The visiting order of a pCRP sweep, `np.random.permutation(range(N))` (pcrpmm.py:86-91), drawn ON THE DEVICE from the

@@ -37,6 +37,7 @@ SIGNATURES = {
     "bgmm_set_mt_lookahead": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_mt_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
+    "bgmm_mt19937_chain_blocks": (ctypes.c_int, []),
     "bgmm_get_staged_uniforms": (ctypes.c_int, [_vp, _vp]),
     "bgmm_stage_permutation_mt19937": (ctypes.c_int, [_vp, _vp, _vp]),
     "bgmm_get_staged_order": (ctypes.c_int, [_vp, _vp]),

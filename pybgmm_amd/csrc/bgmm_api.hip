@@ -1818,6 +1818,8 @@ extern "C" int bgmm_get_safe_stats(bgmm_ctx *c, int64_t *out6) {
     return 0;
 }
 
+extern "C" int bgmm_mt19937_chain_blocks(void) { return mt19937_chain_blocks(); }
+
 extern "C" int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624) {
     if (chain < 1 || chain > 4096 || !coef624) return BGMM_EINVAL;
     std::vector<unsigned> coef;

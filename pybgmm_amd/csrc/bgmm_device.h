@@ -372,6 +372,7 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
 // kernels_rng.hip: the caller's MT19937 continued on the device (chains of 64 blocks from jumped-ahead states)
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();
+int mt19937_chain_blocks();
 bool mt19937_jump_coefficients(int n_chains, std::vector<unsigned> &out);
 void launch_mt19937_raw(const unsigned *key_in, int pos, unsigned *words, long long n_words, const unsigned *coef_dev, int n_chains,
                         unsigned *raw, unsigned *seeds, unsigned *spare_key, int *spare_pos, hipStream_t st);

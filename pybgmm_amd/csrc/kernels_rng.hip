@@ -64,6 +64,7 @@ static constexpr int kPhiDeg = 19937;
 static constexpr int kPolyWords = 624;                   // 32-bit words of a coefficient vector (19968 bits)
 static constexpr int kRawWords = 33 * 624;               // untempered words the convolution reads: x[0 .. 20591]
 int mt19937_raw_words() { return kRawWords; }
+int mt19937_chain_blocks() { return kChainBlocks; }
 static constexpr int kJumpSplits = 16, kJumpTargets = 4; // coefficient range per workgroup / chains per workgroup
 
 // chain `p` of a sweep: seed = block p * kChainBlocks of the stream (key_in for p = 0, a jumped state otherwise);

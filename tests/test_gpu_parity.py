@@ -574,8 +574,8 @@ def test_burnin_against_c_oracle(N, D, K, sep):
 
 
 @pytest.mark.parametrize("N,D,K,sep,flip,budget", [(100000, 16, 100, 1.0, 0, 0.0), (100000, 16, 100, 1.0, 0, 1.0),
-                                                   (100000, 64, 60, 0.5, 0, 0.0), (100000, 64, 40, 4.0, 200, 0.0),
-                                                   (16000, 128, 20, 0.28, 0, 0.0)],
+                                                   (100000, 64, 40, 0.5, 0, 0.0), (100000, 64, 40, 4.0, 200, 0.0),
+                                                   (10000, 128, 20, 0.28, 0, 0.0)],
                          ids=["D16-5pct-movers", "D16-5pct-movers-budget-1.0", "D64-0.6pct-movers", "D64-200-wrong-labels",
                               "D128-overlapping"])
 def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
@@ -620,8 +620,8 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (24000, 128, 40, 300, 0)],
-                         ids=["D64-K200-2000-wrong-labels", "D128-K40-300-wrong-labels"])
+@pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (16000, 128, 40, 200, 0)],
+                         ids=["D64-K200-2000-wrong-labels", "D128-K40-200-wrong-labels"])
 def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
     """the largest problems the C port of the reference finishes in about a minute per sweep, at
     BASELINE's D and K, the truth with wrong labels sprinkled in (the sweep repairs them: movers one per ~50 visits, then

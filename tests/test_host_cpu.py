@@ -198,13 +198,14 @@ def test_wishart_draws_consume_the_streams_like_the_reference():
 
 
 def test_mt19937_jump_polynomials_against_numpy():
-    """bgmm_mt19937_jump_poly: t^(chain * 39936) modulo the characteristic polynomial of MT19937 (Berlekamp-Massey +
+    """bgmm_mt19937_jump_poly: t^(chain * J), J = bgmm_mt19937_chain_blocks() * 624 words, modulo the characteristic polynomial of MT19937 (Berlekamp-Massey +
     shift / multiply-and-reduce on the host, no device).  The state J words ahead must be the GF(2) convolution of the
     next 19937 + 623 words with the coefficient bits -- checked against numpy's generator for two chains."""
     from pybgmm_amd import _lib
     rs = np.random.RandomState(2014)
     key = rs.get_state()[1].astype(np.uint32)
-    n_blocks = 64 * 2 + 34
+    cb = _lib.load().bgmm_mt19937_chain_blocks()          # blocks per chain: J = cb * 624 words
+    n_blocks = cb * 2 + 34
 
     def blocks(mt, nb):          # untempered words: the recurrence, vectorised in its three independent runs
         out = [mt.copy()]
@@ -227,7 +228,7 @@ def test_mt19937_jump_polynomials_against_numpy():
         bits = np.unpackbits(g.view(np.uint8), bitorder="little")
         assert not bits[19937:].any()
         idx = np.nonzero(bits[:19937])[0]
-        J = chain * 64 * 624
+        J = chain * cb * 624
         acc = np.zeros(624, dtype=np.uint32)
         for i in idx:
             acc ^= x[i:i + 624]
