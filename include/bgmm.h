@@ -154,6 +154,9 @@ BGMM_API int bgmm_get_staged_uniforms(bgmm_ctx *ctx, double *u_out);
  */
 BGMM_API int bgmm_stage_permutation_mt19937(bgmm_ctx *ctx, uint32_t *key624, int32_t *pos);
 BGMM_API int bgmm_get_staged_order(bgmm_ctx *ctx, int64_t *order_out);
+/* out4 = {permutations served by the look-ahead, generated on the spot, rounds of draws the last one took to settle, the
+ * most any took so far} (kernels_perm.hip: the rounds are queued blindly, a fixed number at a time). */
+BGMM_API int bgmm_get_permutation_stats(bgmm_ctx *ctx, int64_t *out4);
 
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
  * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no

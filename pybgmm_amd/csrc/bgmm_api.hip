@@ -87,6 +87,7 @@ struct bgmm_ctx {
     bool perm_ahead_valid = false;
     int perm_ahead_pos_in = 0;
     long long perm_hits = 0, perm_misses = 0;
+    int perm_last_rounds = 0, perm_max_rounds = 0;   // rounds of draws until the last / the slowest permutation settled
     bool order_staged = false;       // d_order holds a permutation staged for the NEXT sweep: a stage call without an order keeps it
     unsigned *perm_words = nullptr;  // [key in 624 | key out 624 | pos out 16 | spare key 624 | spare pos 16 | raw | untempered words]
     unsigned *perm_seeds = nullptr;  // the chains' seeds (its own: the uniforms' look-ahead may be running beside it)
@@ -790,8 +791,8 @@ static int perm_ensure(bgmm_ctx *c, PermPtrs &P) {
         CK(c, hipMalloc((void **)&c->perm_uints, sizeof(unsigned) * (3 * (size_t)N + 16)));
         c->perm_temp_bytes = perm_sort_temp_bytes((int)N);
         CK(c, hipMalloc(&c->perm_temp, c->perm_temp_bytes + 256));
-        CK(c, hipMalloc((void **)&c->perm_out, sizeof(long long) * 2));
-        CK(c, hipHostMalloc((void **)&c->perm_host, sizeof(unsigned) * (1280 + (size_t)perm_segments(P.n_words_cap)), hipHostMallocDefault));
+        CK(c, hipMalloc((void **)&c->perm_out, sizeof(long long) * 4));
+        CK(c, hipHostMalloc((void **)&c->perm_host, sizeof(unsigned) * (1344 + (size_t)perm_segments(P.n_words_cap)), hipHostMallocDefault));
         { int rc = dalloc(c, &c->d_order_ahead, (size_t)N); if (rc) return rc; }      // (freed with the context's other buffers)
         CK(c, hipStreamCreateWithFlags(&c->perm_stream, hipStreamNonBlocking));
         CK(c, hipEventCreateWithFlags(&c->perm_done, hipEventDisableTiming));
@@ -822,7 +823,7 @@ static int perm_queue(bgmm_ctx *c, const PermPtrs &P, const unsigned *key_pinned
     const int chains = mt19937_chains_for_words(pos, n_words);
     launch_mt19937_raw(P.dkey, pos, P.dwords, n_words, (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains, P.draw, c->perm_seeds,
                        P.dspare, P.dspare_pos, st);
-    if (!launch_permutation(P.dwords, n_words, (int)N, P.dkey, pos, P.J, P.pred, P.ptr, P.cnt, (int *)(c->perm_host + 1280), P.flags, P.ks,
+    if (!launch_permutation(P.dwords, n_words, (int)N, P.dkey, pos, P.J, P.pred, P.ptr, P.cnt, (int *)(c->perm_host + 1344), P.flags, P.ks,
                             P.idx, P.iota, c->perm_temp, c->perm_temp_bytes, c->perm_out, P.changed, order_dst, P.dkey_out, P.dpos_out, st))
         return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
     CK(c, hipGetLastError());
@@ -836,6 +837,7 @@ static int perm_queue_verdicts(bgmm_ctx *c, const PermPtrs &P, hipStream_t st) {
     CK(c, hipMemcpyAsync(H + 625, P.changed, sizeof(int), hipMemcpyDeviceToHost, st));
     CK(c, hipMemcpyAsync(H + 626, P.flags + perm_rounds() + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     CK(c, hipMemcpyAsync(H + 628, c->perm_out, sizeof(long long) * 2, hipMemcpyDeviceToHost, st));
+    CK(c, hipMemcpyAsync(H + 1280, P.flags, sizeof(int) * (size_t)(perm_rounds() + 2), hipMemcpyDeviceToHost, st));   // (statistics)
     return 0;
 }
 
@@ -864,6 +866,18 @@ static int perm_finish(bgmm_ctx *c, const PermPtrs &P, int pos_in, long long *or
     }
     memcpy(key624, H, sizeof(unsigned) * 624);
     *pos = (int32_t)H[624];
+    {   // the round of draws in which no count changed any more (statistics only)
+        int r = 1;
+        while (r <= perm_rounds() && H[1280 + r] != 0) ++r;
+        c->perm_last_rounds = r;
+        if (r > c->perm_max_rounds) c->perm_max_rounds = r;
+    }
+    return 0;
+}
+
+extern "C" int bgmm_get_permutation_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    out4[0] = c->perm_hits; out4[1] = c->perm_misses; out4[2] = c->perm_last_rounds; out4[3] = c->perm_max_rounds;
     return 0;
 }
 

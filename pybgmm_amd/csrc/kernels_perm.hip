@@ -42,22 +42,24 @@ __device__ __forceinline__ unsigned perm_temper(unsigned y) {
     return y;
 }
 
-static constexpr int kPermRounds = 40;     // rounds of draws queued at a time (those behind the write pass return at once)
+static constexpr int kPermRounds = 30;     // rounds of draws queued at a time (those behind the write pass return at once)
+static constexpr int kPermTailLow = 1 << 14; // steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel)
 static constexpr int kPermSeg = 1024;      // words per segment (one wavefront, 4 KB of LDS)
 int perm_segments(long long n_avail) { return (int)((n_avail + kPermSeg - 1) / kPermSeg); }
 int perm_rounds() { return kPermRounds; }
+// the rounds serve the steps n - 1 .. perm_low(n), the tail the rest (all of them when n is small)
+static int perm_low(int n) { return n - 1 >= kPermTailLow ? kPermTailLow : n; }
 
 // raw: untempered MT19937 words following the caller's position, n_avail of them, cut into segments of kPermSeg words;
-// one wavefront per segment, its words in LDS.  Round r takes the step a segment starts at from round r - 1's counts
-// (cnt_prev) while it writes its own (cnt_new): segment 0 is exact at once, segment t once those in front of it are, and
+// one wavefront per segment, its words in LDS.  A round takes the step a segment starts at from the counts the segments in
+// front of it hold at that moment and writes its own: segment 0 is exact at once, segment t once those in front of it are, and
 // a segment's count depends only weakly on where it starts (a word's fate changes only if its value lies between the two
 // thresholds), so the rounds settle -- a dozen or two of them, launched blindly; a segment whose start has not changed
 // since it last ran keeps its count without running again.  The round in which no count changed had every segment at its
 // true start; the round behind it writes the targets J[i] (i = 1 .. n-1) -- numpy's -- and out[0] = words consumed,
 // out[1] = 0 (by the segment in which step 1 is served), and the rounds behind that return at once.
-__global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int round,
-                                                        const int *__restrict__ cnt_prev, int *__restrict__ cnt_new,
-                                                        int *__restrict__ seen, int *__restrict__ J,
+__global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low, int round,
+                                                        int *cnt, int *__restrict__ seen, int *__restrict__ J,
                                                         long long *__restrict__ out, int *__restrict__ flags) {
     __shared__ unsigned ws[4][kPermSeg];
     // flags[r] = some count changed in round r.  The first round behind a round that changed nothing is the WRITE pass:
@@ -74,25 +76,29 @@ __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restri
     if (seg0 >= n_avail) return;
     const int len = (int)(seg0 + kPermSeg < n_avail ? kPermSeg : n_avail - seg0);
     // the step this segment starts at
+    // (the counts are updated IN PLACE, read past the L1: a segment in front of this one that has already run in this
+    // round is seen with its new count -- the rounds are chaotic iterations, which settle in about half as many launches
+    // as rounds that only see the previous launch's counts; the test for "settled" -- a round in which no count changed,
+    // hence every read saw the final value -- is unaffected)
     long long before = 0;
-    for (int k = lane; k < t; k += 64) before += cnt_prev[k];
+    for (int k = lane; k < t; k += 64) before += __hip_atomic_load(cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
     const long long i0l = (long long)(n - 1) - before;
     const int i0 = i0l > 0 ? (int)i0l : 0;
-    // seen[3 t ..]: the start this segment last ran from, what it accepted then, where it served step 1 (-1: not here).
+    // seen[3 t ..]: the start this segment last ran from, what it accepted then, where it served step `low` (-1: not here).
     // From the same start it would do exactly the same again: its count and the targets it wrote stand.
     int *__restrict__ mine_seen = seen + 3 * (long long)t;
     int accepted = 0, end = -1;
     if (round >= 2 && !write_pass && mine_seen[0] == i0) {
         accepted = mine_seen[1];
         end = mine_seen[2];
-    } else if (i0 >= 1) {
+    } else if (i0 >= low) {
         unsigned *__restrict__ W = ws[wv];
         for (int k = lane; k < len; k += 64) W[k] = perm_temper(raw[seg0 + k]);     // (all of the segment's loads in flight together)
         const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
         int i = i0;
         int p = 0;
-        while (i >= 1 && p < len) {
+        while (i >= low && p < len) {
             const unsigned mask = 0xffffffffu >> __builtin_clz((unsigned)i);
             const int lowi = (int)(mask >> 1) + 1;
             const int a = (p + lane < len) ? (int)(W[p + lane] & mask) : 0x7fffffff;
@@ -115,14 +121,17 @@ __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restri
             accepted += k;
             p += cut;
         }
-        if (i < 1) end = p < len ? p : len;              // step 1 has been served: the stream ends here
+        if (i < low) end = p < len ? p : len;            // step `low` has been served (a mask's range ends there: the run was cut)
     }
     if (lane == 0) {
         mine_seen[0] = i0; mine_seen[1] = accepted; mine_seen[2] = end;
-        cnt_new[t] = accepted;
-        if (!write_pass && cnt_prev[t] != accepted) flags[round] = 1;
-        // (exactly one segment sees the last of the n - 1 steps served inside it)
-        if (write_pass && accepted > 0 && before + accepted == (long long)(n - 1) && end >= 0) { out[0] = seg0 + end; out[1] = 0; }
+        const int was = __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (was != accepted) {
+            __hip_atomic_store(cnt + t, accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!write_pass) flags[round] = 1;
+        }
+        // (exactly one segment sees the last of the rounds' n - low steps served inside it: the tail starts behind it)
+        if (write_pass && accepted > 0 && before + accepted == (long long)(n - low) && end >= 0) { out[2] = seg0 + end; out[3] = 0; }
         if (write_pass && t == 0) flags[kPermRounds + 1] = 1;           // "the targets have been written"
     }
 }
@@ -131,26 +140,74 @@ __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restri
 __global__ void perm_reflag_kernel(int rounds, int *__restrict__ flags, long long *__restrict__ out) {
     if (threadIdx.x != 0) return;
     for (int r = 0; r <= rounds + 1; ++r) flags[r] = r == 0 ? 1 : 0;      // (flags[rounds + 1]: the write pass has run)
-    out[0] = 0; out[1] = 1;
+    out[0] = 0; out[1] = 1;          // the whole stream: words consumed, "ran out" until the tail says otherwise
+    out[2] = 0; out[3] = 1;          // the rounds: where the tail starts, "not reached"
+}
+
+// The steps below `low` (the masks of at most 14 bits: 23 k words or so), one wavefront, strictly in order behind the rounds:
+// every one of these short ranges starts where the one before it ended, so rounds would need one launch per range.
+__global__ __launch_bounds__(64) void perm_tail_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low,
+                                                       int *__restrict__ J, long long *__restrict__ out) {
+    __shared__ unsigned W[4096];
+    const int lane = threadIdx.x;
+    const bool rounds_had_steps = n - 1 >= low;
+    if (rounds_had_steps && out[3] != 0) return;           // (the rounds never reached `low`: the words ran out, or not settled yet)
+    long long p = rounds_had_steps ? out[2] : 0;
+    int i = rounds_had_steps ? low - 1 : n - 1;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    bool failed = false;
+    while (i >= 1) {
+        // the next 4096 words into LDS (all loads in flight together), then runs of 64 out of it
+        const long long base = p;
+        const int len = (int)(base + 4096 < n_avail ? 4096 : n_avail - base);
+        if (len < 64) { failed = true; break; }
+        __syncthreads();
+        for (int k = lane; k < len; k += 64) W[k] = perm_temper(raw[base + k]);
+        __syncthreads();
+        int q = 0;
+        while (i >= 1 && q + 64 <= len) {
+            const unsigned mask = 0xffffffffu >> __builtin_clz((unsigned)i);
+            const int lowi = (int)(mask >> 1) + 1;
+            const int a = (int)(W[q + lane] & mask);
+            unsigned long long acc = __ballot(a <= i);
+            for (;;) {
+                const int c = __builtin_popcountll(acc & below);
+                const unsigned long long acc2 = __ballot(a <= i - c);
+                if (acc2 == acc) break;
+                acc = acc2;
+            }
+            const int c = __builtin_popcountll(acc & below);
+            const int s = i - c;
+            const bool mine = (acc >> lane) & 1ull;
+            const unsigned long long last = __ballot(mine && s == lowi);
+            const int cut = last ? (int)__builtin_ctzll(last) + 1 : 64;
+            if (mine && lane < cut) J[s] = a;
+            const unsigned long long used = cut == 64 ? acc : (acc & (~0ull >> (64 - cut)));
+            i -= (int)__builtin_popcountll(used);
+            q += cut;
+        }
+        p = base + q;
+    }
+    if (lane == 0) { out[0] = p; out[1] = failed ? 1 : 0; }
 }
 
 // The counts round 1 starts from: the EXPECTED progress of the rejection sampling (a word is accepted with probability
 // (i + 1) / 2^k at step i of a mask of k bits), segment by segment -- on the host, a microsecond's worth of arithmetic.
-void perm_guess_host(int T, long long n_avail, int n, int *cnt) {
+void perm_guess_host(int T, long long n_avail, int n, int low, int *cnt) {
     double i = (double)(n - 1);
     for (int t = 0; t < T; ++t) {
         const long long seg0 = (long long)t * kPermSeg;
         double words = (double)(seg0 + kPermSeg < n_avail ? kPermSeg : n_avail - seg0);
         const double i_in = i;
-        while (words > 0.0 && i >= 1.0) {
+        while (words > 0.0 && i >= (double)low) {
             const unsigned ii = (unsigned)i;
             const double m = (double)(0xffffffffu >> __builtin_clz(ii)) + 1.0, lowi = 0.5 * m;
             const double need = m * log((i + 1.0) / lowi);           // words this mask's range still takes (sum of m / (j + 1))
             if (need <= words) { words -= need; i = lowi - 1.0; }
             else { i = (i + 1.0) * exp(-words / m) - 1.0; words = 0.0; }
         }
-        if (i < 0.0) i = 0.0;
-        cnt[t] = (int)(i_in - i + 0.5);
+        if (i < (double)low - 1.0) i = (double)low - 1.0;
+        cnt[t] = i_in >= (double)low ? (int)(i_in - i + 0.5) : 0;
     }
 }
 
@@ -234,11 +291,12 @@ static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int
                               hipStream_t st) {
     const int T = perm_segments(n_avail);
     int *seen = cnt + 2 * (long long)T;              // [3 T]: perm_draw_kernel's memo (round 1 ignores what it holds)
+    (void)parity;
     hipLaunchKernelGGL(perm_reflag_kernel, dim3(1), dim3(64), 0, st, kPermRounds, flags, out);
-    // (round r reads cnt + ((r + 1 + parity) & 1) * T and writes the other half)
+    const int low = perm_low(n);
     for (int r = 1; r <= kPermRounds; ++r)
-        hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, r,
-                           cnt + ((r + 1 + parity) & 1) * T, cnt + ((r + parity) & 1) * T, seen, J, out, flags);
+        hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, low, r, cnt, seen, J, out, flags);
+    hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out);
 }
 
 // everything behind the draws: the swaps (sort by target, links, pointer jumping, assembly) and the generator state
@@ -269,14 +327,14 @@ bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in,
 // raw / n_avail: untempered words behind the caller's position.  Scratch (device): J, pred, ptr [n] ints; cnt [5 x
 // perm_segments] ints; flags [perm_rounds + 2] ints (flags[perm_rounds + 1] == 0 afterwards: the draws have not settled --
 // launch_permutation_draw_more, then launch_permutation_tail again); ks, idx, iota [n] unsigned; temp
-// (perm_sort_temp_bytes); out [2] long long; changed [1] int (!= 0 afterwards: launch_permutation_more).  order: the
+// (perm_sort_temp_bytes); out [4] long long; changed [1] int (!= 0 afterwards: launch_permutation_more).  order: the
 // permutation, int64 [n].  guess_pinned: perm_segments ints of pinned host memory.  key_in (device, 624 words) / pos: the state the words start from; key_out / pos_out (device):
 // the state behind the words consumed.
 bool launch_permutation(const unsigned *raw, long long n_avail, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr,
                         int *cnt, int *guess_pinned, int *flags, unsigned *ks, unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes,
                         long long *out, int *changed, long long *order, unsigned *key_out, int *pos_out, hipStream_t st) {
     const int T = perm_segments(n_avail);
-    perm_guess_host(T, n_avail, n, guess_pinned);
+    perm_guess_host(T, n_avail, n, perm_low(n), guess_pinned);
     if (hipMemcpyAsync(cnt, guess_pinned, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess) return false;   // (round 1 reads cnt[0 .. T))
     queue_draw_rounds(raw, n_avail, n, J, cnt, flags, out, 0, st);
     return launch_permutation_tail(raw, n, key_in, pos, J, pred, ptr, ks, idx, iota, temp, temp_bytes, out, changed, order, key_out,

@@ -238,7 +238,7 @@ def perm(a):
             for _ in range(20):
                 key, pos = ctx.stage_permutation_mt19937(key, pos)
             dt = (time.time() - t0) / 20
-            print("N=%d look-ahead %s: device %.3f ms per permutation" % (N, "on" if ahead else "off", dt * 1e3))
+            print("N=%d look-ahead %s: device %.3f ms per permutation" % (N, "on" if ahead else "off", dt * 1e3), ctx.permutation_stats())
         t0 = time.time()
         for _ in range(5):
             rs.permutation(N)
