@@ -480,19 +480,19 @@ def main():
     for it in range(args.warmup):
         one_sweep(it)
     barrier()
+    tot0 = ctx.totals()                               # (the library sums its per-sweep counters: read at both ends of the loop)
     t0 = time.time()
-    decided = executed = moves = 0
     chunk_marks = []
     for it in range(args.warmup, args.warmup + args.steps):
         one_sweep(it)
-        st = ctx.sweep_stats()
-        decided += st["lik_evals"]
-        executed += ctx.path_stats()["pairs_executed"]
-        moves += st["moves"]
         if (it - args.warmup + 1) % 250 == 0:
             chunk_marks.append(time.time())           # (every call above ends with a stream sync: host time is device time)
     barrier()
     elapsed = time.time() - t0
+    tot1 = ctx.totals()
+    assert tot1["sweeps"] - tot0["sweeps"] == args.steps
+    decided, moves = tot1["lik_evals"] - tot0["lik_evals"], tot1["moves"] - tot0["moves"]
+    executed = tot1["pairs_executed"] - tot0["pairs_executed"]
     chunk_rates = [round(250.0 / (b - a), 1) for a, b in zip([t0] + chunk_marks[:-1], chunk_marks)]
     # the same chain with its inputs already resident (8 sweeps' worth of uniforms / permutations uploaded ahead and
     # cycled through): what the sweep kernels alone sustain -- reported in `extra`, never the headline

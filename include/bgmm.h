@@ -313,6 +313,10 @@ BGMM_API int bgmm_set_home_pass(bgmm_ctx *ctx, int32_t mode);
  * sort it relied on were still valid; otherwise the same window is queued again with the full kernel set.
  * out2 = {short steps that stood, short steps refused} over the life of the context. */
 BGMM_API int bgmm_get_short_step_stats(bgmm_ctx *ctx, int64_t *out2);
+/* Since the context was made: out4 = {sweeps, (visit, component) pairs decided, moves, pairs whose quadratic form was
+ * executed} -- what bgmm_get_sweep_stats / bgmm_get_path_stats report per sweep, summed (a measurement loop reads it once
+ * at each end instead of after every sweep). */
+BGMM_API int bgmm_get_totals(bgmm_ctx *ctx, int64_t *out4);
 
 /* Blocks until all work queued on the context's stream has finished. */
 BGMM_API int bgmm_synchronize(bgmm_ctx *ctx);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "bgmm_stage_mt19937": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "bgmm_set_mt_jump": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_short_step_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_totals": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_mt_lookahead": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_mt_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_mt19937_jump_poly": (ctypes.c_int, [ctypes.c_int32, _vp]),
@@ -209,6 +210,11 @@ class Context(object):
 
     def set_mt_jump(self, on=True):
         self._ck(self.L.bgmm_set_mt_jump(self.h, 1 if on else 0))
+
+    def totals(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_totals(self.h, _ptr(out)))
+        return {"sweeps": int(out[0]), "lik_evals": int(out[1]), "moves": int(out[2]), "pairs_executed": int(out[3])}
 
     def short_step_stats(self):
         out = np.zeros(2, dtype=np.int64)

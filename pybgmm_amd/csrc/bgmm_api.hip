@@ -134,6 +134,7 @@ struct bgmm_ctx {
     bool cur_zero_u = false;
     std::vector<char> res_zero_u;
     std::vector<char> res_perm;      // per resident sweep: its order is a permutation (or absent)
+    long long totals[4] = {0, 0, 0, 0};    // since the context was made: sweeps, pairs decided, moves, pairs executed (bgmm_get_totals)
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats2[4] = {0, 0, 0, 0};   // pairs whose quadratic form was executed, frozen-factor windows, their rows, spare
     // frozen-factor windows (kernels_gram.hip): buffers sized for `gcols` columns, re-allocated when the labels outgrow them
@@ -941,6 +942,12 @@ extern "C" int bgmm_get_staged_order(bgmm_ctx *c, int64_t *order_out) {
     return 0;
 }
 
+extern "C" int bgmm_get_totals(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    for (int k = 0; k < 4; ++k) out4[k] = c->totals[k];
+    return 0;
+}
+
 extern "C" int bgmm_get_short_step_stats(bgmm_ctx *c, int64_t *out2) {
     if (!c || !out2) return BGMM_EINVAL;
     out2[0] = c->short_stood;
@@ -1423,6 +1430,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     c->certified = (long long)h.n_certified;
     c->stats2[0] = (long long)h.n_pairs_exact; c->stats2[1] = h.gram_windows; c->stats2[2] = h.gram_rows_total;
     c->stats2[3] = h.home_in - h.home_out;          // visits home_kernel decided on its own
+    c->totals[0] += 1; c->totals[1] += h.lik_evals; c->totals[2] += h.n_moves; c->totals[3] += (long long)h.n_pairs_exact;
     c->safe_stats[0] = h.safe_windows; c->safe_stats[1] = h.safe_scanned; c->safe_stats[2] = h.safe_rows;
     c->safe_stats[3] = h.safe_cuts; c->safe_stats[4] = (long long)(1e6 * (c->safe_cap_user > 0.0 ? c->safe_cap_user : h.safe_cap));
     c->safe_stats[5] = h.safe_L;

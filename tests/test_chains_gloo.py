@@ -46,3 +46,55 @@ def test_gather_single_process_fallback():
     from pybgmm_amd.chains import gather_chains
     Z, LM = gather_chains(np.arange(10), np.array([1.0, 2.0]))
     assert Z.shape == (1, 10) and LM.shape == (1, 2)
+
+
+def test_lockstep_rendezvous_of_sampler_loops_without_a_gpu(monkeypatch):
+    """chains.run_chains_on_device's host logic (many chains per GPU): G sampler loops in threads meet at a barrier in
+    IGMM._sweep, the last one to arrive sweeps the whole group ONCE per round with every chain's exponent, and a chain that
+    fails breaks the barrier for the others instead of leaving them waiting.  The device is replaced by a stub."""
+    import threading
+    from pybgmm_amd import chains, _lib
+
+    calls = []
+
+    class Ctx(object):
+        pass
+
+    class Comp(object):
+        def __init__(self):
+            self._ctx = Ctx()
+
+    class Model(object):
+        def __init__(self, *a, **kw):
+            self.components = Comp()
+            self.rounds = 0
+            self.fail_at = None
+
+        def collapsed_gibbs_sampler(self, n_iter, true_assignments, num_saved=0):
+            for it in range(n_iter):
+                if self.fail_at == it:
+                    raise ValueError("chain failed")
+                self._lockstep.sweep(self, 1.0 + 0.01 * it)
+                self.rounds += 1
+            return {"rounds": self.rounds}, None
+
+    def fake_group_sweep(ctxs, powers):
+        calls.append((len(ctxs), tuple(powers), threading.current_thread().name))
+    monkeypatch.setattr(_lib, "group_sweep_staged", fake_group_sweep)
+    out = chains.run_chains_on_device(Model, None, None, 1.0, 6, 5, seed=3)
+    assert len(out) == 6 and all(rec["rounds"] == 5 for _, rec in out)
+    assert len(calls) == 5                                        # one group sweep per round, not one per chain
+    assert [c[0] for c in calls] == [6] * 5
+    assert [c[1] for c in calls] == [tuple([1.0 + 0.01 * it] * 6) for it in range(5)]
+    # a failing chain: its exception comes out, nobody hangs
+    made = []
+
+    class Failing(Model):
+        def __init__(self, *a, **kw):
+            Model.__init__(self, *a, **kw)
+            made.append(self)
+            if len(made) == 3:
+                self.fail_at = 2
+    import pytest
+    with pytest.raises(ValueError):
+        chains.run_chains_on_device(Failing, None, None, 1.0, 4, 5, seed=3)

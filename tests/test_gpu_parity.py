@@ -1854,7 +1854,7 @@ def test_run_chains_on_device_equals_solo_runs(model):
     from pybgmm_amd.prior import NIW
     from pybgmm_amd.utils import gendata
     cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
-    N, D, K, s, n_iter, G = 4000, 2, 6, 11, 4, 5
+    N, D, K, s, n_iter, G = 5000, 2, 6, 11, 4, 5        # (N >= 4096: PCRPMM's permutations are drawn on the device, one per thread)
     X, zt = gendata.synth_mixture(N, D, K, seed=3, mu_scale=2.0)
     prior = NIW(*gendata.demo_prior_params(D))
     runs = chains.run_chains_on_device(cls, X, prior, 1.0, G, n_iter, seed=s, true_assignments=zt, K=K, K_max=80)
