@@ -1,13 +1,16 @@
-"""Soak test: the default configuration (certified stays + exact pruning + lean steps + resolver) against
-the plain full evaluation (prune_mode 1, resolver off) over many sweeps, shapes, separations, visiting
-orders, seating exponents and hand-made state changes.  Any difference in the label trajectory is a bug.
+"""Soak test: the default configuration (certified stays + exact pruning + lean steps + resolver; every fourth case the
+benchmarked mode, certified stays off with its short steps) against the plain full evaluation (prune_mode 1, resolver
+off) over many sweeps, shapes, separations, visiting orders, seating exponents and hand-made state changes.  The first
+context takes its inputs the way the classes do -- the uniforms of a random.Random and the permutations of a RandomState
+continued ON THE DEVICE (look-ahead batches, with the caller drawing from its generators in between now and then) --
+the second one from twin generators on the host.  Any difference in the label trajectory is a bug.
     python tools/soak.py [n_cases [seed]]
 (`certified` counts certificates issued: rows behind a mover are examined again by the next window.)"""
-import os, sys, time
+import os, random, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pybgmm_amd import _lib
-from pybgmm_amd.utils import gendata
+from pybgmm_amd.utils import gendata, rng as _rng
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
@@ -40,26 +43,46 @@ for case in range(n_cases):
         c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max, cov_type=cov)
         # (the default configuration keeps pruned windows for long mover-free stretches; every third
         # case forces them in every regime so that the pruning / certification kernels see moving chains)
-        c.set_tuning(prune_mode=(2 if case % 3 == 0 else 0) if mode == 0 else 1, resolver_mode=1 if mode == 1 else 0)
+        c.set_tuning(prune_mode=(2 if case % 3 == 0 else (3 if case % 4 == 1 else 0)) if mode == 0 else 1,
+                     resolver_mode=1 if mode == 1 else 0)
         c.set_assignments(z0)
         ctxs.append(c)
     n_sweeps = 10
     ok = True
     cert = 0
+    # twin generators: the device continues (dev_r, dev_np), the host draws from (host_r, host_np)
+    dev_r, host_r = random.Random(case), random.Random(case)
+    dev_np, host_np = np.random.RandomState(case), np.random.RandomState(case)
+    ctxs[0].set_mt_lookahead(int(rs.choice([-1, -1, 1, 3, 0])))
     for it in range(n_sweeps):
-        u = rs.random_sample(N)
-        order = rs.permutation(N) if pcrp else None
+        if rs.randint(5) == 0:                      # the caller draws from its own generators between two sweeps
+            k = int(rs.randint(1, 5))
+            assert [dev_r.random() for _ in range(k)] == [host_r.random() for _ in range(k)]
+            assert np.array_equal(dev_np.random_sample(k), host_np.random_sample(k))
+        u = _rng.take_uniforms(N, host_r)
+        order = host_np.permutation(N) if pcrp else None
         power = (1.0 + 0.02 * rs.rand()) if (pcrp and it > 0) else None
         edit = None
         if it in (4, 7) and rs.randint(2):
             ii = rs.choice(N, size=20, replace=False)
             edit = [(int(i), int(rs.randint(0, ctxs[0].K))) for i in ii]
-        for c in ctxs:
+        for ci, c in enumerate(ctxs):
             if edit:
                 for i, lab in edit:
                     c.del_item(i)
                     c.add_item(i, min(lab, c.K))
-            c.sweep(u, order, power)
+            if ci == 0:
+                dev_order = _rng.take_permutation_staged(c, N, dev_np) if pcrp else None
+                if dev_order is _rng.STAGED:
+                    dev_order = None
+                assert _rng.stage_uniforms_on_device(c, dev_order, dev_r)
+                c.sweep_staged(power)
+            else:
+                c.sweep(u, order, power)
+        if dev_r.getstate() != host_r.getstate() or not np.array_equal(dev_np.get_state()[1], host_np.get_state()[1]):
+            print("GENERATOR STATE case %d sweep %d: the device left a generator elsewhere than the host" % (case, it))
+            ok = False
+            break
         za, zb = ctxs[0].assignments(), ctxs[1].assignments()
         cert += ctxs[0].prune_stats()["certified_visits"]
         if not np.array_equal(za, zb):
