@@ -40,29 +40,33 @@ class ADAPCRPMM(IGMM):
         start_time = time.time()
         distribution_dict = self.setup_distribution_dict(num_saved)
         adapcrp_power = None
-        for i_iter in range(n_iter):
-            if num_saved == self.components.K and i_iter > 1:
-                distribution_dict = self.update_distribution_dict(distribution_dict, weight_first)
-            powered = flag_adapcrp and i_iter > adapcrp_burnin
-            if powered:
-                # the exponent grows with the share of "small" clusters -- those holding at most
-                # adapcrp_perct of the data -- from 1 (none small) up to r_up (all small): adapcrpmm.py:100-103
-                sizes = np.asarray(self.components._ctx.counts())
-                share_small = np.count_nonzero(sizes <= adapcrp_perct * self.components.N) / float(sizes.size)
-                adapcrp_power = 1.0 + share_small * (r_up - 1.0)
-                if i_iter % 20 == 0:
-                    logging.info('Ada-pCRP power: {}'.format(adapcrp_power))
-            order = None
-            if flag_adapcrp:
-                if adapcrp_power is None:
-                    raise UnboundLocalError("local variable 'adapcrp_power' referenced before assignment")
-                if adapcrp_power > 1:
+        self._lease_generators()
+        try:
+            for i_iter in range(n_iter):
+                if num_saved == self.components.K and i_iter > 1:
+                    distribution_dict = self.update_distribution_dict(distribution_dict, weight_first)
+                powered = flag_adapcrp and i_iter > adapcrp_burnin
+                if powered:
+                    # the exponent grows with the share of "small" clusters -- those holding at most
+                    # adapcrp_perct of the data -- from 1 (none small) up to r_up (all small): adapcrpmm.py:100-103
+                    sizes = np.asarray(self.components._ctx.counts())
+                    share_small = np.count_nonzero(sizes <= adapcrp_perct * self.components.N) / float(sizes.size)
+                    adapcrp_power = 1.0 + share_small * (r_up - 1.0)
                     if i_iter % 20 == 0:
-                        logger.info(" Permutate data")
-                    order = self._draw_order()
-            self._sweep(order=order, power=adapcrp_power if powered else None)
-            record_dict = self.update_record_dict(record_dict, i_iter, true_assignments, start_time)
-            start_time = time.time()
+                        logging.info('Ada-pCRP power: {}'.format(adapcrp_power))
+                order = None
+                if flag_adapcrp:
+                    if adapcrp_power is None:
+                        raise UnboundLocalError("local variable 'adapcrp_power' referenced before assignment")
+                    if adapcrp_power > 1:
+                        if i_iter % 20 == 0:
+                            logger.info(" Permutate data")
+                        order = self._draw_order()
+                self._sweep(order=order, power=adapcrp_power if powered else None)
+                record_dict = self.update_record_dict(record_dict, i_iter, true_assignments, start_time)
+                start_time = time.time()
+        finally:
+            self._release_generators()
         return record_dict, distribution_dict
 
     fit = collapsed_gibbs_sampler

@@ -27,12 +27,16 @@ class CRPMM(IGMM):
         record_dict = self.setup_record_dict()
         start_time = time.time()
         distribution_dict = self.setup_distribution_dict(num_saved)
-        for i_iter in range(n_iter):
-            if num_saved == self.components.K and i_iter > 1:
-                distribution_dict = self.update_distribution_dict(distribution_dict, weight_first)
-            self._sweep(order=None, power=None)
-            record_dict = self.update_record_dict(record_dict, i_iter, true_assignments, start_time)
-            start_time = time.time()
+        self._lease_generators()
+        try:
+            for i_iter in range(n_iter):
+                if num_saved == self.components.K and i_iter > 1:
+                    distribution_dict = self.update_distribution_dict(distribution_dict, weight_first)
+                self._sweep(order=None, power=None)
+                record_dict = self.update_record_dict(record_dict, i_iter, true_assignments, start_time)
+                start_time = time.time()
+        finally:
+            self._release_generators()
         return record_dict, distribution_dict
 
     fit = collapsed_gibbs_sampler

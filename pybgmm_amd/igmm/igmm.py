@@ -46,6 +46,7 @@ class IGMM(GMM):
         self.N, self.D = X.shape
         self._rng = rng
         self._nprng = np.random if nprng is None else nprng
+        self._lease = None              # the generators' states while a sampler loop runs (utils/rng.py: DeviceLease)
 
         if isinstance(assignments, str):
             if assignments == "rand":
@@ -81,6 +82,7 @@ class IGMM(GMM):
         label-switch ordering (igmm.py:128-197).  The matplotlib output of the
         reference for D == 2 is not produced; the ``np.random`` Dirichlet draw is,
         so the caller-visible stream stays aligned."""
+        self._settle_generators()       # (the Dirichlet weights below come out of the caller's numpy stream)
         means, sds = [], []
         for mu, sigma in self.components.map_all():
             means.append(mu)
@@ -125,9 +127,25 @@ class IGMM(GMM):
         return stats.dirichlet(alpha).rvs(size=1, random_state=self._nprng).flatten()
 
     # ------------------------------------------------------------------ #
+    def _lease_generators(self):
+        """Start of a sampler loop: from here to ``_settle_generators`` the device advances the generators' states."""
+        self._lease = _rng.DeviceLease(self._rng, self._nprng)
+
+    def _settle_generators(self):
+        if self._lease is not None:
+            self._lease.settle()
+
+    def _release_generators(self):
+        """End of a sampler loop (also on an exception): the generators are the caller's again."""
+        if self._lease is not None:
+            self._lease.settle()
+            self._lease = None
+
     def _draw_order(self):
         """``np.random.permutation(range(N))`` from the caller's numpy stream as the next sweep's visiting order: drawn on
         the device where the library can (``rng.STAGED``), on the host otherwise (the array)."""
+        if self._lease is not None:
+            return self._lease.stage_permutation(self.components._ctx, self.N)
         return _rng.take_permutation_staged(self.components._ctx, self.N, self._nprng)
 
     def _sweep(self, order=None, power=None):
@@ -135,7 +153,10 @@ class IGMM(GMM):
         ctx = self.components._ctx
         if order is _rng.STAGED:        # (drawn on the device and already in place: _draw_order)
             order = None
-        staged = _rng.stage_uniforms_on_device(ctx, order, self._rng)   # the caller's stream, continued on the GPU
+        if self._lease is not None:
+            staged = self._lease.stage_uniforms(ctx, order)             # the caller's stream, continued on the GPU
+        else:
+            staged = _rng.stage_uniforms_on_device(ctx, order, self._rng)
         if not staged:
             ctx.stage(_rng.take_uniforms(self.N, self._rng), order)
         step = getattr(self, "_lockstep", None)
