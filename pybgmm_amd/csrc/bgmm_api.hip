@@ -963,6 +963,11 @@ extern "C" int bgmm_set_mt_lookahead(bgmm_ctx *c, int32_t sweeps) {
     int rc = mt_wait_batches(c);
     if (rc) return rc;
     for (auto &b : c->mt_b) {
+        // (uniforms staged out of a batch and not swept yet move into the context's own buffer before the batch goes)
+        if (b.u && c->cur_u >= b.u && c->cur_u < b.u + (size_t)c->d.N * (size_t)(c->mt_depth > 0 ? c->mt_depth : 1)) {
+            CK(c, hipMemcpy(c->d_u, c->cur_u, sizeof(double) * (size_t)c->d.N, hipMemcpyDeviceToDevice));
+            c->cur_u = c->d_u;
+        }
         b.launched = false;
         if (b.u) { (void)hipFree(b.u); b.u = nullptr; }
         if (b.host) { (void)hipHostFree(b.host); b.host = nullptr; }
