@@ -26,7 +26,7 @@
 //    where V(i) = the value at position i just before step i, pred(i) = the next larger step with the same target as i
 //    (the most recent earlier swap into that position), and V(i) = V(predV(i)) with predV(i) = the smallest step > i whose
 //    target is i (or i itself, untouched, if there is none).  pred / predV fall out of a stable sort of the steps by
-//    target (rocPRIM radix sort), V out of a few rounds of pointer jumping.
+//    target (rocPRIM radix sort); the chains behind V are a handful of links long and every position walks its own.
 // tests/test_perm_formulation.py holds the same formulation in numpy, checked against np.random on the CPU.
 #include "bgmm_device.h"
 
@@ -244,19 +244,31 @@ __global__ void perm_jump_kernel(int n, int *__restrict__ ptr, int *__restrict__
     }
 }
 
+// V(v): the root of v's chain of "who was swapped in here before" links (ptr[v] = predV(v), or v itself at a root).  The
+// chains are a handful of links long (each link goes to a uniformly later step; the longest of 2e6 about forty), so every
+// position simply walks its own: nothing is written that another thread reads.
+__device__ __forceinline__ int perm_root(const int *__restrict__ ptr, int v) {
+    int p = ptr[v];
+    while (true) {
+        const int pp = ptr[p];
+        if (pp == p) return p;
+        p = pp;
+    }
+}
+
 __global__ void perm_final_kernel(int n, const int *__restrict__ J, const int *__restrict__ pred, const int *__restrict__ ptr,
                                   long long *__restrict__ order) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     int val;
     if (i == 0) {
-        val = ptr[0];
+        val = perm_root(ptr, 0);
     } else {
         const int j = J[i];
-        if (j == i) val = ptr[i];
+        if (j == i) val = perm_root(ptr, i);
         else {
             const int pr = pred[i];
-            val = pr >= 0 ? ptr[pr] : j;
+            val = pr >= 0 ? perm_root(ptr, pr) : j;
         }
     }
     order[i] = (long long)val;
@@ -311,14 +323,9 @@ bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in,
                                       perm_key_bits(n), st) != hipSuccess)
             return false;
         hipLaunchKernelGGL(perm_links_kernel, dim3((unsigned)((n - 1 + 255) / 256)), dim3(256), 0, st, n - 1, ks, idx, pred, ptr);
-        // chains of "who was swapped in here before" are a handful of links long (each link goes to a uniformly later
-        // step): seven rounds of doubling cover 2^7 of them; the eighth only reports whether anything still moved
-        for (int r = 0; r < 7; ++r) hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, (int *)nullptr);
-        (void)hipMemsetAsync(changed, 0, sizeof(int), st);
-        hipLaunchKernelGGL(perm_jump_kernel, dim3(g), dim3(256), 0, st, n, ptr, changed);
-    } else {
-        (void)hipMemsetAsync(changed, 0, sizeof(int), st);
+        // (the chains of links are walked by perm_final_kernel itself: no rounds of pointer jumping)
     }
+    (void)hipMemsetAsync(changed, 0, sizeof(int), st);
     hipLaunchKernelGGL(perm_final_kernel, dim3(g), dim3(256), 0, st, n, J, pred, ptr, order);
     hipLaunchKernelGGL(perm_state_kernel, dim3(1), dim3(256), 0, st, key_in, raw, pos, out, key_out, pos_out);
     return hipGetLastError() == hipSuccess;
