@@ -789,6 +789,9 @@ static int perm_ensure(bgmm_ctx *c, PermPtrs &P) {
         c->perm_chains = mt19937_chains_for_words(624, P.n_words_cap);
         CK(c, hipMalloc((void **)&c->perm_seeds, sizeof(unsigned) * 624 * (size_t)(c->perm_chains + 2)));
         CK(c, hipMalloc((void **)&c->perm_ints, sizeof(int) * (3 * (size_t)N + 64 + 5 * (size_t)perm_segments(P.n_words_cap))));
+        // (targets left over from an earlier permutation are at least valid indices: when a generation's draws have not
+        // settled, the kernels behind them run on whatever J holds before the repair queues them again)
+        CK(c, hipMemset(c->perm_ints, 0, sizeof(int) * (3 * (size_t)N + 64 + 5 * (size_t)perm_segments(P.n_words_cap))));
         CK(c, hipMalloc((void **)&c->perm_uints, sizeof(unsigned) * (3 * (size_t)N + 16)));
         c->perm_temp_bytes = perm_sort_temp_bytes((int)N);
         CK(c, hipMalloc(&c->perm_temp, c->perm_temp_bytes + 256));

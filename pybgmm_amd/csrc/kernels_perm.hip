@@ -224,6 +224,7 @@ __global__ void perm_links_kernel(int m, const unsigned *__restrict__ ks, const 
     const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (q >= m) return;
     const unsigned v = ks[q], i = idx[q];
+    if (v > (unsigned)m) return;                       // (not a target: only in a run whose draws have not settled)
     const bool next_same = q + 1 < m && ks[q + 1] == v;
     if (next_same) pred[i] = (int)idx[q + 1];
     if (q == 0 || ks[q - 1] != v) {
