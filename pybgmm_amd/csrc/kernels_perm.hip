@@ -31,6 +31,7 @@
 #include "bgmm_device.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -42,11 +43,20 @@ __device__ __forceinline__ unsigned perm_temper(unsigned y) {
     return y;
 }
 
-static constexpr int kPermRounds = 30;     // rounds of draws queued at a time (those behind the write pass return at once)
+static constexpr int kPermRoundsDefault = 30;   // rounds of draws queued at a time (those behind the write pass return at once)
+// (BGMM_PERM_ROUNDS in the environment, 3 .. 56: for the test that drives the "not settled yet, more rounds" repair)
+static int perm_rounds_now() {
+    static const int r = [] {
+        const char *e = getenv("BGMM_PERM_ROUNDS");
+        const int v = e ? atoi(e) : kPermRoundsDefault;
+        return v < 3 ? 3 : (v > 56 ? 56 : v);
+    }();
+    return r;
+}
 static constexpr int kPermTailLow = 1 << 14; // steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel)
 static constexpr int kPermSeg = 1024;      // words per segment (one wavefront, 4 KB of LDS)
 int perm_segments(long long n_avail) { return (int)((n_avail + kPermSeg - 1) / kPermSeg); }
-int perm_rounds() { return kPermRounds; }
+int perm_rounds() { return perm_rounds_now(); }
 // the rounds serve the steps n - 1 .. perm_low(n), the tail the rest (all of them when n is small)
 static int perm_low(int n) { return n - 1 >= kPermTailLow ? kPermTailLow : n; }
 
@@ -59,7 +69,7 @@ static int perm_low(int n) { return n - 1 >= kPermTailLow ? kPermTailLow : n; }
 // true start; the round behind it writes the targets J[i] (i = 1 .. n-1) -- numpy's -- and out[0] = words consumed,
 // out[1] = 0 (by the segment in which step 1 is served), and the rounds behind that return at once.
 __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low, int round,
-                                                        int *cnt, int *__restrict__ seen, int *__restrict__ J,
+                                                        int rounds, int *cnt, int *__restrict__ seen, int *__restrict__ J,
                                                         long long *__restrict__ out, int *__restrict__ flags) {
     __shared__ unsigned ws[4][kPermSeg];
     // flags[r] = some count changed in round r.  The first round behind a round that changed nothing is the WRITE pass:
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restri
         }
         // (exactly one segment sees the last of the rounds' n - low steps served inside it: the tail starts behind it)
         if (write_pass && accepted > 0 && before + accepted == (long long)(n - low) && end >= 0) { out[2] = seg0 + end; out[3] = 0; }
-        if (write_pass && t == 0) flags[kPermRounds + 1] = 1;           // "the targets have been written"
+        if (write_pass && t == 0) flags[rounds + 1] = 1;                // "the targets have been written"
     }
 }
 
@@ -305,10 +315,12 @@ static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int
     const int T = perm_segments(n_avail);
     int *seen = cnt + 2 * (long long)T;              // [3 T]: perm_draw_kernel's memo (round 1 ignores what it holds)
     (void)parity;
-    hipLaunchKernelGGL(perm_reflag_kernel, dim3(1), dim3(64), 0, st, kPermRounds, flags, out);
+    const int rounds = perm_rounds_now();
+    hipLaunchKernelGGL(perm_reflag_kernel, dim3(1), dim3(64), 0, st, rounds, flags, out);
     const int low = perm_low(n);
-    for (int r = 1; r <= kPermRounds; ++r)
-        hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, low, r, cnt, seen, J, out, flags);
+    for (int r = 1; r <= rounds; ++r)
+        hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, low, r, rounds, cnt, seen, J, out,
+                           flags);
     hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out);
 }
 
@@ -349,7 +361,7 @@ bool launch_permutation(const unsigned *raw, long long n_avail, int n, const uns
                                    pos_out, st);
 }
 
-// kPermRounds more rounds of draws from the counts the last round left (an even number of rounds: they are back in
+// perm_rounds() more rounds of draws from the counts the last round left (updated in place: they are simply carried on in
 // cnt[0 .. T))
 void launch_permutation_draw_more(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out,
                                   hipStream_t st) {

@@ -1266,6 +1266,42 @@ def test_device_permutation_equals_numpy(N):
     ctx.close()
 
 
+def test_device_permutation_repairs_draws_that_have_not_settled():
+    """The rounds of the permutation's draws are queued blindly, a fixed number at a time; when they have not settled by
+    then, more rounds are queued and everything behind the draws runs again.  With the number of rounds cut to 5
+    (BGMM_PERM_ROUNDS, read when the library is loaded: a process of its own) that repair runs for every permutation --
+    which must still be numpy's, generator state included."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from pybgmm_amd import _lib
+from pybgmm_amd.utils import gendata
+for N in (70000, 1000003):
+    X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(2)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12)
+    ctx.set_assignments(zt)
+    host = np.random.RandomState(N)
+    host.random_sample(33)
+    key, pos = host.get_state()[1].copy(), int(host.get_state()[2])
+    for it in range(3):
+        expect = host.permutation(N)
+        key, pos = ctx.stage_permutation_mt19937(key, pos)
+        assert np.array_equal(ctx.staged_order(), expect), (N, it)
+        assert np.array_equal(key, host.get_state()[1]) and pos == host.get_state()[2]
+    st = ctx.permutation_stats()
+    assert st["rounds_max"] <= 6, st          # (every batch of rounds is 5 long: the statistics count within a batch)
+    ctx.close()
+print("REPAIRED OK")
+""" % root
+    env = dict(os.environ, BGMM_PERM_ROUNDS="5")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "REPAIRED OK" in r.stdout, r.stdout[-2000:]
+
+
 def test_device_permutation_drives_the_pcrp_classes():
     """PCRPMM with the visiting order drawn on the device equals the same run with the order drawn by numpy on the host
     (N < 4096 is the host's: a twin run with a monkey-patched helper gives the host route at the same N)."""
