@@ -362,12 +362,22 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     const int nb = d.nslots + 1;
     for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0;
     __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r0 + BUCKET_ROWS && r < nrows; r += 256) {
-        if (d.use_certify && d.cert[r]) continue;          // (proved to stay: not part of the sort)
-        const long long p = base + r;
-        const long long i = d.order ? d.order[p] : p;
-        atomicAdd(&bins[d.z[i] + 1], 1);
+    // (the four rows of a thread side by side: their index loads, then their label loads, are in flight together --
+    // two dependent round trips per thread instead of eight)
+    long long ii[BUCKET_ROWS / 256];
+    int zz[BUCKET_ROWS / 256];
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
+        const int r = r0 + threadIdx.x + t * 256;
+        const bool ok = r < nrows && !(d.use_certify && d.cert[r < nrows ? r : 0]);     // (proved to stay: not part of the sort)
+        const long long p = base + (r < nrows ? r : 0);
+        ii[t] = ok ? (d.order ? d.order[p] : p) : -1;
     }
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t) zz[t] = ii[t] >= 0 ? d.z[ii[t]] : -2;
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t)
+        if (zz[t] >= -1) atomicAdd(&bins[zz[t] + 1], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256)
         if (bins[b]) atomicAdd(&d.bucket_bins[b], bins[b]);
@@ -518,17 +528,26 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     int *cnt = lds, *res = lds + nb;
     for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
     __syncthreads();
+    // (a thread's four rows side by side: index loads, then label and prior loads, in flight together)
     int myb[BUCKET_ROWS / 256], myk[BUCKET_ROWS / 256];
+    long long ii[BUCKET_ROWS / 256];
+    double lp[BUCKET_ROWS / 256];
 #pragma unroll
     for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
         const int r = r0 + threadIdx.x + t * 256;
-        myb[t] = -1;
-        if (r < nrows && !(d.use_certify && d.cert[r])) {
-            const long long p = base + r;
-            const long long i = d.order ? d.order[p] : p;
-            myb[t] = d.z[i] + 1;
-            myk[t] = atomicAdd(&cnt[myb[t]], 1);          // rank inside (block, bucket)
-        }
+        const bool ok = r < nrows && !(d.use_certify && d.cert[r < nrows ? r : 0]);
+        const long long p = base + (r < nrows ? r : 0);
+        ii[t] = ok ? (d.order ? d.order[p] : p) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
+        myb[t] = ii[t] >= 0 ? d.z[ii[t]] + 1 : -1;
+        lp[t] = d.log_prior[ii[t] >= 0 ? ii[t] : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
+        myk[t] = 0;
+        if (myb[t] >= 0) myk[t] = atomicAdd(&cnt[myb[t]], 1);          // rank inside (block, bucket)
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256)
@@ -539,13 +558,12 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
         if (myb[t] >= 0) {
             const int r = r0 + threadIdx.x + t * 256;
             const int k = res[myb[t]] + myk[t];
-            const long long p = base + r;
             d.wperm[k] = r;
             WRec rec;
-            rec.i = d.order ? d.order[p] : p;
+            rec.i = ii[t];
             rec.home = myb[t] - 1;
             rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
-            rec.mlb0 = d.log_alpha + d.log_prior[rec.i];
+            rec.mlb0 = d.log_alpha + lp[t];
             rec.pad = 0.0;
             d.wrec[k] = rec;
         }
