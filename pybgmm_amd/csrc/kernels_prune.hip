@@ -710,7 +710,7 @@ static void launch_mfma_prune(const Dev &d, const Job *job, double *q, long long
                               hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
     // (home_kernel has decided most of the window's rows: a short grid walks what is left)
-    if (d.use_home && gx > 512) launch_mfma_prune_v<NJ, true>(d, job, q, qstride, 512, st);
+    if (d.use_home && gx > 1024) launch_mfma_prune_v<NJ, true>(d, job, q, qstride, 1024, st);
     else launch_mfma_prune_v<NJ, false>(d, job, q, qstride, gx, st);
 }
 
