@@ -1897,7 +1897,7 @@ def test_run_chains_on_device_equals_solo_runs(model):
     N, D, K, s, n_iter, G = 5000, 2, 6, 11, 4, 5        # (N >= 4096: PCRPMM's permutations are drawn on the device, one per thread)
     X, zt = gendata.synth_mixture(N, D, K, seed=3, mu_scale=2.0)
     prior = NIW(*gendata.demo_prior_params(D))
-    runs = chains.run_chains_on_device(cls, X, prior, 1.0, G, n_iter, seed=s, true_assignments=zt, K=K, K_max=80)
+    runs = cls.sample_chains(X, prior, 1.0, chains=G, n_iter=n_iter, seed=s, true_assignments=zt, K=K, K_max=80)   # (= chains.run_chains_on_device)
     for c in range(G):
         m_solo, rec_solo = chains.run_chain(cls, X, prior, 1.0, n_iter, s, c, 0, true_assignments=zt, K=K, K_max=80)
         npt.assert_array_equal(runs[c][0].components.assignments, m_solo.components.assignments)
