@@ -246,6 +246,9 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // (the look-aheads may still be writing into buffers that are about to go)
+    if (c->mt_stream) (void)hipStreamSynchronize(c->mt_stream);
+    if (c->perm_stream) (void)hipStreamSynchronize(c->perm_stream);
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
