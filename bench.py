@@ -395,6 +395,10 @@ def main():
     ap.add_argument("--numpy-visits", type=int, default=400, help="visits of the numpy-restatement CPU baseline (0 = skip)")
     ap.add_argument("--chains", type=int, default=-1,
                     help="chains of the many_chains leg, all on this GPU (-1: 256 -- one per compute unit -- for D <= 4, none otherwise; 0: skip)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="stage sweep k + 1's inputs while sweep k is in the queue (bgmm_sweep_staged_begin / _end) instead of the "
+                         "plain loop stage, sweep, stage, sweep -- measured: 5 400 against 5 373 sweeps/s at C4, the host's way "
+                         "round the loop is the stream synchronisation and the launch latency, not the staging")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
@@ -461,7 +465,7 @@ def main():
     np_state = rs.get_state()
     np_key, np_pos = np.asarray(np_state[1], dtype=np.uint32), int(np_state[2])
 
-    def one_sweep(it):
+    def one_sweep(it, stage_only=False):
         # what PCRPMM.collapsed_gibbs_sampler does per sweep (pybgmm_amd/igmm/pcrpmm.py): the visiting order is
         # np.random.permutation(N) from the chain's numpy stream -- drawn on the device (bgmm_stage_permutation_mt19937:
         # bit-identical, the state handed back), on the host where the library leaves it to the host
@@ -477,10 +481,30 @@ def main():
             else:
                 np_key, np_pos = nxt
         mt_key, mt_pos = ctx.stage_mt19937(mt_key, mt_pos, order)
-        ctx.sweep_staged(sweep_power(it))
+        if not stage_only:
+            ctx.sweep_staged(sweep_power(it))
 
-    for it in range(args.warmup):
-        one_sweep(it)
+    # --pipeline: sweep k is queued (bgmm_sweep_staged_begin), the inputs of sweep k + 1 are staged while it runs (host
+    # work: a look-ahead hit is a memcmp), then sweep k is waited for and finished (bgmm_sweep_staged_end).  One staging
+    # and one sweep per step, the same calls and the same trajectory as the plain loop
+    # (tests/test_gpu_parity.py::test_pipelined_sweeps_equal_plain_sweeps).  The default is the plain loop -- what the
+    # classes' sampler loops do.
+    def pipelined_sweeps(it0, n):
+        for it in range(it0, it0 + n):
+            ctx.sweep_staged_begin(sweep_power(it))
+            one_sweep(it + 1, stage_only=True)
+            ctx.sweep_staged_end()
+
+    def run_sweeps(it0, n):
+        if not args.pipeline:
+            for it in range(it0, it0 + n):
+                one_sweep(it)
+        else:
+            pipelined_sweeps(it0, n)
+
+    if args.pipeline:
+        one_sweep(0, stage_only=True)            # (the first sweep's inputs; from then on every step stages the next one's)
+    run_sweeps(0, args.warmup)
     barrier()
     # EXACTLY `steps` sweeps between a barrier + synchronize on both sides -- and, when that is a short stretch (the driver's
     # 20 steps are 4 ms at C4), the same measurement REPEATED until at least a second of sweeps has been timed: `value`
@@ -494,10 +518,13 @@ def main():
     while len(repeat_s) < n_repeats:
         barrier()
         t0 = time.time()
-        for it in range(it_next, it_next + args.steps):
-            one_sweep(it)
-            if not repeat_s and (it - it_next + 1) % 250 == 0:
-                chunk_marks.append(time.time())       # (every call above ends with a stream sync: host time is device time)
+        if args.steps >= 500 and not repeat_s:
+            for c0 in range(0, args.steps, 250):      # (250 sweeps at a time, for the spread between stretches)
+                run_sweeps(it_next + c0, min(250, args.steps - c0))
+                if c0 + 250 <= args.steps:
+                    chunk_marks.append(time.time())   # (every sweep ends with a stream sync: host time is device time)
+        else:
+            run_sweeps(it_next, args.steps)
         barrier()
         dt = time.time() - t0
         if not repeat_s:
@@ -574,6 +601,7 @@ def main():
         kernel trace of this command shows; otherwise one extra sweep with resident inputs."""
         set_mode(mode)
         if live_sweeps > 0:
+            # (kernel timing keeps every sweep inside _begin: the plain loop, the same kernels beside the same look-ahead)
             for it in range(4):
                 one_sweep(args.warmup + args.steps + it)
             ctx.set_kernel_timing(True)
@@ -769,6 +797,8 @@ def main():
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
                       "K_final": K_final, "log_marg_rank0": log_marg,
                       "last_sweep": last_stats, "setup_s": round(t_setup, 3),
+                      "host_loop": "plain" if not args.pipeline else "pipelined: sweep k + 1's inputs staged while sweep k is in the queue "
+                                   "(bgmm_sweep_staged_begin / _end)",
                       "value_is": "sweeps/s with every sweep's uniforms generated inside the timed region (the caller's MT19937 "
                                   "continued on the device, bgmm_stage_mt19937: sweep k + 1's are generated on a second stream while "
                                   "sweep k runs) and, for pCRP workloads, its np.random.permutation(N) drawn on the device as well "

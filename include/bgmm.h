@@ -94,6 +94,17 @@ BGMM_API int bgmm_sweep(bgmm_ctx *ctx, const int64_t *order, const double *u, in
 /* Same sweep split in two so that the H2D copy of (order, u) can sit outside a timed region. */
 BGMM_API int bgmm_stage_sweep_inputs(bgmm_ctx *ctx, const int64_t *order, const double *u);
 BGMM_API int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
+/*
+ * The staged sweep in two halves, for a driver that prepares the NEXT sweep's inputs while this one runs (a sweep of a
+ * chain at rest is shorter than the host's way round the loop).  _begin queues the sweep; when its first batch of launches
+ * is all a chain at rest needs -- a lean step with certified stays, a short step without -- it returns without waiting,
+ * otherwise the sweep runs to its end inside _begin.  _end waits and finishes what is left (a refused step is redone in
+ * full) exactly as bgmm_sweep_staged would have: begin + end == bgmm_sweep_staged, same trajectory.  Between the two only
+ * bgmm_stage_* calls are allowed (they stage the sweep AFTER this one; the look-ahead generations they would start are
+ * started by _end, since the running sweep may still read the buffers those write); any other sweep call is refused.
+ */
+BGMM_API int bgmm_sweep_staged_begin(bgmm_ctx *ctx, int32_t use_power, double power);
+BGMM_API int bgmm_sweep_staged_end(bgmm_ctx *ctx);
 
 /*
  * Many chains per GPU (SURVEY.md section 5 `chains=`; 8e: chains are replicas, they exchange nothing).  The staged sweeps of

@@ -45,6 +45,8 @@ SIGNATURES = {
     "bgmm_get_permutation_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
+    "bgmm_sweep_staged_begin": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
+    "bgmm_sweep_staged_end": (ctypes.c_int, [_vp]),
     "bgmm_upload_streams": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp]),
     "bgmm_sweep_resident": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     "bgmm_log_marg": (ctypes.c_int, [_vp, _f64]),
@@ -262,6 +264,14 @@ class Context(object):
     def sweep_staged(self, power=None):
         self._ck(self.L.bgmm_sweep_staged(self.h, 0 if power is None else 1,
                                           1.0 if power is None else float(power)))
+
+    def sweep_staged_begin(self, power=None):
+        """First half of ``sweep_staged``: queues the sweep and, for a chain at rest, returns without waiting -- stage the
+        NEXT sweep's inputs, then ``sweep_staged_end()``."""
+        self._ck(self.L.bgmm_sweep_staged_begin(self.h, 0 if power is None else 1, 1.0 if power is None else float(power)))
+
+    def sweep_staged_end(self):
+        self._ck(self.L.bgmm_sweep_staged_end(self.h))
 
     def upload_streams(self, u_all, order_all=None):
         u_all = np.ascontiguousarray(u_all, dtype=np.float64)

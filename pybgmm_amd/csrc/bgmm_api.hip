@@ -99,6 +99,12 @@ struct bgmm_ctx {
     size_t perm_temp_bytes = 0;
     long long *perm_out = nullptr;   // {words consumed, ran out}
     unsigned *perm_host = nullptr;   // pinned: [key out 624 | pos out | changed | out (2 x 64 bit)]
+    // bgmm_sweep_staged_begin / _end: a sweep whose first batch of launches is in the queue and has not been waited for
+    bool async_pending = false, async_short = false;
+    int async_rc = 0;
+    bool defer_mt = false, defer_mt_hit = false, defer_perm = false;   // look-ahead launches a stage call put off meanwhile
+    int defer_mt_pos = 0;
+    std::vector<uint32_t> defer_mt_key;
     int grp_cap = 0;                 // bgmm_group_sweep_staged: the LDS plan phase 1 of sweep_impl chose for the one-workgroup sweep
     Dev *grp_devs = nullptr;         // device array of the chains' views (owned by the chain that leads a group launch)
     int grp_devs_cap = 0;
@@ -676,6 +682,27 @@ static int mt_wait_batches(bgmm_ctx *c) {
     return 0;
 }
 
+// What comes behind a served request: after one generated on the spot, a fresh batch from the state just handed back
+// (key, pos); towards the end of a batch, the batch behind it (its generation runs beside the sweeps queued meanwhile).
+static int mt_schedule(bgmm_ctx *c, bool hit, const uint32_t *key, int pos) {
+    if (!c->mt_ahead_on) return 0;
+    if (!hit) {
+        int rc = mt_launch_batch(c, 0, key, pos);
+        if (rc) return rc;
+        c->mt_cur = 0;
+        return 0;
+    }
+    bgmm_ctx::MtBatch *B = c->mt_cur >= 0 ? &c->mt_b[c->mt_cur] : nullptr;
+    if (B && B->launched && B->next >= std::max(1, c->mt_depth - 2) && !c->mt_b[c->mt_cur ^ 1].launched) {
+        // (the state behind this batch is known since its generation finished: the next batch is started two sweeps
+        // before it is needed -- under a running sweep a generation takes about two of them)
+        const int Md = c->mt_depth;
+        return mt_launch_batch(c, c->mt_cur ^ 1, B->host + 624 + (size_t)(Md - 1) * 624,
+                               (int)B->host[624 + (size_t)Md * 624 + (size_t)(Md - 1)]);
+    }
+    return 0;
+}
+
 extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *key624, int32_t *pos) {
     if (!c || !key624 || !pos) return BGMM_EINVAL;
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
@@ -754,23 +781,14 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
         c->order_staged = false;
     }
     c->cur_order = (order || keep) ? c->d_order : nullptr;
-    if (c->mt_ahead_on) {
-        // what comes behind: after a request served on the spot, a fresh batch from the state just handed back; towards the
-        // end of a batch, the batch behind it (its generation runs beside the sweeps queued meanwhile)
-        if (!hit) {
-            int rc = mt_launch_batch(c, 0, key624, *pos);
-            if (rc) return rc;
-            c->mt_cur = 0;
-        } else if (B->next >= std::max(1, c->mt_depth - 2) && !c->mt_b[c->mt_cur ^ 1].launched) {
-            // (the state behind this batch is known since its generation finished: the next batch is started two sweeps
-            // before it is needed -- under a running sweep a generation takes about two of them)
-            const int Md = c->mt_depth;
-            int rc = mt_launch_batch(c, c->mt_cur ^ 1, B->host + 624 + (size_t)(Md - 1) * 624,
-                                     (int)B->host[624 + (size_t)Md * 624 + (size_t)(Md - 1)]);
-            if (rc) return rc;
-        }
+    if (c->async_pending) {
+        // (a sweep is in flight -- bgmm_sweep_staged_begin: it may still be reading the buffer the next generation would
+        // write into; bgmm_sweep_staged_end starts it)
+        c->defer_mt = true; c->defer_mt_hit = hit; c->defer_mt_pos = *pos;
+        c->defer_mt_key.assign(key624, key624 + 624);
+        return 0;
     }
-    return 0;
+    return mt_schedule(c, hit, key624, *pos);
 }
 
 // np.random.permutation(N) from the caller's legacy numpy generator, on the device (kernels_perm.hip).
@@ -888,6 +906,16 @@ extern "C" int bgmm_get_permutation_stats(bgmm_ctx *c, int64_t *out4) {
     return 0;
 }
 
+// queues the look-ahead permutation from the state noted in perm_host[640 ..) / perm_ahead_pos_in
+static int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
+    int rc = perm_queue(c, P, c->perm_host + 640, c->perm_ahead_pos_in, c->d_order_ahead, c->perm_stream);
+    if (rc == 0) rc = perm_queue_verdicts(c, P, c->perm_stream);
+    if (rc) return rc;
+    CK(c, hipEventRecord(c->perm_done, c->perm_stream));
+    c->perm_ahead_valid = true;
+    return 0;
+}
+
 extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int32_t *pos) {
     if (!c || !key624 || !pos) return BGMM_EINVAL;
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
@@ -931,11 +959,8 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
         // the next permutation, from the state just handed back, into the other buffer, beside the sweep about to be queued
         memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);
         c->perm_ahead_pos_in = *pos;
-        rc = perm_queue(c, P, key_in_pinned, *pos, c->d_order_ahead, c->perm_stream);
-        if (rc == 0) rc = perm_queue_verdicts(c, P, c->perm_stream);
-        if (rc) return rc;
-        CK(c, hipEventRecord(c->perm_done, c->perm_stream));
-        c->perm_ahead_valid = true;
+        if (c->async_pending) { c->defer_perm = true; return 0; }      // (that buffer is the running sweep's order: after it)
+        return perm_schedule(c, P);
     }
     return 0;
 }
@@ -1082,9 +1107,14 @@ static int ensure_events(bgmm_ctx *c, size_t n) {
 static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     if (!c) return BGMM_EINVAL;
     if (!c->assigned) return fail(c, BGMM_EINVAL, "bgmm_set_assignments has not been called");
+    if (c->async_pending && phase != 4) return fail(c, BGMM_EINVAL, "a sweep is in flight: bgmm_sweep_staged_end first");
     CK(c, hipSetDevice(c->device));
     Dev &d = c->d;
-    if (phase != 2) {
+    // phase 3 (bgmm_sweep_staged_begin): as phase 0, but a first batch that is a lean or a short step -- a chain at rest --
+    // is left in the queue (returns 2); phase 4 (bgmm_sweep_staged_end, which has waited for it and read the control
+    // block) carries on behind it like phase 2 does behind a group launch
+    const bool resume = phase == 2 || phase == 4;
+    if (!resume) {
         d.use_power = use_power ? 1 : 0;
         d.power = use_power ? power : 1.0;
         if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
@@ -1110,7 +1140,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     bool short_step = use_prune && !use_certify && (c->short_ok || c->home_mode == 3) && c->prune_mode != 2 && !partial &&
                       !c->tables_robust && c->resolver_mode == 0;
     hipStream_t st = c->stream;
-    if (phase != 2) {
+    if (!resume) {
         d.seat_dirty = 0;
         if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
             d.seat_dirty = 1;
@@ -1128,7 +1158,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (r > c->win_rows) r = c->win_rows;
         return (int)r;
     };
-    if (phase != 2) {
+    if (!resume) {
         d.batch_rows = rows_for(c->ctrl_host->win_size > 0 ? c->ctrl_host->win_size : c->win_rows, 0);
         if (c->moves_prev != 0 && d.cov_type == COV_FULL && use_prune)
             launch_refresh_stale(d, c->ctrl_host->job.K, st);   // (tight bounds again after a sweep with moves)
@@ -1139,6 +1169,8 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     int seq_plan = 0;                      // labels the one-workgroup sweep would plan LDS for (0: not for this sweep)
     if (phase == 2) {
         seq_plan = c->grp_cap;
+    } else if (phase == 4) {
+        seq_plan = 0;
     } else if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
                c->order_is_perm) {
         int cap = 2;
@@ -1151,9 +1183,15 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         c->grp_cap = seq_plan;
         return 1;
     }
-    if (phase != 2) launch_sweep_begin(d, st);
+    if (!resume) launch_sweep_begin(d, st);
     long long steps_done = 0;
     bool seq_ran = false;
+    if (phase == 4) {                      // (behind a first batch that was waited for elsewhere: nothing lean or short any more)
+        seq_ran = true;
+        steps_done = c->ctrl_host->n_steps;
+        lean = false;
+        short_step = false;
+    }
     if (seq_plan > 0) {
         if (phase != 2) {
             if (!launch_sweep_seq(d, seq_plan, st)) return fail(c, BGMM_EDEVICE, "sequential sweep kernel launch failed");
@@ -1399,6 +1437,11 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             if (!lean) launch_refresh_ctrl(d, st);        // (a lean step moves nothing: apply refuses it otherwise)
         }
         CK(c, hipGetLastError());
+        if (phase == 3 && (lean || short_step) && !c->timing) {
+            c->async_pending = true;
+            c->async_short = short_step;
+            return 2;
+        }
         if (lean || short_step) {
             // (apply_kernel has left the control block in host memory: no copy in the queue)
             CK(c, hipStreamSynchronize(st));
@@ -1458,6 +1501,48 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
 }
 
 extern "C" int bgmm_sweep_staged(bgmm_ctx *c, int32_t use_power, double power) { return sweep_impl(c, use_power, power, 0); }
+
+// The staged sweep in two halves, so that a driver can prepare the NEXT sweep's inputs (bgmm_stage_* calls: host work, a
+// look-ahead hit is a memcmp) while this one runs.  _begin queues the sweep; when its first batch of launches is all a
+// chain at rest needs (a lean step with certified stays, a short step without), it returns without waiting.  _end waits,
+// and finishes whatever is left (a refused step is redone in full) exactly as bgmm_sweep_staged would have.  Every other
+// kind of sweep runs to its end inside _begin.  Between the two only bgmm_stage_* calls are allowed; the look-ahead
+// generations they would start are started by _end (the running sweep may still read the buffers they write).
+extern "C" int bgmm_sweep_staged_begin(bgmm_ctx *c, int32_t use_power, double power) {
+    if (!c) return BGMM_EINVAL;
+    const int rc = sweep_impl(c, use_power, power, 3);
+    c->async_rc = rc == 2 ? 0 : rc;
+    return c->async_rc;
+}
+
+extern "C" int bgmm_sweep_staged_end(bgmm_ctx *c) {
+    if (!c) return BGMM_EINVAL;
+    if (!c->async_pending) return c->async_rc;
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->ctrl_host, c->ctrl_pub, sizeof(Ctrl));     // (lean and short steps publish the control block to host memory)
+    c->async_pending = false;
+    if (c->async_short) { if (c->ctrl_host->retry_full) c->short_refused += 1; else c->short_stood += 1; }
+    if (c->ctrl_host->retry_full) {
+        c->ctrl_host->retry_full = 0;
+        CK(c, hipMemcpy(&c->d.ctrl->retry_full, &c->ctrl_host->retry_full, sizeof(int), hipMemcpyHostToDevice));
+    }
+    // the look-ahead generations the stage calls of the meantime put off
+    int rc = 0;
+    if (c->defer_mt) {
+        c->defer_mt = false;
+        rc = mt_schedule(c, c->defer_mt_hit, c->defer_mt_key.data(), c->defer_mt_pos);
+    }
+    if (rc == 0 && c->defer_perm) {
+        c->defer_perm = false;
+        PermPtrs P;
+        rc = perm_ensure(c, P);
+        if (rc == 0) rc = perm_schedule(c, P);
+    }
+    const int rs = sweep_impl(c, c->d.use_power, c->d.power, 4);
+    c->async_rc = rs ? rs : rc;
+    return c->async_rc;
+}
 
 // Sweeps of several chains that live on ONE device, side by side.  Chains that can take the one-workgroup sweep (D <= 4,
 // full covariance, automatic tuning, labels within the LDS plan) are opened and swept by two launches for all of them

@@ -1834,6 +1834,70 @@ def test_chain_c_equals_a_global_seed_run(model):
     npt.assert_array_equal(np.stack(zs), np.stack([Z[0], zs[1]]))
 
 
+@pytest.mark.parametrize("case", ["rest-evaluated", "rest-certified", "moving", "pcrp-rest", "pcrp-moving", "wrong-labels"])
+@pytest.mark.parametrize("depth", [-1, 1])
+def test_pipelined_sweeps_equal_plain_sweeps(case, depth):
+    """bgmm_sweep_staged_begin / _end: the driver stages sweep k + 1's inputs (device generators: uniforms, for pCRP the
+    permutation) while sweep k is in the queue.  Against the plain loop (stage, sweep, stage, sweep) from twin generators:
+    labels after every sweep, log marginal, generator states -- for chains at rest in both modes (short / lean steps:
+    the halves really overlap), chains that move (the sweep runs to its end inside _begin), wrong labels repaired on the
+    way to rest (refused steps), with look-ahead batches of one sweep (every stage call wants to start a generation into
+    the buffer the running sweep reads: put off until _end) and of the default depth."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    pcrp = case.startswith("pcrp")
+    moving = case.endswith("moving")
+    N, D, K = (30000, 64, 8) if not moving else (30000, 16, 8)
+    X, zt = gendata.synth_mixture(N, D, K, seed=5, mu_scale=1.2 if moving else 4.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    z0 = zt.copy()
+    if case == "wrong-labels":
+        idx = np.random.RandomState(1).choice(N, size=60, replace=False)
+        z0[idx] = (z0[idx] + 1) % K
+    n_sw = 9
+    out = []
+    for pipelined in (True, False):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 6 * K)
+        ctx.set_tuning(prune_mode=0 if case == "rest-certified" else 3)
+        ctx.set_mt_lookahead(depth)
+        ctx.set_assignments(z0)
+        r, nr = random.Random(11), np.random.RandomState(11)
+
+        def stage():
+            order = _rng.take_permutation_staged(ctx, N, nr) if pcrp else None
+            assert _rng.stage_uniforms_on_device(ctx, None if order is _rng.STAGED else order, r)
+        zs = []
+        stage()
+        for it in range(n_sw):
+            power = 1.01 if (pcrp and it > 0) else None
+            if pipelined:
+                ctx.sweep_staged_begin(power)
+                if it + 1 < n_sw:
+                    stage()                          # sweep it + 1's inputs while sweep it runs
+                ctx.sweep_staged_end()
+            else:
+                ctx.sweep_staged(power)
+                if it + 1 < n_sw:
+                    stage()
+            zs.append(ctx.assignments())
+        out.append((zs, ctx.log_marg(), r.getstate(), nr.get_state()[1].copy(), ctx.short_step_stats(), ctx.sweep_stats()["moves"]))
+        if pipelined and case.startswith("rest"):
+            with pytest.raises(_lib.BGMMError):      # (a chain at rest: _begin returns with the sweep in flight) a sweep
+                ctx.sweep_staged_begin(None)         # call between the halves is refused
+                ctx.sweep_staged(None)
+            ctx.sweep_staged_end()
+        ctx.close()
+    for it in range(n_sw):
+        npt.assert_array_equal(out[0][0][it], out[1][0][it], err_msg="sweep %d" % it)
+    assert out[0][1] == out[1][1]
+    assert out[0][2] == out[1][2]
+    npt.assert_array_equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4], (out[0][4], out[1][4])      # the same steps stood and were refused
+    if case == "rest-evaluated":
+        assert out[0][4]["stood"] >= n_sw - 3
+
+
 def test_group_sweep_equals_separate_sweeps():
     """bgmm_group_sweep_staged (many chains per GPU): chains that take the one-workgroup sweep go through ONE pair of
     launches, the others (here: D = 16, and a D = 2 chain pinned to the windowed kernels) are swept on their own -- every
