@@ -269,6 +269,14 @@ def pmc_traffic(args, mode, kernel_names, timeout_s=240):
                         continue
                     dur_us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
                     vals[name].append((float(row["Counter_Value"]), dur_us))
+        if args.keep_pmc:
+            # the evidence behind roofline.traffic: per kernel of interest every launch's raw counter value (KiB) and duration
+            os.makedirs(args.keep_pmc, exist_ok=True)
+            with open(os.path.join(args.keep_pmc, "pmc_%s_%s_%s.csv" % (args.workload, mode, counter)), "w") as f:
+                f.write("kernel,counter,value_KiB,duration_us\n")
+                for k in kernel_names:
+                    for v, dur in vals[k]:
+                        f.write("%s,%s,%.1f,%.2f\n" % (k, counter, v, dur))
         shutil.rmtree(tmp, ignore_errors=True)
         if not vals[kernel_names[0]]:
             return None, "no %s rows for %s (rc %d)" % (counter, kernel_names[0], r.returncode)
@@ -400,6 +408,9 @@ def main():
                          "plain loop stage, sweep, stage, sweep -- measured: 5 400 against 5 373 sweeps/s at C4, the host's way "
                          "round the loop is the stream synchronisation and the launch latency, not the staging")
     ap.add_argument("--no-pmc", action="store_true")
+    ap.add_argument("--keep-pmc", default="", metavar="DIR",
+                    help="keep the per-launch FETCH_SIZE / WRITE_SIZE rows of the roofline kernels (the rocprofv3 --pmc child "
+                         "passes behind roofline.traffic) as CSV files in DIR")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous of the --gpus N ranks over gloo and exit (no GPU work; the CPU test of the launcher)")

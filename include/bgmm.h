@@ -99,9 +99,12 @@ BGMM_API int bgmm_sweep_staged(bgmm_ctx *ctx, int32_t use_power, double power);
  * chain at rest is shorter than the host's way round the loop).  _begin queues the sweep; when its first batch of launches
  * is all a chain at rest needs -- a lean step with certified stays, a short step without -- it returns without waiting,
  * otherwise the sweep runs to its end inside _begin.  _end waits and finishes what is left (a refused step is redone in
- * full) exactly as bgmm_sweep_staged would have: begin + end == bgmm_sweep_staged, same trajectory.  Between the two only
- * bgmm_stage_* calls are allowed (they stage the sweep AFTER this one; the look-ahead generations they would start are
- * started by _end, since the running sweep may still read the buffers those write); any other sweep call is refused.
+ * full, from the inputs the sweep was begun with) exactly as bgmm_sweep_staged would have: begin + end ==
+ * bgmm_sweep_staged, same trajectory.  Between the two, bgmm_stage_* calls stage the sweep AFTER this one: a request the
+ * look-ahead can serve costs a comparison and returns at once (the generations it would start are started by _end, behind
+ * the redo: the running sweep may still read the buffers they write); a request that has to be generated on the spot, host
+ * inputs (bgmm_stage_sweep_inputs) and every other entry point that reads or changes the chain's state first finish the
+ * sweep in flight (what _end would have done; _end then reports its status).  A second sweep call is refused.
  */
 BGMM_API int bgmm_sweep_staged_begin(bgmm_ctx *ctx, int32_t use_power, double power);
 BGMM_API int bgmm_sweep_staged_end(bgmm_ctx *ctx);

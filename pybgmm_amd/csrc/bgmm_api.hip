@@ -101,6 +101,8 @@ struct bgmm_ctx {
     unsigned *perm_host = nullptr;   // pinned: [key out 624 | pos out | changed | out (2 x 64 bit)]
     // bgmm_sweep_staged_begin / _end: a sweep whose first batch of launches is in the queue and has not been waited for
     bool async_pending = false, async_short = false;
+    bool run_zero_u = false, run_order_is_perm = true;   // what the sweep being run was staged with (snapshots: a stage call between
+                                                         // bgmm_sweep_staged_begin and _end describes the NEXT sweep)
     int async_rc = 0;
     bool defer_mt = false, defer_mt_hit = false, defer_perm = false;   // look-ahead launches a stage call put off meanwhile
     int defer_mt_pos = 0;
@@ -199,6 +201,11 @@ static int dalloc(bgmm_ctx *c, T **p, size_t count) {
         int rc_ = dalloc((ctx), &(ptr), (count));       \
         if (rc_) return rc_;                            \
     } while (0)
+
+static int finish_pending(bgmm_ctx *c);
+// Entry points that read or change what a sweep left in the queue by bgmm_sweep_staged_begin is working on finish that
+// sweep first (bgmm_sweep_staged_end then just reports its status).
+#define SETTLE(c) do { if ((c)->async_pending) { const int rc_ = finish_pending(c); if (rc_) return rc_; } } while (0)
 
 static int fail(bgmm_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -523,6 +530,7 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
 
 extern "C" int bgmm_set_assignments(bgmm_ctx *c, const int64_t *z) {
     if (!c || !z) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     const Dev &d = c->d;
     const long long N = d.N;
@@ -595,6 +603,10 @@ static int classify_order(const int64_t *order, long long N) {
 
 extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const double *u) {
     if (!c || !u) return BGMM_EINVAL;
+    // (nothing is touched before the order has been found valid)
+    const int okind = order ? classify_order(order, c->d.N) : 1;
+    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
+    SETTLE(c);                                          // (this call overwrites the buffers a sweep in flight reads)
     CK(c, hipSetDevice(c->device));
     CK(c, hipMemcpyAsync(c->d_u, u, sizeof(double) * c->d.N, hipMemcpyHostToDevice, c->stream));
     c->cur_zero_u = false;
@@ -602,8 +614,6 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
         if (u[i] == 0.0) { c->cur_zero_u = true; break; }
     const bool keep = !order && c->order_staged;        // (bgmm_stage_permutation_mt19937 has put this sweep's order in place)
     c->have_order = order != nullptr || keep;
-    const int okind = order ? classify_order(order, c->d.N) : 1;
-    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
     c->order_is_perm = okind == 1;
     if (order) {
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * c->d.N, hipMemcpyHostToDevice, c->stream));
@@ -706,6 +716,10 @@ static int mt_schedule(bgmm_ctx *c, bool hit, const uint32_t *key, int pos) {
 extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *key624, int32_t *pos) {
     if (!c || !key624 || !pos) return BGMM_EINVAL;
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
+    // (the order is validated before any generator or look-ahead state is touched)
+    const int okind = order ? classify_order(order, c->d.N) : 1;
+    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
+    if (order) SETTLE(c);                               // (an explicit order is copied into the buffer a sweep in flight may read)
     CK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->d.N;
     // device scratch of a request served on the spot: [key in 624 | key out 624 | pos out, zero flag, pad 16 | raw | 2 N
@@ -750,7 +764,8 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     }
     if (!hit) {
         // not foreseen (the first request, or the caller drew from its generator in between): generated on the spot, and
-        // whatever the look-ahead holds is of no use any more
+        // whatever the look-ahead holds is of no use any more.  (A sweep in flight reads d_u, or a batch buffer: finished first.)
+        SETTLE(c);
         int rc = mt_wait_batches(c);
         if (rc) return rc;
         c->mt_b[0].launched = c->mt_b[1].launched = false;
@@ -772,8 +787,6 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
     }
     const bool keep = !order && c->order_staged;        // (bgmm_stage_permutation_mt19937 has put this sweep's order in place)
     c->have_order = order != nullptr || keep;
-    const int okind = order ? classify_order(order, (long long)N) : 1;
-    if (okind < 0) return fail(c, BGMM_EINVAL, "visiting order holds an index outside 0 .. N-1");
     c->order_is_perm = okind == 1;
     if (order) {
         CK(c, hipMemcpyAsync(c->d_order, order, sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
@@ -941,6 +954,7 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
         }
     }
     if (!hit) {
+        SETTLE(c);                                      // (generated on the spot into d_order: a sweep in flight may read it)
         const int pos_in = *pos;
         memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);
         rc = perm_queue(c, P, key_in_pinned, pos_in, c->d_order, c->stream);
@@ -975,12 +989,14 @@ extern "C" int bgmm_get_staged_order(bgmm_ctx *c, int64_t *order_out) {
 
 extern "C" int bgmm_get_totals(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
+    SETTLE(c);
     for (int k = 0; k < 4; ++k) out4[k] = c->totals[k];
     return 0;
 }
 
 extern "C" int bgmm_get_short_step_stats(bgmm_ctx *c, int64_t *out2) {
     if (!c || !out2) return BGMM_EINVAL;
+    SETTLE(c);
     out2[0] = c->short_stood;
     out2[1] = c->short_refused;
     return 0;
@@ -988,6 +1004,7 @@ extern "C" int bgmm_get_short_step_stats(bgmm_ctx *c, int64_t *out2) {
 
 extern "C" int bgmm_set_mt_lookahead(bgmm_ctx *c, int32_t sweeps) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     if (sweeps < -1 || sweeps > kMtMaxMids) return fail(c, BGMM_EINVAL, "look-ahead depth must be -1 (auto), 0 (off) or 1 .. 8 sweeps");
     CK(c, hipSetDevice(c->device));
     // (buffers and batches in flight belong to the old depth)
@@ -1028,6 +1045,7 @@ extern "C" int bgmm_get_staged_uniforms(bgmm_ctx *c, double *u_out) {
 
 extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *u_all, const int64_t *order_all) {
     if (!c || !u_all || n_sweeps < 1) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->d.N;
     std::vector<char> perm_kind((size_t)n_sweeps, 1);
@@ -1123,10 +1141,12 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         c->order_staged = false;            // (a staged permutation serves one sweep)
         d.sweep_visits = c->next_sweep_visits;
         c->next_sweep_visits = 0;
+        c->run_zero_u = c->cur_zero_u;
+        c->run_order_is_perm = c->order_is_perm;
     }
     const bool partial = d.sweep_visits > 0 && d.sweep_visits < d.N;
     resolve_kind(c);
-    const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->cur_zero_u;
+    const bool use_prune = c->prune_mode != 1 && (c->kind == KERNEL_MFMA || d.cov_type != COV_FULL) && !c->run_zero_u;
     d.prune_enabled = use_prune ? 1 : 0;        // (sweep_begin opens the first window under the device's rule)
     // (certify_kernel runs in front of every pruned window: on data it can do nothing for it costs
     // a tenth of the pruning kernel behind it; a rule that left it out after a poor yield misjudged
@@ -1172,7 +1192,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
     } else if (phase == 4) {
         seq_plan = 0;
     } else if (seq_shape(c) && c->kernel_kind == KERNEL_AUTO && c->resolver_mode == 0 && c->prune_mode != 2 &&
-               c->order_is_perm) {
+               c->run_order_is_perm) {
         int cap = 2;
         while (sweep_seq_lds_bytes(d.D, cap + 16) <= 150 * 1024) cap += 16;
         if (c->seq_cap >= 2 && c->seq_cap < cap) cap = c->seq_cap;     // (bgmm_set_seq_plan)
@@ -1244,7 +1264,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         bool use_gram = false, gram_possible = false, use_safe = false;
         d.safe_mode = 0;
         const bool rm_gram = c->resolver_mode == 0 || c->resolver_mode >= 3;      // (3 / 4 force a kind, 5: never safe-stay)
-        if (d.cov_type == COV_FULL && rm_gram && c->order_is_perm &&
+        if (d.cov_type == COV_FULL && rm_gram && c->run_order_is_perm &&
             c->prune_mode != 2 && d.Dp / 16 <= 8 && (c->resolver_mode == 3 || c->kernel_kind != KERNEL_VALU)) {
             const Ctrl &hc = *c->ctrl_host;
             const bool safe_ok = c->resolver_mode != 3 && c->resolver_mode != 5 && c->kind == KERNEL_MFMA &&
@@ -1515,8 +1535,10 @@ extern "C" int bgmm_sweep_staged_begin(bgmm_ctx *c, int32_t use_power, double po
     return c->async_rc;
 }
 
-extern "C" int bgmm_sweep_staged_end(bgmm_ctx *c) {
-    if (!c) return BGMM_EINVAL;
+// Waits for the sweep bgmm_sweep_staged_begin left in the queue and finishes it: a refused step is redone in full FIRST
+// (from the inputs the sweep was begun with), and only then are the look-ahead generations started that the stage calls of
+// the meantime put off -- they write buffers the redo may still read.
+static int finish_pending(bgmm_ctx *c) {
     if (!c->async_pending) return c->async_rc;
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
@@ -1527,7 +1549,7 @@ extern "C" int bgmm_sweep_staged_end(bgmm_ctx *c) {
         c->ctrl_host->retry_full = 0;
         CK(c, hipMemcpy(&c->d.ctrl->retry_full, &c->ctrl_host->retry_full, sizeof(int), hipMemcpyHostToDevice));
     }
-    // the look-ahead generations the stage calls of the meantime put off
+    const int rs = sweep_impl(c, c->d.use_power, c->d.power, 4);
     int rc = 0;
     if (c->defer_mt) {
         c->defer_mt = false;
@@ -1539,9 +1561,13 @@ extern "C" int bgmm_sweep_staged_end(bgmm_ctx *c) {
         rc = perm_ensure(c, P);
         if (rc == 0) rc = perm_schedule(c, P);
     }
-    const int rs = sweep_impl(c, c->d.use_power, c->d.power, 4);
     c->async_rc = rs ? rs : rc;
     return c->async_rc;
+}
+
+extern "C" int bgmm_sweep_staged_end(bgmm_ctx *c) {
+    if (!c) return BGMM_EINVAL;
+    return finish_pending(c);
 }
 
 // Sweeps of several chains that live on ONE device, side by side.  Chains that can take the one-workgroup sweep (D <= 4,
@@ -1638,6 +1664,7 @@ extern "C" int bgmm_sweep(bgmm_ctx *c, const int64_t *order, const double *u, in
 
 extern "C" int bgmm_get_K(bgmm_ctx *c, int32_t *K) {
     if (!c || !K) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1647,6 +1674,7 @@ extern "C" int bgmm_get_K(bgmm_ctx *c, int32_t *K) {
 
 extern "C" int bgmm_get_assignments(bgmm_ctx *c, int64_t *z_out) {
     if (!c || !z_out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     long long *dz;
     CK(c, hipMalloc((void **)&dz, sizeof(long long) * c->d.N));
@@ -1660,6 +1688,7 @@ extern "C" int bgmm_get_assignments(bgmm_ctx *c, int64_t *z_out) {
 
 extern "C" int bgmm_get_counts(bgmm_ctx *c, int64_t *counts_out) {
     if (!c || !counts_out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1676,6 +1705,7 @@ extern "C" int bgmm_get_counts(bgmm_ctx *c, int64_t *counts_out) {
 
 extern "C" int bgmm_get_stats(bgmm_ctx *c, double *m_out, double *S_out, double *logdet_out, double *inv_out) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1711,6 +1741,7 @@ extern "C" int bgmm_get_log_prior(bgmm_ctx *c, double *out) {
 
 extern "C" int bgmm_log_marg(bgmm_ctx *c, double *out) {
     if (!c || !out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     launch_log_marg(c->d, c->util_out, c->util_out + 8, c->stream);
     CK(c, hipMemcpyAsync(out, c->util_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1720,6 +1751,7 @@ extern "C" int bgmm_log_marg(bgmm_ctx *c, double *out) {
 
 extern "C" int bgmm_log_marg_k(bgmm_ctx *c, int32_t k, double *out) {
     if (!c || !out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1732,6 +1764,7 @@ extern "C" int bgmm_log_marg_k(bgmm_ctx *c, int32_t k, double *out) {
 
 extern "C" int bgmm_contingency(bgmm_ctx *c, const int64_t *true_idx, int32_t K_true, int64_t *table_out) {
     if (!c || !table_out || K_true < 1) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     if (!true_idx && !c->true_dev) return fail(c, BGMM_EINVAL, "no reference labelling uploaded yet");
     int rc = fetch_ctrl(c);
@@ -1758,6 +1791,7 @@ extern "C" int bgmm_contingency(bgmm_ctx *c, const int64_t *true_idx, int32_t K_
 
 extern "C" int bgmm_cluster_dispersion(bgmm_ctx *c, double *out) {
     if (!c || !out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1771,6 +1805,7 @@ extern "C" int bgmm_cluster_dispersion(bgmm_ctx *c, double *out) {
 
 extern "C" int bgmm_log_post_pred(bgmm_ctx *c, int64_t i, double *out) {
     if (!c || !out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
     int rc = fetch_ctrl(c);
@@ -1794,6 +1829,7 @@ extern "C" int bgmm_log_post_pred(bgmm_ctx *c, int64_t i, double *out) {
 
 static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
     launch_item_op(c->d, op, i, k, c->stream);
@@ -1813,6 +1849,7 @@ static int item_op(bgmm_ctx *c, int op, int64_t i, int32_t k) {
 
 extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const double *S, int64_t count) {
     if (!c || !m || !S) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1846,6 +1883,7 @@ extern "C" int bgmm_set_stats(bgmm_ctx *c, int32_t k, const double *m, const dou
 
 extern "C" int bgmm_get_raw_stats(bgmm_ctx *c, int32_t k, double *m_out, double *S_out) {
     if (!c || !m_out || !S_out) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1865,6 +1903,7 @@ extern "C" int bgmm_get_raw_stats(bgmm_ctx *c, int32_t k, double *m_out, double 
 
 extern "C" int bgmm_del_component(bgmm_ctx *c, int32_t k) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1880,6 +1919,7 @@ extern "C" int bgmm_del_component(bgmm_ctx *c, int32_t k) {
 
 extern "C" int bgmm_set_sweep_visits(bgmm_ctx *c, int64_t n_visits) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     if (n_visits < 0 || n_visits > c->d.N) return fail(c, BGMM_EINVAL, "n_visits must be in 0 .. N");
     c->next_sweep_visits = n_visits;
     return 0;
@@ -1887,6 +1927,7 @@ extern "C" int bgmm_set_sweep_visits(bgmm_ctx *c, int64_t n_visits) {
 
 extern "C" int bgmm_set_label(bgmm_ctx *c, int64_t i, int32_t k) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     if (i < 0 || i >= c->d.N) return fail(c, BGMM_EINVAL, "data index out of range");
     int rc = fetch_ctrl(c);
@@ -1905,6 +1946,7 @@ extern "C" int bgmm_del_item(bgmm_ctx *c, int64_t i) { return item_op(c, 0, i, 0
 
 extern "C" int bgmm_get_phase_clocks(bgmm_ctx *c, int64_t *out16) {
     if (!c || !out16) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     int rc = fetch_ctrl(c);
     if (rc) return rc;
@@ -1914,24 +1956,28 @@ extern "C" int bgmm_get_phase_clocks(bgmm_ctx *c, int64_t *out16) {
 
 extern "C" int bgmm_get_sweep_stats(bgmm_ctx *c, int64_t *out8) {
     if (!c || !out8) return BGMM_EINVAL;
+    SETTLE(c);
     for (int t = 0; t < 8; ++t) out8[t] = c->stats[t];
     return 0;
 }
 
 extern "C" int bgmm_get_prune_stats(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
+    SETTLE(c);
     out4[0] = c->stats[6]; out4[1] = c->stats[7]; out4[2] = c->prune_mfma; out4[3] = c->certified;
     return 0;
 }
 
 extern "C" int bgmm_get_path_stats(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
+    SETTLE(c);
     for (int t = 0; t < 4; ++t) out4[t] = c->stats2[t];
     return 0;
 }
 
 extern "C" int bgmm_get_safe_stats(bgmm_ctx *c, int64_t *out6) {
     if (!c || !out6) return BGMM_EINVAL;
+    SETTLE(c);
     for (int t = 0; t < 6; ++t) out6[t] = c->safe_stats[t];
     return 0;
 }
@@ -1948,18 +1994,21 @@ extern "C" int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624) {
 
 extern "C" int bgmm_set_mt_jump(bgmm_ctx *c, int32_t enabled) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     c->mt_jump_on = enabled != 0;
     return 0;
 }
 
 extern "C" int bgmm_set_safe_budget(bgmm_ctx *c, double cap) {
     if (!c || !(cap >= 0.0) || cap > 8.0) return BGMM_EINVAL;
+    SETTLE(c);
     c->safe_cap_user = cap;
     return 0;
 }
 
 extern "C" int bgmm_set_kernel_timing(bgmm_ctx *c, int32_t enabled) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     c->timing = enabled != 0;
     c->timed_launches = 0;
     c->timed_ms = 0.0;
@@ -1976,6 +2025,7 @@ extern "C" int bgmm_get_kernel_timing(bgmm_ctx *c, int64_t *n_launches, double *
 extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_kind, int32_t resolver_mode,
                                int32_t prune_mode) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     if (kernel_kind < 0 || kernel_kind > 2) return fail(c, BGMM_EINVAL, "kernel_kind must be 0, 1 or 2");
     if (resolver_mode < 0 || resolver_mode > 5) return fail(c, BGMM_EINVAL, "resolver_mode must be 0 .. 5");
@@ -2000,6 +2050,7 @@ extern "C" int bgmm_set_tuning(bgmm_ctx *c, int32_t max_window, int32_t kernel_k
 
 extern "C" int bgmm_set_home_pass(bgmm_ctx *c, int32_t mode) {
     if (!c || mode < 0 || mode > 3) return BGMM_EINVAL;
+    SETTLE(c);
     c->home_mode = mode;
     c->home_pass = mode != 2;
     return 0;
@@ -2007,12 +2058,14 @@ extern "C" int bgmm_set_home_pass(bgmm_ctx *c, int32_t mode) {
 
 extern "C" int bgmm_set_seq_plan(bgmm_ctx *c, int32_t max_labels) {
     if (!c || max_labels < 0) return BGMM_EINVAL;
+    SETTLE(c);
     c->seq_cap = max_labels;
     return 0;
 }
 
 extern "C" int bgmm_synchronize(bgmm_ctx *c) {
     if (!c) return BGMM_EINVAL;
+    SETTLE(c);
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -2096,6 +2149,7 @@ extern "C" int bgmm_comm_create(int32_t rank, int32_t world_size, const void *id
 
 extern "C" int bgmm_gather_labels(bgmm_ctx *c, void *comm, int32_t world_size, int64_t *z_all_out) {
     if (!c || !comm || !z_all_out || world_size < 1) return BGMM_EINVAL;
+    SETTLE(c);
     int rc = rccl_load();
     if (rc) return rc;
     CK(c, hipSetDevice(c->device));

@@ -669,6 +669,139 @@ def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
         ctx.close()
 
 
+def test_crpmm_class_each_in_own_reproduces_reference_kat3():
+    """The reference's third known-answer test through the CLASS (pybgmm/tests/test_igmm.py:106-146:
+    ``CRPMM(X, prior, 1.0, None, assignments="each-in-own", K=3)``, one sweep, N = 20): the literal 2014 labels, from the
+    caller's seeded global streams -- the init string handled by IGMM.__init__ (igmm/igmm.py:98-99), not a z vector."""
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    g = Golden("kat3_each_in_own")
+    random.seed(1)
+    np.random.seed(1)
+    X, z_true = gendata.demo_mixture(20, 2, 4, rs=np.random)
+    npt.assert_array_equal(X, g.X)
+    mm = CRPMM(X, NIW(*gendata.demo_prior_params(2, v_0=5)), 1.0, None, assignments="each-in-own", K=3)
+    npt.assert_array_equal(mm.components.assignments, np.arange(20))
+    npt.assert_array_equal(mm.components.assignments, g.z_init)
+    assert mm.components.K == 20
+    record, _ = mm.collapsed_gibbs_sampler(1, z_true, num_saved=0)
+    expected = np.array([5, 2, 4, 3, 2, 7, 2, 7, 1, 0, 4, 6, 4, 1, 6, 4, 1, 7, 1, 0])      # test_igmm.py:143
+    npt.assert_array_equal(mm.components.assignments, expected)
+    npt.assert_array_equal(mm.components.assignments, g.z[-1])
+    npt.assert_allclose(record["log_marg"], g.log_marg, rtol=1e-9)
+    assert record["components"] == list(g.K)
+
+
+@pytest.mark.parametrize("case,mode,seed", [("each_in_own_50", "each-in-own", 4), ("one_by_one_50", "one-by-one", 5)])
+def test_crpmm_class_init_strings_reproduce_reference(case, mode, seed):
+    """``assignments="each-in-own"`` / ``"one-by-one"`` (igmm/igmm.py:95-99) through the class: the initial labels the
+    reference builds (arange(N); all -1 but z[0] = 0), then three sweeps from the caller's seeded ``random`` stream --
+    labels, K, counts and log marginal of every sweep as captured from the reference."""
+    import random
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    g = Golden(case)
+    assert int(g.d["seed_random"]) == seed
+    random.seed(seed)
+    np.random.seed(seed)
+    mm = CRPMM(g.X, NIW(*g.prior), g.alpha, None, assignments=mode, K=1)
+    npt.assert_array_equal(mm.components.assignments, g.z_init)
+    zs, lms, Ks = [], [], []
+    for it in range(g.n_iter):                           # (sweep by sweep: the labels after EVERY sweep are pinned)
+        record, _ = mm.collapsed_gibbs_sampler(1, g.d["true_assignments"], num_saved=0)
+        zs.append(mm.components.assignments.copy())
+        lms.append(record["log_marg"][0])
+        Ks.append(record["components"][0])
+        npt.assert_array_equal(mm.components.counts[:Ks[-1]], g.counts_at(it))
+    npt.assert_array_equal(np.array(zs), g.z)
+    npt.assert_allclose(lms, g.log_marg, rtol=1e-9)
+    assert Ks == list(g.K)
+
+
+@pytest.mark.slow
+def test_c3_full_size_against_c_oracle():
+    """BASELINE's C3 at FULL size against the C port of the reference: PCRPMM semantics, N = 1e6, D = 16,
+    K = 100, the truth with 2 000 wrong labels, two sweeps (a fresh permutation each, powered weights in the second:
+    pcrpmm.py:86-112).  The default configuration AND the mode bench.py times against ONE oracle run: labels identical
+    after each sweep, log marginal to 1e-9.  The oracle costs ~12 us per visit at this shape: ~25 s of host time."""
+    from divergence import assert_same_labels, first_divergence
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K, flip = 1000000, 16, 100, 2000
+    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(16)
+    z0 = zt.copy()
+    idx = rs.choice(N, size=flip, replace=False)
+    z0[idx] = rs.randint(0, K, size=flip)
+    n_sw = 2
+    us = rs.random_sample((n_sw, N))
+    orders = [rs.permutation(N).astype(np.int64) for _ in range(n_sw)]
+    powers = [None, 1.01]
+    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+
+    def mk_ctx(prune):
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        c.set_tuning(prune_mode=prune)
+        c.set_assignments(z0)
+        return c
+    o = mk_oracle()
+    ctxs = {prune: mk_ctx(prune) for prune in (0, 3)}
+    moved = 0
+    for it in range(n_sw):
+        o.sweep(us[it], orders[it], powers[it])
+        zo, lo = o.z, o.log_marg()
+        for prune, ctx in ctxs.items():
+            ctx.sweep(us[it], orders[it], powers[it])
+            assert_same_labels(ctx.assignments(), zo, "prune_mode %d, sweep %d" % (prune, it),
+                               lambda: first_divergence(lambda: mk_ctx(prune), mk_oracle, us, orders, powers, it))
+            assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        moved += ctxs[3].sweep_stats()["moves"]
+    assert moved >= flip // 2
+    for ctx in ctxs.values():
+        ctx.close()
+
+
+@pytest.mark.slow
+def test_c4_quarter_size_against_c_oracle():
+    """BASELINE's C4 shape (D = 64, K = 200) at N = 2.5e5 against the C port of the reference: the truth
+    with 500 wrong labels, one whole sweep in the default configuration and in the benchmarked mode -- the largest C4-shaped
+    problem the oracle finishes in about two minutes of host time (0.4 ms per visit)."""
+    from divergence import assert_same_labels, first_divergence
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K, flip = 250000, 64, 200, 500
+    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(64)
+    z0 = zt.copy()
+    idx = rs.choice(N, size=flip, replace=False)
+    z0[idx] = rs.randint(0, K, size=flip)
+    us = rs.random_sample((1, N))
+    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 2 * K, scipy_tables=False)
+
+    def mk_ctx(prune):
+        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 2 * K)
+        c.set_tuning(prune_mode=prune)
+        c.set_assignments(z0)
+        return c
+    o = mk_oracle()
+    o.sweep(us[0])
+    zo, lo = o.z, o.log_marg()
+    for prune in (0, 3):
+        ctx = mk_ctx(prune)
+        ctx.sweep(us[0])
+        assert_same_labels(ctx.assignments(), zo, "prune_mode %d" % prune,
+                           lambda: first_divergence(lambda: mk_ctx(prune), mk_oracle, us, [None], [None], 0))
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        assert ctx.sweep_stats()["moves"] >= flip // 2
+        ctx.close()
+
+
 def test_first_divergence_diagnostic_finds_a_planted_divergence():
     """VERDICT r2 #8(iii) / SURVEY 7.3.2: the diagnostic itself.  The device is handed a uniform stream that differs from
     the oracle's at ONE visit (moved across a CDF boundary of that visit), so the chains part exactly there; the
@@ -1896,6 +2029,130 @@ def test_pipelined_sweeps_equal_plain_sweeps(case, depth):
     assert out[0][4] == out[1][4], (out[0][4], out[1][4])      # the same steps stood and were refused
     if case == "rest-evaluated":
         assert out[0][4]["stood"] >= n_sw - 3
+
+
+@pytest.mark.parametrize("depth", [0, 1, -1])
+@pytest.mark.parametrize("case", ["forced", "flip", "pcrp-forced", "pcrp-flip", "host-inputs"])
+def test_pipelined_sweeps_with_refused_steps_in_flight(case, depth):
+    """The redo path of bgmm_sweep_staged_end: a short step that is REFUSED while the next sweep's inputs have already
+    been staged.  The refused step must be redone from the inputs the sweep was begun with -- not from what the stage
+    calls of the meantime left (on-the-spot generation into d_u / d_order with the look-ahead off, the batch buffer a
+    look-ahead generation would overwrite, the permutation look-ahead's buffer after the swap).
+    `forced`: bgmm_set_home_pass(3) tries a short step in every sweep of a chain that moves (refused again and again);
+    `flip`: a chain at rest (short steps armed), one label set wrong before _begin: the step in flight is refused;
+    `host-inputs`: the next sweep's inputs come through bgmm_stage_sweep_inputs (host arrays into the context's own
+    buffers: the call finishes the sweep in flight first).  Against the plain loop, with refusals asserted."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    pcrp = case.startswith("pcrp")
+    forced = case.endswith("forced")
+    N, D, K = 30000, 16, 8
+    X, zt = gendata.synth_mixture(N, D, K, seed=5, mu_scale=1.2 if forced else 4.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    n_sw = 8
+    flips = {3: 17, 5: 29000, 6: 12345}                  # sweep -> data index whose label is set wrong before _begin
+    out = []
+    for pipelined in (True, False):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 6 * K)
+        ctx.set_tuning(prune_mode=3)
+        if forced:
+            ctx.set_home_pass(3)
+        ctx.set_mt_lookahead(depth)
+        ctx.set_assignments(zt)
+        r, nr = random.Random(11), np.random.RandomState(11)
+        hr = np.random.RandomState(7)
+
+        def stage():
+            if case == "host-inputs":
+                ctx.stage(hr.random_sample(N), hr.permutation(N).astype(np.int64))
+                return
+            order = _rng.take_permutation_staged(ctx, N, nr) if pcrp else None
+            assert _rng.stage_uniforms_on_device(ctx, None if order is _rng.STAGED else order, r)
+        zs = []
+        stage()
+        for it in range(n_sw):
+            power = 1.01 if (pcrp and it > 0) else None
+            if not forced and it in flips:
+                i = flips[it]
+                ctx.set_label(i, (int(ctx.assignments()[i]) + 1) % ctx.K)
+            if pipelined:
+                ctx.sweep_staged_begin(power)
+                if it + 1 < n_sw:
+                    stage()
+                ctx.sweep_staged_end()
+            else:
+                ctx.sweep_staged(power)
+                if it + 1 < n_sw:
+                    stage()
+            zs.append(ctx.assignments())
+        out.append((zs, ctx.log_marg(), r.getstate(), nr.get_state()[1].copy(), ctx.short_step_stats()))
+        ctx.close()
+    for it in range(n_sw):
+        npt.assert_array_equal(out[0][0][it], out[1][0][it], err_msg="sweep %d" % it)
+    assert out[0][1] == out[1][1]
+    assert out[0][2] == out[1][2]
+    npt.assert_array_equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4], (out[0][4], out[1][4])
+    assert out[0][4]["refused"] >= 1, out[0][4]
+
+
+def test_calls_between_begin_and_end_finish_the_sweep_in_flight():
+    """Entry points that read or change the state while bgmm_sweep_staged_begin has left a sweep in the queue finish that
+    sweep first (they used to run against the queued sweep): labels read between the halves are the labels after the sweep,
+    a label set between the halves lands behind it, bgmm_set_mt_lookahead cannot free a buffer the sweep reads, and
+    bgmm_sweep_staged_end then only reports.  An order outside 0 .. N-1 is refused before any generator state moves."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    N, D, K = 20000, 16, 6
+    X, zt = gendata.synth_mixture(N, D, K, seed=3)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    outs = []
+    for pipelined in (True, False):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        ctx.set_tuning(prune_mode=3)
+        ctx.set_assignments(zt)
+        r = random.Random(4)
+        got = []
+        for it in range(6):
+            assert _rng.stage_uniforms_on_device(ctx, None, r)
+            if pipelined:
+                ctx.sweep_staged_begin(None)
+                if it == 2:
+                    got.append(ctx.assignments())        # finishes the sweep in flight
+                    ctx.set_label(5, (int(zt[5]) + 1) % K)
+                if it == 3:
+                    ctx.set_mt_lookahead(1)
+                if it == 4:
+                    got.append(ctx.log_marg())
+                ctx.sweep_staged_end()
+            else:
+                ctx.sweep_staged(None)
+                if it == 2:
+                    got.append(ctx.assignments())
+                    ctx.set_label(5, (int(zt[5]) + 1) % K)
+                if it == 3:
+                    ctx.set_mt_lookahead(1)
+                if it == 4:
+                    got.append(ctx.log_marg())
+        got.append(ctx.assignments())
+        # a bad order: refused, and the generator handed in is where it was
+        state = r.getstate()
+        bad = np.arange(N, dtype=np.int64)
+        bad[7] = N
+        with pytest.raises(_lib.BGMMError):
+            _rng.stage_uniforms_on_device(ctx, bad, r)
+        assert r.getstate() == state
+        assert _rng.stage_uniforms_on_device(ctx, None, r)
+        ctx.sweep_staged(None)
+        got.append(ctx.assignments())
+        outs.append(got)
+        ctx.close()
+    npt.assert_array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    npt.assert_array_equal(outs[0][2], outs[1][2])
+    npt.assert_array_equal(outs[0][3], outs[1][3])
 
 
 def test_group_sweep_equals_separate_sweeps():

@@ -189,7 +189,9 @@ def test_wishart_draws_consume_the_streams_like_the_reference():
             a[r, :r] = np.random.normal(size=(r,))
         a[r, r] = np.sqrt(random.gammavariate(0.5 * (v0 - D + 1), 2.0))
     C = np.linalg.cholesky(sigma)
-    npt.assert_array_equal(W, C.dot(a).dot(a.T).dot(C.T))
+    # (the product is associated differently -- L L' with L = C a: equal up to rounding, symmetric exactly)
+    npt.assert_allclose(W, C.dot(a).dot(a.T).dot(C.T), rtol=1e-13, atol=1e-15)
+    npt.assert_array_equal(W, W.T)
     after = (random.random(), np.random.random_sample())
     random.seed(5)
     np.random.seed(6)
