@@ -7,6 +7,9 @@ no HIP device is visible, the calls raise.  ``oracle/`` is never imported here.
 import ctypes
 import os
 
+# (chains side by side keep one stream each busy: eight hardware queues unless the user has chosen -- see bgmm_api.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 from . import _build

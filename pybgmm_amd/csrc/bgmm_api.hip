@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,11 @@ void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, doub
                          double *inv_out, hipStream_t st);
 
 static thread_local std::string g_create_error;
+
+// Chains side by side on one GPU (bgmm_group_sweep_staged) keep one stream each busy.  The HIP runtime maps a process's
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; streams that share a queue run one behind the other): eight,
+// unless the user has chosen otherwise.  Takes effect when this library is loaded before the runtime's first call.
+static const int g_hw_queues_env = (setenv("GPU_MAX_HW_QUEUES", "8", 0), 0);
 
 struct bgmm_ctx {
     int device = 0;
@@ -1585,7 +1591,26 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
     }
     std::vector<int> deferred;
     int worst = 0;
+    // Chains that can never take the one-workgroup sweep (D > 4, diagonal / fixed covariance) run their whole sweep as
+    // bgmm_sweep_staged would -- but CONCURRENTLY, each on its own stream, each driven by its own host thread (a context is
+    // one host thread's at a time; distinct contexts share nothing).  What bounds such a sweep while the chain still moves is
+    // a latency chain that keeps ONE workgroup busy (kernels_gram.hip: the resolver); G chains side by side keep G of them
+    // busy, and the wide kernels of one chain (cross forms, rebuilds) run beside the resolvers of the others.
+    std::vector<std::thread> workers;
+    std::vector<int> threaded;
+    for (int i = 0; i < n; ++i)
+        if (!seq_shape(ctxs[i])) threaded.push_back(i);
+    if (threaded.size() >= 2) {
+        for (int i : threaded) {
+            const int up = use_power ? use_power[i] : 0;
+            const double pw = (up && power) ? power[i] : 1.0;
+            workers.emplace_back([=]() { rc_out[i] = sweep_impl(ctxs[i], up, pw, 0); });
+        }
+    } else {
+        threaded.clear();
+    }
     for (int i = 0; i < n; ++i) {
+        if (std::find(threaded.begin(), threaded.end(), i) != threaded.end()) continue;
         const int up = use_power ? use_power[i] : 0;
         const int rc = sweep_impl(ctxs[i], up, (up && power) ? power[i] : 1.0, 1);
         if (rc == 1) deferred.push_back(i);
@@ -1643,6 +1668,9 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
             if (rc < 0 && worst == 0) worst = rc;
         }
     }
+    for (auto &w : workers) w.join();
+    for (int i : threaded)
+        if (rc_out[i] < 0 && worst == 0) worst = rc_out[i];
     return worst;
 }
 

@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <vector>
 
 #define BGMM_MAX_D 128
@@ -321,13 +322,14 @@ __host__ __device__ constexpr int bgmm_nfrag(int Dp) { return 2 * (Dp / 16) * (D
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT DEVICE only: what a launcher has
 // already asked for is remembered per device (contexts on different GPUs of one process are independent).
 struct PerDeviceLds {
-    int have[64] = {};
+    std::atomic<int> have[64] = {};     // (chains of one process are driven from several host threads: bgmm_group_sweep_staged)
     bool raise(int lds) {               // true: the attribute must be (re)set on the current device
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-        if (lds <= have[dev]) return false;
-        have[dev] = lds;
-        return true;
+        int cur = have[dev].load(std::memory_order_relaxed);
+        while (lds > cur)
+            if (have[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) return true;
+        return false;
     }
 };
 

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
             g[3] = 0.5 * (double)(v + d.D);
             g[4] = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet0)) - 0.5 * log(kN0 / kN);
             g[5] = (double)nn;
+            g[7] = tab.seat1 + tab.g1 - 0.5 * (double)d.D * tab.lc1;      // (home form: the visited point removed)
         }
     }
     __syncthreads();
@@ -739,11 +740,11 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 cd0 = gram_ld(d.gq0, (unsigned)base * GR + (unsigned)lrow);
             }
             const double *__restrict__ cc = d.gcc + ((unsigned)base * 5 + (unsigned)(eidx >= 0 ? eidx : 2)) * 8;
-            const double ik0 = cc[0], c_ikn = cc[1], c_icv = cc[2], c_hv = cc[3], c_cb = cc[4], logdet0 = cc[6];
+            const double ik0 = cc[0], c_ikn = cc[1], c_icv = cc[2], c_hv = cc[3], c_cb = cc[4], logdet0 = cc[6], c_c7 = cc[7];
             const double rM = rowM[lrow];
             const bool own = rowhome[lrow] == slot && n_new >= 2;
             const double kN_new = d.k0 + (double)n_new;
-            double ikn = c_ikn, inv_cv = c_icv, hv = c_hv, cbase = c_cb;
+            double ikn = c_ikn, inv_cv = c_icv, hv = c_hv, cbase = c_cb, c7 = c_c7;
             if (eidx < 0) {
                 // (rare) a count further from the frozen one than the prepared constants reach
                 const SlotTab tab = load_slot_tab(d, n_new);
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 inv_cv = fm_div(kN_new, kN_new + 1.0);
                 hv = 0.5 * (double)(v + d.D);
                 cbase = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet0)) - 0.5 * log(fm_div(1.0, ik0 * kN_new));
+                c7 = tab.seat1 + tab.g1 - 0.5 * (double)d.D * tab.lc1;
             }
             double acc = crow + ik0, cdv = cd0 + ik0;
             for (int tt = prev0; tt >= 0; tt = termPrev[tt]) {
@@ -770,14 +772,13 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             double ee = fm_exp((cbase - rM) - hv * l1) * rcf_new;
             const unsigned long long mown = __ballot(own && act && lane > r);
             if (mown) {
-                // (rare) rows whose home this column is: the visited point removed from it (slot_math.h, home form)
-                const SlotTab tab = load_slot_tab(d, n_new);
-                const long long v = d.v0 + n_new - d.D + 1;
+                // rows whose home this column is: the visited point removed from it (slot_math.h, home form; the constants
+                // that depend on the count alone came with the column's other constants: no table look-up on the chain)
                 const double a1 = fm_div(kN_new, kN_new - 1.0);
                 const double den = 1.0 - a1 * qv;
-                const double hv1 = 0.5 * (double)(v - 1 + d.D);
-                const double logdet_now = logdet0 - log(ik0 * kN_new * (rcf_new * rcf_new));
-                const double cb1 = tab.seat1 + (tab.g1 - 0.5 * ((double)d.D * tab.lc1 + logdet_now)) - rM;
+                const double hv1 = hv - 0.5;
+                const double logdet_now = logdet0 - fm_log(ik0 * kN_new * (rcf_new * rcf_new));
+                const double cb1 = (c7 - 0.5 * logdet_now) - rM;
                 const double e1 = fm_exp(cb1 - 0.5 * fm_log(den) - hv1 * fm_log(1.0 + fm_div(a1 * qv, den)));
                 ee = own ? e1 : ee;
             }

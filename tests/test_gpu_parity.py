@@ -2039,7 +2039,8 @@ def test_pipelined_sweeps_with_refused_steps_in_flight(case, depth):
     calls of the meantime left (on-the-spot generation into d_u / d_order with the look-ahead off, the batch buffer a
     look-ahead generation would overwrite, the permutation look-ahead's buffer after the swap).
     `forced`: bgmm_set_home_pass(3) tries a short step in every sweep of a chain that moves (refused again and again);
-    `flip`: a chain at rest (short steps armed), one label set wrong before _begin: the step in flight is refused;
+    `flip`: a chain at rest, one label set wrong before _begin (short steps tried in every sweep, as in `forced`): the step
+    in flight meets a mover and is refused;
     `host-inputs`: the next sweep's inputs come through bgmm_stage_sweep_inputs (host arrays into the context's own
     buffers: the call finishes the sweep in flight first).  Against the plain loop, with refusals asserted."""
     import random
@@ -2056,8 +2057,7 @@ def test_pipelined_sweeps_with_refused_steps_in_flight(case, depth):
     for pipelined in (True, False):
         ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 6 * K)
         ctx.set_tuning(prune_mode=3)
-        if forced:
-            ctx.set_home_pass(3)
+        ctx.set_home_pass(3)                             # (a short step in front of EVERY sweep: also right after set_label)
         ctx.set_mt_lookahead(depth)
         ctx.set_assignments(zt)
         r, nr = random.Random(11), np.random.RandomState(11)
@@ -2202,6 +2202,58 @@ def test_group_sweep_equals_separate_sweeps():
     assert not np.array_equal(grouped[0][0].assignments(), grouped[1][0].assignments()), "chains with different seeds must differ"
     with pytest.raises(_lib.BGMMError):                     # (a context twice in one group)
         _lib.group_sweep_staged([grouped[0][0], grouped[0][0]])
+    for ch in grouped + solo:
+        ch[0].close()
+
+
+def test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo():
+    """bgmm_group_sweep_staged with chains that cannot take the one-workgroup sweep (D = 64 / 16 full covariance from the
+    reference's "rand" start -- frozen-factor and safe-stay windows --, a diagonal-covariance chain, a chain at the truth):
+    they run CONCURRENTLY, one stream and one host thread each (G chains at any D).  Every chain label for
+    label, log marginal for log marginal, counter for counter what bgmm_sweep_staged on a twin context gives; a small-D
+    chain in the same group still goes through the one-workgroup launch."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    shapes = [(12000, 64, 12, "full", "rand"), (12000, 64, 12, "full", "rand"), (9000, 16, 8, "full", "rand"),
+              (8000, 16, 6, "diag", "rand"), (12000, 64, 12, "full", "true"), (20000, 2, 20, "full", "rand")]
+    data = {}
+    for (N, D, K, cov, _) in shapes:
+        if (N, D, K) not in data:
+            data[(N, D, K)] = gendata.synth_mixture(N, D, K, seed=N % 89 + D)
+
+    def build():
+        out = []
+        for c, (N, D, K, cov, init) in enumerate(shapes):
+            X, zt = data[(N, D, K)]
+            m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+            if cov == "diag":
+                S_0 = np.ascontiguousarray(np.diag(S_0))
+            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 8 * K, cov_type=cov)
+            z0 = np.unique(np.random.RandomState(40 + c).randint(0, K, N), return_inverse=True)[1] if init == "rand" else zt
+            ctx.set_assignments(z0)
+            _, key, _ = random.Random(200 + c).getstate()
+            out.append([ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
+        return out
+    grouped, solo = build(), build()
+    rs = np.random.RandomState(3)
+    moved = 0
+    for it in range(3):
+        orders = [rs.permutation(sh[0]).astype(np.int64) if (it == 1 and c % 2 == 0) else None for c, sh in enumerate(shapes)]
+        powers = [1.02 if (it == 2 and c % 2 == 0) else None for c in range(len(shapes))]
+        for chains_ in (grouped, solo):
+            for c, ch in enumerate(chains_):
+                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], orders[c])
+        _lib.group_sweep_staged([ch[0] for ch in grouped], powers)
+        for c, ch in enumerate(solo):
+            ch[0].sweep_staged(powers[c])
+        for c in range(len(shapes)):
+            npt.assert_array_equal(grouped[c][0].assignments(), solo[c][0].assignments(), err_msg="sweep %d chain %d" % (it, c))
+            assert grouped[c][0].log_marg() == solo[c][0].log_marg()
+            assert grouped[c][0].sweep_stats() == solo[c][0].sweep_stats()
+        moved += grouped[0][0].sweep_stats()["moves"]
+    assert moved > 5000, "the D = 64 chains are meant to burn in"
+    assert not np.array_equal(grouped[0][0].assignments(), grouped[1][0].assignments()), "chains with different seeds must differ"
     for ch in grouped + solo:
         ch[0].close()
 

@@ -133,6 +133,8 @@ def chain(a, quiet=False):
         w = max(pc[8], 1)
         print("resolver ticks per window: prologue %.0f  draws %.0f  bookkeeping %.0f  update(home) %.0f  update(dest) %.0f  | windows %d" % (
             pc[0] / w, pc[1] / w, pc[2] / w, pc[3] / w, pc[4] / w, pc[8]))
+        print("   gram_finish, workgroup 0, ticks per window: statistics -> LDS %.0f  eigenvalue bound %.0f  blocked factorisation %.0f  "
+              "inverse %.0f  write-back %.0f" % (pc[10] / w, pc[11] / w, pc[12] / w, pc[13] / w, pc[14] / w))
     ctx.close()
     return ok
 
@@ -194,6 +196,48 @@ def chains(a):
         dt = (time.time() - t0) / n
         print("%3d chains: %.2f ms per round of sweeps, %.1f sweeps/s aggregate" % (g, dt * 1e3, g / dt))
         grp.close()
+
+
+def chains_burnin(a):
+    """G chains of one shape from the reference's "rand" start, side by side on one device (bgmm_group_sweep_staged: chains
+    that cannot take the one-workgroup sweep run concurrently, one stream and one host thread each) against one chain:
+    seconds and moves per second of the first sweeps, and every chain's labels against its solo run."""
+    from pybgmm_amd.chains import ChainGroup
+    from pybgmm_amd.utils import gendata
+    N, D, K, G = a.N, a.D, a.K, a.G
+    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    z0s = [start_labels("rand", zt, K, np.random.RandomState(100 + c)) for c in range(G)]
+    res = {}
+    solo = []
+    for g in (1, G):
+        grp = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, n_chains=g, seed=1)
+        grp.set_assignments(z0s[:g])
+        for ctx in grp.ctxs:
+            ctx.synchronize()
+        ts, mv = [], []
+        for it in range(a.sweeps):
+            t0 = time.time(); grp.sweep(); dt = time.time() - t0
+            ts.append(dt); mv.append(sum(ctx.sweep_stats()["moves"] for ctx in grp.ctxs))
+        res[g] = (ts, mv)
+        print("%2d chain(s): sweeps %s s, moves %s -> first sweep %.3g moves/s aggregate" % (
+            g, " / ".join("%.3f" % t for t in ts), " / ".join(str(m) for m in mv), mv[0] / ts[0]), flush=True)
+        if g == 1:
+            solo.append(grp.assignments()[0])
+        else:
+            zg = grp.assignments()
+            ok0 = np.array_equal(zg[0], solo[0])
+            print("   chain 0 of the group == the solo chain: %s" % ok0)
+            if a.check:
+                for c in range(1, G):
+                    one = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, n_chains=1, seed=1 + c)
+                    one.set_assignments([z0s[c]])
+                    for it in range(a.sweeps):
+                        one.sweep()
+                    print("   chain %d of the group == its solo run: %s" % (c, np.array_equal(one.assignments()[0], zg[c])), flush=True)
+                    one.close()
+        grp.close()
+    print("aggregate first-sweep speed-up with %d chains: %.2f x" % (G, (res[G][1][0] / res[G][0][0]) / (res[1][1][0] / res[1][0][0])))
 
 
 def staged(a):
@@ -291,6 +335,11 @@ def parser():
     g.add_argument("G", type=int)
     g.add_argument("N", type=int, nargs="?", default=100000)
     g.add_argument("K", type=int, nargs="?", default=20)
+    gb = sub.add_parser("chains-burnin")
+    for n in ("N", "D", "K", "G"):
+        gb.add_argument(n, type=int)
+    gb.add_argument("--sweeps", type=int, default=2)
+    gb.add_argument("--check", action="store_true", help="every chain of the group against its solo run")
     t = sub.add_parser("staged")
     t.add_argument("N", type=int, nargs="?", default=1000000)
     t.add_argument("D", type=int, nargs="?", default=64)
@@ -312,6 +361,8 @@ if __name__ == "__main__":
         classes(args)
     elif args.cmd == "chains":
         chains(args)
+    elif args.cmd == "chains-burnin":
+        chains_burnin(args)
     elif args.cmd == "staged":
         staged(args)
     elif args.cmd == "perm":
