@@ -41,6 +41,11 @@ enum { REFRESH_SCRATCH = 0,   // Cholesky + inverse of S_N from scratch, O(D^3)
        REFRESH_SUB = 2,       // rank-1 downdate: point refresh_i was removed
        REFRESH_NEW = 3 };     // new component: rank-1 update of the prior's factor (pseudo slot)
 static constexpr int kRefreshEvery = 64;   // rank-1 steps per slot between from-scratch rebuilds
+// ... in the frozen-factor windows (gram_finish_kernel: ~100 slots take a term or two per window, and the kernel lasts as
+// long as its slowest workgroup -- a rebuild).  A window in which some slot is due rebuilds every touched slot beyond half
+// of the interval with it, so that rebuilds come in bunches instead of one in every window.  (Each step is a product with
+// a triangular factor close to the identity: errors add up, ~1e-16 per step.)
+static constexpr int kGramRefreshEvery = 512;
 
 static constexpr unsigned long long kNoMover = ~0ull;
 static constexpr int kMaxChunks = 8;       // grid.y of the likelihood kernels
@@ -132,7 +137,7 @@ struct Ctrl {
     int gram_nmoves;       // moves the last window logged (GramMove records)
     int gram_ntouched;     // live slots whose statistics / factor the finish kernel has to bring up to date
     int gram_stall;        // 1: the window needs more columns than are allocated (host reallocates)
-    int gram_pad;
+    int gram_rebuild;      // 1: a slot of the last window is due for a from-scratch rebuild (the others past half the interval join it)
     unsigned long long n_pairs_exact;   // (visit, component) pairs whose quadratic form was executed this sweep
     long long gram_rows_total, gram_windows;   // rows consumed by / number of frozen-factor windows this sweep
     // safe-stay windows (kernels_safe.hip): frozen-factor windows over the visits that cannot be PROVEN to stay

@@ -339,12 +339,14 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     constexpr unsigned gld = KC;
 #ifdef BGMM_PROFILE
     long long tk = clock64(), tk2;
+    const long long prof_c0 = clock64(), prof_w0 = wall_clock64();
 #endif
 
     if (tid == 0) {
         S.active = 0;
         c->gram_ntouched = 0;                   // (an idle step must not replay the last window's lists)
         c->gram_nmoves = 0;
+        c->gram_rebuild = 0;
         const Job &j = c->job;
         if (j.mode != MODE_DONE && c->error == 0) {
             if (d.gcols != KC || j.K + kGramColSlack > KC || j.K + T / 2 + 2 > 64 * LPL) {
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     long long hk_i = 0;
     // ---- wave 1's registers: the home side of the next visit, fetched ahead ----------------------
     int hp_base = -1, hp_r = -1;
-    double hp_crow = 0.0, hp_cd0 = 0.0;
+    double hp_crow = 0.0, hp_cd0 = 0.0, hp_cc = 0.0;
 
     // Everything of visit r that does not depend on the columns x0 / x1: the lane's cumulative weights.
     // Needs the label cache (cls, tix) and the frozen weights pf of visit r; fetches those of visit r + 1.
@@ -732,15 +734,21 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             const bool act = lane >= r && lane < nrows;
             const int lrow = act ? lane : r;
             // the row of the cross forms, the diagonal, the column's constants for its new count: one round trip
-            double crow, cd0;
+            // (the column's constants for ALL five counts it may have, lane k = the k-th of its 40 doubles: one vector load
+            //  beside the row of cross forms -- the count picks its eight by v_readlane afterwards.  Scalar loads from an
+            //  address that depends on the count were a second round trip to memory behind the first.)
+            double crow, cd0, ccv;
             if (wave == 1 && hp_base == base && hp_r == r) {
-                crow = hp_crow; cd0 = hp_cd0;
+                crow = hp_crow; cd0 = hp_cd0; ccv = hp_cc;
             } else {
                 crow = gram_ld(d.gC, ((unsigned)base * GR + (unsigned)r) * GR + (unsigned)lrow);
                 cd0 = gram_ld(d.gq0, (unsigned)base * GR + (unsigned)lrow);
+                ccv = gram_ld(d.gcc, (unsigned)base * 40 + (unsigned)(lane < 40 ? lane : 0));
             }
-            const double *__restrict__ cc = d.gcc + ((unsigned)base * 5 + (unsigned)(eidx >= 0 ? eidx : 2)) * 8;
-            const double ik0 = cc[0], c_ikn = cc[1], c_icv = cc[2], c_hv = cc[3], c_cb = cc[4], logdet0 = cc[6], c_c7 = cc[7];
+            const int ce = 8 * (eidx >= 0 ? eidx : 2);
+            const double ik0 = wv_readlane(ccv, ce), c_ikn = wv_readlane(ccv, ce + 1), c_icv = wv_readlane(ccv, ce + 2),
+                         c_hv = wv_readlane(ccv, ce + 3), c_cb = wv_readlane(ccv, ce + 4), logdet0 = wv_readlane(ccv, ce + 6),
+                         c_c7 = wv_readlane(ccv, ce + 7);
             const double rM = rowM[lrow];
             const bool own = rowhome[lrow] == slot && n_new >= 2;
             const double kN_new = d.k0 + (double)n_new;
@@ -815,6 +823,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     const int l2 = (lane >= r + 1 && lane < nrows) ? lane : r + 1;
                     hp_crow = gram_ld(d.gC, ((unsigned)hb * GR + (unsigned)(r + 1)) * GR + (unsigned)l2);
                     hp_cd0 = gram_ld(d.gq0, (unsigned)hb * GR + (unsigned)l2);
+                    hp_cc = gram_ld(d.gcc, (unsigned)hb * 40 + (unsigned)(lane < 40 ? lane : 0));
                 }
             }
 #ifdef BGMM_PROFILE
@@ -855,7 +864,10 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         if (cl == cprior || colLast[cl] < 0 || colSlot[cl] < 0) continue;
         const int s = colSlot[cl], n = colN[cl];
         d.n[s] = n;
-        if (n > 0) d.gtouched[atomicAdd(&c->gram_ntouched, 1)] = s;
+        if (n > 0) {
+            d.gtouched[atomicAdd(&c->gram_ntouched, 1)] = s;
+            if (d.nupd[s] + 16 > kGramRefreshEvery) c->gram_rebuild = 1;       // (gram_finish_kernel: rebuilds come in bunches)
+        }
         if (d.safe_mode) {
             // what the label has used of its budget, and what it may still lose / gain, for the stretch's next window
             SafeCol e = safecol_unpack(colE[cl]);
@@ -939,6 +951,8 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
 #ifdef BGMM_PROFILE
         for (int k = 0; k < 8; ++k) c->prof[k] += S.prof[k];
         c->prof[8] += 1;
+        c->prof[6] += clock64() - prof_c0;           // (the whole launch in s_memtime ticks ...
+        c->prof[7] += wall_clock64() - prof_w0;      //  ... and in ticks of the constant 100 MHz counter)
 #endif
         if (S.err < 0) {
             atomicCAS(&c->error, 0, S.err);

@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long nrows = c->n_resid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {            // (diagnostics: residual visits per proof pass, tools/probe.py)
+        c->prof[9] += nrows; c->prof[10] += 1; c->prof[11] += c->n_sorted; c->prof[12] += nrows <= kSafeResidSkip ? 1 : 0;
+    }
     if (nrows <= kSafeResidSkip) return;                  // (the pruning kernel stood aside: these visits stay unproven)
     const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int part = threadIdx.x & 3;

@@ -200,21 +200,29 @@ static void ensure_lds(const void *fn, int bytes, PerDeviceLds &attr) {
 
 // Frozen-factor windows (kernels_gram.hip), last kernel of a step: block b brings slot gtouched[b] up to
 // date -- the window's logged moves replayed on (m, S) in visiting order with the roundings of
-// apply_rank1 (bit-identical statistics), then the derived state rebuilt from scratch.
+// apply_rank1 (bit-identical statistics), then the derived state.
+// Two routes for the derived state.  A slot that took a few terms (the usual case: a window of 64 moves spreads 128
+// terms over ~100 slots) follows them by RANK-1 steps of its inverse factor, one per term, O(D^2) each (slot_math.h:
+// rank1_inverse_factor -- the route of the per-mover kernels), the factor in LDS throughout; the from-scratch
+// factorisation (refresh_blocked.h, O(D^3): 52 000 of the kernel's 90 000 cycles at D = 64) is kept for slots that took
+// many terms, were opened by the window, or are due (kGramRefreshEvery rank-1 steps since their last rebuild; bgmm_device.h).
+// The slot's statistics stay in REGISTERS across its terms (D^2 / 256 doubles per thread): one read and one write
+// of S per window instead of one per term.
 __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ long long mv_i[kGramMaxTerms];
     __shared__ int mv_op[kGramMaxTerms];          // 1: x leaves this slot, 2: joins it, 3: joins and opens it
-    __shared__ int n_ops;
+    __shared__ int n_ops, any_open;
+    __shared__ double xs[BGMM_MAX_D], ms[BGMM_MAX_D], wide_scan[256];
     const Ctrl *c = d.ctrl;
     if ((int)blockIdx.x >= c->gram_ntouched) return;
     const int s = d.gtouched[blockIdx.x];
-    const int D = d.D, nm = c->gram_nmoves;
+    const int D = d.D, nm = c->gram_nmoves, tid = threadIdx.x;
     // this slot's moves, in visiting order (one load per thread, compacted by a ballot scan)
-    if (threadIdx.x == 0) n_ops = 0;
+    if (tid == 0) { n_ops = 0; any_open = 0; }
     __syncthreads();
     for (int k0 = 0; k0 < nm; k0 += TPB) {
-        const int k = k0 + threadIdx.x;
+        const int k = k0 + tid;
         int op = 0;
         long long i = 0;
         if (k < nm) {
@@ -224,32 +232,159 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
         }
         // (nm <= 64 moves per window: the first wavefront holds them all, in order)
         const unsigned long long m = __ballot(op != 0);
-        if (threadIdx.x < 64 && op != 0) {
-            const int pos = n_ops + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        if (tid < 64 && op != 0) {
+            const int pos = n_ops + __popcll(m & ((1ull << (tid & 63)) - 1ull));
             mv_i[pos] = i; mv_op[pos] = op;
+            if (op == 3) any_open = 1;
         }
         __syncthreads();
-        if (threadIdx.x == 0) n_ops += __popcll(m);
+        if (tid == 0) n_ops += __popcll(m);
         __syncthreads();
     }
+    const int nops = n_ops;
     double *m = d.m + (long long)s * D;
     double *S = d.S + (long long)s * D * D;
-    const int nops = n_ops;
+    // rank-1 steps cost ~3.5 us each at D = 64 against ~37 us for the factorisation
+    const int few = D >= 24 ? D / 12 : 1;
+    const int steps = d.nupd[s];
+    const bool rank1 = nops >= 1 && nops <= few && !any_open && steps + nops <= kGramRefreshEvery &&
+                       !(c->gram_rebuild && steps > kGramRefreshEvery / 2);
+#ifdef BGMM_PROFILE
+    long long fk0 = clock64(), fk1;
+#define FPROF(i) do { if (tid == 0 && blockIdx.x == 0) { fk1 = clock64(); d.ctrl->prof[i] += fk1 - fk0; fk0 = fk1; } } while (0)
+#else
+#define FPROF(i) do { } while (0)
+#endif
+#ifndef BGMM_PROFILE
+    if (tid == 0) {                                    // (diagnostics, tools/probe.py: why slots are rebuilt from scratch)
+        Ctrl *cw = d.ctrl;
+        atomicAdd((unsigned long long *)&cw->prof[13], 1ull);
+        if (!rank1) atomicAdd((unsigned long long *)&cw->prof[14], 1ull);
+        if (nops > few) atomicAdd((unsigned long long *)&cw->prof[15], 1ull);
+        if (blockIdx.x == 0) atomicAdd((unsigned long long *)&cw->prof[8], 1ull);
+    }
+#endif
+    if (!rank1) {
+        for (int k = 0; k < nops; ++k) {
+            const int op = mv_op[k];
+            const double *__restrict__ x = d.X + mv_i[k] * D;
+            for (int a = tid; a < D; a += TPB) {
+                if (op == 1) m[a] = __dsub_rn(m[a], x[a]);
+                else m[a] = __dadd_rn(op == 3 ? d.prior_m[a] : m[a], x[a]);
+            }
+            for (int e = tid; e < D * D; e += TPB) {
+                const double xx = __dmul_rn(x[e / D], x[e % D]);
+                if (op == 1) S[e] = __dsub_rn(S[e], xx);
+                else S[e] = __dadd_rn(op == 3 ? d.prior_S[e] : S[e], xx);
+            }
+        }
+        __syncthreads();
+        refresh_slot_blocked(d, s, sm);
+        return;
+    }
+    // ---- the rank-1 route ------------------------------------------------------------------------------------
+    const int ld = D + 1;
+    double *W = sm;
+    double *mu = sm + D * ld, *dv = mu + D, *pv = dv + D, *lv = pv + D, *tv = lv + D;
+    double *scal = tv + 2 * D;
+    // thread -> (row, column) of S and W without a division: column sb = tid mod 2^lg (2^lg >= D), rows sa0 + q * srows
+    constexpr int kSregs = BGMM_MAX_D * BGMM_MAX_D / TPB;
+    int lg = 4;
+    while ((1 << lg) < D) ++lg;
+    const int sb = tid & ((1 << lg) - 1), sa0 = tid >> lg, srows = TPB >> lg;
+    const bool scol = sb < D;
+    double Sreg[kSregs];
+#pragma unroll
+    for (int q = 0; q < kSregs; ++q) { const int a = sa0 + q * srows; Sreg[q] = (scol && a < D) ? S[a * D + sb] : 0.0; }
+    {
+        const double *__restrict__ Wsrc = d.Wrm + (long long)s * D * D;
+        for (int a = sa0; a < D; a += srows)
+            if (scol) W[a * ld + sb] = Wsrc[a * D + sb];
+    }
+    if (tid < D) ms[tid] = m[tid];
+    __syncthreads();
+    FPROF(10);
+    int n_cur = d.n[s];                               // the count BEHIND the window (the resolver has written it) ...
+    for (int k = 0; k < nops; ++k) n_cur += mv_op[k] == 1 ? 1 : -1;     // ... and in front of it
+    double logdet = d.sc[s].logdetC;
+    bool bad = false;
+    // (the rows of the first terms set off together: one round trip to memory for all of them)
+    double xpre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xpre[k] = (k < nops && tid < D) ? d.X[mv_i[k] * D + tid] : 0.0;
     for (int k = 0; k < nops; ++k) {
         const int op = mv_op[k];
-        const double *__restrict__ x = d.X + mv_i[k] * D;
-        for (int a = threadIdx.x; a < D; a += TPB) {
-            if (op == 1) m[a] = __dsub_rn(m[a], x[a]);
-            else m[a] = __dadd_rn(op == 3 ? d.prior_m[a] : m[a], x[a]);
+        double xv = 0.0;
+        if (tid < D) {
+            xv = k < 4 ? (k == 0 ? xpre[0] : (k == 1 ? xpre[1] : (k == 2 ? xpre[2] : xpre[3]))) : d.X[mv_i[k] * D + tid];
+            xs[tid] = xv;
         }
-        for (int e = threadIdx.x; e < D * D; e += TPB) {
-            const double xx = __dmul_rn(x[e / D], x[e % D]);
-            if (op == 1) S[e] = __dsub_rn(S[e], xx);
-            else S[e] = __dadd_rn(op == 3 ? d.prior_S[e] : S[e], xx);
+        const double k_before = d.k0 + (double)n_cur;
+        if (tid < D) {
+            dv[tid] = xv - ms[tid] / k_before;                       // x - mean of the component before the change
+            ms[tid] = op == 1 ? __dsub_rn(ms[tid], xv) : __dadd_rn(ms[tid], xv);
+        }
+        const double a = op == 1 ? -k_before / (k_before - 1.0) : k_before / (k_before + 1.0);
+        n_cur += op == 1 ? -1 : 1;
+        __syncthreads();
+        {
+            const double xb = scol ? xs[sb] : 0.0;
+#pragma unroll
+            for (int q = 0; q < kSregs; ++q) {
+                const int a = sa0 + q * srows;
+                if (a < D) {
+                    const double xx = __dmul_rn(xs[a], xb);
+                    Sreg[q] = op == 1 ? __dsub_rn(Sreg[q], xx) : __dadd_rn(Sreg[q], xx);
+                }
+            }
+        }
+        if (tid == 0) *(int *)&scal[1] = 0;
+        rank1_inverse_factor_wide(W, ld, D, a, dv, pv, lv, tv, wide_scan, &scal[0], (int *)&scal[1], tid);
+        // (every thread reads the step's outcome behind the routine's closing barrier)
+        bad = bad || *(int *)&scal[1] != 0;
+        logdet += log(1.0 + a * scal[0]);
+        __syncthreads();                                             // (xs, dv, scal are rewritten by the next term)
+    }
+    FPROF(11);
+#pragma unroll
+    for (int q = 0; q < kSregs; ++q) { const int a = sa0 + q * srows; if (scol && a < D) S[a * D + sb] = Sreg[q]; }
+    if (tid < D) {
+        m[tid] = ms[tid];
+        mu[tid] = ms[tid] / (d.k0 + (double)d.n[s]);
+    }
+    if (tid == 0 && bad) atomicCAS(&d.ctrl->error, 0, -4);
+    // The eigenvalue bound behind the pruning: the Gershgorin row sums of S_N = S - k_N mu mu', as the from-scratch route
+    // takes them -- from the statistics in registers.  (Carried through the rank-1 steps it could only grow: a component
+    // that has just lost a far outlier would keep the outlier's bound, and the pruned windows their loose exclusions.)
+    double *rowsum = pv;
+    if (tid < D) rowsum[tid] = 0.0;
+    __syncthreads();
+    {
+        const double kN = d.k0 + (double)d.n[s];
+        const double mub = scol ? mu[sb] : 0.0;
+        const int width = lg < 6 ? (1 << lg) : 64;                     // lanes of a wavefront that share a row
+#pragma unroll
+        for (int q = 0; q < kSregs; ++q) {
+            const int a = sa0 + q * srows;
+            if (a < D) {                                               // (uniform per wavefront: a row spans whole wavefronts or parts of one)
+                double v = scol ? fabs(Sreg[q] - kN * (mu[a] * mub)) : 0.0;
+                for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o);
+                if ((tid & (width - 1)) == 0) atomicAdd(&rowsum[a], v);
+            }
         }
     }
     __syncthreads();
-    refresh_slot_blocked(d, s, sm);
+    double lam_g = 0.0;
+    if (tid < 64) {
+        for (int l = tid; l < D; l += 64) lam_g = fmax(lam_g, rowsum[l]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) lam_g = fmax(lam_g, __shfl_xor(lam_g, o));
+    }
+    __syncthreads();                                                   // (rowsum = pv is free again; thread 0 holds the bound)
+    write_slot_wide(d, s, W, ld, mu, logdet, lam_g, tid);
+    if (tid == 0) d.nupd[s] += nops;
+    __syncthreads();
+    FPROF(12);
 }
 
 void launch_gram_finish(const Dev &d, hipStream_t st) {

@@ -202,7 +202,7 @@ __device__ inline void refresh_slot_blocked(const Dev &d, int s, double *sm) {
     __syncthreads();
     RBPROF(13);
     if (tid == 0 && *(int *)&scal[1]) atomicCAS(&d.ctrl->error, 0, -4);
-    write_slot<256>(d, s, A, LD, mu, scal[0], scal[2], tid, nullptr, true);
+    write_slot_wide(d, s, A, LD, mu, scal[0], scal[2], tid);
     if (tid == 0) d.nupd[s] = 0;
     RBPROF(14);
 }

@@ -293,6 +293,124 @@ __device__ inline void rank1_inverse_factor(double *W, int ld, int D, double a, 
     __syncthreads();
 }
 
+// The same step for a whole block of 256 threads with every dependent loop cut short (gram_finish_kernel: the kernel lasts
+// as long as its slowest workgroup, and the plain routine's column sweep is 64 .. 128 dependent LDS round trips on a
+// quarter of the block):
+//   p = W d          four threads per row, partial sums folded with two shuffles;
+//   P, l, t          prefix sums of p^2 through LDS (log2 D doubling steps) -- any D <= 256;
+//   W' = T W         column j by FOUR threads, a quarter of the rows each: first the quarter's sum of p_k W[k][j], then
+//                    the sweep over its own rows from the sums of the quarters above, every load of a quarter set off together.
+// scan: 256 doubles of LDS scratch.  Barriers inside (block wide); all 256 threads call it.
+__device__ inline void rank1_inverse_factor_wide(double *W, int ld, int D, double a, const double *dv,
+                                                 double *pv, double *lv, double *tv, double *scan, double *s_out,
+                                                 int *bad_out, int tid) {
+    constexpr int NT = 256;
+    for (int r0 = 0; r0 < D; r0 += NT / 4) {
+        const int r = r0 + (tid >> 2), part = tid & 3;
+        double acc = 0.0;
+        if (r < D) {
+            const double *__restrict__ wr = W + r * ld;
+#pragma unroll 4
+            for (int l = part; l <= r; l += 4) acc = fma(wr[l], dv[l], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (r < D && part == 0) pv[r] = acc;
+    }
+    __syncthreads();
+    {
+        const double mine = tid < D ? pv[tid] * pv[tid] : 0.0;
+        scan[tid] = mine;
+        for (int o = 1; o < D; o <<= 1) {
+            __syncthreads();
+            const double t = tid >= o ? scan[tid - o] : 0.0;
+            __syncthreads();
+            scan[tid] += t;
+        }
+        __syncthreads();
+        if (tid < D) {
+            const double P = scan[tid], Pm1 = tid > 0 ? scan[tid - 1] : 0.0;
+            const double num = 1.0 + a * Pm1, den = 1.0 + a * P;
+            const bool badl = !(den > 0.0) || !(num > 0.0);
+            const double l = sqrt(num / den);
+            lv[tid] = l;
+            tv[tid] = -a * pv[tid] / (den * l);
+            if (badl) *bad_out = 1;
+            if (tid == D - 1) *s_out = P;
+        }
+    }
+    __syncthreads();
+    // column sweep: thread (j, qr) owns rows [qr * seg, qr * seg + seg) of column j
+    const int seg = (D + 3) >> 2;
+    double *part_sum = scan;                         // [4][64] per pass of 64 columns
+    for (int j0 = 0; j0 < D; j0 += 64) {
+        const int j = j0 + (tid & 63), qr = tid >> 6;
+        const int lo = qr * seg, hi = lo + seg < D ? lo + seg : D;
+        double sacc = 0.0;
+        if (j < D) {
+#pragma unroll 8
+            for (int row = lo > j ? lo : j; row < hi; ++row) sacc = fma(pv[row], W[row * ld + j], sacc);
+        }
+        part_sum[qr * 64 + (tid & 63)] = sacc;
+        __syncthreads();
+        if (j < D) {
+            double r = 0.0;
+            for (int q2 = 0; q2 < qr; ++q2) r += part_sum[q2 * 64 + (tid & 63)];
+#pragma unroll 8
+            for (int row = lo > j ? lo : j; row < hi; ++row) {
+                const double w = W[row * ld + j];
+                W[row * ld + j] = fma(tv[row], r, lv[row] * w);
+                r = fma(pv[row], w, r);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// write_slot for a block of 256 threads with the dependent loops cut short (cvec = Winv mu by four threads per row, |mu|^2
+// by a wavefront).  Same outputs.  Barrier-free; red: 8 doubles of LDS that the caller does not touch meanwhile.
+__device__ inline void write_slot_wide(const Dev &d, int s, const double *W, int ld, const double *mu,
+                                       double logdetC, double lam, int tid) {
+    constexpr int NT = 256;
+    const int D = d.D, Dp = d.Dp;
+    for (int j0 = 0; j0 < Dp; j0 += NT / 4) {
+        const int j = j0 + (tid >> 2), part = tid & 3;
+        double acc = 0.0;
+        if (j < D) {
+            const double *__restrict__ wr = W + j * ld;
+#pragma unroll 4
+            for (int l = part; l <= j; l += 4) acc = fma(wr[l], mu[l], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (j < Dp && part == 0) d.cvec[(long long)s * Dp + j] = acc;
+    }
+    for (int e = tid; e < D * D; e += NT) {
+        const int a = e / D, b = e - a * D;
+        d.Wrm[(long long)s * D * D + e] = (b <= a) ? W[a * ld + b] : 0.0;
+    }
+    double *wf = d.Wfrag + (long long)s * d.nfrag * 64;
+    for (int e = tid; e < d.nfrag * 64; e += NT) {
+        const int f = e >> 6, lane = e & 63;
+        int J = 0;
+        while (2 * (J + 1) * (J + 2) <= f) ++J;
+        const int kk = f - 2 * J * (J + 1);
+        const int j = 16 * J + (lane & 15), l = 4 * kk + (lane >> 4);
+        wf[e] = (j < D && l <= j) ? -W[j * ld + l] : 0.0;
+    }
+    for (int l = tid; l < D; l += NT) d.mu[(long long)s * D + l] = mu[l];
+    if (tid < 64) {
+        double m2 = 0.0;
+        for (int l = tid; l < D; l += 64) m2 = fma(mu[l], mu[l], m2);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o);
+        if (tid == 0) {
+            d.sc[s] = make_consts(d, d.n[s], logdetC, lam, m2);
+            d.mu_ver[s] += 1;                 // what is cached per point against this slot's state is stale now
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Window bookkeeping (one thread)
 // ------------------------------------------------------------------------------------------

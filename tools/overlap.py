@@ -21,9 +21,10 @@ busy += cur_e - cur_s
 tot = sum(e - s for s, e, _ in iv)
 print("span %.1f ms, busy %.1f ms (%.0f %%), sum of kernel durations %.1f ms -> %.2f kernels in flight while busy" % (
     (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0), tot / 1e6, tot / busy))
-by = defaultdict(lambda: [0, 0])
+by = defaultdict(list)
 for s, e, n in iv:
-    by[n][0] += 1
-    by[n][1] += e - s
-for n, (c, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
-    print("  %-44s %7d launches  %9.1f ms  avg %8.1f us" % (n[:44], c, d / 1e6, d / c / 1e3))
+    by[n].append(e - s)
+for n, ds in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:14]:
+    ds.sort()
+    print("  %-40s %7d launches  %9.1f ms  avg %8.1f  median %8.1f  p90 %8.1f us" % (
+        n[:40], len(ds), sum(ds) / 1e6, sum(ds) / len(ds) / 1e3, ds[len(ds) // 2] / 1e3, ds[9 * len(ds) // 10] / 1e3))

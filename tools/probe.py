@@ -119,6 +119,12 @@ def chain(a, quiet=False):
         n, ms = ctx.kernel_timing()
         print("last sweep: %d timed launches, avg %.4f ms" % (n, ms / max(n, 1)))
     pc = np.array(ctx.phase_clocks()) - pc0
+    if not a.prof and pc[13] > 0:
+        print("last sweep: gram_finish: %d windows, %.1f slots each, %.2f rebuilt from scratch per window (%.2f of them for too many terms)" % (
+            pc[8], pc[13] / max(pc[8], 1), pc[14] / max(pc[8], 1), pc[15] / max(pc[8], 1)))
+    if not a.prof and pc[10] > 0:
+        print("last sweep: %d proof passes, %.0f visits each, %.1f left to the exact forms (residual list), %d passes skipped them" % (
+            pc[10], pc[11] / pc[10], pc[9] / pc[10], pc[12]))
     if a.prof and pc[15] > 0 and D >= 12:            # home_kernel's clocks (-DBGMM_HOME_PROF)
         names = ["wait+stage", "issue", "frags", "mfma+reduce", "tail", "records", "blockhead", "switch"]
         tot = float(pc[:8].sum())
@@ -133,6 +139,9 @@ def chain(a, quiet=False):
         w = max(pc[8], 1)
         print("resolver ticks per window: prologue %.0f  draws %.0f  bookkeeping %.0f  update(home) %.0f  update(dest) %.0f  | windows %d" % (
             pc[0] / w, pc[1] / w, pc[2] / w, pc[3] / w, pc[4] / w, pc[8]))
+        print("   whole launch: %.0f s_memtime ticks = %.2f us of the constant 100 MHz counter -> %.0f MHz" % (
+            pc[6] / w, pc[7] / w / 100.0, pc[6] / max(pc[7], 1) * 100.0))
+        print("   gram_finish, workgroup 0, rank-1 route, ticks per window: op list + loads %.0f, terms %.0f, write-back %.0f" % (pc[10] / w, pc[11] / w, pc[12] / w))
         print("   gram_finish, workgroup 0, ticks per window: statistics -> LDS %.0f  eigenvalue bound %.0f  blocked factorisation %.0f  "
               "inverse %.0f  write-back %.0f" % (pc[10] / w, pc[11] / w, pc[12] / w, pc[13] / w, pc[14] / w))
     ctx.close()
