@@ -343,6 +343,38 @@ def burnin_leg(args, X, local_rank, K_true, seed):
             "speedup_over_reference_python": round(ref * N * 1e-6 / first["seconds"], 1) if ref else None}
 
 
+def burnin_chains_leg(args, X, local_rank, single_first):
+    """G chains of the workload from the reference's "rand" start, side by side on THIS GPU ("the 8 XCDs could
+    additionally host independent chains").  A sweep of a chain that still moves is a latency chain that keeps one
+    workgroup busy; bgmm_group_sweep_staged runs such chains concurrently, one stream and one host thread each.  Chain c
+    has its own generator (seed + c, continued on the device) and its own random start."""
+    from pybgmm_amd.chains import ChainGroup
+    N, D, K, model = WORKLOADS[args.workload]
+    G = args.burnin_chains
+    m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
+    z0s = [np.unique(np.random.RandomState(7100 + args.seed + c).randint(0, K, N), return_inverse=True)[1] for c in range(G)]
+    t0 = time.time()
+    grp = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, max(4 * K, 64), n_chains=G, seed=7100 + args.seed, device=local_rank, cov_type=args.cov)
+    grp.set_assignments(z0s)
+    for ctx in grp.ctxs:
+        ctx.synchronize()
+    t_setup = time.time() - t0
+    rs = np.random.RandomState(7100 + args.seed)
+    orders = [rs.permutation(N).astype(np.int64) for _ in range(G)] if model == "PCRPMM" else None
+    t0 = time.time()
+    grp.sweep(orders, None)
+    dt = time.time() - t0
+    moves = [ctx.sweep_stats()["moves"] for ctx in grp.ctxs]
+    grp.close()
+    agg = sum(moves) / dt
+    one = single_first["moves"] / single_first["seconds"]
+    return {"chains": G, "first_sweep_s": round(dt, 3), "moves": int(sum(moves)), "aggregate_moves_per_s": round(agg, 1),
+            "single_chain_moves_per_s": round(one, 1), "aggregate_over_single_chain": round(agg / one, 2), "setup_s": round(t_setup, 2),
+            "how": "bgmm_group_sweep_staged: chains that cannot take the one-workgroup sweep run concurrently, one stream and one "
+                   "host thread each; every chain label for label its solo run (tests/test_gpu_parity.py::"
+                   "test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo)"}
+
+
 def launch_plan(gpus, env, devices_visible):
     """What `--gpus N` means for this process.  ("run", world, rank, local_rank): it is a rank (the only one for
     N = 1, or one that torch.distributed.run started); ("spawn",): N > 1 and no launcher in the environment, so this
@@ -398,6 +430,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-burnin", action="store_true")
+    ap.add_argument("--burnin-chains", type=int, default=8,
+                    help="chains of the burn-in leg's side-by-side measurement (D >= 12; 0 or 1: skip)")
     ap.add_argument("--no-moving", action="store_true", help="skip the steady_moving leg (overlapping clusters)")
     ap.add_argument("--moving-sep", type=float, default=0.55, help="mu_scale of the steady_moving leg's data set")
     ap.add_argument("--numpy-visits", type=int, default=400, help="visits of the numpy-restatement CPU baseline (0 = skip)")
@@ -740,6 +774,8 @@ def main():
     burnin = None
     if single and not args.no_burnin and args.cov == "full":
         burnin = burnin_leg(args, X, local_rank, K, args.seed)
+        if args.burnin_chains > 1 and D >= 12:
+            burnin["chains_side_by_side"] = burnin_chains_leg(args, X, local_rank, burnin["sweeps"][0])
 
     moving = None
     if single and not args.no_moving and args.cov == "full" and D >= 12:

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -115,6 +116,9 @@ struct bgmm_ctx {
     std::vector<uint32_t> defer_mt_key;
     int grp_cap = 0;                 // bgmm_group_sweep_staged: the LDS plan phase 1 of sweep_impl chose for the one-workgroup sweep
     Dev *grp_devs = nullptr;         // device array of the chains' views (owned by the chain that leads a group launch)
+    struct GramCombiner *combiner = nullptr;   // bgmm_group_sweep_staged: the rendezvous of the chains' host threads (below)
+    int combiner_slot = -1;
+    hipEvent_t grp_ev_in = nullptr, grp_ev_out = nullptr;   // this chain's stream has reached the batch / the shared launches are queued
     int grp_devs_cap = 0;
     long long short_stood = 0, short_refused = 0;   // short steps over the life of the context (bgmm_get_short_step_stats)
     bool short_ok = false;           // the previous sweep (certified stays off) was ONE pruned window, moved nothing and
@@ -279,6 +283,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     }
     if (c->mt_words_ahead) (void)hipFree(c->mt_words_ahead);
     if (c->grp_devs) (void)hipFree(c->grp_devs);
+    if (c->grp_ev_in) (void)hipEventDestroy(c->grp_ev_in);
+    if (c->grp_ev_out) (void)hipEventDestroy(c->grp_ev_out);
     if (c->perm_stream) { (void)hipStreamSynchronize(c->perm_stream); (void)hipStreamDestroy(c->perm_stream); }
     if (c->perm_done) (void)hipEventDestroy(c->perm_done);
     if (c->perm_words) (void)hipFree(c->perm_words);
@@ -1124,6 +1130,127 @@ static int ensure_events(bgmm_ctx *c, size_t n) {
     return 0;
 }
 
+// Chains of one group call that are in the frozen-factor regime TOGETHER (burn-in from a random start) share their
+// launches: the hardware runs about four kernels of different streams side by side, whatever the number of streams, so
+// eight chains with four small launches per window each queue up behind one another -- while one launch whose grid is
+// (x, chain) runs the eight resolvers truly side by side (kernels_gram.hip: *_group_kernel).  The chains' host threads meet
+// here.  Every thread declares, once per batch of its sweep loop, either "a batch of frozen-factor windows" (submit: it
+// waits) or "something else" (pass: the others do not wait for it); when nobody is undeclared, one of the waiting threads
+// is made leader and queues the batch for all waiting chains of its shape on its own stream, behind an event of each
+// member's stream; the members' streams wait for the leader's.  Same kernels, same per-chain control blocks: the
+// trajectories are those of separate sweeps.
+struct GramCombiner {
+    enum { UNKNOWN = 0, WAITING = 1, BUSY = 2, DONE = 3 };
+    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int result = 0; hipEvent_t ev = nullptr; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot> slots;
+    int leader = -1;
+    long long shared_batches = 0, shared_members = 0;
+
+    void elect_locked() {
+        if (leader >= 0) return;
+        int first = -1;
+        for (size_t k = 0; k < slots.size(); ++k) {
+            if (slots[k].state == UNKNOWN) return;
+            if (slots[k].state == WAITING && first < 0) first = (int)k;
+        }
+        if (first >= 0) { leader = first; cv.notify_all(); }
+    }
+    void declare(int i, int state) {
+        std::lock_guard<std::mutex> lk(mu);
+        slots[(size_t)i].state = state;
+        elect_locked();
+    }
+};
+
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T);
+
+// Returns 0: the batch has been queued with the group's (the chain's stream waits for it); 1: queue it yourself; < 0: error.
+static int combiner_submit(bgmm_ctx *c, int T) {
+    GramCombiner &G = *c->combiner;
+    const int me = c->combiner_slot;
+    if (!c->grp_ev_in) {
+        if (hipEventCreateWithFlags(&c->grp_ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->grp_ev_out, hipEventDisableTiming) != hipSuccess) return 1;
+    }
+    if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) return 1;
+    std::unique_lock<std::mutex> lk(G.mu);
+    GramCombiner::Slot &S = G.slots[(size_t)me];
+    S.state = GramCombiner::WAITING; S.T = T; S.result = 1; S.ev = nullptr;
+    G.elect_locked();
+    G.cv.wait(lk, [&] { return S.state != GramCombiner::WAITING || G.leader == me; });
+    if (S.state == GramCombiner::WAITING) {
+        // leader: the waiting chains of this chain's shape (device, D, column plan)
+        std::vector<int> members;
+        int Tmax = 0;
+        for (size_t k = 0; k < G.slots.size(); ++k) {
+            const GramCombiner::Slot &o = G.slots[k];
+            if (o.state != GramCombiner::WAITING) continue;
+            if (o.c->device == c->device && o.c->d.D == c->d.D && o.c->d.gcols == c->d.gcols && o.c->gram_lds == c->gram_lds) {
+                members.push_back((int)k);
+                if (o.T > Tmax) Tmax = o.T;
+            }
+        }
+        int rc = 1;
+        if (members.size() >= 2) {
+            lk.unlock();
+            rc = gram_group_launch(G, members, Tmax);
+            lk.lock();
+            if (rc == 0) { G.shared_batches += 1; G.shared_members += (long long)members.size(); }
+        }
+        // everybody who waited goes on: the members with the shared batch (or, if it could not be queued, on their own),
+        // the chains of other shapes on their own
+        for (size_t k = 0; k < G.slots.size(); ++k) {
+            GramCombiner::Slot &o = G.slots[k];
+            if (o.state != GramCombiner::WAITING) continue;
+            const bool member = std::find(members.begin(), members.end(), (int)k) != members.end() && members.size() >= 2;
+            o.result = member ? rc : 1;
+            o.ev = (member && rc == 0) ? c->grp_ev_out : nullptr;
+            o.state = GramCombiner::UNKNOWN;
+        }
+        G.leader = -1;
+        G.cv.notify_all();
+    }
+    const int result = S.result;
+    hipEvent_t ev = S.ev;
+    lk.unlock();
+    if (result == 0 && ev && ev != c->grp_ev_out) {
+        if (hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess) return BGMM_EDEVICE;
+    }
+    return result;
+}
+
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T) {
+    bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
+    const int m = (int)members.size();
+    if (hipSetDevice(lead->device) != hipSuccess) return 1;
+    if (lead->grp_devs_cap < m) {
+        if (lead->grp_devs) (void)hipFree(lead->grp_devs);
+        lead->grp_devs = nullptr; lead->grp_devs_cap = 0;
+        if (hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m) != hipSuccess) return 1;
+        lead->grp_devs_cap = m;
+    }
+    std::vector<Dev> views((size_t)m);
+    int reach = 0;
+    for (int k = 0; k < m; ++k) {
+        bgmm_ctx *o = G.slots[(size_t)members[(size_t)k]].c;
+        views[(size_t)k] = o->d;
+        const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
+        if (r > reach) reach = r;
+        // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
+        if (o != lead && hipStreamWaitEvent(lead->stream, o->grp_ev_in, 0) != hipSuccess) return 1;
+    }
+    // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
+    // have been waited for by every one of its members)
+    if (hipMemcpy(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    for (int t = 0; t < T; ++t)
+        if (!launch_gram_group_step(lead->d, lead->grp_devs, m, reach, lead->gram_lds, lead->stream)) return 1;
+    if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
+    if (hipEventRecord(lead->grp_ev_out, lead->stream) != hipSuccess) return BGMM_EDEVICE;
+    return 0;
+}
+
 // One sweep.  phase 0: all of it.  Phases 1 and 2 split it for bgmm_group_sweep_staged, which opens the sweeps of several
 // chains and runs their one-workgroup sweeps (kernels_seq.hip) in ONE launch each: phase 1 = everything in front of
 // sweep_begin; returns 1 if the chain can take the one-workgroup sweep (bgmm_ctx::grp_cap = its LDS plan; the caller
@@ -1288,6 +1415,9 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             if (!use_safe && dense && !gram_skip && c->resolver_mode != 4) use_gram = ensure_gram(c, hc.job.K);
             gram_possible = !c->gram_off;
         }
+        // (beside other chains of a group call: a batch of frozen-factor windows is queued together with theirs -- declared
+        // when it is submitted; any other kind of batch is this chain's own business, and nobody waits for it meanwhile)
+        if (c->combiner && !(use_gram && !c->timing)) c->combiner->declare(c->combiner_slot, GramCombiner::BUSY);
         if (use_safe) {
             const Ctrl &hc = *c->ctrl_host;
             // windows still needed: from the visits a window has covered on average so far in this sweep
@@ -1358,14 +1488,24 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             long long Tg = (long long)std::ceil((double)remaining / rpw) + 1;
             if (first_batch && Tg > 16) Tg = 16;
             if (Tg > 512) Tg = 512;
+            // (beside other chains of a group call: shorter batches, so that a chain that has fallen out of step with the
+            // others -- it queued a batch of its own while they were busy -- meets them again soon)
+            if (c->combiner && Tg > 128) Tg = 128;
             if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
             d.lean_step = 0; d.publish = 0; d.prune_enabled = 0;
             d.gram_K = hc.job.K;
             lean = false;
             first_batch = false;
-            for (int t = 0; t < (int)Tg; ++t)
-                if (!launch_gram_step(d, c->gram_lds, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
-                    return fail(c, BGMM_EDEVICE, "frozen-factor window launch failed");
+            // (chains of a group call that are here together share the launches: GramCombiner above)
+            int own = 1;
+            if (c->combiner && !c->timing) {
+                own = combiner_submit(c, (int)Tg);
+                if (own < 0) return fail(c, BGMM_EDEVICE, "shared frozen-factor launch failed");
+            }
+            if (own)
+                for (int t = 0; t < (int)Tg; ++t)
+                    if (!launch_gram_step(d, c->gram_lds, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
+                        return fail(c, BGMM_EDEVICE, "frozen-factor window launch failed");
             CK(c, hipGetLastError());
             int rc = fetch_ctrl(c);
             if (rc) return rc;
@@ -1600,11 +1740,22 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
     std::vector<int> threaded;
     for (int i = 0; i < n; ++i)
         if (!seq_shape(ctxs[i])) threaded.push_back(i);
+    GramCombiner comb;
     if (threaded.size() >= 2) {
+        comb.slots.resize(threaded.size());
+        for (size_t k = 0; k < threaded.size(); ++k) {
+            comb.slots[k].c = ctxs[threaded[k]];
+            ctxs[threaded[k]]->combiner_slot = (int)k;
+        }
         for (int i : threaded) {
             const int up = use_power ? use_power[i] : 0;
             const double pw = (up && power) ? power[i] : 1.0;
-            workers.emplace_back([=]() { rc_out[i] = sweep_impl(ctxs[i], up, pw, 0); });
+            workers.emplace_back([=, &comb]() {
+                ctxs[i]->combiner = &comb;
+                rc_out[i] = sweep_impl(ctxs[i], up, pw, 0);
+                comb.declare(ctxs[i]->combiner_slot, GramCombiner::DONE);
+                ctxs[i]->combiner = nullptr;
+            });
         }
     } else {
         threaded.clear();
@@ -1669,6 +1820,9 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
         }
     }
     for (auto &w : workers) w.join();
+    if (getenv("BGMM_DEBUG_GROUP") && !threaded.empty())
+        fprintf(stderr, "[bgmm] group sweep: %zu chains on threads, %lld shared batches of frozen-factor windows, %.1f chains each\n",
+                threaded.size(), comb.shared_batches, comb.shared_batches ? (double)comb.shared_members / (double)comb.shared_batches : 0.0);
     for (int i : threaded)
         if (rc_out[i] < 0 && worst == 0) worst = rc_out[i];
     return worst;

@@ -373,6 +373,8 @@ bool gram_plan_for(int K, int *gcols, int *terms, int *lds);   // LDS plan of th
 bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
 void gram_configure(const Dev &d, int resolve_lds);      // per-device kernel attributes (once per context and plan)
 void launch_gram_finish(const Dev &d, hipStream_t st);
+void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st);
+bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, hipStream_t st);   // G chains, shared launches
 void launch_safe_open(const Dev &d, hipStream_t st);                     // kernels_safe.hip
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish

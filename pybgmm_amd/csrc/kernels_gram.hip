@@ -69,7 +69,7 @@ __device__ __forceinline__ long long gram_pos(const Dev &d, long long pos0, int 
 // the fragment reads Ys[16 t + (lane & 15)][4 kk + (lane >> 4)] are conflict free).
 // ------------------------------------------------------------------------------------------
 template <int NJ>
-__global__ __launch_bounds__(256) void gram_kernel(Dev d) {
+__device__ __forceinline__ void gram_body(const Dev &d) {
     extern __shared__ __attribute__((aligned(16))) double Ys[];
     const Ctrl *c = d.ctrl;
     if (c->job.mode == MODE_DONE || c->error != 0) return;
@@ -177,13 +177,22 @@ __global__ __launch_bounds__(256) void gram_kernel(Dev d) {
         for (int r = 0; r < 4; ++r) Cc[(ti * 16 + lk + 4 * r) * GR + tj * 16 + lr] = acc[r];
     }
 }
+template <int NJ>
+__global__ __launch_bounds__(256) void gram_kernel(Dev d) { gram_body<NJ>(d); }
+// (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
+template <int NJ>
+__global__ __launch_bounds__(256) void gram_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
+    gram_body<NJ>(d);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // gram_weights_kernel: one workgroup per window row.  Reference point M_r = max of the row's frozen log
 // scores (a singleton home is no candidate), frozen weights e0[r][c] = exp(lp0 - M_r), the new table's
 // weight (igmm/crpmm.py:74).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) {
+__device__ __forceinline__ void gram_weights_body(const Dev &d) {
     __shared__ double red[4];
     const Ctrl *c = d.ctrl;
     if (c->job.mode == MODE_DONE || c->error != 0) return;
@@ -219,6 +228,13 @@ __global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) {
     }
     if (threadIdx.x == 0) { d.gM[r] = mx; d.gM[GR + r] = exp(lp_new - mx); }
 }
+__global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) { gram_weights_body(d); }
+// (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
+__global__ __launch_bounds__(256) void gram_weights_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
+    gram_weights_body(d);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // gram_resolve_kernel: one workgroup, 512 threads.
@@ -254,7 +270,7 @@ struct GramShared {
     GramUpd upd[2];
     long long pos0, lik, last_mover;
     double ema_run;
-    long long prof[8];
+    long long prof[16];
 };
 
 // LDS plan, all offsets compile-time (KC columns, T terms): byte offsets from the start of dynamic LDS
@@ -318,7 +334,7 @@ __device__ __forceinline__ double gram_ld(const double *base, unsigned idx) {
 // LPL: labels per lane of the draw wave (label j = lane * LPL + t): 64 LPL - 1 bounds the labels a window can
 // reach.  KC / T: the LDS plan (columns, terms; a term's index is also its line of weights).
 template <int LPL, int KC, int T>
-__global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
+__device__ __forceinline__ void gram_resolve_body(const Dev &d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     static_assert(sizeof(GramShared) <= 512, "GramShared has 512 bytes of LDS");
     using P = GramPlan<KC, T>;
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 S.err = 0; S.cur = 0; S.event = GEV_DONE; S.nmoves = 0; S.upd_n = 0; S.pub_mode = 0;
                 S.lik = 0;
                 S.ema_run = c->ema_run; S.last_mover = c->last_mover;
-                for (int k = 0; k < 8; ++k) S.prof[k] = 0;
+                for (int k = 0; k < 16; ++k) S.prof[k] = 0;
             }
         }
     }
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
     for (int t = 0; t < LPL; ++t) { cls[t] = 0; tix[t] = -1; pf[t] = 0.0; pc[t] = 0.0; pm0[t] = 0.0; pm1[t] = 0.0; }
     // what a move leaves for the time the update waves work
     int hk = 0, hk_h = -1, hk_hcol = -1, hk_pcol = -1, hk_t0 = 0, hk_t1 = 0, hk_has0 = 0;
+    double tch0 = 0.0, tch1 = 0.0, tch2 = 0.0;
     long long hk_i = 0;
     // ---- wave 1's registers: the home side of the next visit, fetched ahead ----------------------
     int hp_base = -1, hp_r = -1;
@@ -591,6 +608,18 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                     hk = 1; hk_h = h; hk_hcol = hcol; hk_pcol = pcol; hk_has0 = has0;
                     hk_t0 = nterms; hk_t1 = nterms + has0;
                     nterms += 1 + has0;
+                    {
+                        // The joined column's row of cross forms, its diagonal and its constants are what the update wave
+                        // fetches on the chain -- ~1 000 cycles behind this point (barrier, bookkeeping reads) and from far
+                        // away (written on other XCDs).  The compute unit's L1 serves all its wavefronts: the same lines are
+                        // asked for HERE, the moment the label is known; nobody waits for them on this wavefront (the values
+                        // are dropped behind the barrier).
+                        const unsigned pb = (unsigned)(pcol < K0 ? pcol : K0);
+                        const unsigned l0 = (unsigned)((lane >= r && lane < nrows) ? lane : r);
+                        tch0 = gram_ld(d.gC, (pb * GR + (unsigned)r) * GR + l0);
+                        tch1 = gram_ld(d.gq0, pb * GR + l0);
+                        tch2 = gram_ld(d.gcc, pb * 40 + (unsigned)(lane < 40 ? lane : 0));
+                    }
                 } else {
                     // ---- (rare) a component is deleted and / or opened: lane 0, step by step ----
                     const long long i_mv = wv_readlane_i64(rw_i, r);
@@ -682,6 +711,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
 #endif
         if (wave == 0) {
             if (hk) {
+                asm volatile("" :: "v"(tch0), "v"(tch1), "v"(tch2));      // (the touched lines: dropped)
                 // ---- what the move leaves to do, while the update waves work ----------------------
 #pragma unroll
                 for (int t = 0; t < LPL; ++t) {
@@ -733,6 +763,13 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             }
             const bool act = lane >= r && lane < nrows;
             const int lrow = act ? lane : r;
+#ifdef BGMM_PROFILE
+            long long uk = tk, uk2;
+#define UP(i, V) do { asm volatile("" :: "v"(V)); if (wave == 2 && lane == 0) { uk2 = clock64(); S.prof[i] += uk2 - uk; uk = uk2; } } while (0)
+            UP(9, lrow);
+#else
+#define UP(i, V) do { } while (0)
+#endif
             // the row of the cross forms, the diagonal, the column's constants for its new count: one round trip
             // (the column's constants for ALL five counts it may have, lane k = the k-th of its 40 doubles: one vector load
             //  beside the row of cross forms -- the count picks its eight by v_readlane afterwards.  Scalar loads from an
@@ -749,6 +786,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
             const double ik0 = wv_readlane(ccv, ce), c_ikn = wv_readlane(ccv, ce + 1), c_icv = wv_readlane(ccv, ce + 2),
                          c_hv = wv_readlane(ccv, ce + 3), c_cb = wv_readlane(ccv, ce + 4), logdet0 = wv_readlane(ccv, ce + 6),
                          c_c7 = wv_readlane(ccv, ce + 7);
+            UP(10, ik0);
             const double rM = rowM[lrow];
             const bool own = rowhome[lrow] == slot && n_new >= 2;
             const double kN_new = d.k0 + (double)n_new;
@@ -770,15 +808,22 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 cdv = fma(-(wl * wl), id, cdv);
             }
             // c_t(y, y) = cdv - acc^2 / D_t,  D_t = sigma + c_{t-1}(x, x);  det S_N now = det S_N (frozen) k_N0 / k_N prod |D_t|
+            UP(11, acc);
             const double Dt = (double)sg + wv_readlane(acc, r);
             const double invD = fm_div(1.0, Dt);
+            UP(12, invD);
             const double qv = fma(-(acc * acc), invD, cdv) - ikn;        // quadratic form of the predictive
             const double f = qv * inv_cv;
             const double rcf_new = rcf_old * fm_rsqrt(fabs(Dt));
             const bool fsmall = fabs(f) < 0.28;
             const double l1 = __builtin_amdgcn_ballot_w64(!fsmall) == 0 ? fm_log1p_small(f) : fm_log(1.0 + f);
+            UP(13, l1);
             double ee = fm_exp((cbase - rM) - hv * l1) * rcf_new;
+            UP(14, ee);
             const unsigned long long mown = __ballot(own && act && lane > r);
+#ifdef BGMM_PROFILE
+            if (wave == 2 && lane == 0 && mown) S.prof[7] += 1;
+#endif
             if (mown) {
                 // rows whose home this column is: the visited point removed from it (slot_math.h, home form; the constants
                 // that depend on the count alone came with the column's other constants: no table look-up on the chain)
@@ -790,6 +835,7 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
                 const double e1 = fm_exp(cb1 - 0.5 * fm_log(den) - hv1 * fm_log(1.0 + fm_div(a1 * qv, den)));
                 ee = own ? e1 : ee;
             }
+            UP(15, ee);
             if (act && lane > r) etT[t * GR + lane] = ee;
             wvv[t * GR + lane] = act ? acc : 0.0;
             if (lane == 0) {
@@ -951,8 +997,9 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
 #ifdef BGMM_PROFILE
         for (int k = 0; k < 8; ++k) c->prof[k] += S.prof[k];
         c->prof[8] += 1;
-        c->prof[6] += clock64() - prof_c0;           // (the whole launch in s_memtime ticks ...
-        c->prof[7] += wall_clock64() - prof_w0;      //  ... and in ticks of the constant 100 MHz counter)
+        for (int k = 9; k < 16; ++k) c->prof[k] += S.prof[k];
+        c->prof[7] += S.prof[7];
+        c->prof[6] += clock64() - prof_c0;           // (the whole launch in s_memtime ticks)
 #endif
         if (S.err < 0) {
             atomicCAS(&c->error, 0, S.err);
@@ -964,6 +1011,15 @@ __global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) {
         }
     }
 }
+template <int LPL, int KC, int T>
+__global__ __launch_bounds__(GRT) void gram_resolve_kernel(Dev d) { gram_resolve_body<LPL, KC, T>(d); }
+// (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
+template <int LPL, int KC, int T>
+__global__ __launch_bounds__(GRT) void gram_resolve_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
+    gram_resolve_body<LPL, KC, T>(d);
+}
+
 
 template <int NJ>
 static void launch_gram_t(const Dev &d, hipStream_t st) {
@@ -972,15 +1028,25 @@ static void launch_gram_t(const Dev &d, hipStream_t st) {
 }
 
 template <int NJ>
+static void launch_gram_group_t(const Dev &lead, const Dev *group, int G, hipStream_t st) {
+    const int lds = GR * (16 * NJ + 2) * (int)sizeof(double);
+    hipLaunchKernelGGL((gram_group_kernel<NJ>), dim3(lead.gcols, G), dim3(256), lds, st, group);
+}
+
+template <int NJ>
 static void configure_gram_t() {
     const int lds = GR * (16 * NJ + 2) * (int)sizeof(double);
-    if (lds > 64 * 1024)
+    if (lds > 64 * 1024) {
         (void)hipFuncSetAttribute((const void *)gram_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)gram_group_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
 }
 
 template <int LPL, int KC, int T>
 static void configure_resolve_t() {
     (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GramPlan<KC, T>::bytes);
+    (void)hipFuncSetAttribute((const void *)gram_resolve_group_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GramPlan<KC, T>::bytes);
 }
 
@@ -1024,5 +1090,31 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
         hipLaunchKernelGGL((gram_resolve_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
     }
     launch_gram_finish(d, st);
+    return true;
+}
+
+// The same step for G chains of one shape (same D, same column plan) in SHARED launches: workgroup (x, c) of every kernel
+// works for chain group[c] (a device array of their views).  `reach`: the labels the widest of them can reach in a window.
+bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, hipStream_t st) {
+    switch (lead.Dp / 16) {
+        case 1: launch_gram_group_t<1>(lead, group, G, st); break;
+        case 2: launch_gram_group_t<2>(lead, group, G, st); break;
+        case 3: launch_gram_group_t<3>(lead, group, G, st); break;
+        case 4: launch_gram_group_t<4>(lead, group, G, st); break;
+        case 5: launch_gram_group_t<5>(lead, group, G, st); break;
+        case 6: launch_gram_group_t<6>(lead, group, G, st); break;
+        case 7: launch_gram_group_t<7>(lead, group, G, st); break;
+        case 8: launch_gram_group_t<8>(lead, group, G, st); break;
+        default: return false;
+    }
+    hipLaunchKernelGGL(gram_weights_group_kernel, dim3(GR, G), dim3(256), 0, st, group);
+    if (lead.gcols == kPlanA_KC) {
+        if (reach <= 128) hipLaunchKernelGGL((gram_resolve_group_kernel<2, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, group);
+        else if (reach <= 256) hipLaunchKernelGGL((gram_resolve_group_kernel<4, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, group);
+        else hipLaunchKernelGGL((gram_resolve_group_kernel<6, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, group);
+    } else {
+        hipLaunchKernelGGL((gram_resolve_group_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1, G), dim3(GRT), resolve_lds, st, group);
+    }
+    launch_gram_finish_group(lead, group, G, st);
     return true;
 }

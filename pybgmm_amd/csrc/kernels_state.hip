@@ -208,7 +208,9 @@ static void ensure_lds(const void *fn, int bytes, PerDeviceLds &attr) {
 // many terms, were opened by the window, or are due (kGramRefreshEvery rank-1 steps since their last rebuild; bgmm_device.h).
 // The slot's statistics stay in REGISTERS across its terms (D^2 / 256 doubles per thread): one read and one write
 // of S per window instead of one per term.
-__global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
+// SREGS: registers a thread holds of the slot's statistics, D 2^ceil(log2 D) / 256 (16 up to D = 64: two workgroups per compute unit)
+template <int SREGS>
+__device__ __forceinline__ void gram_finish_body(const Dev &d) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ long long mv_i[kGramMaxTerms];
     __shared__ int mv_op[kGramMaxTerms];          // 1: x leaves this slot, 2: joins it, 3: joins and opens it
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
     double *mu = sm + D * ld, *dv = mu + D, *pv = dv + D, *lv = pv + D, *tv = lv + D;
     double *scal = tv + 2 * D;
     // thread -> (row, column) of S and W without a division: column sb = tid mod 2^lg (2^lg >= D), rows sa0 + q * srows
-    constexpr int kSregs = BGMM_MAX_D * BGMM_MAX_D / TPB;
+    constexpr int kSregs = SREGS;
     int lg = 4;
     while ((1 << lg) < D) ++lg;
     const int sb = tid & ((1 << lg) - 1), sa0 = tid >> lg, srows = TPB >> lg;
@@ -386,12 +388,40 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) {
     __syncthreads();
     FPROF(12);
 }
+template <int SREGS>
+__global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) { gram_finish_body<SREGS>(d); }
+// (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
+// (three workgroups per compute unit: G x ~90 slots per window want the room; what that costs -- spills on the rare
+// from-scratch route -- the single-chain kernel above does not pay)
+template <int SREGS>
+__global__ __launch_bounds__(TPB, 3) void gram_finish_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
+    gram_finish_body<SREGS>(d);
+}
+
+
+void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st) {
+    const int lds = refresh_lds_bytes(lead.D);
+    static PerDeviceLds attr16, attr64;
+    if (lead.D <= 64) {
+        ensure_lds((const void *)gram_finish_group_kernel<16>, lds, attr16);
+        hipLaunchKernelGGL(gram_finish_group_kernel<16>, dim3(kGramMaxTerms, G), dim3(TPB), lds, st, group);
+    } else {
+        ensure_lds((const void *)gram_finish_group_kernel<64>, lds, attr64);
+        hipLaunchKernelGGL(gram_finish_group_kernel<64>, dim3(kGramMaxTerms, G), dim3(TPB), lds, st, group);
+    }
+}
 
 void launch_gram_finish(const Dev &d, hipStream_t st) {
     const int lds = refresh_lds_bytes(d.D);
-    static PerDeviceLds attr;
-    ensure_lds((const void *)gram_finish_kernel, lds, attr);
-    hipLaunchKernelGGL(gram_finish_kernel, dim3(kGramMaxTerms), dim3(TPB), lds, st, d);
+    static PerDeviceLds attr16, attr64;
+    if (d.D <= 64) {
+        ensure_lds((const void *)gram_finish_kernel<16>, lds, attr16);
+        hipLaunchKernelGGL(gram_finish_kernel<16>, dim3(kGramMaxTerms), dim3(TPB), lds, st, d);
+    } else {
+        ensure_lds((const void *)gram_finish_kernel<64>, lds, attr64);
+        hipLaunchKernelGGL(gram_finish_kernel<64>, dim3(kGramMaxTerms), dim3(TPB), lds, st, d);
+    }
 }
 
 
@@ -441,12 +471,17 @@ void launch_build_seat_table(const Dev &d, double *tabSeat, hipStream_t st) {
 __device__ __forceinline__ void sweep_begin_body(const Dev &d) {
     Ctrl *c = d.ctrl;
     const int K = c->job.K;
-    // seating weights depend on the sweep's exponent (tabSeat was rebuilt by the host if it changed)
-    for (int j = threadIdx.x; j < K; j += TPB) {
-        const int s = d.perm[j];
-        d.sc[s].logseat = d.tabSeat[d.n[s]];
-        d.sc[s].logseat1 = d.n[s] >= 1 ? d.tabSeat[d.n[s] - 1] : 0.0;
-    }
+    // seating weights depend on the sweep's exponent (tabSeat was rebuilt by the host if it changed).  Every change of a
+    // count goes through make_consts, which takes them from the table: while the exponent stands and the last sweep
+    // moved nothing they are what they were (three dependent round trips to memory in front of every sweep of a chain
+    // at rest otherwise).
+    if (d.seat_dirty || c->n_visits == 0 || c->n_moves != 0)
+        for (int j = threadIdx.x; j < K; j += TPB) {
+            const int s = d.perm[j];
+            d.sc[s].logseat = d.tabSeat[d.n[s]];
+            d.sc[s].logseat1 = d.n[s] >= 1 ? d.tabSeat[d.n[s] - 1] : 0.0;
+        }
+    __syncthreads();                   // (thread 0 resets the counters the condition reads)
     if (threadIdx.x == 0) {
         // (a whole sweep without a move: the chain is at rest, back to the optimistic window plan it
         // started with -- the mover-free stretch inside one sweep cannot say more than N)

@@ -4,7 +4,6 @@ set -e
 cd "$(dirname "$0")/../pybgmm_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 hipcc $FLAGS -DBGMM_PROFILE -c kernels_gram.hip -o _obj/kernels_gram_prof.o
-hipcc $FLAGS -DBGMM_PROFILE -c kernels_state.hip -o _obj/kernels_state_prof.o      # (refresh_slot_blocked's clocks: prof[10..14])
-OBJS=$(ls _obj/*.hip.o | grep -v kernels_gram.hip.o | grep -v kernels_state.hip.o)
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libbgmm_hip_prof.so $OBJS _obj/kernels_gram_prof.o _obj/kernels_state_prof.o
+OBJS=$(ls _obj/*.hip.o | grep -v kernels_gram.hip.o)
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libbgmm_hip_prof.so $OBJS _obj/kernels_gram_prof.o
 echo built ../libbgmm_hip_prof.so

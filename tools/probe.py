@@ -125,7 +125,7 @@ def chain(a, quiet=False):
     if not a.prof and pc[10] > 0:
         print("last sweep: %d proof passes, %.0f visits each, %.1f left to the exact forms (residual list), %d passes skipped them" % (
             pc[10], pc[11] / pc[10], pc[9] / pc[10], pc[12]))
-    if a.prof and pc[15] > 0 and D >= 12:            # home_kernel's clocks (-DBGMM_HOME_PROF)
+    if a.prof and pc[15] > 0 and D >= 12 and a.init not in ("rand",):            # home_kernel's clocks (-DBGMM_HOME_PROF)
         names = ["wait+stage", "issue", "frags", "mfma+reduce", "tail", "records", "blockhead", "switch"]
         tot = float(pc[:8].sum())
         for k in range(8):
@@ -139,11 +139,9 @@ def chain(a, quiet=False):
         w = max(pc[8], 1)
         print("resolver ticks per window: prologue %.0f  draws %.0f  bookkeeping %.0f  update(home) %.0f  update(dest) %.0f  | windows %d" % (
             pc[0] / w, pc[1] / w, pc[2] / w, pc[3] / w, pc[4] / w, pc[8]))
-        print("   whole launch: %.0f s_memtime ticks = %.2f us of the constant 100 MHz counter -> %.0f MHz" % (
-            pc[6] / w, pc[7] / w / 100.0, pc[6] / max(pc[7], 1) * 100.0))
-        print("   gram_finish, workgroup 0, rank-1 route, ticks per window: op list + loads %.0f, terms %.0f, write-back %.0f" % (pc[10] / w, pc[11] / w, pc[12] / w))
-        print("   gram_finish, workgroup 0, ticks per window: statistics -> LDS %.0f  eigenvalue bound %.0f  blocked factorisation %.0f  "
-              "inverse %.0f  write-back %.0f" % (pc[10] / w, pc[11] / w, pc[12] / w, pc[13] / w, pc[14] / w))
+        print("   update wave of the joined column, ticks per window: metadata (LDS) %.0f | loads + constants %.0f | row scalars + term chain %.0f | "
+              "D, 1/D %.0f | q, rsqrt, log1p %.0f | exp %.0f | home-form rows %.0f (taken in %.1f moves per window); whole launch %.0f" % (
+                  pc[9] / w, pc[10] / w, pc[11] / w, pc[12] / w, pc[13] / w, pc[14] / w, pc[15] / w, pc[7] / w, pc[6] / w))
     ctx.close()
     return ok
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/<tag>/ on a GPU box:
-#   tools/profile_round.sh r03            (run through gpurun; outputs land in gpurun_out/<tag>/)
+#   tools/profile_round.sh r04            (run through gpurun; outputs land in gpurun_out/<tag>/)
 # 1. the plain bench line (it runs its own rocprofv3 --pmc passes for roofline.traffic),
 # 2. rocprofv3 --kernel-trace --stats of the same command without the burn-in / steady_moving legs and the PMC children
 #    (the at-rest chain alone: what roofline.avg_launch_ms has to agree with),
@@ -9,12 +9,12 @@
 # 4. kernel trace of the burn-in regime alone (C4 from a random start, two sweeps),
 # 5. the other BASELINE shapes' bench lines.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
-python bench.py > "$OUT/bench_C4.json" 2> "$OUT/bench_C4.err"
+python bench.py --keep-pmc "$OUT" > "$OUT/bench_C4.json" 2> "$OUT/bench_C4.err"
 tail -c 400 "$OUT/bench_C4.json"
 cd /tmp
 stats_of() { cp "$(find "$1" -name "*kernel_stats.csv" | head -1)" "$2"; }
@@ -34,7 +34,7 @@ rocprofv3 --kernel-trace --stats -d "$OUT/ktb" -o kt --output-format csv -- \
 stats_of "$OUT/ktb" "$OUT/kernel_stats_C4_burnin.csv"
 cd $REPO
 for WL in C3 C5 C2; do
-    python bench.py --workload $WL --steps 300 > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
+    python bench.py --workload $WL --steps 300 --keep-pmc "$OUT" > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
     tail -c 300 "$OUT/bench_$WL.json"
 done
 rm -rf "$OUT/kt" "$OUT/ktb" "$OUT/ktm" "$OUT/pmcm"

@@ -9,6 +9,27 @@ __global__ void k(long long *out, double *sink, const double *gsrc, int nwaves_a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = (double)((i * 7 + 1) & 4095);
     __syncthreads();
+    if (wave != 0 && nwaves_active > 4) {      // neighbours that COMPUTE (the resolver's update wavefronts): the same arithmetic
+        if (wave < nwaves_active - 4) {
+            double a = 1.0 + lane * 1e-9;
+            const long long t0 = clock64();
+#pragma unroll 1
+            for (int i = 0; i < 4000; ++i) {
+                const double acc = a * 1e-3, cdv = 0.7, Dt = 1.0 + acc;
+                const double invD = fm_div(1.0, Dt);
+                const double qv = fma(-(acc * acc), invD, cdv) - 0.01;
+                const double f = qv * 0.05;
+                const double rcf = 1.0 * fm_rsqrt(fabs(Dt));
+                const double l1 = fm_log1p_small(f);
+                a = fm_exp((2.0 - 1.5) - 30.0 * l1) * rcf;
+                asm volatile("" : "+v"(a));
+            }
+            const long long t1 = clock64();
+            if (lane == 0) out[40 + wave] = (t1 - t0) / 4000;
+            sink[threadIdx.x] = a;
+        }
+        return;
+    }
     if (wave != 0) {                 // optional neighbours on the other SIMDs: spin on LDS like the helpers do
         if (wave < nwaves_active) { volatile double *p = lds; double s = 0; for (int i = 0; i < 20000; ++i) { s += p[lane]; __builtin_amdgcn_s_sleep(2); } sink[threadIdx.x] = s; }
         return;
@@ -193,12 +214,17 @@ int main() {
                            "dependent int mad x256", "dependent rcp_f64 + add x64", "readlane(2) + f64 add x64", "dependent LDS read (f64 -> int) x64",
                            "dpp(2) + f64 add x64", "loop with backward branch x256 (fma inside)", "dependent far global load x32", "dependent cached global load x32",
                            "f64 cmp + mul + add + 2 cndmask x256", "divergent if around one fma x64", "ballot + ffs + readlane + cvt + add x64", "dependent rsq_f64 + add x64", "ds_write -> ds_read (other lane) + add x64", "64 independent LDS reads + adds", "column update arithmetic, one column x16", "column update arithmetic, two columns side by side x16", "libm exp(.. log(..)) x16", "wave scan (4 dpp adds + 3 readlane pairs) x16"};
-    for (int nw = 1; nw <= 4; nw += 3) {
+    for (int nw : {1, 4, 6, 7, 8}) {
         hipMemset(out, 0, 64 * 8);
         hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, 0, out, sink, g, nw);
         hipDeviceSynchronize();
         long long r[64]; hipMemcpy(r, out, 64 * 8, hipMemcpyDeviceToHost);
         printf("== %d wavefront(s) active in the workgroup\n", nw);
+        if (nw > 4) {
+            printf("== %d wavefronts of the workgroup computing beside wavefront 0: column update arithmetic x16 on wavefront 0: %lld cycles (one at a time: see above); "
+                   "per iteration on the neighbours: %lld %lld %lld\n", nw - 5, r[18], r[41], r[42], r[43]);
+            continue;
+        }
         for (int i = 0; i < 22; ++i) printf("%2d %-52s %8lld cycles\n", i, names[i], r[i]);
     }
     return 0;
