@@ -115,9 +115,13 @@ BGMM_API int bgmm_sweep_staged_end(bgmm_ctx *ctx);
  * each, with the same trajectories -- but the chains that can take the one-workgroup sweep of small dimensions (D <= 4, full
  * covariance, automatic tuning, a permutation as visiting order, labels within the LDS plan) are opened and swept by TWO
  * launches for all of them, one workgroup and one compute unit per chain, where separate calls pay two launches and a host
- * round trip per chain and leave 255 of the 256 compute units idle.  Every other chain of the group is swept on its own.
+ * round trip per chain and leave 255 of the 256 compute units idle.  Every other chain of the group (D > 4, diagonal /
+ * fixed covariance) runs its sweep as bgmm_sweep_staged would, CONCURRENTLY with the others: one stream and one host thread
+ * of this call per chain (a sweep of a chain that still moves is one workgroup's latency chain: G of them keep G busy), and
+ * chains of one shape that are in the frozen-factor regime at the same time -- burn-in from the reference's "rand" start --
+ * share their launches (workgroup (x, chain) grids).  8 chains of BASELINE's C4 shape from "rand": 5.3 x one chain's moves/s.
  * use_power / power may be NULL (plain CRP weights).  rc_out[i] = the status of chain i; returns the first failure, or 0.
- * Contexts are not thread-safe: the group call is the one host thread working on all of them.
+ * Contexts are not thread-safe: while the call runs, nobody else may touch the contexts handed to it.
  */
 BGMM_API int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const int32_t *use_power, const double *power,
                                      int32_t *rc_out);
@@ -277,6 +281,10 @@ BGMM_API int bgmm_get_phase_clocks(bgmm_ctx *ctx, int64_t *out16);
  *     [3] windows ended because a component ran out of budget, [4] the budget in force x 1e6, [5] visits the next
  *     proof pass will examine. */
 BGMM_API int bgmm_get_safe_stats(bgmm_ctx *ctx, int64_t *out6);
+/* Batches of safe-stay windows queued so far with [0] the proof pass through the per-home bound tables, [1] the DENSE proof
+ * pass (every (visit, label) pair of a stretch through the likelihood kernel: chains whose clusters overlap, where the tables
+ * prove nothing).  Which one runs never changes the chain, only its cost. */
+BGMM_API int bgmm_get_proof_pass_stats(bgmm_ctx *ctx, int64_t *out2);
 /* Budget of a safe-stay window per component: the sum over the rank-1 terms it takes of |log |D_t|| (D_t = the
  * Sherman-Morrison denominator of the term).  0 = follows the chain (the default); > 0 pins it.  A larger budget
  * lets a window absorb more (or more eccentric) moves and proves fewer visits; it never changes the trajectory. */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "bgmm_get_path_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_phase_clocks": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_safe_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_proof_pass_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_safe_budget": (ctypes.c_int, [_vp, ctypes.c_double]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
@@ -405,6 +406,11 @@ class Context(object):
         self._ck(self.L.bgmm_get_safe_stats(self.h, _ptr(out)))
         return {"windows": int(out[0]), "visits_examined": int(out[1]), "unproven_walked": int(out[2]),
                 "budget_cuts": int(out[3]), "budget": out[4] * 1e-6, "next_stretch": int(out[5])}
+
+    def proof_pass_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._ck(self.L.bgmm_get_proof_pass_stats(self.h, _ptr(out)))
+        return {"table_batches": int(out[0]), "dense_batches": int(out[1])}
 
     def set_safe_budget(self, cap=0.0):
         self._ck(self.L.bgmm_set_safe_budget(self.h, float(cap)))

@@ -165,6 +165,13 @@ struct bgmm_ctx {
     int safe_rest = 0;               // sweeps to go without safe-stay windows: a batch of them covered fewer visits per
                                      // millisecond than the per-mover kernel chain is known to (they are tried again a sweep later)
     // safe-stay windows (kernels_safe.hip)
+    // safe-stay windows: which kind of proof pass the next batch runs (Dev::safe_dense).  -1: the chain decides (dense once the
+    // per-home tables left more than half of a batch's visits to the exact forms; looked at again every eighth sweep);
+    // 0 / 1: pinned (BGMM_SAFE_DENSE in the environment, for experiments and tests)
+    int safe_dense_pin = [] { const char *e = getenv("BGMM_SAFE_DENSE"); return e ? atoi(e) : -1; }();
+    bool safe_dense_on = false;
+    int safe_dense_age = 0;
+    long long proof_batches[2] = {0, 0};      // batches of safe-stay windows queued with a table / a dense proof pass
     double safe_cap_user = 0.0;      // bgmm_set_safe_budget: > 0 pins the per-component budget of a window (0: it follows the chain)
     long long safe_stats[6] = {0, 0, 0, 0, 0, 0};
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
@@ -1294,6 +1301,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                       !c->tables_robust && c->resolver_mode == 0;
     hipStream_t st = c->stream;
     if (!resume) {
+        if (c->safe_dense_on && (++c->safe_dense_age & 7) == 0) c->safe_dense_on = false;     // (the tables get another look)
         d.seat_dirty = 0;
         if (d.use_power != c->seat_use_power || (d.use_power && d.power != c->seat_power)) {
             d.seat_dirty = 1;
@@ -1429,6 +1437,9 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             if (recent_rate == 0.0 && Tg > 4) Tg = 4;         // (nothing has moved lately: look again soon, the chain may be at rest)
             if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
             d.safe_mode = 1; d.lean_step = 0; d.publish = 0; d.prune_enabled = 2; d.use_certify = 0; d.use_home = 1;
+            d.safe_dense = c->safe_dense_pin >= 0 ? (c->safe_dense_pin ? 1 : 0) : (c->safe_dense_on ? 1 : 0);
+            c->proof_batches[d.safe_dense] += 1;
+            const long long resid0 = hc.safe_resid_sum, sorted0 = hc.safe_sorted_sum;
             d.safe_cap = c->safe_cap_user;
             d.gram_K = hc.job.K;
             {   // launch grids: room for the stretch to double twice inside the batch
@@ -1468,12 +1479,17 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 if (mrate < 2e-3 && visits / ms < 0.6 * rate_chain) { safe_skip = true; c->safe_rest = 1; }
                 if ((double)(h.safe_rows - rows0) > kSafeWalkShare * visits) safe_skip = true;      // (too little proven: plain windows)
             }
+            // (where the clusters overlap the per-home tables prove nothing and every visit of a stretch goes to the exact
+            // forms: the dense proof pass does the same arithmetic in three launches instead of eleven)
+            if (!d.safe_dense && h.safe_sorted_sum - sorted0 >= 1024 &&
+                2 * (h.safe_resid_sum - resid0) > h.safe_sorted_sum - sorted0) { c->safe_dense_on = true; c->safe_dense_age = 0; }
             pos = h.job.pos;
             win = h.win_size > 0 ? h.win_size : win;
             rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
             if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
             batch_pos0 = pos; batch_moves0 = h.n_moves;
             d.safe_mode = 0;
+            d.safe_dense = 0;
             c->tables_robust = true;
             continue;
         }
@@ -2161,6 +2177,14 @@ extern "C" int bgmm_get_safe_stats(bgmm_ctx *c, int64_t *out6) {
     if (!c || !out6) return BGMM_EINVAL;
     SETTLE(c);
     for (int t = 0; t < 6; ++t) out6[t] = c->safe_stats[t];
+    return 0;
+}
+
+extern "C" int bgmm_get_proof_pass_stats(bgmm_ctx *c, int64_t *out2) {
+    if (!c || !out2) return BGMM_EINVAL;
+    SETTLE(c);
+    out2[0] = c->proof_batches[0];
+    out2[1] = c->proof_batches[1];
     return 0;
 }
 

@@ -160,6 +160,7 @@ struct Ctrl {
     int safe_phase_cnt, safe_try, safe_next_dir, safe_pad;
     double safe_cap_built; // the budget the robust tables were built for -- the one the resolver enforces ...
     long long safe_epoch_built;   // ... and the state epoch: valid while both still match
+    long long safe_resid_sum, safe_sorted_sum;   // this sweep, over the proof passes through the per-home tables: visits they had to leave to the exact forms / visits they looked at
     long long safe_windows, safe_scanned, safe_rows, safe_cuts;   // this sweep: windows, visits examined by the proof pass,
                                                                   // rows walked by the resolver, windows ended by the budget
 };
@@ -298,6 +299,10 @@ struct Dev {
     // safe-stay windows (kernels_safe.hip)
     int safe_mode;               // 1: this batch of steps runs them (home_kernel classifies instead of drawing, the
                                  // frozen-factor kernels take their rows from glist)
+    int safe_dense;              // 1: the proof pass of this batch of safe-stay windows is DENSE -- every (visit, label) pair of the stretch
+                                 // through the plain likelihood kernel and a verdict per visit from all K exact forms; no bucket sort,
+                                 // no per-home tables, no home pass.  For chains whose clusters overlap: there the table bound proves
+                                 // nothing and the pruning kernel keeps every pair anyway (kernels_safe.hip)
     double safe_cap;             // > 0: pins the budget per column and window (sum of |log |D_t|| over the rank-1 terms it
                                  // takes); 0: Ctrl::safe_cap, which follows the chain
     long long *glist;            // [kSafeList + 1] visit positions of the stretch's unproven visits, ascending

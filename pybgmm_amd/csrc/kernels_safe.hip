@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
         c->safe_epoch_pos0 = base;
         c->safe_scanned += nrows;
         c->n_resid = 0;                 // (the residual list of this proof pass has been worked through)
-        c->tables_valid = 1;
+        if (!d.safe_dense) c->tables_valid = 1;         // (a dense proof pass builds no tables)
         c->safe_epoch_built = c->state_epoch;
         c->safe_cap_built = safe_cap_now(d, c);
     }
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long nrows = c->n_resid;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {            // (diagnostics: residual visits per proof pass, tools/probe.py)
-        c->prof[9] += nrows; c->prof[10] += 1; c->prof[11] += c->n_sorted; c->prof[12] += nrows <= kSafeResidSkip ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {            // (what the host decides between the two kinds of proof pass on)
+        c->safe_resid_sum += nrows; c->safe_sorted_sum += c->n_sorted;
     }
     if (nrows <= kSafeResidSkip) return;                  // (the pruning kernel stood aside: these visits stay unproven)
     const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
@@ -308,12 +308,85 @@ __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
     if (R < 0.25 && u >= R + 1e-12 && u <= 1.0 - R - 1e-12) d.cert[wrow] = 1;
 }
 
+// The DENSE proof pass (Dev::safe_dense): the plain likelihood kernel has left the exact frozen quadratic form of every
+// (visit, label) pair of the stretch in q[slot][row]; four threads per visit sum the robust upper bounds of ALL other labels
+// against the home's robust lower bound -- the same bounds as above, with nothing excluded and nothing tabulated (sixteen threads per visit).  Where the
+// clusters overlap the per-home tables prove nothing and the pruning kernel keeps every pair: then this is the same arithmetic
+// without the bucket sort, the three table kernels, the home pass and the work lists (3 launches instead of 11 per stretch).
+__global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
+    Ctrl *c = d.ctrl;
+    if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
+    const long long base = c->job.win_base, nrows = c->job.win_hi - base;
+    const long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;      // sixteen threads per visit
+    const int part = threadIdx.x & 15;
+    if (r >= nrows) return;                               // (whole groups leave together)
+    const int K = c->job.K;
+    const long long p = base + r;
+    const long long i = d.order ? d.order[p] : p;
+    const int h = d.z[i];
+    const int a = h >= 0 ? d.label_of_slot[h] : -1;
+    const double *__restrict__ gg = d.rtab + (long long)(d.nslots - 1) * 8;
+    const double emcap = gg[0], ecap = gg[1];
+    bool ok = false;
+    double lb = 0.0, R = 0.0;
+    if (a >= 0 && a < K) {
+        const double *__restrict__ rh = d.rtab + (long long)a * 8;
+        const double qh = d.q[(long long)h * d.qstride + r];
+        const double chi = (qh + rh[3]) * ecap;
+        if (rh[6] > 0.5 && qh >= 0.0 && chi < 1.0) {
+            ok = true;
+            lb = rh[4] + rh[5] * log(1.0 - chi);
+            // (four labels' loads in flight together: slot, constants, quadratic form)
+            for (int t0 = part; t0 < K; t0 += 64) {
+                int sl[4];
+                double qv[4], r0[4], r1[4], r3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int t = t0 + 16 * k; sl[k] = t < K ? d.perm[t] : 0; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + 16 * k;
+                    const double *__restrict__ rt = d.rtab + (long long)(t < K ? t : 0) * 8;
+                    r0[k] = rt[0]; r1[k] = rt[1]; r3[k] = rt[3];
+                    qv[k] = d.q[(long long)sl[k] * d.qstride + r];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + 16 * k;
+                    if (t >= K || t == a) continue;
+                    const double clb = ((qv[k] > 0.0 ? qv[k] * (1.0 - 1e-9) : 0.0) + r3[k]) * emcap;
+                    R += exp_above(r0[k] - r1[k] * log1p_below(clb) - lb);
+                }
+            }
+        }
+    }
+    R += __shfl_xor(R, 1);
+    R += __shfl_xor(R, 2);
+    R += __shfl_xor(R, 4);
+    R += __shfl_xor(R, 8);
+    if (part != 0) return;
+    bool safe = false;
+    if (ok) {
+        R += exp(d.log_alpha + d.log_prior[i] - lb);       // the new table, exactly (igmm/crpmm.py:74)
+        R *= 1.0 + 1e-6;
+        const double u = d.u[p];
+        safe = R < 0.25 && u >= R + 1e-12 && u <= 1.0 - R - 1e-12;
+    }
+    d.cert[r] = safe ? 1 : 0;
+}
+
 void launch_safe_open(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(safe_open_kernel, dim3(1), dim3(256), 0, st, d);
 }
 
 // One safe-stay step.  The Dev of a safe batch has prune_enabled = 2, use_certify = 0, use_home = 1, safe_mode = 1.
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (d.safe_dense) {
+        hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+        launch_score(d, KERNEL_MFMA, &d.ctrl->job, d.q, d.qstride, -1, max_rows, 2, st);   // every pair of the stretch, exactly
+        hipLaunchKernelGGL(safe_dense_choice_kernel, dim3((unsigned)((max_rows + 15) / 16)), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(safe_compact_kernel, dim3(1), dim3(1024), 0, st, d);
+        return launch_gram_core(d, resolve_lds, st, ev0, ev1);
+    }
     launch_prune_tables(d, st);                                          // centre distances, radii (exit while valid)
     hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
     hipLaunchKernelGGL(safe_ftab_kernel, dim3(d.nslots), dim3(256), d.nslots * 5 * (int)sizeof(double), st, d);

@@ -82,9 +82,15 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
                                                             double *__restrict__ q, long long qstride,
                                                             int col_override, int skip_pruned_jobs) {
     const JobView job = load_job(jobp);
-    if (job.mode == MODE_DONE || (skip_pruned_jobs && job_is_pruned(d, job.mode, job.prune))) return;
+    // (skip_pruned_jobs 2: the dense proof pass of a safe-stay stretch -- runs whatever the window's kind, but only in front of
+    // a stretch whose proofs are to be made, kernels_safe.hip)
+    if (job.mode == MODE_DONE || (skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
+        (skip_pruned_jobs == 2 && d.ctrl->safe_epoch_valid)) return;
     const int chunk = blockIdx.y;
-    if (chunk >= job.chunks || chunk >= job.nlist) return;
+    // (the dense proof pass covers a few thousand rows: its launch brings its own, finer split of the labels -- grid.y --
+    // so that every compute unit holds two or three workgroups and a wavefront's factor loads hide behind its neighbours')
+    const int nchunks = skip_pruned_jobs == 2 ? (int)gridDim.y : job.chunks;
+    if (chunk >= nchunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = 16 * RB;              // rows per wave
     constexpr int NF = 2 * NJ * (NJ + 1);
     constexpr int PF = pick_pf(NF);
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
     for (int J = 0; J < NJ; ++J) cj[J] = d.cvec[(long long)s * d.Dp + 16 * J + lr];
 
     for (;;) {
-        const int tn = t + job.chunks;
+        const int tn = t + nchunks;
         const bool has_next = tn < job.nlist;
         const int sn = has_next ? job_slot(d, job, tn) : s;
         const double *__restrict__ wfn = d.Wfrag + (long long)sn * nfrag64 + lane;
@@ -182,7 +188,15 @@ template <int NJ>
 static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                         long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, kMaxChunks), dim3(256), 0, st, d, job, q,
+    // (skip_pruned_jobs 2 = the dense proof pass of a safe-stay stretch: max_rows is a few thousand -- enough label chunks for
+    // ~700 workgroups)
+    unsigned gy = kMaxChunks;
+    if (skip_pruned_jobs == 2) {
+        const unsigned gx_used = gx >= 4 ? gx / 4 : 1;        // (the grid is sized for four times the stretch: bgmm_api.hip)
+        gy = (700 + gx_used - 1) / gx_used;
+        gy = gy < kMaxChunks ? kMaxChunks : (gy > 32 ? 32 : gy);
+    }
+    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, gy), dim3(256), 0, st, d, job, q,
                        qstride, col_override, skip_pruned_jobs);
 }
 

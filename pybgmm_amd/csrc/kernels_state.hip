@@ -496,7 +496,7 @@ __device__ __forceinline__ void sweep_begin_body(const Dev &d) {
         c->n_kept_blocks = 0; c->n_bound_blocks = 0; c->n_prune_mfma = 0; c->n_certified = 0;
         c->n_resid = 0; c->home_in = 0; c->home_out = 0;
         c->n_pairs_exact = 0; c->gram_rows_total = 0; c->gram_windows = 0; c->gram_ntouched = 0; c->gram_nmoves = 0;
-        c->safe_windows = 0; c->safe_scanned = 0; c->safe_rows = 0; c->safe_cuts = 0;
+        c->safe_windows = 0; c->safe_scanned = 0; c->safe_rows = 0; c->safe_cuts = 0; c->safe_resid_sum = 0; c->safe_sorted_sum = 0;
         c->safe_epoch_valid = 0;        // (new uniforms, maybe a new visiting order: the proofs were about the old ones)
         if (d.seat_dirty) { c->tables_valid = 0; c->state_epoch += 1; }   // (the tables carry log seating weights)
         if (d.order) c->wsort_valid = 0; // (a fresh permutation every sweep)

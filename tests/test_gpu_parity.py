@@ -619,6 +619,55 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
     ctx.close()
 
 
+def test_dense_and_table_proof_passes_give_the_same_chain():
+    """Safe-stay windows prove which visits stay in two ways: through the per-home bound tables + the pruning kernel's exact
+    forms, or DENSELY (every (visit, label) pair of a stretch through the likelihood kernel, bgmm_get_proof_pass_stats).
+    On overlapping clusters the chain picks the dense pass by itself after its first batch; pinned to either kind
+    (BGMM_SAFE_DENSE, read when the context is made) the labels, the log marginal, the windows and the visits left on the
+    resolver's chain are the same -- which kind runs changes the cost, never the chain."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 60000, 64, 40
+    X, zt = gendata.synth_mixture(N, D, K, seed=141, mu_scale=0.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    us = np.random.RandomState(8).random_sample((3, N))
+    out = {}
+    old = os.environ.get("BGMM_SAFE_DENSE")
+    try:
+        for pin in ("0", "1", None):
+            if pin is None:
+                os.environ.pop("BGMM_SAFE_DENSE", None)
+            else:
+                os.environ["BGMM_SAFE_DENSE"] = pin
+            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+            ctx.set_assignments(zt)
+            zs, ss = [], []
+            for it in range(3):
+                ctx.sweep(us[it])
+                zs.append(ctx.assignments())
+                st = ctx.safe_stats()
+                ss.append((st["windows"], st["unproven_walked"], st["budget_cuts"], ctx.sweep_stats()["moves"]))
+            out[pin] = (zs, ss, ctx.log_marg(), ctx.proof_pass_stats())
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("BGMM_SAFE_DENSE", None)
+        else:
+            os.environ["BGMM_SAFE_DENSE"] = old
+    assert sum(s[0] for s in out["0"][1]) > 0, "the case is meant to run safe-stay windows"
+    assert sum(s[3] for s in out["0"][1]) > 50, "the case is meant to have movers"
+    assert out["0"][3]["dense_batches"] == 0 and out["0"][3]["table_batches"] > 0
+    assert out["1"][3]["table_batches"] == 0 and out["1"][3]["dense_batches"] > 0
+    assert out[None][3]["dense_batches"] > 0, "overlapping clusters: the chain is meant to go over to the dense proof pass"
+    for pin in ("1", None):
+        for it in range(3):
+            npt.assert_array_equal(out[pin][0][it], out["0"][0][it], err_msg="pin %s sweep %d" % (pin, it))
+        assert out[pin][2] == out["0"][2]
+    # (the proofs of the two kinds are not the same proofs -- the dense one bounds every label from its exact form -- so
+    #  the visits left to the resolver may differ; the moves may not)
+    assert [s[3] for s in out["1"][1]] == [s[3] for s in out["0"][1]]
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (16000, 128, 40, 200, 0)],
                          ids=["D64-K200-2000-wrong-labels", "D128-K40-200-wrong-labels"])

@@ -115,6 +115,7 @@ def chain(a, quiet=False):
                       pr["kept_blocks"], msg), flush=True)
         if not ok:
             break
+    print("proof passes of the safe-stay windows so far: %(table_batches)d batches through the per-home tables, %(dense_batches)d dense" % ctx.proof_pass_stats())
     if a.timing:
         n, ms = ctx.kernel_timing()
         print("last sweep: %d timed launches, avg %.4f ms" % (n, ms / max(n, 1)))
@@ -122,9 +123,6 @@ def chain(a, quiet=False):
     if not a.prof and pc[13] > 0:
         print("last sweep: gram_finish: %d windows, %.1f slots each, %.2f rebuilt from scratch per window (%.2f of them for too many terms)" % (
             pc[8], pc[13] / max(pc[8], 1), pc[14] / max(pc[8], 1), pc[15] / max(pc[8], 1)))
-    if not a.prof and pc[10] > 0:
-        print("last sweep: %d proof passes, %.0f visits each, %.1f left to the exact forms (residual list), %d passes skipped them" % (
-            pc[10], pc[11] / pc[10], pc[9] / pc[10], pc[12]))
     if a.prof and pc[15] > 0 and D >= 12 and a.init not in ("rand",):            # home_kernel's clocks (-DBGMM_HOME_PROF)
         names = ["wait+stage", "issue", "frags", "mfma+reduce", "tail", "records", "blockhead", "switch"]
         tot = float(pc[:8].sum())
