@@ -203,9 +203,15 @@ struct PCacheExact {
 
 // Safe-stay windows: what a component has used of its budget since the last proof pass, and the counts between which
 // that pass's proofs hold (kernels_safe.hip); per slot in global memory between windows, per column in LDS inside one.
+// TWO accounts (round 4): log c_t(x, x) - log c_0(x, x) lies in [-W+, +W-] and logdet A_t - logdet A_0 = W+ - W- with W+ / W- the
+// sums of |log |D_t|| over the terms that ADDED a member / REMOVED one.  A label's upper bound as somebody's alternative takes
+// +W-/2 on the log-determinant and e^-W+ on the quadratic form, a home's lower bound -W+/2 and e^+W-: every bound uses one
+// of the two, so each may run up to the budget on its own -- twice the movers per stretch when joins and leaves are mixed.
 struct SafeCol {
-    float w;               // sum of |log |D_t|| (rounded up)
+    float w;               // W+: sum of |log |D_t|| over the terms that added a member (rounded up)
     short lo, hi;          // members it may still lose / gain (32767: no limit)
+    float wm;              // W-: the same over the terms that removed one
+    int pad;
 };
 
 struct Dev {

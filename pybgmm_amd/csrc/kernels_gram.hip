@@ -49,6 +49,7 @@ __device__ __forceinline__ SafeCol safecol_unpack(long long v) {
     e.w = __uint_as_float((unsigned)((unsigned long long)v & 0xffffffffull));
     e.lo = (short)(((unsigned long long)v >> 32) & 0xffffull);
     e.hi = (short)(((unsigned long long)v >> 48) & 0xffffull);
+    e.wm = 0.0f; e.pad = 0;                                     // (the removals' account travels beside the packed word)
     return e;
 }
 
@@ -296,7 +297,8 @@ struct GramPlan {
     static constexpr unsigned oColLast = oColLab + KC * 4;
     static constexpr unsigned oLabCol = oColLast + KC * 4;
     static constexpr unsigned oPermL = oLabCol + KC * 4;
-    static constexpr unsigned bytes = oPermL + KC * 4;
+    static constexpr unsigned oColWm = oPermL + KC * 4;           // colWm[KC] floats: the removals' account (SafeCol::wm)
+    static constexpr unsigned bytes = oColWm + KC * 4;
 };
 
 // the two plans the host chooses between (columns, terms)
@@ -350,6 +352,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                   colN = (lds_i32)(lb + P::oColN), colN0 = (lds_i32)(lb + P::oColN0), colBase = (lds_i32)(lb + P::oColBase),
                   colLab = (lds_i32)(lb + P::oColLab), colLast = (lds_i32)(lb + P::oColLast),
                   labCol = (lds_i32)(lb + P::oLabCol), permL = (lds_i32)(lb + P::oPermL);
+    LDS_AS float *const colWm = (LDS_AS float *)(lb + P::oColWm);
     Ctrl *c = d.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr unsigned gld = KC;
@@ -414,8 +417,10 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
         colRCF[j] = 1.0;
         {
             SafeCol e; e.w = 0.0f; e.lo = 0; e.hi = 0;                      // (a column opened inside the window: no allowance)
+            e.wm = 0.0f; e.pad = 0;
             if (d.safe_mode && j < K0 && s >= 0) e = d.ep_state[s];
             colE[j] = safecol_pack(e);
+            colWm[j] = e.wm;
         }
         if (j < K0) {
             const int n = d.n[s];
@@ -652,7 +657,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                                 const int t = permL[Kn];
                                 dcol = nc++;
                                 colSlot[dcol] = t; colN[dcol] = 0; colBase[dcol] = cprior;
-                                colN0[dcol] = 0; colRCF[dcol] = 1.0; colE[dcol] = 0ll;
+                                colN0[dcol] = 0; colRCF[dcol] = 1.0; colE[dcol] = 0ll; colWm[dcol] = 0.0f;
                                 colLast[dcol] = -1;
                                 colLab[dcol] = Kn; labCol[Kn] = dcol;
                                 d.label_of_slot[t] = Kn;
@@ -849,14 +854,18 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                     // A column that leaves its budget (or drifts kSafeDn members from its frozen count) ends the window
                     // right behind this move -- and so does a component OPENED by it: the proofs are about the frozen labels.
                     SafeCol e = safecol_unpack(colE[cl]);
+                    float wm = colWm[cl];
                     const bool small_col = e.lo == 32767;                        // (a small label: what leaves it is free)
                     const double wterm = fabs(log(fabs(Dt)));
-                    if (!(small_col && sg < 0)) e.w = (float)((double)e.w + wterm) * 1.000001f;     // (rounded up)
+                    // (two accounts, bgmm_device.h: joins and leaves are charged separately, rounded up)
+                    if (sg > 0) e.w = (float)((double)e.w + wterm) * 1.000001f;
+                    else if (!small_col) wm = (float)((double)wm + wterm) * 1.000001f;
                     colE[cl] = safecol_pack(e);
+                    colWm[cl] = wm;
                     S.wsum2[wave - 1] += wterm;                                  // (waves 1 and 2 each keep their own)
                     S.wterms2[wave - 1] += 1;
                     const int dn = n_new - colN0[cl];
-                    if ((double)e.w > S.cap) S.cut = 1;                          // (out of budget: the budget follows, below)
+                    if ((double)(e.w > wm ? e.w : wm) > S.cap) S.cut = 1;        // (out of budget: the budget follows, below)
                     else if (cl >= K0 || dn > (int)e.hi || -dn > (int)e.lo) S.cut = 2;
                 }
             }
@@ -920,6 +929,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
             const int dn = n - colN0[cl];
             if (e.lo != 32767) e.lo = (short)((int)e.lo + dn);
             if (e.hi != 32767) e.hi = (short)((int)e.hi - dn);
+            e.wm = colWm[cl]; e.pad = 0;
             d.ep_state[s] = e;
         }
     }

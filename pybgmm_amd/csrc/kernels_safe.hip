@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
     for (int a = threadIdx.x; a < K; a += 1024) {
         const double dn_tab = d.rtab[(long long)a * 8 + 7];
         SafeCol e;
-        e.w = 0.0f;
+        e.w = 0.0f; e.wm = 0.0f; e.pad = 0;
         e.hi = (short)(int)fabs(dn_tab);
         e.lo = dn_tab < 0.0 ? (short)32767 : e.hi;
         d.ep_state[d.perm[a]] = e;
