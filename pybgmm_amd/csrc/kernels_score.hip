@@ -86,12 +86,20 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
     // a stretch whose proofs are to be made, kernels_safe.hip)
     if (job.mode == MODE_DONE || (skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
         (skip_pruned_jobs == 2 && d.ctrl->safe_epoch_valid)) return;
+    constexpr int ROWS_W_ = 16 * RB;
     const int chunk = blockIdx.y;
     // (the dense proof pass covers a few thousand rows: its launch brings its own, finer split of the labels -- grid.y --
     // so that every compute unit holds two or three workgroups and a wavefront's factor loads hide behind its neighbours')
-    const int nchunks = skip_pruned_jobs == 2 ? (int)gridDim.y : job.chunks;
+    int nchunks = job.chunks;
+    if (skip_pruned_jobs == 2) {
+        // ~1 400 workgroups whatever the stretch's length (measured: 197 ms per sweep at 0.5 % movers against 207 with 700, 240
+        // with 400), at most one label chunk per grid row
+        const long long rb = (job.win_hi - job.pos + 4 * ROWS_W_ - 1) / (4 * ROWS_W_);
+        long long ch = rb > 0 ? (1400 + rb - 1) / rb : 1;
+        nchunks = (int)(ch < 2 ? 2 : (ch > (long long)gridDim.y ? (long long)gridDim.y : ch));
+    }
     if (chunk >= nchunks || chunk >= job.nlist) return;
-    constexpr int ROWS_W = 16 * RB;              // rows per wave
+    constexpr int ROWS_W = ROWS_W_;              // rows per wave
     constexpr int NF = 2 * NJ * (NJ + 1);
     constexpr int PF = pick_pf(NF);
     const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
@@ -188,14 +196,8 @@ template <int NJ>
 static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                         long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
-    // (skip_pruned_jobs 2 = the dense proof pass of a safe-stay stretch: max_rows is a few thousand -- enough label chunks for
-    // ~700 workgroups)
-    unsigned gy = kMaxChunks;
-    if (skip_pruned_jobs == 2) {
-        const unsigned gx_used = gx >= 4 ? gx / 4 : 1;        // (the grid is sized for four times the stretch: bgmm_api.hip)
-        gy = (700 + gx_used - 1) / gx_used;
-        gy = gy < kMaxChunks ? kMaxChunks : (gy > 32 ? 32 : gy);
-    }
+    // (skip_pruned_jobs 2 = the dense proof pass of a safe-stay stretch, a few thousand rows: up to 64 label chunks)
+    const unsigned gy = skip_pruned_jobs == 2 ? 64 : kMaxChunks;      // (the kernel picks its split from the stretch's real length)
     hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, gy), dim3(256), 0, st, d, job, q,
                        qstride, col_override, skip_pruned_jobs);
 }
