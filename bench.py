@@ -875,7 +875,14 @@ def main():
                       "sweeps_per_s_per_rank": per_rank_rate,
                       "gathered_shape": list(z_all.shape)},
         }
-        print(json.dumps(out))
+        # (librccl prints its version banner through C stdio when the label gather loads it: flushed here, so that the JSON
+        # line is the LAST line this process writes)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -5,7 +5,7 @@
 // argument-reduction + minimax-polynomial forms (error below 1 ulp for log and exp, W. Kahan / K. C. Ng,
 // as published in FreeBSD msun e_log.c / e_exp.c: restated here, ~35 instructions each).
 // Arguments: log -- finite, positive, normal; exp -- any finite (underflows to 0 below -700).
-// Host-compilable (tests/test_fast_math.py checks them against libm on the CPU).
+// Host-compilable (tests/test_host_cpu.py::test_short_log_exp_against_libm checks them against libm on the CPU).
 //
 // The constants and the reduction scheme of fm_log / fm_exp are those of fdlibm's e_log.c / e_exp.c, whose
 // notice asks to be kept:
