@@ -1177,11 +1177,15 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
 static int combiner_submit(bgmm_ctx *c, int T) {
     GramCombiner &G = *c->combiner;
     const int me = c->combiner_slot;
+    // (a chain that cannot take part queues its batch itself -- and says so, or the others would wait for its declaration)
     if (!c->grp_ev_in) {
         if (hipEventCreateWithFlags(&c->grp_ev_in, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->grp_ev_out, hipEventDisableTiming) != hipSuccess) return 1;
+            hipEventCreateWithFlags(&c->grp_ev_out, hipEventDisableTiming) != hipSuccess) {
+            G.declare(me, GramCombiner::BUSY);
+            return 1;
+        }
     }
-    if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) return 1;
+    if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) { G.declare(me, GramCombiner::BUSY); return 1; }
     std::unique_lock<std::mutex> lk(G.mu);
     GramCombiner::Slot &S = G.slots[(size_t)me];
     S.state = GramCombiner::WAITING; S.T = T; S.result = 1; S.ev = nullptr;
@@ -1251,8 +1255,10 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
     // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
     // have been waited for by every one of its members)
     if (hipMemcpy(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    // (from here on a failure is an error for every member, not a reason to queue their batches separately: part of the shared
+    // batch may already be in the queue, and separate launches would run beside it on the same chains)
     for (int t = 0; t < T; ++t)
-        if (!launch_gram_group_step(lead->d, lead->grp_devs, m, reach, lead->gram_lds, lead->stream)) return 1;
+        if (!launch_gram_group_step(lead->d, lead->grp_devs, m, reach, lead->gram_lds, lead->stream)) return BGMM_EDEVICE;
     if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
     if (hipEventRecord(lead->grp_ev_out, lead->stream) != hipSuccess) return BGMM_EDEVICE;
     return 0;
