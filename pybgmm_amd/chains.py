@@ -8,9 +8,12 @@ final labels (int64[N] per chain) and the per-sweep log marginals.  With
 ``torch.distributed`` backend "nccl" that collective is RCCL over xGMI; the CPU
 tests run the identical code over "gloo".
 
-Many chains on ONE GPU (``chains=``): at small dimensions a sweep is one workgroup's chain of
-dependent draws (kernels_seq.hip) and a GPU has 256 compute units.  ``ChainGroup`` keeps G contexts on one device and
-sweeps them side by side through ``bgmm_group_sweep_staged`` (two launches for all of them); ``run_chains_on_device``
+Many chains on ONE GPU (``chains=``; 8e): a sweep of a chain that still moves is one workgroup's
+chain of dependent draws -- the whole sweep at D <= 4 (kernels_seq.hip), the window resolver at larger D (kernels_gram.hip) --
+and a GPU has 256 compute units.  ``ChainGroup`` keeps G contexts on one device and sweeps them side by side through
+``bgmm_group_sweep_staged`` (D <= 4: two launches for all of them; any other shape: the chains run concurrently inside the
+call and share their launches while they burn in together: 8 chains of BASELINE's C4 shape from "rand" at 4.5 - 5.3 x one
+chain's rate); ``run_chains_on_device``
 does the same for G model objects (CRPMM / PCRPMM / ADAPCRPMM), each with its own seeded generators, whose sampler
 loops run in lockstep.  Chain c is label for label the chain a solo run with seed ``seed + c`` produces.
 """
@@ -156,7 +159,8 @@ def run_chains_on_device(model_cls, X, prior, alpha, n_chains, n_iter, seed=0, d
     and ``RandomState``: the streams a solo run under ``random.seed(seed + c); np.random.seed(seed + c)`` consumes),
     their ``collapsed_gibbs_sampler`` loops in lockstep so that every round of sweeps is one group call
     (``bgmm_group_sweep_staged``).  Returns ``[(model, record_dict), ...]``; ``record_dict["sample_time"]`` of a chain is
-    the time of the ROUND it took part in.  Worth it where a sweep cannot fill the GPU on its own: D <= 4.
+    the time of the ROUND it took part in.  Worth it where a sweep cannot fill the GPU on its own: D <= 4 in every regime,
+    any dimension while the chains still move (burn-in, overlapping clusters); chains at rest at D >= 12 fill the GPU alone.
     """
     models = []
     for c in range(int(n_chains)):

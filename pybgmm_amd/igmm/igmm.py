@@ -74,8 +74,9 @@ class IGMM(GMM):
     @classmethod
     def sample_chains(cls, X, kernel_prior, alpha, chains, n_iter, seed=0, device=0, true_assignments=None, **kwargs):
         """``chains`` independent chains of this model on ONE GPU (``chains=``), chain c seeded
-        ``seed + c``, their sampler loops in lockstep so that a round of sweeps is one group call -- what pays at
-        small dimensions, where a sweep is one workgroup's chain of dependent draws and a GPU has 256 compute units.
+        ``seed + c``, their sampler loops in lockstep so that a round of sweeps is one group call -- what pays wherever
+        a sweep is one workgroup's chain of dependent draws (D <= 4 always; any dimension while the chains still move)
+        and a GPU has 256 compute units.
         Returns ``[(model, record_dict), ...]``; see ``pybgmm_amd.chains.run_chains_on_device`` for the keywords."""
         from .. import chains as _chains
         return _chains.run_chains_on_device(cls, X, kernel_prior, alpha, chains, n_iter, seed=seed, device_index=device,
