@@ -2307,6 +2307,31 @@ def test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo():
         ch[0].close()
 
 
+@pytest.mark.parametrize("model,D", [("CRPMM", 16), ("PCRPMM", 64)])
+def test_sample_chains_at_larger_dimensions_equals_solo_runs(model, D):
+    """`CRPMM.sample_chains` / `PCRPMM.sample_chains` at dimensions whose chains cannot take the one-workgroup sweep: the
+    group call runs them concurrently (one stream + host thread each) and, from the reference's "rand" start, shares their
+    frozen-factor launches.  Chain c through the CLASSES -- its own `random.Random` / `RandomState`, device permutations for
+    PCRPMM -- is the chain a solo run with seed s + c gives: labels, K per sweep, log marginals."""
+    from pybgmm_amd import chains
+    from pybgmm_amd.igmm import CRPMM, PCRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    N, K, s, n_iter, G = 6000, 8, 23, 3, 3
+    X, zt = gendata.synth_mixture(N, D, K, seed=5 + D, mu_scale=2.0)
+    prior = NIW(*gendata.demo_prior_params(D))
+    runs = cls.sample_chains(X, prior, 1.0, chains=G, n_iter=n_iter, seed=s, true_assignments=zt, K=K, K_max=64)
+    moved = 0
+    for c in range(G):
+        m_solo, rec_solo = chains.run_chain(cls, X, prior, 1.0, n_iter, s, c, 0, true_assignments=zt, K=K, K_max=64)
+        npt.assert_array_equal(runs[c][0].components.assignments, m_solo.components.assignments)
+        npt.assert_array_equal(np.array(runs[c][1]["components"]), np.array(rec_solo["components"]))
+        npt.assert_array_equal(np.array(runs[c][1]["log_marg"]), np.array(rec_solo["log_marg"]))
+        moved += int(np.sum(runs[c][0].components.assignments != zt))
+    assert not np.array_equal(runs[0][0].components.assignments, runs[1][0].components.assignments)
+
+
 @pytest.mark.parametrize("model", ["CRPMM", "PCRPMM"])
 def test_run_chains_on_device_equals_solo_runs(model):
     """chains.run_chains_on_device: G model objects on one GPU, their sampler loops in lockstep, every round of sweeps one
