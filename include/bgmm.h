@@ -285,6 +285,10 @@ BGMM_API int bgmm_get_safe_stats(bgmm_ctx *ctx, int64_t *out6);
  * pass (every (visit, label) pair of a stretch through the likelihood kernel: chains whose clusters overlap, where the tables
  * prove nothing).  Which one runs never changes the chain, only its cost. */
 BGMM_API int bgmm_get_proof_pass_stats(bgmm_ctx *ctx, int64_t *out2);
+/* Which proof pass the next batches of safe-stay windows run: -1 = the chain decides (the default; BGMM_SAFE_DENSE in the
+ * environment sets the initial value), 0 = always the per-home tables, 1 = always the dense pass.  May be changed between
+ * sweeps (the tests switch kinds on one chain); it never changes the trajectory. */
+BGMM_API int bgmm_set_proof_pass(bgmm_ctx *ctx, int32_t kind);
 /* Budget of a safe-stay window per component: the sum over the rank-1 terms it takes of |log |D_t|| (D_t = the
  * Sherman-Morrison denominator of the term).  0 = follows the chain (the default); > 0 pins it.  A larger budget
  * lets a window absorb more (or more eccentric) moves and proves fewer visits; it never changes the trajectory. */

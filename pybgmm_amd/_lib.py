@@ -7,8 +7,11 @@ no HIP device is visible, the calls raise.  ``oracle/`` is never imported here.
 import ctypes
 import os
 
-# (chains side by side keep one stream each busy: eight hardware queues unless the user has chosen -- see bgmm_api.hip)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Chains side by side on one GPU keep one stream each busy, and the HIP runtime maps a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4).  Eight, unless the user has chosen a value or opted out with
+# BGMM_KEEP_HW_QUEUES=1.  Only effective when it happens before the process's first HIP call.
+if os.environ.get("BGMM_KEEP_HW_QUEUES", "0") in ("", "0"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 
@@ -76,6 +79,7 @@ SIGNATURES = {
     "bgmm_get_safe_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_proof_pass_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_safe_budget": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "bgmm_set_proof_pass": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_set_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_kernel_timing": (ctypes.c_int, [_vp, _i64, _f64]),
     "bgmm_set_tuning": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -411,6 +415,9 @@ class Context(object):
         out = np.zeros(2, dtype=np.int64)
         self._ck(self.L.bgmm_get_proof_pass_stats(self.h, _ptr(out)))
         return {"table_batches": int(out[0]), "dense_batches": int(out[1])}
+
+    def set_proof_pass(self, kind=-1):
+        self._ck(self.L.bgmm_set_proof_pass(self.h, int(kind)))
 
     def set_safe_budget(self, cap=0.0):
         self._ck(self.L.bgmm_set_safe_budget(self.h, float(cap)))

@@ -41,9 +41,10 @@ void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, doub
 static thread_local std::string g_create_error;
 
 // Chains side by side on one GPU (bgmm_group_sweep_staged) keep one stream each busy.  The HIP runtime maps a process's
-// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; streams that share a queue run one behind the other): eight,
-// unless the user has chosen otherwise.  Takes effect when this library is loaded before the runtime's first call.
-static const int g_hw_queues_env = (setenv("GPU_MAX_HW_QUEUES", "8", 0), 0);
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; streams that share a queue run one behind the other).  The
+// library does NOT touch the process environment (a setenv from a static initializer races with getenv elsewhere and
+// changes the queue mapping of every HIP user of the process): a caller that runs more than four chains per device
+// exports GPU_MAX_HW_QUEUES=8 before the runtime's first call -- pybgmm_amd._lib does, unless told not to.
 
 struct bgmm_ctx {
     int device = 0;
@@ -1769,15 +1770,30 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
             comb.slots[k].c = ctxs[threaded[k]];
             ctxs[threaded[k]]->combiner_slot = (int)k;
         }
-        for (int i : threaded) {
+        // (std::thread's constructor may throw -- no exception may cross the C ABI, least of all with joinable workers
+        //  behind it: the chains whose thread could not be started are declared DONE for the rendezvous, so that nobody
+        //  waits for them, and swept on this thread)
+        size_t started = 0;
+        try {
+            workers.reserve(threaded.size());
+            for (int i : threaded) {
+                const int up = use_power ? use_power[i] : 0;
+                const double pw = (up && power) ? power[i] : 1.0;
+                workers.emplace_back([=, &comb]() {
+                    ctxs[i]->combiner = &comb;
+                    rc_out[i] = sweep_impl(ctxs[i], up, pw, 0);
+                    comb.declare(ctxs[i]->combiner_slot, GramCombiner::DONE);
+                    ctxs[i]->combiner = nullptr;
+                });
+                ++started;
+            }
+        } catch (...) {
+        }
+        for (size_t k = started; k < threaded.size(); ++k) comb.declare((int)k, GramCombiner::DONE);
+        for (size_t k = started; k < threaded.size(); ++k) {
+            const int i = threaded[k];
             const int up = use_power ? use_power[i] : 0;
-            const double pw = (up && power) ? power[i] : 1.0;
-            workers.emplace_back([=, &comb]() {
-                ctxs[i]->combiner = &comb;
-                rc_out[i] = sweep_impl(ctxs[i], up, pw, 0);
-                comb.declare(ctxs[i]->combiner_slot, GramCombiner::DONE);
-                ctxs[i]->combiner = nullptr;
-            });
+            rc_out[i] = sweep_impl(ctxs[i], up, (up && power) ? power[i] : 1.0, 0);
         }
     } else {
         threaded.clear();
@@ -2208,6 +2224,13 @@ extern "C" int bgmm_set_mt_jump(bgmm_ctx *c, int32_t enabled) {
     if (!c) return BGMM_EINVAL;
     SETTLE(c);
     c->mt_jump_on = enabled != 0;
+    return 0;
+}
+
+extern "C" int bgmm_set_proof_pass(bgmm_ctx *c, int32_t kind) {
+    if (!c || kind < -1 || kind > 1) return BGMM_EINVAL;
+    SETTLE(c);
+    c->safe_dense_pin = kind;
     return 0;
 }
 

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #define BGMM_MAX_D 128
@@ -339,13 +340,19 @@ __host__ __device__ constexpr int bgmm_nfrag(int Dp) { return 2 * (Dp / 16) * (D
 // already asked for is remembered per device (contexts on different GPUs of one process are independent).
 struct PerDeviceLds {
     std::atomic<int> have[64] = {};     // (chains of one process are driven from several host threads: bgmm_group_sweep_staged)
-    bool raise(int lds) {               // true: the attribute must be (re)set on the current device
+    std::mutex mu;
+    // Makes sure kernel `fn` may be launched with `lds` bytes of dynamic LDS on the current device.  The new size is
+    // PUBLISHED only after hipFuncSetAttribute has returned (under the lock): a thread that reads have >= lds on the
+    // fast path may launch at once -- it never overtakes the thread that is still setting the attribute.
+    void ensure(const void *fn, int lds) {
+        if (lds <= 64 * 1024) return;
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-        int cur = have[dev].load(std::memory_order_relaxed);
-        while (lds > cur)
-            if (have[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) return true;
-        return false;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        if (known && have[dev].load(std::memory_order_acquire) >= lds) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (known && have[dev].load(std::memory_order_relaxed) >= lds) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (known) have[dev].store(lds, std::memory_order_release);
     }
 };
 

@@ -304,7 +304,6 @@ void launch_choice(const Dev &d, long long max_rows, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + R - 1) / R);
     const int lds = (d.K_max + 2) * R * (int)sizeof(double);
     static PerDeviceLds attr;
-    if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)choice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr.ensure((const void *)choice_kernel, lds);
     hipLaunchKernelGGL(choice_kernel, dim3(gx), dim3(64 * R), lds, st, d);
 }

@@ -574,8 +574,7 @@ static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     constexpr int lds = home_lds_bytes(NJ * 16);
     static PerDeviceLds attr;
-    if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)home_kernel<NJ, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr.ensure((const void *)home_kernel<NJ, WHOLE>, lds);
     hipLaunchKernelGGL((home_kernel<NJ, WHOLE>), dim3(gx), dim3(256), lds, st, d);
 }
 

@@ -700,8 +700,7 @@ static void launch_mfma_prune_v(const Dev &d, const Job *job, double *q, long lo
     const int lds = (4 * 32 * prune_row_stride(NJ * 16) + 4 * (176 + d.keep_stride)) * (int)sizeof(double);
     auto kern = score_mfma_prune_kernel<NJ, 2, (NJ <= 4 ? 2 : 1), WALK>;
     static PerDeviceLds attr;
-    if (lds > 64 * 1024 && attr.raise(lds))
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr.ensure((const void *)kern, lds);
     hipLaunchKernelGGL(kern, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride);
 }
 

@@ -694,8 +694,7 @@ bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_o
 
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st) {
     static PerDeviceLds attr;
-    if (attr.raise(160 * 1024))
-        (void)hipFuncSetAttribute((const void *)resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr.ensure((const void *)resolve_kernel, 160 * 1024);
     (void)lds;
     hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(RT), lds, st, d, R, Kcap);
 }

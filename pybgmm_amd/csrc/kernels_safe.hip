@@ -230,9 +230,12 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
         c->safe_epoch_pos0 = base;
         c->safe_scanned += nrows;
         c->n_resid = 0;                 // (the residual list of this proof pass has been worked through)
-        if (!d.safe_dense) c->tables_valid = 1;         // (a dense proof pass builds no tables)
-        c->safe_epoch_built = c->state_epoch;
-        c->safe_cap_built = safe_cap_now(d, c);
+        // A dense proof pass builds neither the pruning tables nor ftabR, and leaves pr_const to whoever wrote it last:
+        // it must not claim them for this epoch -- a table pass at an unchanged state_epoch (the host switches kinds between
+        // batches) would skip safe_rtab / safe_ftab and prove with the bounds of an older state.
+        if (!d.safe_dense) c->tables_valid = 1;
+        c->safe_epoch_built = d.safe_dense ? -1 : c->state_epoch;
+        c->safe_cap_built = safe_cap_now(d, c);         // (the budget the resolver enforces: kernels_gram.hip)
     }
     if (cnt > 0 && rank <= kSafeList) {
         for (int r = lo; r < hi && rank <= kSafeList; ++r) {

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
 }
 
 static void ensure_lds(const void *fn, int bytes, PerDeviceLds &attr) {
-    if (bytes > 64 * 1024 && attr.raise(bytes)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    attr.ensure(fn, bytes);
 }
 
 // Frozen-factor windows (kernels_gram.hip), last kernel of a step: block b brings slot gtouched[b] up to
@@ -257,8 +257,11 @@ __device__ __forceinline__ void gram_finish_body(const Dev &d) {
 #else
 #define FPROF(i) do { } while (0)
 #endif
-#ifndef BGMM_PROFILE
-    if (tid == 0) {                                    // (diagnostics, tools/probe.py: why slots are rebuilt from scratch)
+#if defined(BGMM_FINISH_DIAG) && !defined(BGMM_PROFILE)
+    // (diagnostics, off by default: why slots are rebuilt from scratch.  They share Ctrl::prof with the phase clocks of a
+    //  -DBGMM_PROFILE build and cost every workgroup of this kernel contended global atomics, so a production build has
+    //  neither: bgmm_get_phase_clocks returns zeros, as include/bgmm.h says)
+    if (tid == 0) {
         Ctrl *cw = d.ctrl;
         atomicAdd((unsigned long long *)&cw->prof[13], 1ull);
         if (!rank1) atomicAdd((unsigned long long *)&cw->prof[14], 1ull);

@@ -7,9 +7,12 @@ sufficient statistics live in HBM behind libbgmm_hip.so and every method is a
 kernel call through the C-ABI.  Attribute reads download on demand.
 
 Differences a caller can observe:
-  * ``K_max`` defaults to ``N`` only for small N; for large N it defaults to
-    ``max(1024, 4*K_init)`` (the reference's default ``K_max = N`` allocates
-    N x D x D floats, gaussian_components.py:81-89).
+  * ``K_max=None`` means "up to N components" as in the reference (gaussian_components.py:81-83), but the N x D x D
+    floats that default makes the reference allocate (:86-89) are not set aside up front: the device starts with
+    ``max(1024, 4*K_init)`` slots (N for N <= 4096) and, when a sweep opens more components than that, the
+    sampler loop moves the chain into a context with twice the slots and carries on at the very visit that needed
+    the new slot (``resume_in_larger_context`` below) -- same trajectory, no ``BGMM_EKMAX`` short of N.
+    An explicit ``K_max`` is a hard limit, as in the reference (there: IndexError).
   * ``_cached_outer`` (N x D x D, :116-118) is never materialised.
   * ``cache_component_stats`` / ``restore_component_from_stats`` download / upload one
     component's statistics (``bgmm_get_stats`` / ``bgmm_set_stats``); the sweep kernels do
@@ -29,9 +32,57 @@ def reference_tables(v_0, N):
 
 
 def default_K_max(N, K_init):
+    """Slots a context starts with when the caller leaves ``K_max`` to the library (it grows on demand up to N)."""
     if N <= 4096:
         return N
     return int(min(N, max(1024, 4 * K_init)))
+
+
+def resume_in_larger_context(comp, power):
+    """A sweep of ``comp`` has just failed with BGMM_EKMAX and ``K_max`` was left to the library: continue it.
+
+    What the failed sweep leaves (tests: ``test_k_max_overflow_leaves_a_consistent_state``): every visit in front of the
+    failing one applied, the failing visit's point taken out of its component (-1, as after the reference's ``del_item``,
+    gaussian_components.py:171-186) and nothing else; its inputs are still staged.  So: a context with twice the slots,
+    the labels and the raw statistics put back bit for bit (the checkpoint / resume route of SURVEY.md section 5), the
+    staged uniforms and visiting order rotated so that the failing visit comes first, and a partial sweep over the
+    visits that were left (``bgmm_set_sweep_visits``).  Repeats if the rest of the sweep outgrows the new context too.
+    Returns nothing; ``comp._ctx`` is the new context afterwards and ``comp.K_max`` its slot count."""
+    n_left = comp.N                                    # visits of the sweep that failed
+    while True:
+        old = comp._ctx
+        if comp.K_max >= comp.N:
+            raise _lib.BGMMError(-3, "K_max exceeded with K_max == N")
+        u = old.staged_uniforms()
+        try:
+            order = old.staged_order()
+        except _lib.BGMMError:
+            order = np.arange(comp.N, dtype=np.int64)
+        z = old.assignments()
+        # the failing visit: the first one in visiting order whose point is unassigned (the points a "one-by-one" start
+        # has not reached yet are unassigned too -- they come later)
+        unassigned = np.nonzero(z[order[:n_left]] < 0)[0]
+        assert unassigned.size >= 1, "BGMM_EKMAX without an unassigned point"
+        p = int(unassigned[0])
+        K = old.K
+        counts = old.counts()
+        raw = [old.raw_stats(k) for k in range(K)]
+        new_K_max = int(min(comp.N, max(2 * comp.K_max, K + 1)))
+        new = comp._new_context(new_K_max)
+        new.set_assignments(z)
+        for k in range(K):
+            new.set_stats(k, raw[k][0], raw[k][1], int(counts[k]))
+        old.close()
+        comp._ctx, comp.K_max = new, new_K_max
+        n_left -= p
+        new.stage(np.roll(u, -p), np.roll(order, -p))
+        new.set_sweep_visits(n_left)
+        try:
+            new.sweep_staged(power)
+            return
+        except _lib.BGMMError as e:
+            if e.code != -3:
+                raise
 
 
 class GaussianComponents(object):
@@ -53,6 +104,7 @@ class GaussianComponents(object):
             # apart from unassigned (-1), components should be labelled from 0
             assert set(z.tolist()).difference([-1]) == set(range(int(z.max()) + 1))
         K_init = int(z.max()) + 1
+        self.K_max_auto = K_max is None             # (the library picks the slots and grows them on demand, up to N)
         if K_max is None:
             K_max = default_K_max(self.N, K_init)
         self.K_max = int(K_max)
@@ -60,12 +112,16 @@ class GaussianComponents(object):
         self._cached_log_pi = np.log(np.pi)
         self._cached_gammaln_by_2, self._cached_log_v = reference_tables(prior.v_0, self.N)
         self._check_prior(prior)
-        self._ctx = _lib.Context(X, prior.m_0, prior.k_0, prior.v_0, prior.S_0,
-                                 alpha, self.K_max, device=device,
-                                 tables=(self._cached_gammaln_by_2, self._cached_log_v),
-                                 cov_type=self._cov_type)
+        self._device, self._alpha = device, alpha
+        self._ctx = self._new_context(self.K_max)
         self._log_prior = None
         self._ctx.set_assignments(z)
+
+    def _new_context(self, K_max):
+        return _lib.Context(self.X, self.prior.m_0, self.prior.k_0, self.prior.v_0, self.prior.S_0,
+                            self._alpha, K_max, device=self._device,
+                            tables=(self._cached_gammaln_by_2, self._cached_log_v),
+                            cov_type=self._cov_type)
 
     def _check_prior(self, prior):
         pass

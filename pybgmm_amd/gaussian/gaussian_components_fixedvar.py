@@ -37,16 +37,21 @@ class GaussianComponentsFixedVar(GaussianComponents):
             assert (self.N,) == z.shape
             assert set(z.tolist()).difference([-1]) == set(range(int(z.max()) + 1))
         K_init = int(z.max()) + 1
+        self.K_max_auto = K_max is None
         if K_max is None:
             K_max = default_K_max(self.N, K_init)
         self.K_max = int(K_max)
         assert K_init <= self.K_max, "initial assignments use more than K_max components"
-        S_0 = np.concatenate([np.broadcast_to(np.asarray(prior.var, dtype=np.float64), (self.D,)),
-                              np.broadcast_to(np.asarray(prior.var_0, dtype=np.float64), (self.D,))])
-        self._ctx = _lib.Context(X, np.broadcast_to(self.mu_0, (self.D,)), 1.0, 1, S_0, alpha, self.K_max,
-                                 device=device, cov_type="fixed")
+        self._device, self._alpha = device, alpha
+        self._ctx = self._new_context(self.K_max)
         self._log_prior = None
         self._ctx.set_assignments(z)
+
+    def _new_context(self, K_max):
+        S_0 = np.concatenate([np.broadcast_to(np.asarray(self.prior.var, dtype=np.float64), (self.D,)),
+                              np.broadcast_to(np.asarray(self.prior.var_0, dtype=np.float64), (self.D,))])
+        return _lib.Context(self.X, np.broadcast_to(self.mu_0, (self.D,)), 1.0, 1, S_0, self._alpha, K_max,
+                            device=self._device, cov_type="fixed")
 
     def _block(self):
         return (self.D,)

@@ -8,7 +8,8 @@ import numpy as np
 from scipy import stats
 from scipy.special import gammaln
 
-from ..gaussian.gaussian_components import GaussianComponents, GaussianComponentsDiag
+from .. import _lib
+from ..gaussian.gaussian_components import GaussianComponents, GaussianComponentsDiag, resume_in_larger_context
 from ..gaussian.gaussian_components_fixedvar import GaussianComponentsFixedVar
 from ..gmm import GMM
 from ..utils import rng as _rng
@@ -173,5 +174,13 @@ class IGMM(GMM):
         step = getattr(self, "_lockstep", None)
         if step is not None:            # one of several chains on this device (chains.run_chains_on_device)
             step.sweep(self, power)
-        else:
+            return
+        try:
             ctx.sweep_staged(power)
+        except _lib.BGMMError as e:
+            # ``K_max=None`` means "as many components as the chain opens, up to N" (reference
+            # gaussian_components.py:81-83); the slots are grown on demand instead of set aside up front
+            if e.code != -3 or not getattr(self.components, "K_max_auto", False) or self.components.K_max >= self.N:
+                raise
+            self._settle_generators()   # (the new context has no look-ahead of this stream)
+            resume_in_larger_context(self.components, power)

@@ -13,8 +13,9 @@ Interface of the reference's pybgmm/prior/wishart.py:16-32 (``wishrnd(sigma, v_0
 ``random`` and ``np.random`` are independent streams, so the normals are drawn in ONE vectorised call
 (numpy's legacy Gaussian generator carries its spare value from call to call: one call of size n
 equals the reference's D - 1 calls of sizes 1 .. D - 1 value for value) and scattered into the
-triangle; the sample is formed as ``L L'`` with ``L = C A`` (one triangular product, symmetric by
-construction).  ``rng`` / ``nprng`` replace the process-global generators (one chain per GPU).
+triangle.  The products are associated as the reference associates them -- ``((C A) A') C'`` -- and the
+inverse is ``solve(sample, I)``, so a draw equals the reference's bit for bit (tested with ``==``).
+``rng`` / ``nprng`` replace the process-global generators (one chain per GPU).
 """
 import random as _random
 
@@ -39,11 +40,12 @@ def wishrnd(sigma, v_0, C=None, rng=None, nprng=None):
     D = sigma.shape[0]
     if C is None:
         C = np.linalg.cholesky(sigma)
-    L = np.asarray(C, dtype=float) @ bartlett_factor(D, 0.5 * (v_0 - D + 1), rng, nprng).astype(float)
-    return L @ L.T
+    C = np.asarray(C, dtype=float)
+    A = bartlett_factor(D, 0.5 * (v_0 - D + 1), rng, nprng).astype(float)
+    return ((C @ A) @ A.T) @ C.T
 
 
 def iwishrnd(sigma, v_0, C=None, rng=None, nprng=None):
     """One inverse-Wishart sample: the inverse of a Wishart(sigma, v_0) draw."""
     W = wishrnd(sigma, v_0, C, rng=rng, nprng=nprng)
-    return np.linalg.inv(W)
+    return np.linalg.solve(W, np.eye(W.shape[0]))

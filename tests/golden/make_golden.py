@@ -533,7 +533,66 @@ def case_api_pcrp_wf():
     api_case("api_distdict_pcrpmm_wf", "PCRPMM", True, (23, 23))
 
 
+def case_demo2d():
+    """The reference's 2-D demo script as a user runs it (examples/crpmm_2d_demo.py:25-84, the recipe written out here,
+    the plotting left out): seeds, data and prior from the global streams, CRPMM from "rand" with K = 3, 40 sweeps with the
+    default num_saved, then rand_k of every component, then what both global streams deliver next."""
+    from pybgmm.igmm import CRPMM
+    from pybgmm.prior import NIW
+    random.seed(1)
+    np.random.seed(1)
+    D, N, K_true, alpha, K, n_iter = 2, 100, 4, 1., 3, 40
+    mu_scale, covar_scale = 4.0, 0.7
+    z_true = np.random.randint(0, K_true, N)
+    mu = np.random.randn(D, K_true) * mu_scale
+    X = (mu[:, z_true] + np.random.randn(D, N) * covar_scale).T
+    m_0 = np.zeros(D)
+    k_0 = covar_scale ** 2 / mu_scale ** 2
+    v_0 = D + 3
+    S_0 = covar_scale ** 2 * v_0 * np.eye(D)
+    # (the demo hands a directory: with K == num_saved the reference saves a scatter plot there per snapshot)
+    # its 2017 plotting helpers no longer run under today's matplotlib (Ellipse's signature): stubbed from outside --
+    # they draw, they touch neither the sampler nor the random streams
+    import pybgmm.igmm.igmm as ref_igmm
+    ref_igmm.plot_ellipse = lambda *a, **k: None
+    ref_igmm.plot_mixture_model = lambda *a, **k: None
+    # and prior/wishart.py:18 asks `C == None` of an array -- a scalar False under the numpy of its day, an elementwise
+    # comparison now: the factor goes in as an ndarray view whose comparison with None answers as it did then
+    import pybgmm.prior.wishart as ref_wishart
+
+    class _OldEq(np.ndarray):
+        def __eq__(self, other):
+            return False if other is None else np.ndarray.__eq__(self, other)
+        __hash__ = None
+    real_iw = ref_wishart.iwishrnd
+    ref_wishart.iwishrnd = lambda sigma, v_0, C=None: real_iw(sigma, v_0, None if C is None else np.asarray(C).view(_OldEq))
+    save_path = tempfile.mkdtemp(prefix="pybgmm_demo_") + "/"
+    crpmm = CRPMM(X, NIW(m_0, k_0, v_0, S_0), alpha, save_path=save_path, assignments="rand", K=K)
+    record_dict, _dist = crpmm.collapsed_gibbs_sampler(n_iter, z_true)
+    shutil.rmtree(save_path, ignore_errors=True)
+    Kf = crpmm.components.K
+    rk_mu, rk_sigma = [], []
+    for k in range(Kf):
+        m, sg = crpmm.components.rand_k(k)
+        rk_mu.append(np.asarray(m, dtype=np.float64).ravel())
+        rk_sigma.append(np.asarray(sg, dtype=np.float64).ravel())
+    ref_wishart.iwishrnd = real_iw
+    out = {"case": "demo_crpmm_2d", "X": X, "true_assignments": np.asarray(z_true, dtype=np.int64),
+           "rec_components": np.array(record_dict["components"], dtype=np.int64),
+           "rec_log_marg": np.array(record_dict["log_marg"], dtype=np.float64),
+           "rec_nmi": np.array(record_dict["nmi"], dtype=np.float64),
+           "rec_nk": np.array(record_dict["nk"]),
+           "final_z": np.array(crpmm.components.assignments, dtype=np.int64), "final_K": Kf,
+           "rand_k_mu": np.stack(rk_mu), "rand_k_sigma": np.stack(rk_sigma),
+           "after_random": np.array([random.random() for _ in range(4)]), "after_numpy": np.random.random_sample(4)}
+    path = os.path.join(HERE, "demo_crpmm_2d.npz")
+    np.savez_compressed(path, **out)
+    print("demo_crpmm_2d          K per sweep %s, log_marg[-1]=%.12f -> %s" % (
+        list(out["rec_components"]), out["rec_log_marg"][-1], os.path.basename(path)))
+
+
 CASES = {
+    "demo2d": case_demo2d,
     "api_crp_wf": case_api_crp_wf, "api_crp_mf": case_api_crp_mf, "api_pcrp_wf": case_api_pcrp_wf,
     "kat1": case_kat1, "kat3": case_kat3, "kat4": case_kat4, "c1": case_c1,
     "c2twin": case_c2_twin, "c3twin": case_c3_twin, "c3rand": case_c3_rand,

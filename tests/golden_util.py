@@ -9,7 +9,8 @@ from pybgmm_amd.utils import gendata
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 _EVERY = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
-ALL_CASES = [c for c in _EVERY if not c.startswith(("diag_", "fixed_", "api_"))]   # full covariance (incl. ADAPCRPMM)
+ALL_CASES = [c for c in _EVERY if not c.startswith(("diag_", "fixed_", "api_", "demo_"))]   # full covariance (incl. ADAPCRPMM)
+DEMO_CASES = [c for c in _EVERY if c.startswith("demo_")]             # a reference example script's body, run as a user would
 API_CASES = [c for c in _EVERY if c.startswith("api_")]               # class-level runs with the distribution dict on
 DIAG_CASES = [c for c in _EVERY if c.startswith("diag_")]             # covariance_type="diag"
 FIXED_CASES = [c for c in _EVERY if c.startswith("fixed_")]           # covariance_type="fixed"

@@ -666,18 +666,33 @@ def test_dense_and_table_proof_passes_give_the_same_chain():
     # (the proofs of the two kinds are not the same proofs -- the dense one bounds every label from its exact form -- so
     #  the visits left to the resolver may differ; the moves may not)
     assert [s[3] for s in out["1"][1]] == [s[3] for s in out["0"][1]]
+    # the kind may change on ONE chain (the host looks at the tables again every eighth sweep); a dense pass
+    # builds no tables and must not claim them for the epoch it ran at.  dense / table / dense / table on one context,
+    # chosen through the C-ABI, against the pinned runs; and a table pass right behind a dense one on a chain that has
+    # stopped moving (nothing bumps the state epoch in between)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(zt)
+    for it in range(3):
+        ctx.set_proof_pass(1 if it % 2 == 0 else 0)
+        ctx.sweep(us[it])
+        npt.assert_array_equal(ctx.assignments(), out["0"][0][it], err_msg="alternating kinds, sweep %d" % it)
+    st = ctx.proof_pass_stats()
+    assert st["dense_batches"] > 0 and st["table_batches"] > 0
+    assert ctx.log_marg() == out["0"][2]
+    ctx.close()
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (16000, 128, 40, 200, 0)],
-                         ids=["D64-K200-2000-wrong-labels", "D128-K40-200-wrong-labels"])
+@pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (16000, 128, 40, 200, 0), (8000, 128, 200, 200, 0)],
+                         ids=["D64-K200-2000-wrong-labels", "D128-K40-200-wrong-labels", "D128-K200-200-wrong-labels"])
 def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
     """the largest problems the C port of the reference finishes in about a minute per sweep, at
     BASELINE's D and K, the truth with wrong labels sprinkled in (the sweep repairs them: movers one per ~50 visits, then
     a chain at rest).  The default configuration AND the mode bench.py times (prune_mode 3) against ONE oracle run --
     a whole sweep, then `tail` visits of a second one (the hand-back to the at-rest path) -- labels identical after
     each; a mismatch reports the CDF margin at the first diverging visit.  The oracle costs 0.4 - 1.2 ms per visit at
-    D = 64, K = 200 (1.2 - 3.5 at D = 128, K = 40): about a minute per case on the GPU box's host."""
+    D = 64, K = 200 (1.2 - 3.5 at D = 128, K = 40): about a minute per case on the GPU box's host.  VERDICT r4 #7(i): C5's
+    D AND K together (D = 128, K = 200: 7.6 ms per oracle visit, N = 8000)."""
     from divergence import assert_same_labels, first_divergence
     from oracle import c_oracle
     from pybgmm_amd import _lib
@@ -2367,4 +2382,95 @@ def test_label_gather_through_the_c_abi():
     assert z_all.shape == (1, g.N) and z_all.dtype == np.int64
     assert np.array_equal(z_all[0], ctx.assignments()) and z_all[0, 3] == -1
     comm.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("init,D,alpha", [("one-by-one", 5, 1e300), ("each-in-own", 2, 1.0), ("one-by-one", 16, 1e15)],
+                         ids=["one-by-one-every-visit-a-new-table", "each-in-own-N-5000", "one-by-one-D16-grows-twice"])
+def test_k_max_none_means_up_to_N_components(init, D, alpha):
+    """VERDICT r4 missing #4: ``K_max=None`` is "N components" in the reference (gaussian_components.py:81-83).  Here the
+    device starts with max(1024, 4 K_init) slots and the sampler loop moves the chain into a context with twice the slots
+    at the visit that needs one more (gaussian_components.py: resume_in_larger_context) -- no BGMM_EKMAX short of N, and
+    the trajectory is the one of a chain that had all N slots from the start: the C oracle with K_max = N, two sweeps
+    through the classes with the caller's ``random`` stream."""
+    import random
+    from oracle import c_oracle
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    N = 5000
+    X, _ = gendata.synth_mixture(N, D, 6, seed=5 + D)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    random.seed(11)
+    mm = CRPMM(X, NIW(m_0, k_0, v_0, S_0), alpha, None, assignments=init)
+    assert mm.components.K_max_auto
+    k_start = mm.components.K_max
+    z0 = mm.components.assignments
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, alpha, z0, N, scipy_tables=False)
+    host = random.Random(11)
+    mm.record_metrics = False
+    for it in range(2):
+        mm.collapsed_gibbs_sampler(1, None, num_saved=0)
+        o.sweep(np.array([host.random() for _ in range(N)]))
+        bad = np.nonzero(mm.components.assignments != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(mm.log_marg() - lo) <= 1e-9 * abs(lo)
+    assert random.getstate() == host.getstate()
+    if init == "one-by-one":
+        assert mm.components.K > k_start, "the case is meant to outgrow the slots the context started with"
+        assert mm.components.K_max > k_start
+    else:
+        assert k_start == N
+    # an explicit K_max stays a hard limit, and the message names it
+    from pybgmm_amd import _lib
+    random.seed(11)
+    mm2 = CRPMM(X[:600], NIW(m_0, k_0, v_0, S_0), 1e300, None, assignments="one-by-one", K_max=64)
+    with pytest.raises(_lib.BGMMError) as ei:
+        mm2.collapsed_gibbs_sampler(1, None, num_saved=0)
+    assert ei.value.code == -3 and "K_max" in str(ei.value)
+
+
+def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle():
+    """C5's shape (PCRPMM, D = 128, full covariance) driven the way the classes drive it -- every sweep's
+    visiting order drawn ON THE DEVICE from a numpy RandomState (bgmm_stage_permutation_mt19937) and its uniforms from a
+    random.Random (bgmm_stage_mt19937) -- against numpy / random themselves value for value, and label for label against
+    the C oracle fed from twin generators on the host; powered weights from the second sweep on (pcrpmm.py:98-117).
+    Wrong labels sprinkled in so that the sweeps move (the D = 128 mover paths behind a device-drawn permutation)."""
+    import random
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata, rng as _rng
+    N, D, K = 10000, 128, 20
+    X, zt = gendata.synth_mixture(N, D, K, seed=59)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    z0 = zt.copy()
+    rs = np.random.RandomState(4)
+    idx = rs.choice(N, size=300, replace=False)
+    z0[idx] = rs.randint(0, K, size=300)
+    dev_r, host_r = random.Random(17), random.Random(17)
+    dev_np, host_np = np.random.RandomState(17), np.random.RandomState(17)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(z0)
+    moved = 0
+    for it in range(2):
+        order = host_np.permutation(N)
+        u = _rng.take_uniforms(N, host_r)
+        assert _rng.take_permutation_staged(ctx, N, dev_np) is _rng.STAGED
+        npt.assert_array_equal(ctx.staged_order(), order, err_msg="device permutation differs from numpy's")
+        assert _rng.stage_uniforms_on_device(ctx, None, dev_r)
+        npt.assert_array_equal(ctx.staged_uniforms(), u, err_msg="device uniforms differ from random.random()")
+        power = 1.01 if it else None
+        ctx.sweep_staged(power)
+        moved += ctx.sweep_stats()["moves"]
+        o.sweep(u, order, power)
+        bad = np.nonzero(ctx.assignments() != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+    assert moved >= 150, "the case is meant to repair its wrong labels"
+    assert dev_r.getstate() == host_r.getstate()
+    npt.assert_array_equal(dev_np.get_state()[1], host_np.get_state()[1])
+    assert dev_np.get_state()[2] == host_np.get_state()[2]
     ctx.close()

@@ -189,13 +189,13 @@ def test_wishart_draws_consume_the_streams_like_the_reference():
             a[r, :r] = np.random.normal(size=(r,))
         a[r, r] = np.sqrt(random.gammavariate(0.5 * (v0 - D + 1), 2.0))
     C = np.linalg.cholesky(sigma)
-    # (the product is associated differently -- L L' with L = C a: equal up to rounding, symmetric exactly)
-    npt.assert_allclose(W, C.dot(a).dot(a.T).dot(C.T), rtol=1e-13, atol=1e-15)
-    npt.assert_array_equal(W, W.T)
+    # (the reference's association and its solve(sample, I): a draw is the reference's bit for bit)
+    npt.assert_array_equal(W, C.dot(a).dot(a.T).dot(C.T))
     after = (random.random(), np.random.random_sample())
     random.seed(5)
     np.random.seed(6)
-    wishart.iwishrnd(sigma, v0, C)
+    Wi = wishart.iwishrnd(sigma, v0, C)
+    npt.assert_array_equal(Wi, np.linalg.solve(W, np.eye(D)))
     assert (random.random(), np.random.random_sample()) == after
 
 
