@@ -7,9 +7,12 @@ bench.py -- collapsed-Gibbs sweeps/s of the CRP Gaussian mixture on MI355X.
 
 A "step" is one full Gibbs sweep (N_data reassignment visits) of BASELINE.json's headline
 configuration, configs[3]: CRPMM, D=64, N=1e6, K~200, synthetic isotropic mixture (SURVEY.md 8d
-recipe).  Inputs (X, the per-visit uniforms of all timed sweeps) are resident in HBM before the timed
-region; the PCIe-inclusive rate is reported separately in `extra`.  The chains are replicas
-(SURVEY.md 8e): no data-path collective; one RCCL all-gather of the final labels after the timed region.
+recipe).  X is resident in HBM before the timed region; every sweep's N uniforms (and, for pCRP workloads,
+its np.random.permutation(N)) are GENERATED INSIDE the timed region, on the device, as the continuation of
+the chain's own MT19937 streams -- SURVEY 8(d)'s t_sweep = inputs + kernels, what the classes' sampler loops
+pay per sweep.  The rate with the inputs resident ahead of time and the PCIe-inclusive rate (host uniforms
+uploaded per sweep) are reported in `extra`, never as `value`.  The chains are replicas: no
+data-path collective; one RCCL all-gather of the final labels after the timed region.
 
 What `value` measures (--mode):
   evaluated (default)  the chain at the truth, every visit EVALUATED every sweep: its row of X is read,
@@ -26,6 +29,9 @@ The JSON line also carries
                   script (FETCH_SIZE, WRITE_SIZE, separate passes) run as child processes
   burnin       -- the mover-dense regime: the same workload from the reference's default "rand"
                   initialisation (igmm.py:86-94), sweep by sweep until fewer than 1 % of the visits move
+  class_api    -- the API the north star names: CRPMM / PCRPMM(X, NIW(..), 1.0, None, assignments=z_true)
+                  .collapsed_gibbs_sampler(n, z_true), median record["sample_time"] (gmm/gmm.py:76) with the per-sweep
+                  clustering metrics off and on, beside the C-ABI loop that `value` times
   cpu_baseline -- the C oracle (a port of the reference algorithm, 1 thread) on a bounded sample
 """
 import argparse
@@ -306,6 +312,47 @@ def inner_pmc(args):
     ctx.close()
 
 
+def class_api_leg(args, X, z_true, local_rank, abi_ms_per_step):
+    """The API the north star names (the timing is record_dict["sample_time"], reference
+    gmm/gmm.py:76): the model classes on the benchmarked workload, chain at the truth, the caller's two global generators
+    seeded as a reference script seeds them.  The classes run the library's default configuration; `evaluated` sets the
+    mode `value` is measured in (certified stays off) on the model's context before the sampler loop, so that the two
+    medians can be compared with the C-ABI loop directly.  record_metrics off / on = without / with the per-sweep
+    NMI / MI / VI / loss of the record dict (device contingency table + dispersion, gmm/gmm.py:85-104)."""
+    import random as _random
+    from pybgmm_amd.igmm import CRPMM, PCRPMM
+    from pybgmm_amd.prior import NIW
+    N, D, K, model = WORKLOADS[args.workload]
+    m_0, k_0, v_0, S_0 = prior_for("full", D)
+    cls = {"CRPMM": CRPMM, "PCRPMM": PCRPMM}[model]
+    out = {"call": "%s(X, NIW(m_0, k_0, v_0, S_0), 1.0, None, assignments=z_true, K_max=%d).collapsed_gibbs_sampler(n, z_true, "
+                   "num_saved=0)" % (model, 4 * K),
+           "c_abi_loop_ms_per_step": round(abi_ms_per_step, 4)}
+    n = 120 if N * D <= 64000000 else 60
+    for mode in ("evaluated", "default"):
+        for metrics in (False, True):
+            _random.seed(args.seed)
+            np.random.seed(args.seed)
+            mm = cls(X, NIW(m_0, k_0, v_0, S_0), 1.0, None, assignments=z_true, K_max=4 * K, device=local_rank)
+            mm.record_metrics = metrics
+            if mode == "evaluated":
+                mm.components._ctx.set_tuning(prune_mode=MODES["evaluated"])
+            t0 = time.time()
+            record, _ = mm.collapsed_gibbs_sampler(n, z_true, num_saved=0)
+            wall = time.time() - t0
+            st = np.array(record["sample_time"][n // 4:])
+            med = float(np.median(st))
+            out["%s_metrics_%s" % (mode, "on" if metrics else "off")] = {
+                "sweeps": n, "sample_time_median_ms": round(1e3 * med, 4), "sample_time_mean_ms": round(1e3 * float(st.mean()), 4),
+                "sweeps_per_s_from_sample_time": round(1.0 / med, 1),
+                "loop_wall_ms_per_sweep_incl_record": round(1e3 * wall / n, 4),
+                "moves_last_sweep": mm.components._ctx.sweep_stats()["moves"], "K": record["components"][-1],
+                "log_marg": record["log_marg"][-1]}
+            mm.components._ctx.close()
+    out["sample_time_over_c_abi_loop"] = round(out["evaluated_metrics_off"]["sample_time_median_ms"] / abi_ms_per_step, 3)
+    return out
+
+
 def burnin_leg(args, X, local_rank, K_true, seed):
     """The same data from the reference's default initialisation ("rand": uniform labels over K, igmm.py:86-94),
     swept until fewer than 1 % of the visits move (at most 6 sweeps)."""
@@ -433,6 +480,7 @@ def main():
     ap.add_argument("--burnin-chains", type=int, default=8,
                     help="chains of the burn-in leg's side-by-side measurement (D >= 12; 0 or 1: skip)")
     ap.add_argument("--no-moving", action="store_true", help="skip the steady_moving leg (overlapping clusters)")
+    ap.add_argument("--no-class-api", action="store_true", help="skip the class_api leg (CRPMM / PCRPMM.collapsed_gibbs_sampler)")
     ap.add_argument("--moving-sep", type=float, default=0.55, help="mu_scale of the steady_moving leg's data set")
     ap.add_argument("--numpy-visits", type=int, default=400, help="visits of the numpy-restatement CPU baseline (0 = skip)")
     ap.add_argument("--chains", type=int, default=-1,
@@ -777,6 +825,10 @@ def main():
         if args.burnin_chains > 1 and D >= 12:
             burnin["chains_side_by_side"] = burnin_chains_leg(args, X, local_rank, burnin["sweeps"][0])
 
+    class_api = None
+    if single and not args.no_class_api and args.cov == "full" and args.mode == "evaluated" and args.init == "true":
+        class_api = class_api_leg(args, X, z_true, local_rank, 1e3 * elapsed / args.steps)
+
     moving = None
     if single and not args.no_moving and args.cov == "full" and D >= 12:
         moving = steady_moving_leg(args, local_rank)
@@ -839,6 +891,7 @@ def main():
             "roofline": roofline,
             "burnin": burnin,
             "steady_moving": moving,
+            "class_api": class_api,
             "many_chains": many,
             "cpu_baseline": cpu,
             "extra": {"moves_per_sweep": moves_total / max(sweeps_total, 1),
