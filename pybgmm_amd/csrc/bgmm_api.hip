@@ -386,7 +386,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     d.choice_rows = choice_rows_for(K_max);
     DALLOC(c, d.q, (size_t)rows * d.nslots);
     DALLOC(c, d.choice, (size_t)rows);
-    DALLOC(c, d.wperm, (size_t)rows);
+    const size_t rows_pad = (size_t)rows + (size_t)kHomeBlock * (d.nslots + 2);   // (home_kernel's padded evaluation order)
+    DALLOC(c, d.wperm, rows_pad);
     {
         const size_t ng = ((size_t)d.nslots + 15) / 16;
         DALLOC(c, d.pr_mufrag, ng * (size_t)(d.Dp / 4) * 64);
@@ -394,7 +395,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.pr_slot, ng * 16);
         DALLOC(c, d.pr_dcc, (size_t)d.nslots * d.nslots);
         DALLOC(c, d.pr_rms, (size_t)d.nslots);
-        DALLOC(c, d.wrec, (size_t)rows);
+        DALLOC(c, d.wrec, rows_pad);
         DALLOC(c, d.wrecR, (size_t)rows);
         DALLOC(c, d.wpermR, (size_t)rows);
         DALLOC(c, d.pr_counts, 1024);
@@ -412,6 +413,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.keep64, (size_t)(rows / 16 + 1) * d.keep_stride);
     DALLOC(c, d.bucket_bins, ns + 4);
     CK(c, hipMemsetAsync(d.bucket_bins, 0, sizeof(int) * (ns + 4), c->stream));
+    DALLOC(c, d.bucket_end, 2 * (ns + 4));
     CK(c, hipHostMalloc((void **)&c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
     CK(c, hipHostMalloc((void **)&c->ctrl_pub, sizeof(Ctrl), hipHostMallocMapped));
     CK(c, hipHostGetDevicePointer((void **)&d.ctrl_pub, c->ctrl_pub, 0));
@@ -1351,6 +1353,9 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         c->grp_cap = seq_plan;
         return 1;
     }
+    // (sweep_begin opens the first window, and whether the kept bucket sort can serve it depends on the layout the
+    //  batch wants -- padded for the home pass: the view it gets must already say so)
+    d.use_home = (d.cov_type == COV_FULL && c->kind == KERNEL_MFMA && c->home_pass) ? 1 : 0;
     if (!resume) launch_sweep_begin(d, st);
     long long steps_done = 0;
     bool seq_ran = false;

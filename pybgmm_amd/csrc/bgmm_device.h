@@ -60,6 +60,7 @@ static constexpr int kGramMaxTerms = 128;
 static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a window may open (new components + the prior)
 // safe-stay windows: how far a column's count may drift from its frozen value inside one window (the bounds of
 // the proof pass hold for every count in that range)
+static constexpr int kHomeBlock = 256;    // rows per workgroup step of home_kernel (4 waves x 64); its evaluation order is padded to this per home
 static constexpr int kSafeDn = 16;
 static constexpr int kSafeList = 4096;   // unproven visits a proof pass lists (a stretch ends at the next one)
 static constexpr int kSafeResidSkip = 64; // a proof pass that leaves at most this many visits to the pruning kernel skips it (they are walked)
@@ -128,6 +129,11 @@ struct Ctrl {
     int retry_full;       // a lean step (certify only) met a visit it could not certify: queue full steps
     long long state_epoch;  // bumped by every change of the sampler's state (move, rebuild, new seating weights)
     int n_sorted;         // rows of the open pruned window that went through the bucket sort (the uncertified ones)
+    // home_kernel's evaluation order is PADDED (kernels_state.hip: bucket_prefix_kernel): every home's run of rows starts
+    // at a multiple of kHomeBlock, the slots behind its last row hold dead records (i = -1) -- no block of kHomeBlock
+    // rows holds two homes.  n_sorted_pad = extent of that layout (0: the sort was made unpadded); wsort_padded: the kept
+    // sort (wsort_valid) is a padded one -- reusable only by a batch that wants the same layout
+    int n_sorted_pad, wsort_padded;
     long long home_in, home_out;   // this sweep: rows home_kernel looked at / rows it had to pass on
     int n_resid;          // of those, the rows home_kernel could not decide (the pruning kernel's work list; kernels_home.hip)
     long long wsort_base, wsort_hi;
@@ -266,6 +272,7 @@ struct Dev {
     double *q;
     int *choice;
     int *bucket_bins;            // nslots + 2 counters of the per-window bucket sort
+    int *bucket_end;             // [2][nslots + 2] of the last sort: end of bin b's live rows / start of the next bin (the pad between them)
     unsigned long long *keep64;  // pruned windows: per 16-visit block, bitmask over labels of the kept q lines
     int keep_stride;             // 64-bit words per block of keep64
     // pruned windows: per group of 16 labels (label-ordered, rebuilt at the start of every pruned

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
     constexpr int NS = home_slots(NJ);
-    const long long nrows = c->n_sorted;
+    const long long nrows = c->n_sorted_pad;                          // (every home's run padded to whole blocks: bucket_prefix_kernel)
     const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         const bool ok_after = b + 2 < b1 && k_after < nrows;
         i_after = d.wrec[ok_after ? k_after : 0].i;
         const int hf = __builtin_amdgcn_readfirstlane(hf_cur), hl = __builtin_amdgcn_readfirstlane(hl_cur);
+#ifdef HX_NOGENERAL
+        const bool one_home = hf >= 0;
+#else
         const bool one_home = hf == hl && hf >= 0;                    // (the same decision in all four wavefronts)
+#endif
         HP(6)
         if (one_home && hf != cur_home) {
             __syncthreads();                                          // everybody is done with the previous home
@@ -306,8 +310,10 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     // (the distance to the home's mean, one block of 16 columns per block row: four constants live at a
                     //  time instead of D/4, and the FP64 VALU work spread between the MFMAs)
                     asm volatile("" ::: "memory");
+#ifndef HX_NODPART
 #pragma unroll
                     for (int kk = 4 * J; kk < 4 * J + 4; ++kk) { const double tq = xf[kk] - hmu[4 * kk + lk]; dpart = fma(tq, tq, dpart); }
+#endif
                     const double cj = hcv[16 * J + lr];
                     v4d acc = (v4d){cj, cj, cj, cj};
 #pragma unroll
@@ -452,6 +458,10 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #endif
             if (live) d.cert[wrow_cur] = safe ? 1 : 0;
             easy = !resid;
+#ifdef HX_NOTAIL
+        } else if (live && hmine >= 0) {
+            easy = sideQ[lane] + sideRho[lane] > -1.0;
+#endif
         } else if (live && hmine >= 0) {
             const double q_t = sideQ[lane], rho2_t = sideRho[lane];
             const int a = rcur.home_label;
@@ -569,7 +579,7 @@ static int home_cu_count() {
 
 template <int NJ, bool WHOLE>
 static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
-    const long long want = (max_rows + 255) / 256;
+    const long long want = (max_rows + 255) / 256 + d.nslots + 1;     // (+ the pads of the evaluation order: at most one block per bin)
     const long long cap = (long long)home_waves_per_simd(NJ) * home_cu_count();      // (a workgroup = one wavefront per SIMD)
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     constexpr int lds = home_lds_bytes(NJ * 16);

@@ -668,25 +668,47 @@ __global__ __launch_bounds__(256) void prune_ftable_kernel(Dev d) {
 
 // exclusive prefix over the bins of the bucket sort (one block)
 __global__ __launch_bounds__(1024) void bucket_prefix_kernel(Dev d) {
-    __shared__ int wsum_[16];
+    __shared__ int wsum_[16], wlive_[16];
     const Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->skip_sort || (d.safe_mode && c->safe_epoch_valid)) return;
     const int nb = d.nslots + 1;
+    // home_kernel walks the order in blocks of kHomeBlock rows with the block's home factor in LDS: a block that
+    // straddled two homes took a path three times as long, and the kernel lasts as long as its slowest workgroup
+    // (measured at C4: 131 us with one component, 155 with 200).  So with the home pass in front every bin's run is
+    // padded to a multiple of kHomeBlock (bucket_scatter_kernel fills the pad with dead records); the other consumers
+    // of the order (the pruning kernels without a home pass in front) get it compact.
+    const bool pad = d.use_home != 0;
     // exclusive prefix over nb <= ~1k bins: every thread owns a contiguous run
     const int per = (nb + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
-    int local = 0;
-    for (int b = lo; b < hi; ++b) local += d.bucket_bins[b];
-    int incl = local;
+    auto padded = [&](int v) { return pad ? (v + kHomeBlock - 1) / kHomeBlock * kHomeBlock : v; };
+    int local = 0, live = 0;
+    for (int b = lo; b < hi; ++b) { const int v = d.bucket_bins[b]; local += padded(v); live += v; }
+    int incl = local, incl_live = live;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wsum_[w] = incl;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o), tl = __shfl_up(incl_live, o);
+        if (lane >= o) { incl += t; incl_live += tl; }
+    }
+    if (lane == 63) { wsum_[w] = incl; wlive_[w] = incl_live; }
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < w; ++k) woff += wsum_[k];
     int run = woff + incl - local;
-    for (int b = lo; b < hi; ++b) { const int v = d.bucket_bins[b]; d.bucket_bins[b] = run; run += v; }
-    if (threadIdx.x == 1023) d.ctrl->n_sorted = run;          // rows that take part (all but the certified ones)
+    for (int b = lo; b < hi; ++b) {
+        const int v = d.bucket_bins[b];
+        d.bucket_bins[b] = run;
+        d.bucket_end[b] = run + v;
+        run += padded(v);
+        d.bucket_end[nb + 1 + b] = run;
+    }
+    if (threadIdx.x == 1023) {
+        int total_live = 0;
+        for (int k = 0; k < 16; ++k) total_live += wlive_[k];
+        d.ctrl->n_sorted = total_live;                        // rows that take part (all but the certified ones)
+        d.ctrl->n_sorted_pad = pad ? run : 0;                 // extent of the padded layout
+        d.ctrl->wsort_padded = pad ? 1 : 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
@@ -696,8 +718,24 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
     const int r0 = blockIdx.x * BUCKET_ROWS;
-    if (r0 >= nrows) return;
     const int nb = d.nslots + 1;
+    // the pads of the padded layout (home_kernel's): dead records that carry their bin's home, so that a block reads as
+    // one home from its first row to its last  (every block of the grid takes its share, also those beyond the window)
+    if (d.use_home)
+        for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+            const int e0 = d.bucket_end[b], e1 = d.bucket_end[nb + 1 + b];
+            for (int k = e0 + threadIdx.x; k < e1; k += 256) {
+                WRec rec;
+                rec.i = -1;
+                rec.home = b - 1;
+                rec.home_label = -1;
+                rec.mlb0 = 0.0;
+                rec.pad = 0.0;
+                d.wrec[k] = rec;
+                d.wperm[k] = 0;
+            }
+        }
+    if (r0 >= nrows) return;
     int *cnt = lds, *res = lds + nb;
     for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
     __syncthreads();

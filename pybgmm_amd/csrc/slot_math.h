@@ -450,7 +450,8 @@ __device__ inline void start_window(const Dev &d, Ctrl *c, long long pos) {
     j.n_dirty = 0;
     j.prune = 0;
     // (with certify_kernel in front the sorted subset follows its verdicts: re-sorted every time)
-    c->skip_sort = (!d.use_certify && c->wsort_valid && c->wsort_base == pos && c->wsort_hi == hi) ? 1 : 0;
+    c->skip_sort = (!d.use_certify && c->wsort_valid && c->wsort_base == pos && c->wsort_hi == hi &&
+                    c->wsort_padded == (d.use_home ? 1 : 0)) ? 1 : 0;
     if (pos >= c->n_visits) {
         j.mode = MODE_DONE;
     } else {

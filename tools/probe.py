@@ -61,9 +61,9 @@ def start_labels(init, zt, K, rs, flip=0):
 
 
 def chain(a, quiet=False):
-    if a.prof:
+    if a.prof or a.lib:
         from pybgmm_amd import _build
-        _build.LIB = os.path.join(os.path.dirname(_build.LIB), "libbgmm_hip_prof.so")
+        _build.LIB = os.path.join(os.path.dirname(_build.LIB), "libbgmm_hip_%s.so" % (a.lib or "prof"))
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
     N, D, K = a.N, a.D, a.K
@@ -330,6 +330,7 @@ def parser():
     c.add_argument("--oracle", action="store_true")
     c.add_argument("--timing", action="store_true")
     c.add_argument("--prof", action="store_true")
+    c.add_argument("--lib", default="", help="load libbgmm_hip_<name>.so (tools/build_variant.sh)")
     sub.add_parser("safe-check")
     k = sub.add_parser("classes")
     for n in ("N", "D", "K"):
