@@ -403,6 +403,8 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.cert, (size_t)rows);
         DALLOC(c, d.ftab, (size_t)d.nslots * 64);
         DALLOC(c, d.finv, (size_t)d.nslots);
+        DALLOC(c, d.ftab2, (size_t)d.nslots * 64);
+        DALLOC(c, d.nbr, (size_t)d.nslots * 4);
     }
     DALLOC(c, d.glist, (size_t)kSafeList + 1);
     DALLOC(c, d.ep_state, ns);

@@ -60,6 +60,7 @@ static constexpr int kGramMaxTerms = 128;
 static constexpr int kGramColSlack = kGramMaxTerms / 2 + 2;   // columns a window may open (new components + the prior)
 // safe-stay windows: how far a column's count may drift from its frozen value inside one window (the bounds of
 // the proof pass hold for every count in that range)
+static constexpr int kHomeNbr = 4;        // neighbours of a home that home_kernel scores exactly (D <= 32)
 static constexpr int kHomeBlock = 256;    // rows per workgroup step of home_kernel (4 waves x 64); its evaluation order is padded to this per home
 static constexpr int kSafeDn = 16;
 static constexpr int kSafeList = 4096;   // unproven visits a proof pass lists (a stretch ends at the next one)
@@ -256,6 +257,11 @@ struct Dev {
     unsigned char *cert;         // pruned windows, per window row: 1 = certify_kernel proved that the visit stays
     double *ftab, *finv;         // per home label a: ftab[a][j] = upper bound of every other component's score for
                                  // a visit of a at distance <= j / finv[a] from a's mean, j = 0 .. 63
+    // home_kernel scores the home's nearest neighbours EXACTLY where the table above cannot exclude them (clusters a
+    // dozen sigma apart, D <= 32): nbr[a][0 .. kHomeNbr) = the labels whose bound at the largest tabulated radius is
+    // highest, ascending (-1: none), ftab2[a][j] = the bound of ftab over every label but a and those
+    int *nbr;
+    double *ftab2;
     int seat_dirty;              // this sweep's seating weights differ from the last sweep's (exponent changed)
     int use_certify;             // 1: certify_kernel runs in front of the bucket sort (which then skips its rows)
     int lean_step;               // 1: this batch queues certify_kernel WITHOUT the pruning and draw kernels (the

@@ -59,9 +59,14 @@ static constexpr double kHomeFar = 80.0;             // beyond this the excluded
 
 // LDS plan (doubles).  Per workgroup: the home's factor fragments (permuted), cvec, mu (permuted, zero padded),
 // its row of ftab, 16 scalars; per wavefront: quadratic forms, distances, home slots of its 64 rows.
-__host__ __device__ constexpr int home_wave_doubles() { return 64 + 64 + 32; }
-__host__ __device__ constexpr int home_shared_doubles(int Dp) { return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16 + 8; }
-__host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles()) * 8; }
+// neighbours scored exactly (kHomeNbr of them) up to D = 32: their fragments, cvec and 8 scalars each + the second
+// bound table + the candidates' order; per wavefront their quadratic forms
+__host__ __device__ constexpr int home_nbr(int Dp) { return Dp <= 32 ? kHomeNbr : 0; }
+__host__ __device__ constexpr int home_wave_doubles(int Dp) { return 64 + 64 + 32 + 64 * home_nbr(Dp); }
+__host__ __device__ constexpr int home_shared_doubles(int Dp) {
+    return bgmm_nfrag(Dp) * 64 + 2 * Dp + 64 + 16 + 8 + (home_nbr(Dp) ? home_nbr(Dp) * (bgmm_nfrag(Dp) * 64 + Dp + 8) + 64 + 8 : 0);
+}
+__host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_doubles(Dp) + 4 * home_wave_doubles(Dp)) * 8; }
 // wavefronts per SIMD (a tile of 16 rows is 2 D/16 registers; one in the matrix pipe, one on its way): two up to
 // D = 64, one above (at two the D = 128 kernel spills, and a scratch access waits for every row load in flight)
 __host__ __device__ constexpr int home_waves_per_simd(int NJ) {
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
     constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
     constexpr int NS = home_slots(NJ);
+    constexpr int NB = WHOLE ? home_nbr(NJ * 16) : 0;                 // neighbours of the home scored exactly (D = 16, 32)
     const long long nrows = c->n_sorted_pad;                          // (every home's run padded to whole blocks: bucket_prefix_kernel)
     const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
@@ -139,9 +145,19 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     LDS_AS double *const hft = hmu + Dp;                              // ftab[label of the home][64]
     LDS_AS double *const hsc = hft + 64;                              // SlotConst (12), finv, (n, version)
     LDS_AS double *const hsr = hsc + 16;                              // safe-stay windows: the home's robust constants (rtab row)
-    LDS_AS double *const sideQ = hsr + 8 + w * home_wave_doubles();   // exact home form of row rho [64]
+    // (NB > 0) the neighbours: fragments [NB][NF][64], cvec [NB][Dp], scalars [NB][8] = {logseat + A, half_vd, inv_cv, label,
+    // slot}, the second bound table [64], [8] ints: how many neighbours, then the candidates (home = -1, neighbour m) in
+    // label order
+    LDS_AS double *const nBf = hsr + 8;
+    LDS_AS double *const ncv = nBf + NB * NF * 64;
+    LDS_AS double *const nsc = ncv + NB * Dp;
+    LDS_AS double *const hft2 = nsc + NB * 8;
+    LDS_AS int *const ncand = (LDS_AS int *)(hft2 + (NB ? 64 : 0));
+    LDS_AS double *const wave0 = hsr + 8 + (NB ? NB * (NF * 64 + Dp + 8) + 64 + 8 : 0);
+    LDS_AS double *const sideQ = wave0 + w * home_wave_doubles(Dp);   // exact home form of row rho [64]
     LDS_AS double *const sideRho = sideQ + 64;                        // |x - mu_home|^2 [64]
     LDS_AS int *const sideH = (LDS_AS int *)(sideRho + 64);           // home slot [64]
+    LDS_AS double *const sideQn = sideRho + 64 + 32;                  // (NB > 0) [NB][64] the rows' forms under the neighbours
     const bool keep_caches = d.use_certify != 0;                      // (nobody reads the per-point caches otherwise)
     const long long win_base = c->job.win_base;
     const long long epoch = c->state_epoch;
@@ -244,29 +260,66 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         HP(6)
         if (one_home && hf != cur_home) {
             __syncthreads();                                          // everybody is done with the previous home
-            const double *__restrict__ src = d.Wfrag + (long long)hf * (NF * 64);
             // (read in storage order, two doubles per thread and step; written where the permutation puts them:
             //  column c16 = 4 (ks % 4) + lks of its block goes to k-slice 2 (c16 / 8) + (c16 & 1), k-lane (c16 & 7) / 2
             //  -- six loads in flight per thread: one round trip to L2 per batch instead of one per piece)
-            constexpr int FB = 6;
-            for (int e0 = tid; e0 < NF * 32; e0 += 256 * FB) {
-                home_d2 v[FB];
+            auto copy_factor = [&](int slot, LDS_AS double *dstB) {
+                const double *__restrict__ src = d.Wfrag + (long long)slot * (NF * 64);
+                constexpr int FB = 6;
+                for (int e0 = tid; e0 < NF * 32; e0 += 256 * FB) {
+                    home_d2 v[FB];
 #pragma unroll
-                for (int k = 0; k < FB; ++k) {
-                    const int e2 = e0 + 256 * k;
-                    v[k] = ((const home_d2 *)src)[e2 < NF * 32 ? e2 : tid];
+                    for (int k = 0; k < FB; ++k) {
+                        const int e2 = e0 + 256 * k;
+                        v[k] = ((const home_d2 *)src)[e2 < NF * 32 ? e2 : tid];
+                    }
+#pragma unroll
+                    for (int k = 0; k < FB; ++k) {
+                        const int e2 = e0 + 256 * k;
+                        const int e = 2 * e2, f = e >> 6, ln = e & 63;       // lanes ln, ln + 1: same fragment, same k-lane
+                        const int ks = f & 3, lks = ln >> 4;                  // (2 J (J + 1) is a multiple of 4)
+                        const int c16 = 4 * ks + lks;
+                        const int dst = (f - ks + 2 * (c16 >> 3) + (c16 & 1)) * 64 + (ln & 15) + 16 * ((c16 & 7) >> 1);
+                        if (e2 < NF * 32) { dstB[dst] = v[k].x; dstB[dst + 1] = v[k].y; }
+                    }
                 }
+            };
+            copy_factor(hf, Bf);
+            const int a = d.label_of_slot[hf];
+            if (NB > 0 && !d.safe_mode) {
+                // the home's neighbours (prune_ftable_kernel): factor, cvec, the constants of the as-is predictive
+                const int *__restrict__ nl = d.nbr + (long long)a * 4;
+                int nn = 0;
 #pragma unroll
-                for (int k = 0; k < FB; ++k) {
-                    const int e2 = e0 + 256 * k;
-                    const int e = 2 * e2, f = e >> 6, ln = e & 63;       // lanes ln, ln + 1: same fragment, same k-lane
-                    const int ks = f & 3, lks = ln >> 4;                  // (2 J (J + 1) is a multiple of 4)
-                    const int c16 = 4 * ks + lks;
-                    const int dst = (f - ks + 2 * (c16 >> 3) + (c16 & 1)) * 64 + (ln & 15) + 16 * ((c16 & 7) >> 1);
-                    if (e2 < NF * 32) { Bf[dst] = v[k].x; Bf[dst + 1] = v[k].y; }
+                for (int m = 0; m < NB; ++m) {
+                    const int t = nl[m];
+                    if (t < 0) continue;
+                    const int s = d.perm[t];
+                    copy_factor(s, nBf + nn * NF * 64);
+                    for (int e = tid; e < Dp; e += 256) ncv[nn * Dp + e] = d.cvec[(long long)s * d.Dp + e];
+                    if (tid == 100 + m) {
+                        const SlotConst sc = d.sc[s];
+                        nsc[nn * 8 + 0] = sc.logseat + sc.A; nsc[nn * 8 + 1] = sc.half_vd; nsc[nn * 8 + 2] = sc.inv_cv;
+                        LDS_AS int *ni = (LDS_AS int *)(nsc + nn * 8 + 3);
+                        ni[0] = t; ni[1] = s;
+                    }
+                    ++nn;
+                }
+                if (tid >= 128 && tid < 192) hft2[tid - 128] = d.ftab2[(long long)a * 64 + (tid - 128)];
+                if (tid == 95) {
+                    // the candidates in label order: the neighbours come sorted, the home goes in where its label belongs
+                    ncand[0] = nn;
+                    int pos = 1, mm = 0;
+                    bool home_in = false;
+                    for (int m = 0; m < NB; ++m) {
+                        const int t = nl[m];
+                        if (t < 0) continue;
+                        if (!home_in && a < t) { ncand[pos++] = -1; home_in = true; }
+                        ncand[pos++] = mm++;
+                    }
+                    if (!home_in) ncand[pos++] = -1;
                 }
             }
-            const int a = d.label_of_slot[hf];
             for (int e = tid; e < Dp; e += 256) {
                 hcv[e] = d.cvec[(long long)hf * d.Dp + e];
                 const int col = 16 * (e >> 4) + home_col((e >> 2) & 3, e & 3);     // e = 4 kk + lk
@@ -336,6 +389,28 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 dpart += __shfl_xor(dpart, 16);
                 dpart += __shfl_xor(dpart, 32);
                 if (lk == 0) sideRho[r0 + lr] = dpart;
+                if (NB > 0 && !d.safe_mode) {
+                    // ---- the same rows under the home's neighbours (their as-is forms: nobody is removed from them)
+                    const int nn = __builtin_amdgcn_readfirstlane(ncand[0]);
+#pragma unroll 1
+                    for (int m = 0; m < nn; ++m) {
+                        LDS_AS const double *const wn = nBf + m * NF * 64 + lane;
+                        double qn[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int J = 0; J < NJ; ++J) {
+                            const double cj = ncv[m * Dp + 16 * J + lr];
+                            v4d acc = (v4d){cj, cj, cj, cj};
+#pragma unroll
+                            for (int kk = 0; kk < 4 * (J + 1); ++kk)
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], wn[(2 * J * (J + 1) + kk) * 64], acc, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qn[r] = fma(acc[r], acc[r], qn[r]);
+                        }
+                        n_mfma += NF;
+                        const double v = home_row_sum4(qn, lane);
+                        if (lr < 4) sideQn[m * 64 + r0 + lk + 4 * lr] = v;
+                    }
+                }
                 }
                 HP(3)
             }
@@ -526,6 +601,65 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                         d.pcache2[imine] = pe;
                     }
                     if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
+                } else if (NB > 0 && one_home && den > 0.0 && jf < 62.0) {
+                    // ---- the table could not exclude everybody: the home's neighbours exactly, everyone else by the second
+                    // table.  The reference's arithmetic over the candidates that are left (crpmm.py:75, utils.py:15-20, as
+                    // choice_sparse_kernel does it): scores in label order, exp(v - logsumexp), u -= p.
+                    const int nn = ncand[0];
+                    double vn[NB > 0 ? NB : 1];
+                    double mx2 = mx;
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) {
+                        vn[m] = -INFINITY;
+                        if (m < nn) {
+                            const double qm = sideQn[m * 64 + lane];
+                            vn[m] = nsc[m * 8] - nsc[m * 8 + 1] * fm_log(1.0 + qm * nsc[m * 8 + 2]);
+                            mx2 = fmax(mx2, vn[m]);
+                        }
+                    }
+                    if (hft2[(int)jf + 1] < mx2 - margin) {
+                        easy = true;
+                        const long long p = win_base + wrow_cur;
+                        const double u_cur = d.u[p];
+                        double tot = 0.0, toth = 0.0;
+#pragma unroll
+                        for (int ci = 0; ci < NB + 1; ++ci) {
+                            if (ci > nn) continue;
+                            const int who = ncand[1 + ci];
+                            double v = vh;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m) v = who == m ? vn[m] : v;
+                            const double e = fm_exp(v - mx2);
+                            tot += e;
+                            if (who >= 0) toth += e;
+                        }
+                        { const double e = fm_exp(vnew - mx2); tot += e; toth += e; }
+                        const double lse = fm_log(tot) + mx2;
+                        double uu = u_cur;
+                        int pick = K;
+#pragma unroll
+                        for (int ci = 0; ci < NB + 1; ++ci) {
+                            if (ci > nn || pick != K) continue;
+                            const int who = ncand[1 + ci];
+                            double v = vh;
+                            int lab = a;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m)
+                                if (who == m) { v = vn[m]; lab = ((LDS_AS const int *)(nsc + m * 8 + 3))[0]; }
+                            uu -= fm_exp(v - lse);
+                            if (uu < 0.0) pick = lab;
+                        }
+                        if (pick != a) d.choice[wrow_cur] = pick;
+                        if (keep_caches) {
+                            PCacheExact pe;
+                            pe.epoch = epoch;
+                            const double b2 = hft2[(int)jf + 1];
+                            const double rest = b2 < mx2 - kHomeFar ? 1.8048513878454153e-35 : fm_exp(b2 - mx2);
+                            pe.log_alt = mx2 - vh + fm_log(toth + (double)K * rest);
+                            d.pcache2[imine] = pe;
+                        }
+                        if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
+                    }
                 }
             }
         }

@@ -627,6 +627,7 @@ __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
 // in j.  Runs after prune_tables_kernel (same validity flag, set by apply_kernel afterwards).
 __global__ __launch_bounds__(256) void prune_ftable_kernel(Dev d) {
     __shared__ double red[4][64];
+    __shared__ int nbl[4];
     const Ctrl *c = d.ctrl;
     if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid || (d.safe_mode && c->safe_epoch_valid)) return;
     // thread = (radius j, quarter of the labels): the other labels are dealt to the four wavefronts, a maximum each
@@ -644,11 +645,9 @@ __global__ __launch_bounds__(256) void prune_ftable_kernel(Dev d) {
     const double rms = d.pr_rms[a];
     const double step = K > 1 ? (rms > 0.0 ? 2.0 * rms : 0.5 * dmin) / 63.0 : 1.0;
     const double rj = (double)j * step * (1.0 + 1e-9);
-    double f = -INFINITY;
-    for (int t = part; t < K; t += 4) {
-        if (t == a) continue;
+    auto ub = [&](int t, double r) {
         const double *__restrict__ g = d.pr_const + (long long)(t >> 4) * 128 + (t & 15);
-        double dl = dc[t] * (1.0 - 1e-9) - rj;
+        double dl = dc[t] * (1.0 - 1e-9) - r;
         dl = dl > 0.0 ? dl : 0.0;
         const double tt = dl * dl * g[32];
         // (log1p_lower of kernels_prune.hip, restated: frexp + chord)
@@ -656,13 +655,57 @@ __global__ __launch_bounds__(256) void prune_ftable_kernel(Dev d) {
         const double m = __builtin_amdgcn_frexp_mant(y);
         const int e = __builtin_amdgcn_frexp_exp(y);
         const double L = 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
-        f = fmax(f, g[0] - g[16] * (fixed ? tt : L));
-    }
+        return g[0] - g[16] * (fixed ? tt : L);
+    };
+    double f = -INFINITY;
+    for (int t = part; t < K; t += 4)
+        if (t != a) f = fmax(f, ub(t, rj));
     red[part][j] = f;
+    // the home's neighbours (home_kernel scores them exactly, full covariance): the kHomeNbr labels whose bound at the
+    // largest tabulated radius is highest -- wave 0, lane = label mod 64, kHomeNbr rounds of a wave-wide arg max
+    if (part == 0) {
+        const double r63 = 63.0 * step * (1.0 + 1e-9);
+        int picked[kHomeNbr];
+        for (int m = 0; m < kHomeNbr; ++m) {
+            double best = -INFINITY;
+            int bt = -1;
+            for (int t = j; t < K; t += 64) {
+                if (t == a) continue;
+                bool taken = false;
+                for (int q = 0; q < m; ++q) taken = taken || picked[q] == t;
+                if (taken) continue;
+                const double v = ub(t, r63);
+                if (v > best || bt < 0) { best = v; bt = t; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(best, o);
+                const int ot = __shfl_xor(bt, o);
+                if (ot >= 0 && (bt < 0 || ov > best || (ov == best && ot < bt))) { best = ov; bt = ot; }
+            }
+            picked[m] = bt;                                   // (-1: fewer than m + 1 other labels)
+        }
+        // ascending by label (the draw walks its candidates in label order), -1 last
+        for (int x = 0; x < kHomeNbr; ++x)
+            for (int y = x + 1; y < kHomeNbr; ++y) {
+                const int px = picked[x], py = picked[y];
+                if (py >= 0 && (px < 0 || py < px)) { picked[x] = py; picked[y] = px; }
+            }
+        static_assert(kHomeNbr <= 4, "nbr holds four labels per home");
+        if (j < 4) { const int v = j < kHomeNbr ? picked[j < kHomeNbr ? j : 0] : -1; nbl[j] = v; d.nbr[(long long)a * 4 + j] = v; }
+    }
+    __syncthreads();
+    // the same bound over every label but the home and its neighbours
+    double f2 = -INFINITY;
+    for (int t = part; t < K; t += 4)
+        if (t != a && t != nbl[0] && t != nbl[1] && t != nbl[2] && t != nbl[3]) f2 = fmax(f2, ub(t, rj));
+    f = fmax(fmax(red[0][j], red[1][j]), fmax(red[2][j], red[3][j]));
+    __syncthreads();
+    red[part][j] = f2;
     __syncthreads();
     if (part != 0) return;
-    f = fmax(fmax(red[0][j], red[1][j]), fmax(red[2][j], red[3][j]));
+    f2 = fmax(fmax(red[0][j], red[1][j]), fmax(red[2][j], red[3][j]));
     d.ftab[(long long)a * 64 + j] = f;
+    d.ftab2[(long long)a * 64 + j] = f2;
     if (j == 0) d.finv[a] = (step > 0.0 && step < INFINITY) ? 1.0 / step : 0.0;
 }
 
