@@ -1176,7 +1176,7 @@ struct GramCombiner {
     }
 };
 
-static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T);
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
 
 // Returns 0: the batch has been queued with the group's (the chain's stream waits for it); 1: queue it yourself; < 0: error.
 static int combiner_submit(bgmm_ctx *c, int T) {
@@ -1209,9 +1209,10 @@ static int combiner_submit(bgmm_ctx *c, int T) {
             }
         }
         int rc = 1;
+        std::vector<hipEvent_t> ev_of;                  // per member: the event its stream waits for (its sub-group's)
         if (members.size() >= 2) {
             lk.unlock();
-            rc = gram_group_launch(G, members, Tmax);
+            rc = gram_group_launch(G, members, Tmax, ev_of);
             lk.lock();
             if (rc == 0) { G.shared_batches += 1; G.shared_members += (long long)members.size(); }
         }
@@ -1220,9 +1221,10 @@ static int combiner_submit(bgmm_ctx *c, int T) {
         for (size_t k = 0; k < G.slots.size(); ++k) {
             GramCombiner::Slot &o = G.slots[k];
             if (o.state != GramCombiner::WAITING) continue;
-            const bool member = std::find(members.begin(), members.end(), (int)k) != members.end() && members.size() >= 2;
+            const auto it = std::find(members.begin(), members.end(), (int)k);
+            const bool member = it != members.end() && members.size() >= 2;
             o.result = member ? rc : 1;
-            o.ev = (member && rc == 0) ? c->grp_ev_out : nullptr;
+            o.ev = (member && rc == 0) ? ev_of[(size_t)(it - members.begin())] : nullptr;
             o.state = GramCombiner::UNKNOWN;
         }
         G.leader = -1;
@@ -1231,15 +1233,22 @@ static int combiner_submit(bgmm_ctx *c, int T) {
     const int result = S.result;
     hipEvent_t ev = S.ev;
     lk.unlock();
-    if (result == 0 && ev && ev != c->grp_ev_out) {
+    if (result == 0 && ev && ev != c->grp_ev_out) {       // (a sub-group's leader queued the batch on its own stream)
         if (hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess) return BGMM_EDEVICE;
     }
     return result;
 }
 
-static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T) {
+// The shared batch is queued as a few SUB-GROUPS, each on the stream of its first member: the one-workgroup resolvers of
+// one sub-group run beside the wide kernels (cross forms, rebuilds) of the others -- with every chain in ONE launch
+// sequence the chip idles through each window's resolver phase and the resolvers wait through its wide phases (eight
+// C4 chains: 201 + 132 us per window whatever runs beside them).  One stream per chain, the other extreme, keeps only
+// about four kernels in flight and stretches every one of them.  BGMM_GROUP_SPLIT
+// overrides the number of sub-groups (1: one launch sequence for all).
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of) {
     bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
     const int m = (int)members.size();
+    ev_of.assign((size_t)m, nullptr);
     if (hipSetDevice(lead->device) != hipSuccess) return 1;
     if (lead->grp_devs_cap < m) {
         if (lead->grp_devs) (void)hipFree(lead->grp_devs);
@@ -1247,25 +1256,41 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
         if (hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m) != hipSuccess) return 1;
         lead->grp_devs_cap = m;
     }
+    static const int split_env = [] { const char *e = getenv("BGMM_GROUP_SPLIT"); return e ? atoi(e) : 0; }();
+    int n_sub = split_env > 0 ? split_env : (m >= 4 ? 2 : 1);
+    if (n_sub > m / 2) n_sub = m / 2 > 0 ? m / 2 : 1;
     std::vector<Dev> views((size_t)m);
-    int reach = 0;
-    for (int k = 0; k < m; ++k) {
-        bgmm_ctx *o = G.slots[(size_t)members[(size_t)k]].c;
-        views[(size_t)k] = o->d;
-        const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
-        if (r > reach) reach = r;
-        // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
-        if (o != lead && hipStreamWaitEvent(lead->stream, o->grp_ev_in, 0) != hipSuccess) return 1;
+    std::vector<int> reach_of((size_t)n_sub, 0), lo_of((size_t)n_sub + 1, 0);
+    for (int g = 0; g <= n_sub; ++g) lo_of[(size_t)g] = (int)((long long)m * g / n_sub);
+    for (int g = 0; g < n_sub; ++g) {
+        bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+        for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k) {
+            bgmm_ctx *o = G.slots[(size_t)members[(size_t)k]].c;
+            views[(size_t)k] = o->d;
+            const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
+            if (r > reach_of[(size_t)g]) reach_of[(size_t)g] = r;
+            // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
+            if (o != sl && hipStreamWaitEvent(sl->stream, o->grp_ev_in, 0) != hipSuccess) return 1;
+            ev_of[(size_t)k] = sl->grp_ev_out;
+        }
     }
     // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
     // have been waited for by every one of its members)
     if (hipMemcpy(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
     // (from here on a failure is an error for every member, not a reason to queue their batches separately: part of the shared
     // batch may already be in the queue, and separate launches would run beside it on the same chains)
+    // window by window across the sub-groups, so that the host queues them at the same pace
     for (int t = 0; t < T; ++t)
-        if (!launch_gram_group_step(lead->d, lead->grp_devs, m, reach, lead->gram_lds, lead->stream)) return BGMM_EDEVICE;
+        for (int g = 0; g < n_sub; ++g) {
+            bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+            if (!launch_gram_group_step(sl->d, lead->grp_devs + lo_of[(size_t)g], lo_of[(size_t)g + 1] - lo_of[(size_t)g],
+                                        reach_of[(size_t)g], sl->gram_lds, sl->stream)) return BGMM_EDEVICE;
+        }
     if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
-    if (hipEventRecord(lead->grp_ev_out, lead->stream) != hipSuccess) return BGMM_EDEVICE;
+    for (int g = 0; g < n_sub; ++g) {
+        bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+        if (hipEventRecord(sl->grp_ev_out, sl->stream) != hipSuccess) return BGMM_EDEVICE;
+    }
     return 0;
 }
 

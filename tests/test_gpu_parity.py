@@ -2474,3 +2474,39 @@ def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle():
     npt.assert_array_equal(dev_np.get_state()[1], host_np.get_state()[1])
     assert dev_np.get_state()[2] == host_np.get_state()[2]
     ctx.close()
+
+
+def test_thirty_two_chains_burn_in_side_by_side_and_equal_their_solo_runs():
+    """G = 32 chains of one shape from the reference's "rand" start in ONE group call -- their frozen-factor
+    windows shared in two sub-groups of launches on two streams (bgmm_api.hip: gram_group_launch), a host thread each --
+    every chain label for label its solo run, two sweeps."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K, G = 6000, 64, 10, 32
+    X, zt = gendata.synth_mixture(N, D, K, seed=21)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+
+    def build(c):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 8 * K)
+        ctx.set_assignments(np.unique(np.random.RandomState(300 + c).randint(0, K, N), return_inverse=True)[1])
+        _, key, _ = random.Random(500 + c).getstate()
+        return [ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])]
+    grouped = [build(c) for c in range(G)]
+    for it in range(2):
+        for ch in grouped:
+            ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], None)
+        _lib.group_sweep_staged([ch[0] for ch in grouped], [None] * G)
+    zs = [ch[0].assignments() for ch in grouped]
+    lms = [ch[0].log_marg() for ch in grouped]
+    for ch in grouped:
+        ch[0].close()
+    assert len({z.tobytes() for z in zs}) == G, "chains with different seeds must differ"
+    for c in range(G):
+        ch = build(c)
+        for it in range(2):
+            ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], None)
+            ch[0].sweep_staged(None)
+        npt.assert_array_equal(ch[0].assignments(), zs[c], err_msg="chain %d" % c)
+        assert ch[0].log_marg() == lms[c]
+        ch[0].close()
