@@ -531,7 +531,10 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
     if (cov_type != BGMM_COV_FULL && cov_type != BGMM_COV_DIAG && cov_type != BGMM_COV_FIXED)
         return fail(nullptr, BGMM_EUNSUPPORTED, "covariance_type must be full (0), diag (1) or fixed (2)");
     if (!X || !m_0 || !S_0 || N < 1 || D < 1 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
-    if (D > BGMM_MAX_D) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 128 is not supported yet");
+    if (cov_type == BGMM_COV_FULL && D > BGMM_MAX_D)
+        return fail(nullptr, BGMM_EUNSUPPORTED, "full covariance supports D <= 128 (a component's D x D factor has to fit the LDS of a "
+                                                "compute unit); covariance_type diag / fixed take D up to 4096");
+    if (D > BGMM_MAX_D_DIAG) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 4096 is not supported");
     if (N >= (1ll << 31) - 256) return fail(nullptr, BGMM_EUNSUPPORTED, "N must fit int32");
     if (v_0 < D && cov_type == BGMM_COV_FULL)
         return fail(nullptr, BGMM_EINVAL, "v_0 must be larger or equal to dimension of data");

@@ -30,7 +30,9 @@
 #include <mutex>
 #include <vector>
 
-#define BGMM_MAX_D 128
+#define BGMM_MAX_D 128            /* full covariance: the factor of a component has to fit LDS (refresh, MFMA tiles)      */
+#define BGMM_MAX_D_DIAG 4096      /* diag / fixed: the state is a D-vector; above kDiagLdsMaxD the rows are read through the
+                                     cache instead of an LDS tile (score_diag*_kernel)                                       */
 #define BGMM_LOG_PI 1.1447298858494001741434273513530587116472948129153
 
 enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
@@ -399,7 +401,7 @@ void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   /
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);
 bool resolve_plan(const Dev &d, int K_now, int *R_out, int *Kcap_out, int *lds_out);
 void launch_resolve(const Dev &d, int R, int Kcap, int lds, hipStream_t st);
-int refresh_lds_bytes(int D);
+int refresh_lds_bytes(int D, int cov_type = COV_FULL);
 bool gram_plan_for(int K, int *gcols, int *terms, int *lds);   // LDS plan of the window resolver for K labels
 bool launch_gram_step(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
 void gram_configure(const Dev &d, int resolve_lds);      // per-device kernel attributes (once per context and plan)

@@ -745,23 +745,27 @@ bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstr
 // exactly by the lanes (D logarithms / squares per pair).
 // ------------------------------------------------------------------------------------------
 // as-is log density of visit `lane` under slot s
-__device__ __forceinline__ double diag_pair_score(const Dev &d, const double *__restrict__ xs, int lane, int s) {
+__device__ __forceinline__ double diag_pair_score(const Dev &d, const double *__restrict__ xs, const double *__restrict__ xg,
+                                                  int lane, int s) {
     const int D = d.D;
+    const bool xlds = D <= kDiagLdsMaxD;
+#define XAT(l) (xlds ? xs[(l) * kDiagLd + lane] : xg[(l)])
     const double *__restrict__ mu = d.mu + (long long)s * D;
     const double *__restrict__ dw = d.dw + (long long)s * D;
     double acc = 0.0;
     if (d.cov_type == COV_FIXED) {
         for (int l = 0; l < D; ++l) {
-            const double dl = xs[l * kDiagLd + lane] - mu[l];
+            const double dl = XAT(l) - mu[l];
             acc += (dl * dl) * dw[l];
         }
     } else {
         for (int l = 0; l < D; ++l) {
-            const double dl = xs[l * kDiagLd + lane] - mu[l];
+            const double dl = XAT(l) - mu[l];
             acc += log(1.0 + dl * dl * dw[l]);
         }
     }
     return d.sc[s].A - d.sc[s].half_vd * acc;
+#undef XAT
 }
 
 __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job *__restrict__ jobp,
@@ -773,7 +777,8 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
     const long long k0 = (long long)blockIdx.x * kValuRows;
     if (k0 >= nrows) return;
     const int D = d.D, K = job.nlist;
-    double *__restrict__ sM = xs + D * kDiagLd;                   // best-score lower bound per visit
+    const bool xlds = D <= kDiagLdsMaxD;                          // (beyond: no tile, the rows through the cache)
+    double *__restrict__ sM = xs + (xlds ? D * kDiagLd : 0);      // best-score lower bound per visit
     double *__restrict__ sRho = sM + kValuRows;                   // |x - mu_home|
     long long *__restrict__ sI = (long long *)(sRho + kValuRows); // data index (-1: dead row)
     int *__restrict__ sH = (int *)(sI + kValuRows);               // home slot
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
     }
     __syncthreads();
     // (8 row-contiguous loads in flight per thread, then the transposing LDS writes)
-    for (int e0 = tid; e0 < kValuRows * D; e0 += 256 * 8) {
+    for (int e0 = tid; xlds && e0 < kValuRows * D; e0 += 256 * 8) {
         double v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -816,6 +821,8 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
     double *__restrict__ sHomeLp = sPart + 12 * kValuRows;        // exact home score (no seating weight)
     const int hv = sH[lane];
     const bool live = sI[lane] >= 0;
+    const double *__restrict__ xg = d.X + (live ? sI[lane] : 0) * D;
+#define XAT(l) (xlds ? xs[(l) * kDiagLd + lane] : xg[(l)])
     const bool fixed = d.cov_type == COV_FIXED;
     const int nhv = hv >= 0 ? d.n[hv] : 0;
     {
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
             const long long v1 = d.v0 + nhv - 1;
             const double scale1 = (k1 + 1.0) / (k1 * (double)v1), inv_v1 = 1.0 / (double)v1;
             for (int l = w; l < D; l += 4) {
-                const double x = xs[l * kDiagLd + lane];
+                const double x = XAT(l);
                 const double t = x - mh[l];
                 r2 = fma(t, t, r2);
                 if (nhv >= 2) {
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
             const bool my_block = ((bl >> (lane & 48)) & 0xFFFFull) != 0ull;
             if (my_block && live) {
                 const bool own = hv == s && nhv >= 2;
-                const double lp = own ? sHomeLp[lane] : diag_pair_score(d, xs, lane, s);
+                const double lp = own ? sHomeLp[lane] : diag_pair_score(d, xs, xg, lane, s);
                 q[((blk0 + (lane >> 4)) * (long long)d.nslots + t) * 16 + (lane & 15)] = lp;
             }
         }
@@ -991,10 +998,11 @@ __global__ __launch_bounds__(256) void score_diag_prune_kernel(Dev d, const Job 
         atomicAdd(&d.pr_counts[256 + (blockIdx.x & 255)], (unsigned long long)n_bound);
     }
 }
+#undef XAT
 
 static void launch_diag_prune(const Dev &d, const Job *job, double *q, long long max_rows, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
-    const int lds = (d.D * kDiagLd + 17 * kValuRows) * (int)sizeof(double);   // tile + per-visit arrays + partial sums
+    const int lds = ((d.D <= kDiagLdsMaxD ? d.D * kDiagLd : 0) + 17 * kValuRows) * (int)sizeof(double);   // tile + per-visit arrays + partial sums
     hipLaunchKernelGGL(score_diag_prune_kernel, dim3(gx), dim3(256), lds, st, d, job, q);
 }
 

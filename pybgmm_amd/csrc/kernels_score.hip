@@ -251,8 +251,9 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
     const long long p0 = job.pos + (long long)blockIdx.x * kValuRows;
     if (p0 >= job.win_hi) return;
     const int D = d.D;
+    const bool xlds = D <= kDiagLdsMaxD;          // (beyond: no tile -- every lane reads its row through the cache, XAT below)
     // (8 row-contiguous loads in flight per thread, then the transposing LDS writes)
-    for (int e0 = threadIdx.x; e0 < kValuRows * D; e0 += 256 * 8) {
+    for (int e0 = threadIdx.x; xlds && e0 < kValuRows * D; e0 += 256 * 8) {
         double v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -275,6 +276,8 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long p = p0 + lane;
     const bool live = p < job.win_hi;
+    const double *__restrict__ xg = d.X + (live ? (d.order ? d.order[p] : p) : 0) * D;
+#define XAT(l) (xlds ? xs[(l) * kDiagLd + lane] : xg[(l)])
     // (utility jobs -- log_prior, log_post_pred -- score every slot as it is)
     int home = -1;
     if (live && home_correction) {
@@ -291,12 +294,12 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
         double acc = 0.0;
         if (fixed) {                // product of normals: sum (x - mu)^2 * predictive precision
             for (int l = 0; l < D; ++l) {
-                const double dl = xs[l * kDiagLd + lane] - mu[l];
+                const double dl = XAT(l) - mu[l];
                 acc += (dl * dl) * dw[l];
             }
         } else {
             for (int l = 0; l < D; ++l) {
-                const double dl = xs[l * kDiagLd + lane] - mu[l];
+                const double dl = XAT(l) - mu[l];
                 acc += log(1.0 + dl * dl * dw[l]);
             }
         }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
             const double *__restrict__ SS = d.S + (long long)s * 2 * D;
             double lpp = 0.0, a1 = 0.0;
             for (int l = 0; l < D; ++l) {
-                const double x = xs[l * kDiagLd + lane];
+                const double x = XAT(l);
                 const double p = d.prior_S[D + l];
                 const double mn = __dsub_rn(mS[l], __dmul_rn(p, x));
                 const double pN = __dsub_rn(SS[l], p);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
             const double scale1 = (k1 + 1.0) / (k1 * (double)v1), inv_v1 = 1.0 / (double)v1;
             double lpv = 0.0, a1 = 0.0;
             for (int l = 0; l < D; ++l) {
-                const double x = xs[l * kDiagLd + lane];
+                const double x = XAT(l);
                 const double m1 = __dsub_rn(mS[l], x);
                 const double S1 = __dsub_rn(SS[l], __dmul_rn(x, x));
                 const double mean = m1 / k1;
@@ -341,13 +344,14 @@ __global__ __launch_bounds__(256) void score_diag_kernel(Dev d, const Job *__res
         }
         if (live) q[(long long)(col_override >= 0 ? col_override : s) * qstride + (p - job.win_base)] = lp;
     }
+#undef XAT
 }
 
 void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                        long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     if (max_rows <= 0) return;
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
-    const int lds = d.D * kDiagLd * (int)sizeof(double);
+    const int lds = (d.D <= kDiagLdsMaxD ? d.D * kDiagLd : 1) * (int)sizeof(double);
     hipLaunchKernelGGL(score_diag_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
                        col_override, job == &d.ctrl->job ? 1 : 0, skip_pruned_jobs);
 }

@@ -101,9 +101,11 @@ void launch_init_stats(const Dev &d, const int *members, const long long *offset
 // Two routes (slot_math.h): from scratch, O(D^3); or a rank-1 change of Winv, O(D^2).
 // LDS: W[D][D+1] + 6 D + 4 doubles.
 // ------------------------------------------------------------------------------------------
-int refresh_lds_bytes(int D) {
+int refresh_lds_bytes(int D, int cov_type) {
     const int Dp = (D + 15) / 16 * 16;
-    const int rank1 = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double), diag = 2 * 256 * (int)sizeof(double);
+    const int diag = 2 * 256 * (int)sizeof(double);
+    if (cov_type != COV_FULL) return diag;              // (D-vector state: two reduction arrays, whatever D)
+    const int rank1 = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double);
     const int blocked = refresh_blocked_lds_doubles(Dp) * (int)sizeof(double);
     int v = rank1 > diag ? rank1 : diag;
     return v > blocked ? v : blocked;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(TPB, 3) void gram_finish_group_kernel(const Dev *__
 
 
 void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st) {
-    const int lds = refresh_lds_bytes(lead.D);
+    const int lds = refresh_lds_bytes(lead.D, lead.cov_type);
     static PerDeviceLds attr16, attr64;
     if (lead.D <= 64) {
         ensure_lds((const void *)gram_finish_group_kernel<16>, lds, attr16);
@@ -416,7 +418,7 @@ void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStrea
 }
 
 void launch_gram_finish(const Dev &d, hipStream_t st) {
-    const int lds = refresh_lds_bytes(d.D);
+    const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr16, attr64;
     if (d.D <= 64) {
         ensure_lds((const void *)gram_finish_kernel<16>, lds, attr16);
@@ -430,7 +432,7 @@ void launch_gram_finish(const Dev &d, hipStream_t st) {
 
 void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) {
     if (n <= 0) return;
-    const int lds = refresh_lds_bytes(d.D);
+    const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
     ensure_lds((const void *)refresh_list_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_list_kernel, dim3(n), dim3(TPB), lds, st, d, slots, n);
@@ -438,14 +440,14 @@ void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) 
 
 void launch_refresh_stale(const Dev &d, int K, hipStream_t st) {
     if (K <= 0) return;
-    const int lds = refresh_lds_bytes(d.D);
+    const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
     ensure_lds((const void *)refresh_stale_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_stale_kernel, dim3(K), dim3(TPB), lds, st, d);
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
-    const int lds = refresh_lds_bytes(d.D);
+    const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
     ensure_lds((const void *)refresh_ctrl_kernel, lds, attr);
     hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(1024) void prune_tables_kernel(Dev d) {
     if (!job_is_pruned(d, c->job.mode, c->job.prune) || c->tables_valid || (d.safe_mode && c->safe_epoch_valid)) return;
     const int n_tab_blocks = ((d.nslots + 15) / 16 + 15) / 16;
     if ((int)blockIdx.x >= n_tab_blocks) {
-        __shared__ double mua[BGMM_MAX_D];
+        __shared__ double mua[BGMM_MAX_D_DIAG];
         const int K = c->job.K, a = (int)blockIdx.x - n_tab_blocks, D = d.D;
         if (a >= K) return;
         const double *__restrict__ pa = d.mu + (long long)d.perm[a] * D;

@@ -49,6 +49,9 @@ __device__ __forceinline__ int job_slot(const Dev &d, const JobView &job, int t)
 // x tile of the diag / fixed kernels in LDS: element (dimension l, visit r) at xs[l * kDiagLd + r];
 // the odd stride keeps the transposing writes (consecutive l) off a single bank
 static constexpr int kDiagLd = kValuRows + 1;
+// up to this many dimensions the 64 rows of a block sit transposed in LDS (58 KB + the per-visit arrays: under the 64 KB a
+// launch gets without asking); beyond, every lane reads its own row through the cache, dimension by dimension
+static constexpr int kDiagLdsMaxD = 112;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {

@@ -441,7 +441,25 @@ def case_diag_64d():
              recipe="synth_mixture(800,64,8,seed=44)")
 
 
+def case_diag_256d():
+    # diagonal components beyond D = 128 (the state is a D-vector: no limit in the reference,
+    # gaussian_components_diag.py:92)
+    X, z_true = gendata.synth_mixture(400, 256, 6, seed=45)
+    run_case("diag_crpmm_256d", "CRPMM", X, diag_prior(256), 1.0, "rand", 6, 48, 2, (8, 8),
+             true_assignments=z_true, store_X=False, skip_metrics=True, cov_type="diag",
+             recipe="synth_mixture(400,256,6,seed=45)")
+
+
 # ---- fixed-variance components ------------------------------------------ #
+def case_fixed_256d():
+    X, z_true = gendata.synth_mixture(400, 256, 6, seed=65)
+    prior = (0.49 * np.ones(256), np.zeros(256), 16.0 * np.ones(256))
+    run_case("fixed_pcrp_256d", "PCRPMM", X, prior, 1.0, "rand", 6, 48, 2, (15, 15),
+             sampler_kwargs=dict(n_power=1.1, power_burnin=0), true_assignments=z_true, store_X=False,
+             skip_metrics=True, cov_type="fixed", recipe="synth_mixture(400,256,6,seed=65)")
+
+
+
 def case_fixed_2d():
     X, z_true = gendata.synth_mixture(300, 2, 5, seed=61)
     prior = (np.array([0.49, 0.6]), np.array([0.5, -0.3]), np.array([16.0, 12.0]))   # var, mu_0, var_0
@@ -601,7 +619,8 @@ CASES = {
     "pcrp_burnin": case_pcrp_burnin, "pcrp_flagoff": case_pcrp_flag_off,
     "general_prior": case_general_prior, "d12": case_d12,
     "diag_kat": case_diag_kat, "diag_each_in_own": case_diag_each_in_own, "diag_pcrp": case_diag_pcrp,
-    "diag_general": case_diag_general, "diag_64d": case_diag_64d, "adap": case_adap,
+    "diag_general": case_diag_general, "diag_64d": case_diag_64d, "diag_256d": case_diag_256d, "adap": case_adap,
+    "fixed_256d": case_fixed_256d,
     "fixed_2d": case_fixed_2d, "fixed_each_in_own": case_fixed_each_in_own, "fixed_pcrp": case_fixed_pcrp_16d,
 }
 

@@ -1016,7 +1016,7 @@ def test_diag_components_match_univariate_student_t():
                             np.sum(t_logpdf(X[0], m_N, S_N * (k_N + 1) / (k_N * v_N), v_N)))
 
 
-@pytest.mark.parametrize("N,D,K", [(5000, 16, 30), (3000, 64, 12)])
+@pytest.mark.parametrize("N,D,K", [(5000, 16, 30), (3000, 64, 12), (2000, 128, 8), (1500, 300, 6)])
 def test_diag_against_c_oracle(N, D, K):
     from oracle import c_oracle
     from pybgmm_amd import _lib
@@ -1163,7 +1163,7 @@ def test_diag_fixed_pruning_does_not_change_trajectory(case, prune):
 
 
 @pytest.mark.parametrize("cov", ["diag", "fixed"])
-@pytest.mark.parametrize("N,D,K,sep", [(20000, 16, 40, 4.0), (12000, 24, 300, 1.2), (6000, 8, 900, 4.0)])
+@pytest.mark.parametrize("N,D,K,sep", [(20000, 16, 40, 4.0), (12000, 24, 300, 1.2), (6000, 8, 900, 4.0), (4000, 200, 12, 1.0)])
 def test_diag_fixed_pruned_against_c_oracle(cov, N, D, K, sep):
     """Steady-state start (labels at the truth, a few unassigned): the pruned-window kernels run by
     the default policy and, second context, in every window."""
@@ -2510,3 +2510,21 @@ def test_thirty_two_chains_burn_in_side_by_side_and_equal_their_solo_runs():
         npt.assert_array_equal(ch[0].assignments(), zs[c], err_msg="chain %d" % c)
         assert ch[0].log_marg() == lms[c]
         ch[0].close()
+
+
+def test_dimension_limits_are_errors_that_say_so():
+    """diag / fixed components take any D up to 4096 (their state is a D-vector: goldens diag_crpmm_256d /
+    fixed_pcrp_256d, the oracle cases at D = 200 / 300); full covariance stops at D = 128 -- a component's D x D factor
+    has to fit the LDS of a compute unit -- and says so at construction (BGMM_EUNSUPPORTED), where the reference has no
+    limit (gaussian_components.py:86-90)."""
+    from pybgmm_amd import _lib
+    D = 130
+    X = np.random.RandomState(0).randn(300, D)
+    with pytest.raises(_lib.BGMMError) as ei:
+        _lib.Context(X, np.zeros(D), 0.03, D + 3, np.eye(D), 1.0, 16)
+    assert ei.value.code == -5 and "128" in str(ei.value) and "diag" in str(ei.value)
+    ctx = _lib.Context(X, np.zeros(D), 0.03, D + 3, np.ones(D), 1.0, 16, cov_type="diag")
+    ctx.set_assignments(np.zeros(300, dtype=np.int64))
+    ctx.sweep(np.random.RandomState(1).random_sample(300))
+    assert ctx.counts().sum() == 300
+    ctx.close()
