@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgmm_hip.so")
 SOURCES = ["bgmm_api.hip", "kernels_state.hip", "kernels_score.hip", "kernels_prune.hip", "kernels_choice.hip",
            "kernels_resolve.hip", "kernels_rng.hip", "kernels_seq.hip", "kernels_gram.hip", "kernels_home.hip", "kernels_safe.hip",
-           "kernels_perm.hip"]
+           "kernels_perm.hip", "kernels_resid.hip"]
 # every header next to the sources + the public one: editing any of them rebuilds every object
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "bgmm.h")]
 # -ffp-contract=off: the sufficient-statistics updates must round product and sum

@@ -1317,6 +1317,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (!c->cur_u) return fail(c, BGMM_EINVAL, "no sweep inputs staged");
         d.u = c->cur_u;
         d.order = c->cur_order;
+        d.order_perm = c->order_is_perm ? 1 : 0;
         c->order_staged = false;            // (a staged permutation serves one sweep)
         d.sweep_visits = c->next_sweep_visits;
         c->next_sweep_visits = 0;
@@ -1479,6 +1480,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             if (recent_rate == 0.0 && Tg > 4) Tg = 4;         // (nothing has moved lately: look again soon, the chain may be at rest)
             if (c->timing) { int rc = ensure_events(c, (size_t)Tg); if (rc) return rc; }
             d.safe_mode = 1; d.lean_step = 0; d.publish = 0; d.prune_enabled = 2; d.use_certify = 0; d.use_home = 1;
+            d.resid_dense = 0;
             d.safe_dense = c->safe_dense_pin >= 0 ? (c->safe_dense_pin ? 1 : 0) : (c->safe_dense_on ? 1 : 0);
             c->proof_batches[d.safe_dense] += 1;
             const long long resid0 = hc.safe_resid_sum, sorted0 = hc.safe_sorted_sum;
@@ -1625,6 +1627,9 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (pmode != 2) lean = false;
         d.lean_step = lean ? 1 : 0;
         d.use_home = (d.cov_type == COV_FULL && c->kind == KERNEL_MFMA && c->home_pass) ? 1 : 0;
+        // (a short residual list -- D <= 32: clusters a dozen sigma apart leave home_kernel a fraction of a per cent -- is settled
+        //  by one dense launch; with certified stays on the sparse draw kernel also feeds the certificates, so not then)
+        d.resid_dense = (d.use_home && !d.use_certify && d.Dp <= 32 && resid_dense_lds_bytes(d) <= 150 * 1024) ? 1 : 0;
         if ((pmode != 2 && !(pmode == 1 && c->home_mode == 3)) || !first_batch || !d.use_home || lean) short_step = false;
         d.short_step = short_step ? (d.order ? 2 : 1) : 0;
         d.publish = (lean || short_step) ? 1 : 0;
@@ -1641,6 +1646,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
                 if (d.short_step == 2) launch_bucket_rows(d, grid_rows, st);
                 launch_home(d, grid_rows, st);
+                launch_resid_dense(d, st);
                 if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
                 launch_apply(d, st);
                 continue;
@@ -1650,7 +1656,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (pmode >= 1 && use_certify) launch_certify(d, grid_rows, st);
             if (pmode >= 1 && !lean) launch_bucket_rows(d, grid_rows, st);
-            if (pmode >= 1 && !lean && d.use_home) launch_home(d, grid_rows, st);
+            if (pmode >= 1 && !lean && d.use_home) { launch_home(d, grid_rows, st); launch_resid_dense(d, st); }
             if (pmode >= 1) { if (!lean) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st); }
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);
             if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));

@@ -298,8 +298,11 @@ struct Dev {
     struct WRec *wrecR;          // the residual list home_kernel leaves (same record / row format)
     int *wpermR;
     int use_home;                // 1: home_kernel runs in front of the pruning kernel, which then works on the residual list
+    int resid_dense;             // 1: resid_dense_kernel (kernels_resid.hip) is queued behind home_kernel: a SHORT residual list is
+                                 // settled there, every label exactly, and the pruning / sparse draw kernels see an empty list
     const double *u;
     const long long *order;      // may be null (identity)
+    int order_perm;              // 1: the visiting order visits every point exactly once (null, or a permutation)
     long long sweep_visits;      // visits of the sweep being queued (0 or N: all of them; bgmm_set_sweep_visits)
     int use_power;
     double power;
@@ -342,7 +345,13 @@ __device__ inline double safe_cap_now(const Dev &d, const Ctrl *c) { return d.sa
 // The list the pruning kernel and the sparse draw kernel work through
 __host__ __device__ inline const WRec *prune_list(const Dev &d) { return d.use_home ? d.wrecR : d.wrec; }
 __host__ __device__ inline const int *prune_rows(const Dev &d) { return d.use_home ? d.wpermR : d.wperm; }
-__device__ inline long long prune_count(const Dev &d) { return d.use_home ? d.ctrl->n_resid : d.ctrl->n_sorted; }
+static constexpr int kResidDenseMax = 16384;     // residual visits resid_dense_kernel takes (its grid: one workgroup per sixteen)
+__host__ __device__ inline bool resid_dense_takes(const Dev &d, const Ctrl *c) {
+    return d.use_home && d.resid_dense && !d.safe_mode && c->n_resid > 0 && c->n_resid <= kResidDenseMax;
+}
+// rows of the residual list that are left to the general kernels (and count as "not decided by the home pass")
+__device__ inline long long resid_left(const Dev &d, const Ctrl *c) { return resid_dense_takes(d, c) ? 0 : c->n_resid; }
+__device__ inline long long prune_count(const Dev &d) { return d.use_home ? resid_left(d, d.ctrl) : d.ctrl->n_sorted; }
 
 // Is the (fresh) window described by (mode, prune flag) evaluated by the pruned-window kernels?
 __host__ __device__ inline bool job_is_pruned(const Dev &d, int mode, int prune_flag) {
@@ -396,6 +405,8 @@ bool launch_score_pruned(const Dev &d, const Job *job, double *q, long long qstr
 void launch_certify(const Dev &d, long long max_rows, hipStream_t st);
 void launch_prune_tables(const Dev &d, hipStream_t st);
 void launch_home(const Dev &d, long long max_rows, hipStream_t st);            // kernels_home.hip
+void launch_resid_dense(const Dev &d, hipStream_t st);                         // kernels_resid.hip
+int resid_dense_lds_bytes(const Dev &d);
 void launch_choice(const Dev &d, long long max_rows, hipStream_t st);
 void launch_choice_sparse(const Dev &d, long long max_rows, hipStream_t st);   // pruned windows
 void launch_bucket_rows(const Dev &d, long long max_rows, hipStream_t st);

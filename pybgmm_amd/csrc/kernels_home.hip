@@ -392,17 +392,24 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 if (NB > 0 && !d.safe_mode) {
                     // ---- the same rows under the home's neighbours (their as-is forms: nobody is removed from them)
                     const int nn = __builtin_amdgcn_readfirstlane(ncand[0]);
-#pragma unroll 1
-                    for (int m = 0; m < nn; ++m) {
+                    // (a neighbour's fragments come into registers in one batch, the next neighbour's while this one's
+                    //  products run: a ds_read per MFMA would put an LDS round trip between every two of them)
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) {
+                        if (m >= nn) break;
                         LDS_AS const double *const wn = nBf + m * NF * 64 + lane;
+                        double bn[NF], cjn[NJ];
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) bn[f] = wn[f * 64];
+#pragma unroll
+                        for (int J = 0; J < NJ; ++J) cjn[J] = ncv[m * Dp + 16 * J + lr];
                         double qn[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int J = 0; J < NJ; ++J) {
-                            const double cj = ncv[m * Dp + 16 * J + lr];
-                            v4d acc = (v4d){cj, cj, cj, cj};
+                            v4d acc = (v4d){cjn[J], cjn[J], cjn[J], cjn[J]};
 #pragma unroll
                             for (int kk = 0; kk < 4 * (J + 1); ++kk)
-                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], wn[(2 * J * (J + 1) + kk) * 64], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bn[2 * J * (J + 1) + kk], acc, 0, 0, 0);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) qn[r] = fma(acc[r], acc[r], qn[r]);
                         }
@@ -568,6 +575,73 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double jf = rad * finv_a;
                 double bound = INFINITY;
                 if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftab[(long long)a * 64 + (int)jf + 1];
+                if (NB > 0 && one_home) {
+                    // ---- D = 16 / 32: ONE draw for every row (a wavefront executes both sides of a branch its lanes split
+                    // over, and here nearly every wavefront has rows of both kinds): the candidates are the home, the new
+                    // table and -- for a row the first table cannot settle -- the home's neighbours, scored exactly; everyone
+                    // else is excluded by the first table (no neighbours needed) or by the second.  The reference's
+                    // arithmetic over the candidates that are left (crpmm.py:75, utils.py:15-20): weights exp(v - max) in
+                    // label order, p = weight / total, u -= p.
+                    const bool first_ok = den > 0.0 && bound < mx - margin;
+                    const int nn = ncand[0];
+                    double vn[NB > 0 ? NB : 1];
+                    double mx2 = mx;
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) {
+                        vn[m] = -INFINITY;
+                        if (m < nn && !first_ok) {
+                            const double qm = sideQn[m * 64 + lane];
+                            vn[m] = nsc[m * 8] - nsc[m * 8 + 1] * fm_log(1.0 + qm * nsc[m * 8 + 2]);
+                            mx2 = fmax(mx2, vn[m]);
+                        }
+                    }
+                    const double b2 = jf < 62.0 ? hft2[(int)jf + 1] : INFINITY;
+                    if (den > 0.0 && (first_ok || b2 < mx2 - margin)) {
+                        easy = true;
+                        const long long p = win_base + wrow_cur;
+                        const double u_cur = d.u[p];
+                        double tot = 0.0, toth = 0.0, ec[NB + 1];
+#pragma unroll
+                        for (int ci = 0; ci < NB + 1; ++ci) {
+                            ec[ci] = 0.0;
+                            if (ci > nn) continue;
+                            const int who = ncand[1 + ci];
+                            double v = vh;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m) v = who == m ? vn[m] : v;
+                            const double e = v == -INFINITY ? 0.0 : fm_exp(v - mx2);      // (a neighbour left out weighs nothing)
+                            ec[ci] = e;
+                            tot += e;
+                            if (who >= 0) toth += e;
+                        }
+                        const double en = fm_exp(vnew - mx2);
+                        tot += en; toth += en;
+                        const double inv_tot = fm_div(1.0, tot);
+                        double uu = u_cur;
+                        int pick = K;
+#pragma unroll
+                        for (int ci = 0; ci < NB + 1; ++ci) {
+                            if (ci > nn || pick != K) continue;
+                            const int who = ncand[1 + ci];
+                            int lab = a;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m)
+                                if (who == m) lab = ((LDS_AS const int *)(nsc + m * 8 + 3))[0];
+                            uu -= ec[ci] * inv_tot;
+                            if (uu < 0.0) pick = lab;
+                        }
+                        if (pick != a) d.choice[wrow_cur] = pick;
+                        if (keep_caches) {
+                            PCacheExact pe;
+                            pe.epoch = epoch;
+                            const double bb = first_ok ? bound : b2;
+                            const double rest = bb < mx2 - kHomeFar ? 1.8048513878454153e-35 : fm_exp(bb - mx2);
+                            pe.log_alt = mx2 - vh + fm_log(toth + (double)K * rest);
+                            d.pcache2[imine] = pe;
+                        }
+                        if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
+                    }
+                } else
                 if (den > 0.0 && bound < mx - margin) {
                     // two candidates: prob = exp(lp - logsumexp), u -= prob in label order (crpmm.py:75, utils.py:15-20).
                     // With eh = exp(vh - mx), en = exp(vnew - mx) one of the two is exp(0) = 1; and when the new table
@@ -601,65 +675,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                         d.pcache2[imine] = pe;
                     }
                     if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
-                } else if (NB > 0 && one_home && den > 0.0 && jf < 62.0) {
-                    // ---- the table could not exclude everybody: the home's neighbours exactly, everyone else by the second
-                    // table.  The reference's arithmetic over the candidates that are left (crpmm.py:75, utils.py:15-20, as
-                    // choice_sparse_kernel does it): scores in label order, exp(v - logsumexp), u -= p.
-                    const int nn = ncand[0];
-                    double vn[NB > 0 ? NB : 1];
-                    double mx2 = mx;
-#pragma unroll
-                    for (int m = 0; m < NB; ++m) {
-                        vn[m] = -INFINITY;
-                        if (m < nn) {
-                            const double qm = sideQn[m * 64 + lane];
-                            vn[m] = nsc[m * 8] - nsc[m * 8 + 1] * fm_log(1.0 + qm * nsc[m * 8 + 2]);
-                            mx2 = fmax(mx2, vn[m]);
-                        }
-                    }
-                    if (hft2[(int)jf + 1] < mx2 - margin) {
-                        easy = true;
-                        const long long p = win_base + wrow_cur;
-                        const double u_cur = d.u[p];
-                        double tot = 0.0, toth = 0.0;
-#pragma unroll
-                        for (int ci = 0; ci < NB + 1; ++ci) {
-                            if (ci > nn) continue;
-                            const int who = ncand[1 + ci];
-                            double v = vh;
-#pragma unroll
-                            for (int m = 0; m < NB; ++m) v = who == m ? vn[m] : v;
-                            const double e = fm_exp(v - mx2);
-                            tot += e;
-                            if (who >= 0) toth += e;
-                        }
-                        { const double e = fm_exp(vnew - mx2); tot += e; toth += e; }
-                        const double lse = fm_log(tot) + mx2;
-                        double uu = u_cur;
-                        int pick = K;
-#pragma unroll
-                        for (int ci = 0; ci < NB + 1; ++ci) {
-                            if (ci > nn || pick != K) continue;
-                            const int who = ncand[1 + ci];
-                            double v = vh;
-                            int lab = a;
-#pragma unroll
-                            for (int m = 0; m < NB; ++m)
-                                if (who == m) { v = vn[m]; lab = ((LDS_AS const int *)(nsc + m * 8 + 3))[0]; }
-                            uu -= fm_exp(v - lse);
-                            if (uu < 0.0) pick = lab;
-                        }
-                        if (pick != a) d.choice[wrow_cur] = pick;
-                        if (keep_caches) {
-                            PCacheExact pe;
-                            pe.epoch = epoch;
-                            const double b2 = hft2[(int)jf + 1];
-                            const double rest = b2 < mx2 - kHomeFar ? 1.8048513878454153e-35 : fm_exp(b2 - mx2);
-                            pe.log_alt = mx2 - vh + fm_log(toth + (double)K * rest);
-                            d.pcache2[imine] = pe;
-                        }
-                        if (pick != a) atomicMin(&c->first_mover, (unsigned long long)p);
-                    }
                 }
             }
         }

@@ -535,6 +535,23 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(Dev d) {
     const int r0 = blockIdx.x * BUCKET_ROWS;
     if (r0 >= nrows) return;
     const int nb = d.nslots + 1;
+    // A window that is the WHOLE sweep of a visiting order that comes by every point once sorts every point: the bins are
+    // the components' counts, no pass over the rows needed (a chain at rest under a fresh permutation per sweep: a third of
+    // the sort's time).
+    if (d.order_perm && !d.use_certify && !d.safe_mode && base == 0 && c->job.win_hi == d.N && c->n_visits == d.N) {
+        if (blockIdx.x != 0) return;
+        __shared__ int asg[256];
+        int mine = 0;
+        for (int s = threadIdx.x; s < d.nslots; s += 256) { const int v = d.n[s]; d.bucket_bins[s + 1] = v; mine += v; }
+        asg[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tot = 0;
+            for (int t = 0; t < 256; ++t) tot += asg[t];
+            d.bucket_bins[0] = (int)(d.N - tot);          // the unassigned points
+        }
+        return;
+    }
     for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0;
     __syncthreads();
     // (the four rows of a thread side by side: their index loads, then their label loads, are in flight together --
@@ -1030,7 +1047,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
         __shared__ int refuse;
         if (threadIdx.x == 0) {
             const bool ok = job_is_pruned(d, c->job.mode, c->job.prune) && c->tables_valid &&
-                            (d.short_step == 2 || c->skip_sort) && c->n_resid == 0 && c->first_mover == kNoMover;
+                            (d.short_step == 2 || c->skip_sort) && resid_left(d, c) == 0 && c->first_mover == kNoMover;
             refuse = ok ? 0 : 1;
             if (refuse) { c->retry_full = 1; c->n_refresh = 0; c->n_resid = 0; c->first_mover = kNoMover; __threadfence(); }
         }
@@ -1065,7 +1082,7 @@ __global__ __launch_bounds__(TPB) void apply_kernel(Dev d) {
     if (threadIdx.x == 0) {
         do_move = 0;
         Job &j = c->job;
-        if (d.use_home && !d.lean_step && job_is_pruned(d, j.mode, j.prune) && !c->skip_apply) { c->home_in += c->n_sorted; c->home_out += c->n_resid; }
+        if (d.use_home && !d.lean_step && job_is_pruned(d, j.mode, j.prune) && !c->skip_apply) { c->home_in += c->n_sorted; c->home_out += resid_left(d, c); }
         c->n_resid = 0;                 // (home_kernel's list of this step has been worked through)
         c->n_refresh = 0;               // (a consumed or idle step must not re-run a refresh)
         if (c->skip_apply) {
