@@ -17,7 +17,7 @@ data-path collective; one RCCL all-gather of the final labels after the timed re
 What `value` measures (--mode):
   evaluated (default)  the chain at the truth, every visit EVALUATED every sweep: its row of X is read,
                        the predictive under its own component computed exactly (v_mfma_f64), every other
-                       component excluded by an exact bound -- home_kernel, with score_mfma_prune_kernel behind it
+                       component excluded by an exact bound -- home_kernel, with resid_dense_kernel (D <= 32) or score_mfma_prune_kernel behind it
                        for the visits the per-home bound table cannot decide.  Certified stays
                        (visits proven to stay from cached state, X untouched) are OFF: that shortcut
                        makes the sweep a memo lookup on well separated data and is reported in `extra` only.
@@ -242,7 +242,10 @@ def pruned_window_kernels(args, mode, D, home_decided, handled):
     decides most visits, score_mfma_prune_kernel on what it passes on."""
     name = heavy_kernel_name(args, mode, D)
     if name == "score_mfma_prune_kernel" and handled > 0 and home_decided > 0.5 * handled:
-        return ("home_kernel", name)
+        # (D <= 32 with certified stays off: a short residual list is settled by resid_dense_kernel, kernels_resid.hip, and
+        #  the visits it settles count as decided by the home pass)
+        behind = "resid_dense_kernel" if (D <= 32 and mode == "evaluated") else name
+        return ("home_kernel", behind)
     return (name,)
 
 

@@ -1643,8 +1643,10 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             // only serves the re-scoring after a move; the events bracket the one that works in
             // the steady state.
             if (short_step) {
-                if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
+                // (the events bracket the kernels that stream the rows -- what bench.py's roofline names --, not the sort of
+                //  a fresh visiting order in front of them)
                 if (d.short_step == 2) launch_bucket_rows(d, grid_rows, st);
+                if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
                 launch_home(d, grid_rows, st);
                 launch_resid_dense(d, st);
                 if (c->timing) CK(c, hipEventRecord(c->ev1[t], st));
@@ -1653,9 +1655,10 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             }
             if (pmode == 1) launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 1, st);
             if (pmode >= 1 && !lean) launch_prune_tables(d, st);
+            if (pmode >= 1 && !lean && !use_certify) launch_bucket_rows(d, grid_rows, st);
             if (c->timing) CK(c, hipEventRecord(c->ev0[t], st));
             if (pmode >= 1 && use_certify) launch_certify(d, grid_rows, st);
-            if (pmode >= 1 && !lean) launch_bucket_rows(d, grid_rows, st);
+            if (pmode >= 1 && !lean && use_certify) launch_bucket_rows(d, grid_rows, st);
             if (pmode >= 1 && !lean && d.use_home) { launch_home(d, grid_rows, st); launch_resid_dense(d, st); }
             if (pmode >= 1) { if (!lean) launch_score_pruned(d, &d.ctrl->job, d.q, d.qstride, grid_rows, st); }
             else launch_score(d, c->kind, &d.ctrl->job, d.q, d.qstride, -1, grid_rows, 0, st);

@@ -565,7 +565,25 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 pc.qhome = q_t; pc.rho2 = rho2_t; pc.pad = 0.0;
                 d.pcache[imine] = pc;
             }
-            if (nh >= 2) {
+            // ---- a chain at rest (D >= 48: no neighbour pass): every row of the wavefront stays by a wide margin, and that can be
+            // seen without the two logarithms, the division and the square root of the exact tail.  With t_ub >= coef1 q / den
+            // (hardware reciprocal, rounded up): vh >= vh_lb = base1 - half_vd1 t_ub (log(1 + t) <= t; -log(den) / 2 >= 0), the
+            // radius from above by the hardware square root rounded up (the table grows with the radius).  A row with
+            // vnew < vh_lb - 37.5 and every other component below vh_lb - margin is exactly a row the exact tail lets stay
+            // without its uniform (dv < -37 there): the same decision, nothing else is left behind when the caches are off.
+            bool all_fast = false;
+            if (NB == 0 && one_home && !keep_caches && nh >= 2) {
+                const double den = 1.0 - a1 * q_t;
+                const double t_ub = coef1 * q_t * __builtin_amdgcn_rcp(den) * (1.0 + 1e-6);
+                const double vh_lb = base1 - half_vd1 * t_ub;
+                const double jf_ub = __builtin_amdgcn_sqrt(rho2_t) * (1.0 + 1e-6) * finv_a;
+                const bool fast = den > 0.5 && q_t >= 0.0 && jf_ub < 62.0 && rcur.mlb0 < vh_lb - 37.5 &&
+                                  hft[(int)jf_ub + 1] < vh_lb - margin;
+                all_fast = __ballot(!fast) == 0ull;
+            }
+            if (all_fast) {
+                easy = true;
+            } else if (nh >= 2) {
                 // the visited point removed from its own component (slot_math.h: home form)
                 const double den = 1.0 - a1 * q_t;
                 const double vh = base1 - 0.5 * fm_log(den) - half_vd1 * fm_log(1.0 + fm_div(coef1 * q_t, den));

@@ -53,7 +53,9 @@ static int perm_rounds_now() {
     }();
     return r;
 }
-static constexpr int kPermTailLow = 1 << 14; // steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel)
+// steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel); BGMM_PERM_TAIL_LOG2 overrides (10 .. 16)
+static const int kPermTailLow = [] { const char *e = getenv("BGMM_PERM_TAIL_LOG2"); const int v = e ? atoi(e) : 14;
+                                     return 1 << (v < 10 ? 10 : (v > 16 ? 16 : v)); }();
 static constexpr int kPermSeg = 1024;      // words per segment (one wavefront, 4 KB of LDS)
 int perm_segments(long long n_avail) { return (int)((n_avail + kPermSeg - 1) / kPermSeg); }
 int perm_rounds() { return perm_rounds_now(); }
