@@ -157,7 +157,14 @@ struct bgmm_ctx {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats2[4] = {0, 0, 0, 0};   // pairs whose quadratic form was executed, frozen-factor windows, their rows, spare
     // frozen-factor windows (kernels_gram.hip): buffers sized for `gcols` columns, re-allocated when the labels outgrow them
-    void *gram_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *gram_mem[24] = {};         // [0 .. 9] the window buffers, [10 .. 19] their twins (pipelined windows), [20] gX
+    // pipelined frozen-factor windows (kernels_gram.hip): a second stream for gram_finish / the cross forms of the window after
+    // next, events between the two
+    hipStream_t pipe_stream = nullptr;
+    std::vector<hipEvent_t> pipe_ev;
+    int pipe_mode = [] { const char *e = getenv("BGMM_GRAM_PIPE"); return e ? atoi(e) : 1; }();   // 0: never (plain windows)
+    long long pipe_batches = 0, pipe_breaks = 0;
+    int pipe_hold = 0;               // plain batches to go before pipelined ones are tried again (after a break)
     int gram_lds = 0;
     bool gram_off = false;           // this context cannot use them (their buffers failed to allocate three times)
     int gram_alloc_fail = 0;
@@ -306,6 +313,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (c->mt_coef) (void)hipFree(c->mt_coef);
     if (c->mt_seeds) (void)hipFree(c->mt_seeds);
     for (void *p : c->gram_mem) if (p) (void)hipFree(p);
+    if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
+    for (auto e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->true_dev) (void)hipFree(c->true_dev);
     if (c->table_dev) (void)hipFree(c->table_dev);
     if (c->res_u) (void)hipFree(c->res_u);
@@ -1102,6 +1111,8 @@ extern "C" int bgmm_upload_streams(bgmm_ctx *c, int32_t n_sweeps, const double *
 
 // Buffers and LDS plan of the frozen-factor windows for K labels now (room for the labels a batch of
 // windows may open).  Returns false when no plan fits (the classic kernels carry on).
+static void gram_point(bgmm_ctx *c, int par);
+
 static bool ensure_gram(bgmm_ctx *c, int K) {
     Dev &d = c->d;
     if (c->gram_off) return false;
@@ -1110,22 +1121,24 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
     if (d.gcols != cols || !c->gram_mem[0]) {
         (void)hipStreamSynchronize(c->stream);
         for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
-        const size_t sz[8] = {sizeof(double) * (size_t)cols * kGramRows * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
-                              sizeof(double) * (size_t)cols * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
-                              sizeof(GramMove) * (size_t)kGramMaxTerms, sizeof(int) * (size_t)kGramMaxTerms,
-                              sizeof(double) * 2 * kGramRows, sizeof(double) * (size_t)cols * 40};
-        for (int t = 0; t < 8; ++t)
-            if (hipMalloc(&c->gram_mem[t], sz[t] + 64) != hipSuccess) {
+        const size_t sz[10] = {sizeof(double) * (size_t)cols * kGramRows * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
+                               sizeof(double) * (size_t)cols * kGramRows, sizeof(double) * (size_t)cols * kGramRows,
+                               sizeof(GramMove) * (size_t)kGramMaxTerms, sizeof(int) * (size_t)kGramMaxTerms,
+                               sizeof(double) * 2 * kGramRows, sizeof(double) * (size_t)cols * 40,
+                               sizeof(int) * (16 + kGramMaxTerms), sizeof(GramXp)};
+        for (int t = 0; t < 22; ++t) {
+            const size_t bytes = t < 20 ? sz[t % 10] : sz[0];         // (two sets of window buffers, then gX twice)
+            if (hipMalloc(&c->gram_mem[t], bytes + 64) != hipSuccess) {
                 for (void *&p : c->gram_mem) { if (p) (void)hipFree(p); p = nullptr; }
                 d.gcols = 0;
                 if (++c->gram_alloc_fail >= 3) c->gram_off = true;      // (latched only when memory keeps failing)
                 return false;
             }
-        d.gC = (double *)c->gram_mem[0]; d.gq0 = (double *)c->gram_mem[1];
-        d.glp0 = (double *)c->gram_mem[2]; d.ge0 = (double *)c->gram_mem[3];
-        d.gmoves = (GramMove *)c->gram_mem[4]; d.gtouched = (int *)c->gram_mem[5];
-        d.gM = (double *)c->gram_mem[6];
-        d.gcc = (double *)c->gram_mem[7];
+            if (t % 10 >= 8 && t < 20) (void)hipMemset(c->gram_mem[t], 0, bytes);
+        }
+        gram_point(c, 0);
+        d.gX = (double *)c->gram_mem[20];
+        d.pipe = 0; d.pipe_pos = 0; d.xp_in = nullptr;
         d.gcols = cols;
         d.gram_terms = T;
         c->gram_lds = lds;
@@ -1133,6 +1146,73 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
     }
     return true;
 }
+
+// the window buffers of set `par` into a device view (pipelined windows alternate between the two sets; plain ones use set 0)
+static void gram_point_view(bgmm_ctx *c, Dev &v, int par) {
+    void **m = c->gram_mem + 10 * par;
+    v.gC = (double *)m[0]; v.gq0 = (double *)m[1]; v.glp0 = (double *)m[2]; v.ge0 = (double *)m[3];
+    v.gmoves = (GramMove *)m[4]; v.gtouched = (int *)m[5]; v.gM = (double *)m[6]; v.gcc = (double *)m[7];
+    v.gfin = (int *)m[8]; v.xp_out = (unsigned char *)m[9];
+    v.gX = (double *)c->gram_mem[20 + par];
+}
+
+// A batch of T PIPELINED frozen-factor windows from visit `pos` on (kernels_gram.hip, "Pipelined windows"): window k starts
+// at pos + 64 k and works in buffer set k & 1.
+//   main stream   cross(0)  resolve(0)  carry(1) resolve(1)  carry(2) resolve(2) ...
+//   second stream     cross(1)      finish(0) cross(2)   finish(1) cross(3) ...
+// cross(k) is made against the factors as finish(k - 2) left them -- the state at the start of window k - 1 --, carry(k)
+// applies window k - 1's terms; finish(k) needs resolve(k), resolve(k) needs cross(k) (+ carry).  If the chain breaks on the
+// device (Ctrl::pipe_break) the rest of the batch stands still; the caller reads the control block and goes on from there.
+static int gram_pipe_batch(bgmm_ctx *c, int T, long long pos) {
+    Dev &d = c->d;
+    hipStream_t M = c->stream;
+    if (!c->pipe_stream) CK(c, hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+    hipStream_t S = c->pipe_stream;
+    while (c->pipe_ev.size() < (size_t)(2 * T + 2)) {
+        hipEvent_t e;
+        CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+    }
+    auto evG = [&](int k) { return c->pipe_ev[(size_t)(2 + 2 * k)]; };
+    auto evR = [&](int k) { return c->pipe_ev[(size_t)(3 + 2 * k)]; };
+    Dev v[2] = {d, d};
+    for (int p = 0; p < 2; ++p) { gram_point_view(c, v[p], p); v[p].pipe = 1; }
+    auto view = [&](int k) -> Dev & {
+        Dev &x = v[k & 1];
+        x.pipe = k == 0 ? 2 : 1;
+        x.pipe_pos = pos + (long long)kGramRows * k;
+        x.xp_in = v[(k + 1) & 1].xp_out;            // what window k - 1 exported
+        return x;
+    };
+    CK(c, hipMemsetAsync(&d.ctrl->pipe_break, 0, sizeof(int), M));
+    if (!launch_gram_cross(view(0), false, M)) return fail(c, BGMM_EDEVICE, "frozen-factor window launch failed");
+    CK(c, hipEventRecord(c->pipe_ev[0], M));
+    CK(c, hipStreamWaitEvent(S, c->pipe_ev[0], 0));
+    if (T > 1) {
+        launch_gram_cross(view(1), true, S);
+        CK(c, hipEventRecord(evG(1), S));
+    }
+    for (int k = 0; k < T; ++k) {
+        if (k > 0) {
+            CK(c, hipStreamWaitEvent(M, evG(k), 0));
+            launch_gram_carry(view(k), M);
+        }
+        launch_gram_resolve_only(view(k), c->gram_lds, M);
+        CK(c, hipEventRecord(evR(k), M));
+        CK(c, hipStreamWaitEvent(S, evR(k), 0));
+        launch_gram_finish(view(k), S);
+        if (k + 2 < T) {
+            launch_gram_cross(view(k + 2), true, S);
+            CK(c, hipEventRecord(evG(k + 2), S));
+        }
+    }
+    CK(c, hipEventRecord(c->pipe_ev[1], S));
+    CK(c, hipStreamWaitEvent(M, c->pipe_ev[1], 0));
+    CK(c, hipGetLastError());
+    c->pipe_batches += 1;
+    return 0;
+}
+static void gram_point(bgmm_ctx *c, int par) { gram_point_view(c, c->d, par); }
 
 static int ensure_events(bgmm_ctx *c, size_t n) {
     while (c->ev0.size() < n) {
@@ -1555,6 +1635,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             d.lean_step = 0; d.publish = 0; d.prune_enabled = 0;
             d.gram_K = hc.job.K;
             lean = false;
+            const bool was_first = first_batch;
             first_batch = false;
             // (chains of a group call that are here together share the launches: GramCombiner above)
             int own = 1;
@@ -1562,10 +1643,31 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 own = combiner_submit(c, (int)Tg);
                 if (own < 0) return fail(c, BGMM_EDEVICE, "shared frozen-factor launch failed");
             }
-            if (own)
+            // (a chain on its own, far inside the mover-dense regime: the windows pipelined -- gram_finish and the next cross
+            //  forms on a second stream beside the resolver; after a break of the chain a couple of plain batches first)
+            bool piped = false;
+            if (own && c->pipe_mode && !c->combiner && !c->timing && c->resolver_mode != 1 && remaining >= 4 * kGramRows &&
+                (was_first || hc.job.pos == pos)) {
+                if (c->pipe_hold > 0) c->pipe_hold -= 1;
+                else {
+                    long long Tp = remaining / kGramRows;
+                    if (Tp > Tg) Tp = Tg;
+                    if (Tp > 128) Tp = 128;
+                    if (Tp >= 4) {
+                        gram_point(c, 0);
+                        const int rcp = gram_pipe_batch(c, (int)Tp, pos);
+                        if (rcp) return rcp;
+                        piped = true;
+                    }
+                }
+            }
+            if (own && !piped) {
+                gram_point(c, 0);
+                d.pipe = 0;
                 for (int t = 0; t < (int)Tg; ++t)
                     if (!launch_gram_step(d, c->gram_lds, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
                         return fail(c, BGMM_EDEVICE, "frozen-factor window launch failed");
+            }
             CK(c, hipGetLastError());
             int rc = fetch_ctrl(c);
             if (rc) return rc;
@@ -1586,10 +1688,11 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
                 // (the plan -- columns, terms, the draw wave's width -- is re-picked for the labels there are now)
             }
+            if (piped && h.pipe_break) { c->pipe_breaks += 1; c->pipe_hold = 2; }
             if (h.error != 0 || h.job.mode == MODE_DONE) break;
             // (a batch of windows that consumed no visit and asked for no new plan would be queued again forever:
             // the classic kernels take the rest of this sweep)
-            if (h.job.pos == pos && !stalled) gram_skip = true;
+            if (h.job.pos == pos && !stalled && !piped) gram_skip = true;
             pos = h.job.pos;
             win = h.win_size > 0 ? h.win_size : win;
             rate = pos > 0 ? (double)h.n_moves / (double)pos : rate;
@@ -1708,6 +1811,9 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
         batch_pos0 = pos; batch_moves0 = h.n_moves;
     }
+    if (getenv("BGMM_DEBUG_PIPE"))
+        fprintf(stderr, "[bgmm] pipelined batches so far %lld, chains broken %lld; this sweep %lld windows\n", c->pipe_batches, c->pipe_breaks,
+                (long long)c->ctrl_host->gram_windows);
     c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;

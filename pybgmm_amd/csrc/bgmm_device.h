@@ -147,6 +147,8 @@ struct Ctrl {
     int gram_nmoves;       // moves the last window logged (GramMove records)
     int gram_ntouched;     // live slots whose statistics / factor the finish kernel has to bring up to date
     int gram_stall;        // 1: the window needs more columns than are allocated (host reallocates)
+    int pipe_break;        // pipelined windows: 1 = the chain of carried windows broke (a window ended early, a component was
+                           // opened or deleted, an error): the rest of the batch stands still, the host goes on unpipelined
     int gram_rebuild;      // 1: a slot of the last window is due for a from-scratch rebuild (the others past half the interval join it)
     unsigned long long n_pairs_exact;   // (visit, component) pairs whose quadratic form was executed this sweep
     long long gram_rows_total, gram_windows;   // rows consumed by / number of frozen-factor windows this sweep
@@ -319,6 +321,22 @@ struct Dev {
     int gcols;                   // columns allocated (also the leading dimension of glp0 / ge0)
     GramMove *gmoves;            // [kGramMaxTerms]
     int *gtouched;               // [kGramMaxTerms]
+    // What a window's resolver leaves for gram_finish_kernel: gfin[0] slots on gtouched, [1] moves on gmoves, [2] 1: a slot
+    // is due for a rebuild (the others past half the interval join it); gfin[16 + k]: the count of slot gtouched[k] behind
+    // the window.  (Per launch: pipelined windows keep two sets.)
+    int *gfin;
+    // PIPELINED frozen-factor windows (kernels_gram.hip, "Pipelined windows"): window w's cross forms are made against the
+    // factors as they stood at the start of window w - 1 -- while window w - 1 is still being walked -- together with the
+    // cross forms between its rows and that window's (gX); gram_carry_kernel then applies window w - 1's logged terms to
+    // them (a rank-k change of a 64 x 64 matrix per touched column), so that the resolver starts from the true state.
+    // gram_finish / the next cross forms run on a second stream beside the resolver.
+    int pipe;                    // 1: this launch belongs to a pipelined batch; 2: ... and its window is the batch's first
+                                 // (the components' counts are in Dev::n; later windows take them from the window before:
+                                 // gram_finish, which brings Dev::n up to date, runs beside the next resolver)
+    long long pipe_pos;          // the visit the launch's window starts at (the host's prediction: 64 visits per window)
+    double *gX;                  // [gcols][64][64]: c_0(new row r, old row r') - 1/k_N under the column's frozen factor
+    unsigned char *xp_out;       // what the resolver exports for the carry of the NEXT window (GramXp layout below)
+    const unsigned char *xp_in;  // ... and what the window before left for this one
     int gram_terms;              // terms the resolver's LDS plan holds (<= kGramMaxTerms)
     int gram_K;                  // labels when the current batch of windows was queued (host side: picks the draw wave's width)
     // safe-stay windows (kernels_safe.hip)
@@ -338,6 +356,19 @@ struct Dev {
                                  // queued steps: 0 never (only the dense kernels are launched), 1 the device
                                  // decides per window (job.prune; both kernel sets are launched), 2 every
                                  // window (only the pruned-window kernels are launched)
+};
+
+// A window's export for the next one's carry (pipelined windows).  Sized for the larger column plan.
+struct GramXp {
+    static constexpr int KCmax = 1024, T = kGramMaxTerms;
+    int hdr[16];                 // [0] touched columns listed, [1] terms, [2] 1: the window closed cleanly (all 64 rows walked, no
+                                 // component opened or deleted, no error): the next window may be carried from it
+    int tcol[T];                 // the touched columns (aligned with gtouched)
+    int termCol[T], termRow[T], termPrev[T], termSigma[T];
+    double termInvD[T];
+    int colLast[KCmax], colN[KCmax], colN0[KCmax], colSlot[KCmax];
+    double colRCF[KCmax];
+    double wv[T * kGramRows];    // the terms' w vectors over the window's rows
 };
 
 __device__ inline double safe_cap_now(const Dev &d, const Ctrl *c) { return d.safe_cap > 0.0 ? d.safe_cap : c->safe_cap; }
@@ -422,6 +453,10 @@ bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach,
 void launch_safe_open(const Dev &d, hipStream_t st);                     // kernels_safe.hip
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
+// pipelined windows: the pieces, queued by the host on two streams (bgmm_api.hip: gram_pipe_batch)
+bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st);   // cross forms (+ those with the window before) + weights
+void launch_gram_carry(const Dev &d, hipStream_t st);
+bool launch_gram_resolve_only(const Dev &d, int resolve_lds, hipStream_t st);
 // kernels_rng.hip: the caller's MT19937 continued on the device (chains of 64 blocks from jumped-ahead states)
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();

@@ -60,6 +60,13 @@ __device__ __forceinline__ int gram_nrows(const Dev &d, const Ctrl *c) {
     const long long left = c->n_visits - c->job.pos;
     return left < GR ? (int)left : GR;
 }
+// (pipelined windows: the launch's window starts where the host predicted, whatever window the control block has open)
+__device__ __forceinline__ long long gram_pos0(const Dev &d, const Ctrl *c) { return d.pipe ? d.pipe_pos : c->job.pos; }
+__device__ __forceinline__ int gram_nrows_at(const Dev &d, const Ctrl *c, long long pos0) {
+    if (d.safe_mode) return c->gl_n;
+    const long long left = c->n_visits - pos0;
+    return left < GR ? (left > 0 ? (int)left : 0) : GR;
+}
 __device__ __forceinline__ long long gram_pos(const Dev &d, long long pos0, int row) {
     return d.safe_mode ? d.glist[d.ctrl->gl_off + row] : pos0 + row;
 }
@@ -70,17 +77,17 @@ __device__ __forceinline__ long long gram_pos(const Dev &d, long long pos0, int 
 // the fragment reads Ys[16 t + (lane & 15)][4 kk + (lane >> 4)] are conflict free).
 // ------------------------------------------------------------------------------------------
 template <int NJ>
-__device__ __forceinline__ void gram_body(const Dev &d) {
+__device__ __forceinline__ void gram_body(const Dev &d, bool with_previous = false) {
     extern __shared__ __attribute__((aligned(16))) double Ys[];
     const Ctrl *c = d.ctrl;
-    if (c->job.mode == MODE_DONE || c->error != 0) return;
+    if (c->job.mode == MODE_DONE || c->error != 0 || (d.pipe && c->pipe_break)) return;
     const int K = c->job.K;
     if (K + kGramColSlack > d.gcols) return;               // (the resolver reports the stall)
     const int col = blockIdx.x;
     if (col > K) return;
     const int s = col < K ? d.perm[col] : d.K_max;
-    const long long pos0 = c->job.pos;
-    const int nrows = gram_nrows(d, c);
+    const long long pos0 = gram_pos0(d, c);
+    const int nrows = gram_nrows_at(d, c, pos0);
     if (nrows <= 0) return;
     constexpr int Dp = 16 * NJ, LD = Dp + 2, NF = 2 * NJ * (NJ + 1), PF = pick_pf(NF);
     const int D = d.D;
@@ -177,9 +184,59 @@ __device__ __forceinline__ void gram_body(const Dev &d) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cc[(ti * 16 + lk + 4 * r) * GR + tj * 16 + lr] = acc[r];
     }
+    // ---- pipelined windows: the cross forms between this window's rows and the rows of the window BEFORE it (whose moves
+    // are not in the factor yet: gram_carry_kernel applies them as terms) -- a(x) of the old rows into the second half of
+    // the tile, then the full 64 x 64 block new x old
+    if (d.pipe && with_previous && pos0 >= GR) {
+        double *__restrict__ Ys2 = Ys + GR * LD;
+        {
+            const int row = w * 16 + lr;
+            const long long p = pos0 - GR + row;
+            const long long i = d.order ? d.order[p] : p;
+            const double *__restrict__ xrow = d.X + i * D;
+            double xo[NJ * 4];
+#pragma unroll
+            for (int kk = 0; kk < NJ * 4; ++kk) {
+                const int l = 4 * kk + lk;
+                xo[kk] = l < D ? xrow[l] : 0.0;
+            }
+            double ring2[PF];
+#pragma unroll
+            for (int i2 = 0; i2 < PF; ++i2) ring2[i2] = wf[i2 * 64];
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+                v4d acc = (v4d){cj[J], cj[J], cj[J], cj[J]};
+#pragma unroll
+                for (int kk = 0; kk < 4 * (J + 1); ++kk) {
+                    const int f = 2 * J * (J + 1) + kk;
+                    const double b = ring2[f % PF];
+                    if (f + PF < NF) ring2[f % PF] = wf[(f + PF) * 64];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xo[kk], b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ys2[(w * 16 + lk + 4 * r) * LD + 16 * J + lr] = acc[r];
+            }
+        }
+        __syncthreads();
+        double *__restrict__ Xc = d.gX + (long long)col * GR * GR;
+        for (int t = w; t < 16; t += 4) {
+            const int ti = t >> 2, tj = t & 3;
+            if (ti * 16 >= nrows) continue;
+            const double *__restrict__ ya = Ys + (ti * 16 + lr) * LD + lk;
+            const double *__restrict__ yb = Ys2 + (tj * 16 + lr) * LD + lk;
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+            for (int kk = 0; kk < Dp / 4; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[4 * kk], yb[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xc[(ti * 16 + lk + 4 * r) * GR + tj * 16 + lr] = acc[r];
+        }
+    }
 }
 template <int NJ>
 __global__ __launch_bounds__(256) void gram_kernel(Dev d) { gram_body<NJ>(d); }
+template <int NJ>
+__global__ __launch_bounds__(256) void gram_cross_kernel(Dev d, int with_previous) { gram_body<NJ>(d, with_previous != 0); }
 // (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
 template <int NJ>
 __global__ __launch_bounds__(256) void gram_group_kernel(const Dev *__restrict__ group) {
@@ -196,11 +253,11 @@ __global__ __launch_bounds__(256) void gram_group_kernel(const Dev *__restrict__
 __device__ __forceinline__ void gram_weights_body(const Dev &d) {
     __shared__ double red[4];
     const Ctrl *c = d.ctrl;
-    if (c->job.mode == MODE_DONE || c->error != 0) return;
+    if (c->job.mode == MODE_DONE || c->error != 0 || (d.pipe && c->pipe_break)) return;
     const int K = c->job.K;
     if (K + kGramColSlack > d.gcols) return;
-    const long long pos0 = c->job.pos;
-    const int nrows = gram_nrows(d, c);
+    const long long pos0 = gram_pos0(d, c);
+    const int nrows = gram_nrows_at(d, c, pos0);
     const int r = blockIdx.x;
     if (r >= nrows) return;
     const long long p = gram_pos(d, pos0, r);
@@ -265,6 +322,7 @@ struct GramShared {
     int pub_mode, pub_hcol, pub_pcol, pub_has0, pub_term, upd_n, K, nmoves;
     int cut, pad_;                 // safe-stay windows: a column ran out of budget (1) / drifted too far or was opened (2):
                                    // the window ends behind this move
+    int nterms_end, mapver_end;    // at the end of the walk: terms made / changes of the label map (pipelined windows)
     double cap;                    // the budget the robust tables of this window were built for
     double wsum2[2];               // sum of |log |D_t|| over the window's terms, and their number (per update wave)
     int wterms2[2];
@@ -298,7 +356,10 @@ struct GramPlan {
     static constexpr unsigned oLabCol = oColLast + KC * 4;
     static constexpr unsigned oPermL = oLabCol + KC * 4;
     static constexpr unsigned oColWm = oPermL + KC * 4;           // colWm[KC] floats: the removals' account (SafeCol::wm)
-    static constexpr unsigned bytes = oColWm + KC * 4;
+    static constexpr unsigned oTermRow = oColWm + KC * 4;         // per term [T] ints: the row that made it, its sign, its column
+    static constexpr unsigned oTermSig = oTermRow + T * 4;        // (what the next window's carry needs: pipelined windows)
+    static constexpr unsigned oTermCol = oTermSig + T * 4;
+    static constexpr unsigned bytes = oTermCol + T * 4;
 };
 
 // the two plans the host chooses between (columns, terms)
@@ -353,6 +414,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                   colLab = (lds_i32)(lb + P::oColLab), colLast = (lds_i32)(lb + P::oColLast),
                   labCol = (lds_i32)(lb + P::oLabCol), permL = (lds_i32)(lb + P::oPermL);
     LDS_AS float *const colWm = (LDS_AS float *)(lb + P::oColWm);
+    const lds_i32 termRow = (lds_i32)(lb + P::oTermRow), termSig = (lds_i32)(lb + P::oTermSig), termCol = (lds_i32)(lb + P::oTermCol);
     Ctrl *c = d.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr unsigned gld = KC;
@@ -363,13 +425,17 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
 
     if (tid == 0) {
         S.active = 0;
-        c->gram_ntouched = 0;                   // (an idle step must not replay the last window's lists)
-        c->gram_nmoves = 0;
-        c->gram_rebuild = 0;
+        d.gfin[0] = 0;                          // (an idle step must not replay the last window's lists)
+        d.gfin[1] = 0;
+        d.gfin[2] = 0;
+        if (d.pipe) ((GramXp *)d.xp_out)->hdr[2] = 0;
         const Job &j = c->job;
-        if (j.mode != MODE_DONE && c->error == 0) {
+        if (d.pipe && j.mode != MODE_DONE && c->error == 0 && (c->pipe_break || j.pos != d.pipe_pos)) {
+            c->pipe_break = 1;                  // (the window is not where the carried cross forms are: the batch stands still)
+        } else if (j.mode != MODE_DONE && c->error == 0) {
             if (d.gcols != KC || j.K + kGramColSlack > KC || j.K + T / 2 + 2 > 64 * LPL) {
                 c->gram_stall = 1;              // more columns than the plan / labels than the draw wave holds
+                if (d.pipe) c->pipe_break = 1;
             } else {
                 S.active = 1;
                 S.pos0 = j.pos;
@@ -423,7 +489,8 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
             colWm[j] = e.wm;
         }
         if (j < K0) {
-            const int n = d.n[s];
+            // (a carried window: the counts behind the window before -- Dev::n is being brought up to date beside this kernel)
+            const int n = d.pipe == 1 ? ((const GramXp *)d.xp_in)->colN[j] : d.n[s];
             colSlot[j] = s;
             colN[j] = n;
             colN0[j] = n;
@@ -845,6 +912,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
             wvv[t * GR + lane] = act ? acc : 0.0;
             if (lane == 0) {
                 termInvD[t] = invD;
+                termRow[t] = r; termSig[t] = sg; termCol[t] = cl;
                 colRCF[cl] = rcf_new;
                 if (mode == 0) { termPrev[t] = prev0; colLast[cl] = t; colN[cl] = n_new; }
                 if (!((double)sg * Dt > 0.0) || !(rcf_new > 0.0)) S.err = -4;
@@ -894,6 +962,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
     }
     if (wave == 0 && lane == 0) {
         S.K = K; S.nmoves = nmoves; S.lik = lik; S.ema_run = ema_run; S.last_mover = last_mover; S.ncols = ncols;
+        S.nterms_end = nterms; S.mapver_end = mapver;      // (mapver > 0: a component was opened or deleted inside the window)
     }
     __syncthreads();
 
@@ -918,10 +987,17 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
     for (int cl = tid; cl < S.ncols; cl += GRT) {
         if (cl == cprior || colLast[cl] < 0 || colSlot[cl] < 0) continue;
         const int s = colSlot[cl], n = colN[cl];
-        d.n[s] = n;
+        // (pipelined windows: gram_finish_kernel writes the count -- it runs beside the NEXT resolver, whose close would
+        //  otherwise overwrite the count this window's finish still has to read)
+        if (!d.pipe || n <= 0) d.n[s] = n;
         if (n > 0) {
-            d.gtouched[atomicAdd(&c->gram_ntouched, 1)] = s;
-            if (d.nupd[s] + 16 > kGramRefreshEvery) c->gram_rebuild = 1;       // (gram_finish_kernel: rebuilds come in bunches)
+            const int at = atomicAdd(&d.gfin[0], 1);
+            d.gtouched[at] = s;
+            d.gfin[16 + at] = n;
+            if (d.pipe) ((GramXp *)d.xp_out)->tcol[at] = cl;
+            // (gram_finish_kernel: rebuilds come in bunches -- not for pipelined windows, whose finish kernels run beside
+            //  the next resolver: a flag read from counters they are updating would make the route a matter of timing)
+            if (!d.pipe && d.nupd[s] + 16 > kGramRefreshEvery) d.gfin[2] = 1;
         }
         if (d.safe_mode) {
             // what the label has used of its budget, and what it may still lose / gain, for the stretch's next window
@@ -931,6 +1007,33 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
             if (e.hi != 32767) e.hi = (short)((int)e.hi - dn);
             e.wm = colWm[cl]; e.pad = 0;
             d.ep_state[s] = e;
+        }
+    }
+    if (d.pipe) {
+        // ---- what the next window's carry needs: the terms (column, row, sign, 1 / D, chain links, w vectors over this
+        // window's rows) and every column's count before / after, slot, last term and prod |D|^-1/2
+        GramXp *xp = (GramXp *)d.xp_out;
+        const int nt = S.nterms_end;
+        for (int t = tid; t < nt; t += GRT) {
+            xp->termCol[t] = termCol[t]; xp->termRow[t] = termRow[t]; xp->termPrev[t] = termPrev[t]; xp->termSigma[t] = termSig[t];
+            xp->termInvD[t] = termInvD[t];
+        }
+        for (int e = tid; e < nt * GR; e += GRT) xp->wv[e] = wvv[e];
+        for (int cl = tid; cl < S.ncols; cl += GRT) {
+            xp->colLast[cl] = colLast[cl]; xp->colN[cl] = colN[cl]; xp->colN0[cl] = colN0[cl]; xp->colSlot[cl] = colSlot[cl];
+            xp->colRCF[cl] = colRCF[cl];
+        }
+        __syncthreads();                               // (the list of touched columns is complete)
+        if (tid == 0) {
+            // carried on from here only if the window was walked to its end as it was laid out: all its rows, the labels
+            // unchanged, nothing wrong
+            const bool clean = S.err >= 0 && S.cut == 0 && S.mapver_end == 0 && consumed == nrows && S.event == GEV_DONE;
+            xp->hdr[0] = atomicAdd(&d.gfin[0], 0);
+            xp->hdr[1] = nt;
+            xp->hdr[3] = S.ncols;
+            __threadfence();
+            xp->hdr[2] = clean ? 1 : 0;
+            if (!clean) c->pipe_break = 1;
         }
     }
     if (tid == 0) {
@@ -943,7 +1046,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
         c->n_pairs_exact += (unsigned long long)nrows * (unsigned long long)(j.K + 1);
         c->lik_evals += S.lik;
         c->n_moves += S.nmoves;
-        c->gram_nmoves = S.nmoves;
+        d.gfin[1] = S.nmoves;
         if (d.safe_mode) {
             const long long adv = next_pos - pos0;
             c->safe_windows += 1;
@@ -1031,6 +1134,150 @@ __global__ __launch_bounds__(GRT) void gram_resolve_group_kernel(const Dev *__re
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// Pipelined windows.  A window costs the resolver's walk (one workgroup, ~180 us for 64 moves at D = 64) plus, in series
+// with it, gram_finish (the touched factors rebuilt: ~48 us), the next window's cross forms (~14 us), its weights and four
+// launch gaps: a quarter of the chain is work that does not have to be on it.  The reference's state after window w - 1
+// is the state before it PLUS that window's logged terms (igmm/crpmm.py:82-88: a move is a rank-1 change of two
+// components) -- and terms are what the resolver is built on.  So the cross forms of window w are made against the factors
+// as they stood BEFORE window w - 1 (gram_cross_kernel: on a second stream, beside the resolver of window w - 1, together
+// with the cross forms between the two windows' rows), and gram_carry_kernel -- one workgroup per component window w - 1
+// touched, in parallel, ~10 us on the chain -- applies window w - 1's terms to them by the recursion of the header,
+//     w_i(y) = c_0(y, x_i) - sum_{j < i} w_j(y) w_j(x_i) / D_j,      c'(y, y') = c_0(y, y') - sum_i w_i(y) w_i(y') / D_i,
+// counts and log determinants included: what the resolver of window w then sees is a frozen state equal to the true one,
+// and nothing else about it changes.  gram_finish of window w - 1 and the cross forms of window w + 1 follow on the second
+// stream while window w is walked.  A window that ends early, opens or deletes a component or fails breaks the chain
+// (Ctrl::pipe_break): the rest of the batch stands still and the host goes on with plain windows.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) double wn_raw[];      // [terms of the column][64] w over the NEW rows
+    __shared__ int chain[kGramMaxTerms];
+    __shared__ double chain_id[kGramMaxTerms];
+    Ctrl *c = d.ctrl;
+    if (c->job.mode == MODE_DONE || c->error != 0 || c->pipe_break) return;
+    const GramXp *__restrict__ xp = (const GramXp *)d.xp_in;
+    const int b = blockIdx.x;
+    // (one round trip: the verdict on the window before, how many columns it touched, this workgroup's column, the terms)
+    const int clean = xp->hdr[2], ntouched = xp->hdr[0], nt = xp->hdr[1];
+    const int cl_ = xp->tcol[b < kGramMaxTerms ? b : 0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int tc0 = -1, tc1 = -1;
+    if (tid < 64) { tc0 = xp->termCol[lane]; tc1 = xp->termCol[64 + lane]; }
+    if (!clean || b >= ntouched) return;              // (not clean: that window's resolver has broken the chain)
+    const int cl = cl_;
+    const long long pos0 = d.pipe_pos;
+    const int nrows = gram_nrows_at(d, c, pos0);
+    if (nrows <= 0) return;
+    LDS_AS double *const wn = (LDS_AS double *)wn_raw;
+    const double *__restrict__ Xc = d.gX + (long long)cl * GR * GR;
+    double *__restrict__ Cc = d.gC + (long long)cl * GR * GR;
+    // the column's block of cross forms sets off now (16 entries per thread), its terms are sorted out meanwhile
+    double cv[GR * GR / 256];
+#pragma unroll
+    for (int k = 0; k < GR * GR / 256; ++k) cv[k] = Cc[tid + 256 * k];
+    const int s = xp->colSlot[cl];
+    const int n0 = xp->colN0[cl], n1 = xp->colN[cl];
+    const double rcf = xp->colRCF[cl];
+    const double logdet0 = d.gcc[((long long)cl * 5 + 2) * 8 + 6];
+    // the column's terms in the order they were made: a column's terms carry increasing indices
+    int m = 0;
+    if (tid < 64) {
+        const unsigned long long m0 = __ballot(lane < nt && tc0 == cl), m1 = __ballot(64 + lane < nt && tc1 == cl);
+        const int c0n = __popcll(m0);
+        m = c0n + __popcll(m1);
+        if (lane < nt && tc0 == cl) chain[__popcll(m0 & ((1ull << lane) - 1ull))] = lane;
+        if (64 + lane < nt && tc1 == cl) chain[c0n + __popcll(m1 & ((1ull << lane) - 1ull))] = 64 + lane;
+    }
+    const double kN0 = d.k0 + (double)n0, kN1 = d.k0 + (double)n1, ik0 = 1.0 / kN0, ik1 = 1.0 / kN1;
+    // ---- the terms' w over the new rows (wave 0, lane = new row: the recursion runs along the column's short chain)
+    double q_new = 0.0;
+    if (tid < 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double xr[4], idv[4];
+        int rov[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                 // (the first terms' loads side by side: most columns have one or two)
+            const int t = a < m ? chain[a] : 0;
+            rov[a] = xp->termRow[t];
+            idv[a] = xp->termInvD[t];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xr[a] = Xc[lane * GR + rov[a]];
+        for (int a = 0; a < m; ++a) {
+            const int t = chain[a];
+            const int ro = a < 4 ? rov[a] : xp->termRow[t];
+            double w = (a < 4 ? xr[a] : Xc[lane * GR + ro]) + ik0;
+            for (int q = 0; q < a; ++q) w = fma(-(wn[q * GR + lane] * xp->wv[chain[q] * GR + ro]), chain_id[q], w);
+            wn[a * GR + lane] = w;
+            if (lane == 0) chain_id[a] = a < 4 ? idv[a] : xp->termInvD[t];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        double v = d.gq0[(long long)cl * GR + lane] + (ik0 - ik1);
+        for (int a = 0; a < m; ++a) v = fma(-(wn[a * GR + lane] * wn[a * GR + lane]), chain_id[a], v);
+        d.gq0[(long long)cl * GR + lane] = v;
+        q_new = v;                                     // c'(y, y) - 1 / k_N1: the quadratic form of the predictive at the new count
+        if (lane == 0) chain[kGramMaxTerms - 1] = m;
+    }
+    __syncthreads();
+    m = chain[kGramMaxTerms - 1];
+    // ---- the cross forms of the new window under the true state: every entry of the column's 64 x 64 block (the stored
+    // form leaves 1 / k_N out: the resolver adds the NEW count's, so the old one's is swapped for it here)
+    const double shift = ik0 - ik1;
+#pragma unroll
+    for (int k = 0; k < GR * GR / 256; ++k) {
+        const int e = tid + 256 * k, r = e >> 6, r2 = e & 63;
+        double v = cv[k] + shift;
+        for (int a = 0; a < m; ++a) v = fma(-(wn[a * GR + r] * wn[a * GR + r2]), chain_id[a], v);
+        Cc[e] = v;
+    }
+    // ---- the column's constants for the counts around its new one (gram_body's block, with the carried log determinant:
+    // logdet S_N now = logdet S_N (frozen) + log(k_N0 / k_N1) + sum log |D_i|, and prod |D_i|^-1/2 is what the resolver kept)
+    const double logdet1 = logdet0 + fm_log(kN0 * ik1) - 2.0 * fm_log(rcf);
+    if (tid >= 64 && tid < 69) {
+        const int e5 = tid - 64, nn = n1 + e5 - 2;
+        double *g = d.gcc + ((long long)cl * 5 + e5) * 8;
+        g[0] = ik1; g[6] = logdet1; g[5] = -1.0;
+        if (nn >= 1) {
+            const SlotTab tab = load_slot_tab(d, nn);
+            const double kN = d.k0 + (double)nn;
+            const long long v = d.v0 + nn - d.D + 1;
+            g[1] = 1.0 / kN;
+            g[2] = kN / (kN + 1.0);
+            g[3] = 0.5 * (double)(v + d.D);
+            g[4] = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet1)) - 0.5 * fm_log(kN1 / kN);
+            g[5] = (double)nn;
+            g[7] = tab.seat1 + tab.g1 - 0.5 * (double)d.D * tab.lc1;
+        }
+    }
+    // ---- the frozen weights of the new rows under this column: exp(lp - M_r), as an update wave of the resolver would
+    // leave them for a column without a term
+    if (tid < 64 && lane < nrows && n1 >= 1) {
+        const SlotTab tab = load_slot_tab(d, n1);
+        const long long v = d.v0 + n1 - d.D + 1;
+        const double inv_cv = kN1 / (kN1 + 1.0), hv = 0.5 * (double)(v + d.D);
+        const double cbase = tab.seat + (tab.g - 0.5 * ((double)d.D * tab.lc + logdet1));
+        const double rM = d.gM[lane];
+        const long long p = pos0 + lane;
+        const long long i = d.order ? d.order[p] : p;
+        const bool own = d.z[i] == s && n1 >= 2;
+        double ee = fm_exp((cbase - rM) - hv * fm_log(1.0 + q_new * inv_cv));
+        if (own) {
+            const double a1 = kN1 / (kN1 - 1.0), den = 1.0 - a1 * q_new, hv1 = hv - 0.5;
+            const double c7 = tab.seat1 + tab.g1 - 0.5 * (double)d.D * tab.lc1;
+            ee = fm_exp(((c7 - 0.5 * logdet1) - rM) - 0.5 * fm_log(den) - hv1 * fm_log(1.0 + a1 * q_new / den));
+        }
+        d.ge0[(long long)lane * d.gcols + cl] = ee;
+    }
+}
+
+void launch_gram_carry(const Dev &d, hipStream_t st) {
+    const int lds = kGramMaxTerms * GR * (int)sizeof(double);
+    static PerDeviceLds attr;
+    attr.ensure((const void *)gram_carry_kernel, lds);
+    hipLaunchKernelGGL(gram_carry_kernel, dim3(kGramMaxTerms), dim3(256), lds, st, d);
+}
+
 template <int NJ>
 static void launch_gram_t(const Dev &d, hipStream_t st) {
     const int lds = GR * (16 * NJ + 2) * (int)sizeof(double);
@@ -1100,6 +1347,42 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
         hipLaunchKernelGGL((gram_resolve_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
     }
     launch_gram_finish(d, st);
+    return true;
+}
+
+template <int NJ>
+static void launch_gram_cross_t(const Dev &d, bool with_previous, hipStream_t st) {
+    const int lds = 2 * GR * (16 * NJ + 2) * (int)sizeof(double);
+    static PerDeviceLds attr;
+    attr.ensure((const void *)gram_cross_kernel<NJ>, lds);
+    hipLaunchKernelGGL((gram_cross_kernel<NJ>), dim3(d.gcols), dim3(256), lds, st, d, with_previous ? 1 : 0);
+}
+
+bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st) {
+    switch (d.Dp / 16) {
+        case 1: launch_gram_cross_t<1>(d, with_previous, st); break;
+        case 2: launch_gram_cross_t<2>(d, with_previous, st); break;
+        case 3: launch_gram_cross_t<3>(d, with_previous, st); break;
+        case 4: launch_gram_cross_t<4>(d, with_previous, st); break;
+        case 5: launch_gram_cross_t<5>(d, with_previous, st); break;
+        case 6: launch_gram_cross_t<6>(d, with_previous, st); break;
+        case 7: launch_gram_cross_t<7>(d, with_previous, st); break;
+        case 8: launch_gram_cross_t<8>(d, with_previous, st); break;
+        default: return false;
+    }
+    hipLaunchKernelGGL(gram_weights_kernel, dim3(GR), dim3(256), 0, st, d);
+    return true;
+}
+
+bool launch_gram_resolve_only(const Dev &d, int resolve_lds, hipStream_t st) {
+    const int reach = d.gram_K + d.gram_terms / 2 + 2 + 32;
+    if (d.gcols == kPlanA_KC) {
+        if (reach <= 128) hipLaunchKernelGGL((gram_resolve_kernel<2, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+        else if (reach <= 256) hipLaunchKernelGGL((gram_resolve_kernel<4, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+        else hipLaunchKernelGGL((gram_resolve_kernel<6, kPlanA_KC, kPlanA_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+    } else {
+        hipLaunchKernelGGL((gram_resolve_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1), dim3(GRT), resolve_lds, st, d);
+    }
     return true;
 }
 

@@ -218,10 +218,13 @@ __device__ __forceinline__ void gram_finish_body(const Dev &d) {
     __shared__ int mv_op[kGramMaxTerms];          // 1: x leaves this slot, 2: joins it, 3: joins and opens it
     __shared__ int n_ops, any_open;
     __shared__ double xs[BGMM_MAX_D], ms[BGMM_MAX_D], wide_scan[256];
-    const Ctrl *c = d.ctrl;
-    if ((int)blockIdx.x >= c->gram_ntouched) return;
+    if ((int)blockIdx.x >= d.gfin[0]) return;
     const int s = d.gtouched[blockIdx.x];
-    const int D = d.D, nm = c->gram_nmoves, tid = threadIdx.x;
+    if (d.pipe) {              // (the slot's count behind this window: the resolver left it on the list, see there)
+        if (threadIdx.x == 0) d.n[s] = d.gfin[16 + blockIdx.x];
+        __syncthreads();
+    }
+    const int D = d.D, nm = d.gfin[1], tid = threadIdx.x;
     // this slot's moves, in visiting order (one load per thread, compacted by a ballot scan)
     if (tid == 0) { n_ops = 0; any_open = 0; }
     __syncthreads();
@@ -252,7 +255,7 @@ __device__ __forceinline__ void gram_finish_body(const Dev &d) {
     const int few = D >= 24 ? D / 12 : 1;
     const int steps = d.nupd[s];
     const bool rank1 = nops >= 1 && nops <= few && !any_open && steps + nops <= kGramRefreshEvery &&
-                       !(c->gram_rebuild && steps > kGramRefreshEvery / 2);
+                       !(d.gfin[2] && steps > kGramRefreshEvery / 2);
 #ifdef BGMM_PROFILE
     long long fk0 = clock64(), fk1;
 #define FPROF(i) do { if (tid == 0 && blockIdx.x == 0) { fk1 = clock64(); d.ctrl->prof[i] += fk1 - fk0; fk0 = fk1; } } while (0)
