@@ -9,7 +9,7 @@
 # 4. kernel trace of the burn-in regime alone (C4 from a random start, two sweeps),
 # 5. the other BASELINE shapes' bench lines.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -32,9 +32,15 @@ python $REPO/tools/summarize_pmc.py "$OUT/pmcm" gram_resolve_kernel gram_kernel 
 rocprofv3 --kernel-trace --stats -d "$OUT/ktb" -o kt --output-format csv -- \
     python $REPO/tools/probe.py chain 1000000 64 200 --init rand --sweeps 2 > "$OUT/burnin_C4_under_rocprof.log" 2> "$OUT/ktb.err"
 stats_of "$OUT/ktb" "$OUT/kernel_stats_C4_burnin.csv"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt3" -o kt --output-format csv -- \
+    python $REPO/bench.py --workload C3 --steps 300 --cpu-visits 0 --numpy-visits 0 --no-burnin --no-moving --no-pmc --no-class-api > "$OUT/bench_C3_under_rocprof.json" 2> "$OUT/kt3.err"
+stats_of "$OUT/kt3" "$OUT/kernel_stats_C3.csv"
+rocprofv3 --kernel-trace --stats -d "$OUT/ktb5" -o kt --output-format csv -- \
+    python $REPO/tools/probe.py chain 2000000 128 200 --init rand --sweeps 1 --pcrp > "$OUT/burnin_C5_under_rocprof.log" 2> "$OUT/ktb5.err"
+stats_of "$OUT/ktb5" "$OUT/kernel_stats_C5_burnin.csv"
 cd $REPO
 for WL in C3 C5 C2; do
     python bench.py --workload $WL --steps 300 --keep-pmc "$OUT" > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
     tail -c 300 "$OUT/bench_$WL.json"
 done
-rm -rf "$OUT/kt" "$OUT/ktb" "$OUT/ktm" "$OUT/pmcm"
+rm -rf "$OUT/kt" "$OUT/ktb" "$OUT/ktm" "$OUT/pmcm" "$OUT/kt3" "$OUT/ktb5"
