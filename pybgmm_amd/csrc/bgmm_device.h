@@ -194,7 +194,9 @@ struct WRec {
     int home;           // home slot (-1: unassigned)
     int home_label;     // its label in this window's frozen state
     double mlb0;        // log(alpha) + log_prior[i]: the "new table" score, first lower bound of the best score
-    double pad;
+    double u;           // the visit's uniform, as of the sweep the record was written in (bucket_scatter_kernel): good for
+                        // the launches behind that scatter only -- an order kept across sweeps (skip_sort, safe-stay
+                        // epochs) keeps the records and reads d.u
 };
 
 // What score_mfma_prune_kernel leaves per DATA POINT for certify_kernel: its exact quadratic form

@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     constexpr int NS = home_slots(NJ);
     constexpr int NB = WHOLE ? home_nbr(NJ * 16) : 0;                 // neighbours of the home scored exactly (D = 16, 32)
     const long long nrows = c->n_sorted_pad;                          // (every home's run padded to whole blocks: bucket_prefix_kernel)
+    // the records were written for this very window (bucket_scatter_kernel ran in front): they carry the visits' uniforms
+    const bool u_in_rec = !c->skip_sort;
     const long long nblocks = (nrows + 255) >> 8;
     const int D = d.D, K = c->job.K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     // everything but the home, relative to it: the other labels (together below `bound`), the new table
                     // (exact); a component opened inside the window ends it (kernels_gram.hip)
                     const double R = (exp(bound - lb) + exp(rcur.mlb0 - lb)) * (1.0 + 1e-6);
-                    const double u_cur = d.u[win_base + wrow_cur];
+                    const double u_cur = u_in_rec ? rcur.u : d.u[win_base + wrow_cur];
                     safe = R < 0.25 && u_cur >= R + 1e-12 && u_cur <= 1.0 - R - 1e-12;
                     // the table's triangle bound may be what fails: such a visit goes on the residual list, where the
                     // components it cannot exclude are scored exactly (score_mfma_prune_kernel, safe_choice_kernel)
@@ -617,7 +619,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     if (den > 0.0 && (first_ok || b2 < mx2 - margin)) {
                         easy = true;
                         const long long p = win_base + wrow_cur;
-                        const double u_cur = d.u[p];
                         double tot = 0.0, toth = 0.0, ec[NB + 1];
 #pragma unroll
                         for (int ci = 0; ci < NB + 1; ++ci) {
@@ -635,7 +636,12 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                         const double en = fm_exp(vnew - mx2);
                         tot += en; toth += en;
                         const double inv_tot = fm_div(1.0, tot);
-                        double uu = u_cur;
+                        // (the visit's uniform is fetched only when the draw depends on it -- a scattered 8-byte read per
+                        //  visit otherwise: when everything but the home weighs less than 1e-17 of the total, the labels in
+                        //  front of the home subtract less than that from a uniform that is at least 2^-53 and the home's own
+                        //  probability is 1 to rounding: the visit stays)
+                        const bool need_u = !(toth * inv_tot < 1e-17);
+                        double uu = u_in_rec ? rcur.u : (need_u ? d.u[p] : 0.5);
                         int pick = K;
 #pragma unroll
                         for (int ci = 0; ci < NB + 1; ++ci) {
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     if (!(dv < -37.0)) {
                         // (the visit's uniform is fetched only here: a scattered 8-byte read per visit otherwise, for a
                         //  draw whose outcome does not depend on it)
-                        const double u_cur = d.u[p];
+                        const double u_cur = u_in_rec ? rcur.u : d.u[p];
                         const double eo = fm_exp(-fabs(dv));
                         const double eh = dv <= 0.0 ? 1.0 : eo;
                         en = dv <= 0.0 ? eo : 1.0;

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
                 rec.home = b - 1;
                 rec.home_label = -1;
                 rec.mlb0 = 0.0;
-                rec.pad = 0.0;
+                rec.u = 0.5;
                 d.wrec[k] = rec;
                 d.wperm[k] = 0;
             }
@@ -807,13 +807,14 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
     // (a thread's four rows side by side: index loads, then label and prior loads, in flight together)
     int myb[BUCKET_ROWS / 256], myk[BUCKET_ROWS / 256];
     long long ii[BUCKET_ROWS / 256];
-    double lp[BUCKET_ROWS / 256];
+    double lp[BUCKET_ROWS / 256], uu[BUCKET_ROWS / 256];
 #pragma unroll
     for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
         const int r = r0 + threadIdx.x + t * 256;
         const bool ok = r < nrows && !(d.use_certify && d.cert[r < nrows ? r : 0]);
         const long long p = base + (r < nrows ? r : 0);
         ii[t] = ok ? (d.order ? d.order[p] : p) : -1;
+        uu[t] = d.u[p];                                // (read here in storage order: a scattered read per visit in home_kernel)
     }
 #pragma unroll
     for (int t = 0; t < BUCKET_ROWS / 256; ++t) {
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(Dev d) {
             rec.home = myb[t] - 1;
             rec.home_label = rec.home >= 0 ? d.label_of_slot[rec.home] : -1;
             rec.mlb0 = d.log_alpha + lp[t];
-            rec.pad = 0.0;
+            rec.u = uu[t];
             d.wrec[k] = rec;
         }
 }
