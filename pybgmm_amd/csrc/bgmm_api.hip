@@ -107,6 +107,36 @@ struct bgmm_ctx {
     size_t perm_temp_bytes = 0;
     long long *perm_out = nullptr;   // {words consumed, ran out}
     unsigned *perm_host = nullptr;   // pinned: [key out 624 | pos out | changed | out (2 x 64 bit)]
+    // Permutations in flight (look-ahead of the caller's numpy stream, "permutations in flight" below): kPermAhead generations
+    // queued behind the one being handed out, each taking its place in the word stream from the one in front of it ON THE
+    // DEVICE.  Three streams: the draws (perm_stream: the only serial chain from one generation to the next), the swaps
+    // (fin: sort, links, assembly, verdicts), the words (rawst: chunks of one long stream, far ahead of the draws).
+    struct PermPipe {
+        static constexpr int kAhead = 3;
+        bool built = false, valid = false;
+        hipStream_t fin = nullptr, rawst = nullptr;
+        hipEvent_t ev_draw[kAhead] = {}, ev_fin[kAhead] = {}, ev_raw = nullptr, ev_sweep = nullptr;
+        unsigned *era_raw = nullptr;        // era_raw[k]: the k-th (untempered) output behind the state the era began at
+        long long era_cap = 0;              // words the buffer holds
+        long long era_gen_words = 0;        // ... that have been queued for generation
+        unsigned *era_key = nullptr;        // device: [624] the state the era began at
+        unsigned *era_key_host = nullptr;   // pinned
+        int era_pos = 0;
+        long long *goffs = nullptr;         // device ring [8]: where generation g starts in the era (g % 8); -1: failed
+        int *cnt0 = nullptr, *cnt = nullptr;
+        int *J[kAhead] = {}, *flags[kAhead] = {};
+        long long *out[kAhead] = {};
+        unsigned *keyout[kAhead] = {};      // [624 key | pos, went through]
+        long long *ord[kAhead] = {};
+        long long *parked = nullptr;        // the order buffer released by the last call: written again one call later at the
+                                            // earliest (a sweep begun and not yet ended may be redone from it: finish_pending)
+        unsigned *host[kAhead] = {};        // pinned verdicts, laid out like perm_host
+        long long gen_next = 0, gen_queued = 0;   // the generation the next call takes / generations queued so far
+        long long off_exact = 0;            // where generation gen_next starts in the era
+        long long cap_words = 0;            // words one generation may read
+        uint32_t expect_key[624] = {};      // the caller's state iff it took the last permutation and drew nothing else
+        int expect_pos = -1;
+    } pp;
     // bgmm_sweep_staged_begin / _end: a sweep whose first batch of launches is in the queue and has not been waited for
     bool async_pending = false, async_short = false;
     bool run_zero_u = false, run_order_is_perm = true;   // what the sweep being run was staged with (snapshots: a stage call between
@@ -287,6 +317,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     // (the look-aheads may still be writing into buffers that are about to go)
     if (c->mt_stream) (void)hipStreamSynchronize(c->mt_stream);
     if (c->perm_stream) (void)hipStreamSynchronize(c->perm_stream);
+    if (c->pp.fin) (void)hipStreamSynchronize(c->pp.fin);
+    if (c->pp.rawst) (void)hipStreamSynchronize(c->pp.rawst);
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
@@ -300,7 +332,18 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (c->grp_devs) (void)hipFree(c->grp_devs);
     if (c->grp_ev_in) (void)hipEventDestroy(c->grp_ev_in);
     if (c->grp_ev_out) (void)hipEventDestroy(c->grp_ev_out);
+    if (c->pp.fin) { (void)hipStreamSynchronize(c->pp.fin); (void)hipStreamDestroy(c->pp.fin); }
+    if (c->pp.rawst) { (void)hipStreamSynchronize(c->pp.rawst); (void)hipStreamDestroy(c->pp.rawst); }
     if (c->perm_stream) { (void)hipStreamSynchronize(c->perm_stream); (void)hipStreamDestroy(c->perm_stream); }
+    for (int k = 0; k < bgmm_ctx::PermPipe::kAhead; ++k) {
+        if (c->pp.ev_draw[k]) (void)hipEventDestroy(c->pp.ev_draw[k]);
+        if (c->pp.ev_fin[k]) (void)hipEventDestroy(c->pp.ev_fin[k]);
+        if (c->pp.host[k]) (void)hipHostFree(c->pp.host[k]);
+    }
+    if (c->pp.ev_raw) (void)hipEventDestroy(c->pp.ev_raw);
+    if (c->pp.ev_sweep) (void)hipEventDestroy(c->pp.ev_sweep);
+    if (c->pp.era_raw) (void)hipFree(c->pp.era_raw);
+    if (c->pp.era_key_host) (void)hipHostFree(c->pp.era_key_host);
     if (c->perm_done) (void)hipEventDestroy(c->perm_done);
     if (c->perm_words) (void)hipFree(c->perm_words);
     if (c->perm_seeds) (void)hipFree(c->perm_seeds);
@@ -725,6 +768,7 @@ static int mt_wait_batches(bgmm_ctx *c) {
     for (auto &b : c->mt_b)
         if (b.launched && !b.synced) { CK(c, hipEventSynchronize(b.done)); b.synced = true; }
     if (c->perm_ahead_valid) CK(c, hipEventSynchronize(c->perm_done));     // (the permutation's look-ahead reads the same tables)
+    if (c->pp.rawst) CK(c, hipStreamSynchronize(c->pp.rawst));
     return 0;
 }
 
@@ -965,6 +1009,177 @@ static int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
     return 0;
 }
 
+// ---- permutations in flight ---------------------------------------------------------------------------------------------
+// One generation is a chain of ~0.64 ms at N = 1e6 (words 100 us, 30 rounds of draws 250, the serial tail 84, the swaps 190,
+// verdicts) in front of a pCRP sweep of 0.23 ms -- and the next generation needs only TWO things from it: where its words
+// end, and that they were generated.  So (BGMM_PERM_PIPE=0: the single look-ahead of round 3):
+//   * the words are one long stream (an "era": era_raw[k] = the k-th output behind the state the era began at), generated in
+//     chunks on their own stream far ahead of the draws -- a chunk continues from the last block of the one before it, which
+//     IS the generator's state there;
+//   * a generation reads its words at the offset the generation in front of it leaves on the device (PermPipe::goffs) and
+//     leaves its own end there: the draws of kAhead generations are queued back to back on one stream, no host in between;
+//   * the swaps of generation g (sort by target, links, assembly) and its verdicts run on a third stream beside the draws
+//     of generation g + 1.
+// The host sees a generation again when it is handed out: verdicts (settled, words left, the state numpy would be in), the
+// caller's state compared with the state the last call handed back -- anything else (a caller that drew from the stream in
+// between, draws that did not settle in the queued rounds) drains the three streams and goes the old way, on the spot.
+static bool perm_pipe_wanted() {
+    static const bool on = [] { const char *e = getenv("BGMM_PERM_PIPE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+static int perm_pipe_drain(bgmm_ctx *c) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    if (!Q.built) return 0;
+    CK(c, hipStreamSynchronize(Q.rawst));
+    CK(c, hipStreamSynchronize(c->perm_stream));
+    CK(c, hipStreamSynchronize(Q.fin));
+    Q.valid = false;
+    Q.gen_next = Q.gen_queued;          // (whatever was in flight is dropped)
+    return 0;
+}
+
+static int perm_pipe_ensure(bgmm_ctx *c) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    if (Q.built) return 0;
+    constexpr int A = bgmm_ctx::PermPipe::kAhead;
+    const long long N = c->d.N;
+    Q.cap_words = 2 * N + 1248;
+    const int T = perm_segments(Q.cap_words);
+    // the era: 64 generations' worth of words, within 1 GiB, never less than what kAhead + 2 generations may read
+    // (BGMM_PERM_ERA: generations' worth, for the test that walks through several eras)
+    static const int era_gens = [] { const char *e = getenv("BGMM_PERM_ERA"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();
+    long long cap = era_gens * Q.cap_words;
+    if (cap > (1ll << 28)) cap = 1ll << 28;
+    if (cap < (A + 3) * Q.cap_words) cap = (A + 3) * Q.cap_words;
+    Q.era_cap = 624 * ((cap + 623) / 624) + 1248;
+    CK(c, hipMalloc((void **)&Q.era_raw, sizeof(unsigned) * (size_t)Q.era_cap));
+    CK(c, hipHostMalloc((void **)&Q.era_key_host, sizeof(unsigned) * 640, hipHostMallocDefault));
+    { int rc = dalloc(c, &Q.era_key, (size_t)640); if (rc) return rc; }
+    { int rc = dalloc(c, &Q.goffs, (size_t)8); if (rc) return rc; }
+    { int rc = dalloc(c, &Q.cnt0, (size_t)T + 16); if (rc) return rc; }
+    { int rc = dalloc(c, &Q.cnt, 5 * (size_t)T + 16); if (rc) return rc; }
+    std::vector<int> guess((size_t)T);
+    perm_guess(Q.cap_words, (int)N, guess.data());
+    CK(c, hipMemcpy(Q.cnt0, guess.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice));
+    for (int k = 0; k < A; ++k) {
+        { int rc = dalloc(c, &Q.J[k], (size_t)N + 16); if (rc) return rc; }
+        CK(c, hipMemset(Q.J[k], 0, sizeof(int) * (size_t)N));
+        { int rc = dalloc(c, &Q.flags[k], (size_t)64); if (rc) return rc; }
+        { int rc = dalloc(c, &Q.out[k], (size_t)4); if (rc) return rc; }
+        { int rc = dalloc(c, &Q.keyout[k], (size_t)640); if (rc) return rc; }
+        { int rc = dalloc(c, &Q.ord[k], (size_t)N); if (rc) return rc; }
+        CK(c, hipHostMalloc((void **)&Q.host[k], sizeof(unsigned) * 1344, hipHostMallocDefault));
+        memset(Q.host[k], 0, sizeof(unsigned) * 1344);
+        CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], hipEventDisableTiming));
+        CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], hipEventDisableTiming));
+    }
+    { int rc = dalloc(c, &Q.parked, (size_t)N); if (rc) return rc; }
+    CK(c, hipEventCreateWithFlags(&Q.ev_raw, hipEventDisableTiming));
+    CK(c, hipEventCreateWithFlags(&Q.ev_sweep, hipEventDisableTiming));
+    CK(c, hipStreamCreateWithFlags(&Q.fin, hipStreamNonBlocking));
+    CK(c, hipStreamCreateWithFlags(&Q.rawst, hipStreamNonBlocking));
+    Q.built = true;
+    return 0;
+}
+
+// a new era from a state the host knows (all three streams idle)
+static int perm_pipe_start_era(bgmm_ctx *c, const uint32_t *key624, int pos) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    memcpy(Q.era_key_host, key624, sizeof(unsigned) * 624);
+    CK(c, hipMemcpyAsync(Q.era_key, Q.era_key_host, sizeof(unsigned) * 624, hipMemcpyHostToDevice, Q.rawst));
+    Q.era_pos = pos;
+    Q.era_gen_words = 0;
+    Q.off_exact = 0;
+    Q.gen_next = Q.gen_queued;
+    CK(c, hipMemsetAsync(Q.goffs + (Q.gen_queued & 7), 0, sizeof(long long), c->perm_stream));
+    Q.valid = true;
+    return 0;
+}
+
+// more words of the era on the words' stream, until `upto` of them are queued
+static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    if (upto > Q.era_cap) upto = Q.era_cap;
+    const long long chunk = 624 * ((Q.cap_words + 623) / 624);
+    bool any = false;
+    while (Q.era_gen_words < upto) {
+        const bool first = Q.era_gen_words == 0;
+        // (the first chunk ends on a block boundary of the stream; every later one starts behind the last block of the words
+        //  so far -- that block is the generator's state there -- and is whole blocks long)
+        const int pos = first ? Q.era_pos : 624;
+        long long n_words = first ? 624 * (((long long)pos + chunk + 623) / 624) - pos : chunk;
+        if (Q.era_gen_words + n_words > Q.era_cap) n_words = 624 * ((Q.era_cap - Q.era_gen_words) / 624);
+        if (n_words < 624) break;
+        const unsigned *key_in = first ? Q.era_key : Q.era_raw + Q.era_gen_words - 624;
+        const int chains = mt19937_chains_for_words(pos, n_words);
+        launch_mt19937_raw(key_in, pos, Q.era_raw + Q.era_gen_words, n_words, (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains,
+                           P.draw, c->perm_seeds, P.dspare, P.dspare_pos, Q.rawst);
+        CK(c, hipGetLastError());
+        Q.era_gen_words += n_words;
+        any = true;
+    }
+    if (any) CK(c, hipEventRecord(Q.ev_raw, Q.rawst));
+    return 0;
+}
+
+// queues one more generation; 1: the era has no room for it
+static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    constexpr int A = bgmm_ctx::PermPipe::kAhead;
+    const long long N = c->d.N;
+    const long long g = Q.gen_queued;
+    const int slot = (int)(g % A);
+    // where it starts at the latest (every generation in front of it reads at most cap_words), what it may read
+    const long long hi = Q.off_exact + (g - Q.gen_next) * Q.cap_words;
+    const long long need = hi + Q.cap_words + 1248;
+    if (need > Q.era_cap - 1248) return 1;
+    int rc = perm_pipe_words(c, P, need + 2 * Q.cap_words);
+    if (rc) return rc;
+    if (Q.era_gen_words < need) return 1;
+    hipStream_t D = c->perm_stream;
+    CK(c, hipStreamWaitEvent(D, Q.ev_raw, 0));
+    if (!launch_permutation_draws_chained(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
+                                          Q.J[slot], Q.cnt, Q.cnt0, Q.flags[slot], Q.out[slot], Q.keyout[slot],
+                                          (int *)(Q.keyout[slot] + 624), D))
+        return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+    CK(c, hipEventRecord(Q.ev_draw[slot], D));
+    // the swaps beside the next generation's draws; the order buffer they fill may be the one a sweep in flight still reads
+    // (it was swapped out when its permutation was taken): behind everything the sweeps' stream holds now
+    hipStream_t F = Q.fin;
+    CK(c, hipEventRecord(Q.ev_sweep, c->stream));
+    CK(c, hipStreamWaitEvent(F, Q.ev_sweep, 0));
+    CK(c, hipStreamWaitEvent(F, Q.ev_draw[slot], 0));
+    if (!launch_permutation_swaps((int)N, Q.J[slot], P.pred, P.ptr, P.ks, P.idx, P.iota, c->perm_temp, c->perm_temp_bytes, P.changed,
+                                  Q.ord[slot], F))
+        return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+    unsigned *H = Q.host[slot];
+    CK(c, hipMemcpyAsync(H, Q.keyout[slot], sizeof(unsigned) * 626, hipMemcpyDeviceToHost, F));            // key, pos, went through
+    CK(c, hipMemcpyAsync(H + 627, P.changed, sizeof(int), hipMemcpyDeviceToHost, F));
+    CK(c, hipMemcpyAsync(H + 628, Q.out[slot], sizeof(long long) * 2, hipMemcpyDeviceToHost, F));
+    CK(c, hipMemcpyAsync(H + 1280, Q.flags[slot], sizeof(int) * (size_t)(perm_rounds() + 2), hipMemcpyDeviceToHost, F));
+    CK(c, hipEventRecord(Q.ev_fin[slot], F));
+    Q.gen_queued += 1;
+    return 0;
+}
+
+static int perm_pipe_fill(bgmm_ctx *c, const PermPtrs &P) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    while (Q.gen_queued - Q.gen_next < bgmm_ctx::PermPipe::kAhead) {
+        const int rc = perm_pipe_queue_one(c, P);
+        if (rc == 1) break;
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static void perm_note_rounds(bgmm_ctx *c, const unsigned *H) {
+    int r = 1;
+    while (r <= perm_rounds() && H[1280 + r] != 0) ++r;
+    c->perm_last_rounds = r;
+    if (r > c->perm_max_rounds) c->perm_max_rounds = r;
+}
+
 extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int32_t *pos) {
     if (!c || !key624 || !pos) return BGMM_EINVAL;
     if (*pos < 0 || *pos > 624) return fail(c, BGMM_EINVAL, "MT19937 position must be in 0 .. 624");
@@ -975,10 +1190,40 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     int rc = perm_ensure(c, P);
     if (rc) return rc;
     unsigned *key_in_pinned = c->perm_host + 640;                 // [640, 1264): the state a generation starts from
-    // The permutation BEHIND the last one was started when that one was handed out (look-ahead, as for the uniforms): taken
-    // iff the caller's generator is exactly where that call left it.
+    const bool piped = c->mt_ahead_on && perm_pipe_wanted();
     bool hit = false;
-    if (c->perm_ahead_valid) {
+    if (piped && c->pp.built && c->pp.valid) {
+        bgmm_ctx::PermPipe &Q = c->pp;
+        const bool same = *pos == Q.expect_pos && memcmp(key624, Q.expect_key, sizeof(unsigned) * 624) == 0;
+        if (same && Q.gen_queued == Q.gen_next) {
+            // (the era ran out of room and the generations in it have all been taken: the next one from here)
+            rc = perm_pipe_drain(c);
+            if (rc == 0) rc = perm_pipe_start_era(c, key624, *pos);
+            if (rc == 0) rc = perm_pipe_fill(c, P);
+            if (rc) return rc;
+        }
+        if (same && Q.valid && Q.gen_queued > Q.gen_next) {
+            const int slot = (int)(Q.gen_next % bgmm_ctx::PermPipe::kAhead);
+            CK(c, hipEventSynchronize(Q.ev_fin[slot]));
+            const unsigned *H = Q.host[slot];
+            long long out[2];
+            memcpy(out, H + 628, sizeof(out));
+            if (H[625] == 1 && H[627] == 0 && out[1] == 0 && out[0] > 0) {
+                memcpy(key624, H, sizeof(unsigned) * 624);
+                *pos = (int32_t)H[624];
+                perm_note_rounds(c, H);
+                std::swap(c->d_order, Q.ord[slot]);
+                std::swap(Q.ord[slot], Q.parked);
+                Q.off_exact += out[0];
+                Q.gen_next += 1;
+                c->perm_hits += 1;
+                hit = true;
+            }
+        }
+        if (!hit) { rc = perm_pipe_drain(c); if (rc) return rc; }
+    } else if (!piped && c->perm_ahead_valid) {
+        // The permutation BEHIND the last one was started when that one was handed out (look-ahead, as for the uniforms): taken
+        // iff the caller's generator is exactly where that call left it.
         CK(c, hipEventSynchronize(c->perm_done));
         c->perm_ahead_valid = false;
         hit = c->mt_ahead_on && *pos == c->perm_ahead_pos_in && memcmp(key624, key_in_pinned, sizeof(unsigned) * 624) == 0;
@@ -991,6 +1236,7 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     }
     if (!hit) {
         SETTLE(c);                                      // (generated on the spot into d_order: a sweep in flight may read it)
+        if (c->pp.built) { rc = perm_pipe_drain(c); if (rc) return rc; }
         const int pos_in = *pos;
         memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);
         rc = perm_queue(c, P, key_in_pinned, pos_in, c->d_order, c->stream);
@@ -1005,6 +1251,16 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     c->order_is_perm = true;
     c->have_order = true;
     c->cur_order = c->d_order;
+    if (piped) {
+        // the generations behind this one, from the state just handed back
+        rc = perm_pipe_ensure(c);
+        if (rc) return rc;
+        bgmm_ctx::PermPipe &Q = c->pp;
+        if (!Q.valid) { rc = perm_pipe_start_era(c, key624, *pos); if (rc) return rc; }
+        memcpy(Q.expect_key, key624, sizeof(unsigned) * 624);
+        Q.expect_pos = *pos;
+        return perm_pipe_fill(c, P);
+    }
     if (c->mt_ahead_on) {
         // the next permutation, from the state just handed back, into the other buffer, beside the sweep about to be queued
         memcpy(key_in_pinned, key624, sizeof(unsigned) * 624);

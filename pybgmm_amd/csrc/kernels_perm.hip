@@ -70,10 +70,18 @@ static int perm_low(int n) { return n - 1 >= kPermTailLow ? kPermTailLow : n; }
 // since it last ran keeps its count without running again.  The round in which no count changed had every segment at its
 // true start; the round behind it writes the targets J[i] (i = 1 .. n-1) -- numpy's -- and out[0] = words consumed,
 // out[1] = 0 (by the segment in which step 1 is served), and the rounds behind that return at once.
+// goff (may be null): where this generation's words start in `raw`, left on the device by the generation in front of it
+// (pipelined generations, bgmm_api.hip "permutations in flight"); negative: that generation failed, and this one stands aside.
 __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low, int round,
                                                         int rounds, int *cnt, int *__restrict__ seen, int *__restrict__ J,
-                                                        long long *__restrict__ out, int *__restrict__ flags) {
+                                                        long long *__restrict__ out, int *__restrict__ flags,
+                                                        const long long *__restrict__ goff) {
     __shared__ unsigned ws[4][kPermSeg];
+    if (goff) {
+        const long long off = *goff;
+        if (off < 0) return;
+        raw += off;
+    }
     // flags[r] = some count changed in round r.  The first round behind a round that changed nothing is the WRITE pass:
     // every segment runs from its (now true) start once more and leaves its targets in J; the rounds behind it return.
     const bool settled = round >= 2 && flags[round - 1] == 0;
@@ -159,9 +167,15 @@ __global__ void perm_reflag_kernel(int rounds, int *__restrict__ flags, long lon
 // The steps below `low` (the masks of at most 14 bits: 23 k words or so), one wavefront, strictly in order behind the rounds:
 // every one of these short ranges starts where the one before it ended, so rounds would need one launch per range.
 __global__ __launch_bounds__(64) void perm_tail_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low,
-                                                       int *__restrict__ J, long long *__restrict__ out) {
+                                                       int *__restrict__ J, long long *__restrict__ out,
+                                                       const long long *__restrict__ goff) {
     __shared__ unsigned W[4096];
     const int lane = threadIdx.x;
+    if (goff) {
+        const long long off = *goff;
+        if (off < 0) return;
+        raw += off;
+    }
     const bool rounds_had_steps = n - 1 >= low;
     if (rounds_had_steps && out[3] != 0) return;           // (the rounds never reached `low`: the words ran out, or not settled yet)
     long long p = rounds_had_steps ? out[2] : 0;
@@ -298,6 +312,27 @@ __global__ void perm_state_kernel(const unsigned *__restrict__ key_in, const uns
     if (threadIdx.x == 0) pos_out[0] = (int)(g - 624 * nb);
 }
 
+// The same for a generation that reads its words at *goff_in of a longer stream (era_raw[k] = the k-th output behind
+// (era_key, era_pos)): the state behind it, and where the next generation starts (*goff_out; -1 when this one did not get
+// through -- its draws have not settled within the queued rounds, the words ran out, or the one in front of it failed).
+__global__ void perm_state_pipe_kernel(const unsigned *__restrict__ era_key, const unsigned *__restrict__ era_raw, int era_pos,
+                                       const long long *__restrict__ goff_in, const long long *__restrict__ out,
+                                       const int *__restrict__ written, unsigned *__restrict__ key_out, int *__restrict__ pos_out,
+                                       long long *__restrict__ goff_out) {
+    const long long off = *goff_in;
+    const bool ok = off >= 0 && *written == 1 && out[1] == 0 && out[0] > 0;
+    const long long total = ok ? off + out[0] : 0;
+    const long long g = (long long)era_pos + total;
+    const long long nb = total > 0 ? (g - 1) / 624 : 0;
+    for (int k = threadIdx.x; k < 624; k += blockDim.x)
+        key_out[k] = nb == 0 ? era_key[k] : era_raw[624 * nb - era_pos + k];
+    if (threadIdx.x == 0) {
+        pos_out[0] = (int)(g - 624 * nb);
+        pos_out[1] = ok ? 1 : 0;
+        *goff_out = ok ? total : -1;
+    }
+}
+
 static unsigned perm_key_bits(int n) {
     unsigned bits = 1;
     while ((1ll << bits) < (long long)n) ++bits;
@@ -313,7 +348,7 @@ size_t perm_sort_temp_bytes(int n) {
 }
 
 static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out, int parity,
-                              hipStream_t st) {
+                              hipStream_t st, const long long *goff = nullptr) {
     const int T = perm_segments(n_avail);
     int *seen = cnt + 2 * (long long)T;              // [3 T]: perm_draw_kernel's memo (round 1 ignores what it holds)
     (void)parity;
@@ -322,14 +357,13 @@ static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int
     const int low = perm_low(n);
     for (int r = 1; r <= rounds; ++r)
         hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, low, r, rounds, cnt, seen, J, out,
-                           flags);
-    hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out);
+                           flags, goff);
+    hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out, goff);
 }
 
-// everything behind the draws: the swaps (sort by target, links, pointer jumping, assembly) and the generator state
-bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr, unsigned *ks,
-                             unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes, long long *out, int *changed, long long *order,
-                             unsigned *key_out, int *pos_out, hipStream_t st) {
+// the swaps: sort by target, links, assembly
+bool launch_permutation_swaps(int n, int *J, int *pred, int *ptr, unsigned *ks, unsigned *idx, unsigned *iota, void *temp,
+                              size_t temp_bytes, int *changed, long long *order, hipStream_t st) {
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(perm_init_kernel, dim3(g), dim3(256), 0, st, n, pred, ptr);
     if (n > 1) {
@@ -342,9 +376,32 @@ bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in,
     }
     (void)hipMemsetAsync(changed, 0, sizeof(int), st);
     hipLaunchKernelGGL(perm_final_kernel, dim3(g), dim3(256), 0, st, n, J, pred, ptr, order);
+    return hipGetLastError() == hipSuccess;
+}
+
+// everything behind the draws: the swaps and the generator state
+bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in, int pos, int *J, int *pred, int *ptr, unsigned *ks,
+                             unsigned *idx, unsigned *iota, void *temp, size_t temp_bytes, long long *out, int *changed, long long *order,
+                             unsigned *key_out, int *pos_out, hipStream_t st) {
+    if (!launch_permutation_swaps(n, J, pred, ptr, ks, idx, iota, temp, temp_bytes, changed, order, st)) return false;
     hipLaunchKernelGGL(perm_state_kernel, dim3(1), dim3(256), 0, st, key_in, raw, pos, out, key_out, pos_out);
     return hipGetLastError() == hipSuccess;
 }
+
+// A generation in flight behind another one (bgmm_api.hip "permutations in flight"): the draws of n steps from the words at
+// era_raw + *goff_in (n_avail of them), the state behind them and *goff_out.  cnt0: the expected counts (perm_guess_host for
+// n_avail words), device copy; cnt: [5 x perm_segments(n_avail)] scratch.
+bool launch_permutation_draws_chained(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
+                                      long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *cnt0, int *flags,
+                                      long long *out, unsigned *key_out, int *pos_out, hipStream_t st) {
+    const int T = perm_segments(n_avail);
+    if (hipMemcpyAsync(cnt, cnt0, sizeof(int) * (size_t)T, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    queue_draw_rounds(era_raw, n_avail, n, J, cnt, flags, out, 0, st, goff_in);
+    hipLaunchKernelGGL(perm_state_pipe_kernel, dim3(1), dim3(256), 0, st, era_key, era_raw, era_pos, goff_in, (const long long *)out,
+                       (const int *)(flags + perm_rounds_now() + 1), key_out, pos_out, goff_out);
+    return hipGetLastError() == hipSuccess;
+}
+void perm_guess(long long n_avail, int n, int *cnt_host) { perm_guess_host(perm_segments(n_avail), n_avail, n, perm_low(n), cnt_host); }
 
 // raw / n_avail: untempered words behind the caller's position.  Scratch (device): J, pred, ptr [n] ints; cnt [5 x
 // perm_segments] ints; flags [perm_rounds + 2] ints (flags[perm_rounds + 1] == 0 afterwards: the draws have not settled --
