@@ -46,6 +46,13 @@ static thread_local std::string g_create_error;
 // changes the queue mapping of every HIP user of the process): a caller that runs more than four chains per device
 // exports GPU_MAX_HW_QUEUES=8 before the runtime's first call -- pybgmm_amd._lib does, unless told not to.
 
+// scratch of the device permutations (perm_ensure)
+struct PermPtrs {
+    unsigned *dkey, *dkey_out, *dspare, *draw, *dwords, *ks, *idx, *iota;
+    int *dpos_out, *dspare_pos, *J, *pred, *ptr, *changed, *flags, *cnt;
+    long long n_words_cap;
+};
+
 struct bgmm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -123,7 +130,14 @@ struct bgmm_ctx {
         unsigned *era_key_host = nullptr;   // pinned
         int era_pos = 0;
         long long *goffs = nullptr;         // device ring [8]: where generation g starts in the era (g % 8); -1: failed
-        int *cnt0 = nullptr, *cnt = nullptr;
+        int *cnt = nullptr;                 // [5 T] the segments' counts and memos
+        int *pre0 = nullptr;                // [T + 1] prefix of the expected counts: round 1's starts
+        int *zero[2] = {};                  // {block sums, round flags}: two blocks, alternating, each cleared by the generation in front
+        int nblk_pad = 0;
+        int rounds_q = 36;                  // rounds queued per generation (follows what the slowest generation so far needed)
+        int rounds_floor = 0;               // ... never fewer than this (raised when a generation did not settle in rounds_q)
+        int rounds_fixed = [] { const char *e = getenv("BGMM_PERM_CHAIN_ROUNDS"); const int v = e ? atoi(e) : 0;
+                                return v < 0 ? 0 : (v > 60 ? 60 : v); }();   // (for the test of that repair)
         int *J[kAhead] = {}, *flags[kAhead] = {};
         long long *out[kAhead] = {};
         unsigned *keyout[kAhead] = {};      // [624 key | pos, went through]
@@ -136,6 +150,16 @@ struct bgmm_ctx {
         long long cap_words = 0;            // words one generation may read
         uint32_t expect_key[624] = {};      // the caller's state iff it took the last permutation and drew nothing else
         int expect_pos = -1;
+        // Queueing a generation is ~65 launches (237 us of host time, measured) -- more than the sweep it feeds takes on the
+        // device.  A thread of the context does it: the stage call posts how many generations should be in the queues
+        // (target) and goes on to queue the sweep.  mu guards target / gen_queued / gen_next / off_exact / busy / full / wrc.
+        PermPtrs P = {};
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        long long target = 0;
+        bool busy = false, quit = false, full = false;     // full: the era has no room for another generation
+        int wrc = 0;
     } pp;
     // bgmm_sweep_staged_begin / _end: a sweep whose first batch of launches is in the queue and has not been waited for
     bool async_pending = false, async_short = false;
@@ -315,6 +339,11 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     // (the look-aheads may still be writing into buffers that are about to go)
+    if (c->pp.worker.joinable()) {
+        { std::lock_guard<std::mutex> g(c->pp.mu); c->pp.quit = true; }
+        c->pp.cv.notify_all();
+        c->pp.worker.join();
+    }
     if (c->mt_stream) (void)hipStreamSynchronize(c->mt_stream);
     if (c->perm_stream) (void)hipStreamSynchronize(c->perm_stream);
     if (c->pp.fin) (void)hipStreamSynchronize(c->pp.fin);
@@ -768,7 +797,16 @@ static int mt_wait_batches(bgmm_ctx *c) {
     for (auto &b : c->mt_b)
         if (b.launched && !b.synced) { CK(c, hipEventSynchronize(b.done)); b.synced = true; }
     if (c->perm_ahead_valid) CK(c, hipEventSynchronize(c->perm_done));     // (the permutation's look-ahead reads the same tables)
-    if (c->pp.rawst) CK(c, hipStreamSynchronize(c->pp.rawst));
+    if (c->pp.built) {
+        // (the words' chunks read the jump tables: nothing new from the worker, what it is at finished)
+        {
+            std::unique_lock<std::mutex> lk(c->pp.mu);
+            c->pp.target = c->pp.gen_queued;
+            c->pp.cv.wait(lk, [&] { return !c->pp.busy; });
+            c->pp.target = c->pp.gen_queued;
+        }
+        CK(c, hipStreamSynchronize(c->pp.rawst));
+    }
     return 0;
 }
 
@@ -885,11 +923,6 @@ extern "C" int bgmm_stage_mt19937(bgmm_ctx *c, const int64_t *order, uint32_t *k
 }
 
 // np.random.permutation(N) from the caller's legacy numpy generator, on the device (kernels_perm.hip).
-struct PermPtrs {
-    unsigned *dkey, *dkey_out, *dspare, *draw, *dwords, *ks, *idx, *iota;
-    int *dpos_out, *dspare_pos, *J, *pred, *ptr, *changed, *flags, *cnt;
-    long long n_words_cap;
-};
 
 static int perm_ensure(bgmm_ctx *c, PermPtrs &P) {
     const long long N = c->d.N;
@@ -917,7 +950,7 @@ static int perm_ensure(bgmm_ctx *c, PermPtrs &P) {
         launch_perm_iota((int)N, c->perm_uints + 2 * (size_t)N, c->stream);
         CK(c, hipStreamSynchronize(c->stream));
     }
-    if (c->perm_chains > c->mt_chains) {
+    if (c->perm_chains >= 2 && c->perm_chains > c->mt_chains) {       // (mt_ensure_tables has nothing to do for one chain)
         int rc = mt_wait_batches(c);
         if (rc) return rc;
         rc = mt_ensure_tables(c, c->perm_chains);
@@ -1023,6 +1056,8 @@ static int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
 // The host sees a generation again when it is handed out: verdicts (settled, words left, the state numpy would be in), the
 // caller's state compared with the state the last call handed back -- anything else (a caller that drew from the stream in
 // between, draws that did not settle in the queued rounds) drains the three streams and goes the old way, on the spot.
+static void perm_pipe_worker(bgmm_ctx *c);
+
 static bool perm_pipe_wanted() {
     static const bool on = [] { const char *e = getenv("BGMM_PERM_PIPE"); return !(e && atoi(e) == 0); }();
     return on;
@@ -1031,10 +1066,19 @@ static bool perm_pipe_wanted() {
 static int perm_pipe_drain(bgmm_ctx *c) {
     bgmm_ctx::PermPipe &Q = c->pp;
     if (!Q.built) return 0;
+    {
+        std::unique_lock<std::mutex> lk(Q.mu);
+        Q.target = Q.gen_queued;         // (what the worker has not begun stays unqueued)
+        Q.cv.wait(lk, [&] { return !Q.busy; });
+        Q.target = Q.gen_queued;
+    }
     CK(c, hipStreamSynchronize(Q.rawst));
     CK(c, hipStreamSynchronize(c->perm_stream));
     CK(c, hipStreamSynchronize(Q.fin));
+    std::lock_guard<std::mutex> g(Q.mu);
     Q.valid = false;
+    Q.full = false;
+    Q.wrc = 0;
     Q.gen_next = Q.gen_queued;          // (whatever was in flight is dropped)
     return 0;
 }
@@ -1057,11 +1101,17 @@ static int perm_pipe_ensure(bgmm_ctx *c) {
     CK(c, hipHostMalloc((void **)&Q.era_key_host, sizeof(unsigned) * 640, hipHostMallocDefault));
     { int rc = dalloc(c, &Q.era_key, (size_t)640); if (rc) return rc; }
     { int rc = dalloc(c, &Q.goffs, (size_t)8); if (rc) return rc; }
-    { int rc = dalloc(c, &Q.cnt0, (size_t)T + 16); if (rc) return rc; }
     { int rc = dalloc(c, &Q.cnt, 5 * (size_t)T + 16); if (rc) return rc; }
-    std::vector<int> guess((size_t)T);
-    perm_guess(Q.cap_words, (int)N, guess.data());
-    CK(c, hipMemcpy(Q.cnt0, guess.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice));
+    CK(c, hipMemset(Q.cnt, 0, sizeof(int) * 5 * (size_t)T));
+    std::vector<int> pre((size_t)T + 1);
+    Q.nblk_pad = perm_chain_guess(Q.cap_words, (int)N, pre.data());
+    if (Q.rounds_fixed) Q.rounds_q = Q.rounds_fixed;
+    { int rc = dalloc(c, &Q.pre0, (size_t)T + 16); if (rc) return rc; }
+    CK(c, hipMemcpy(Q.pre0, pre.data(), sizeof(int) * ((size_t)T + 1), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; ++k) {
+        { int rc = dalloc(c, &Q.zero[k], (size_t)Q.nblk_pad + 64); if (rc) return rc; }
+        CK(c, hipMemset(Q.zero[k], 0, sizeof(int) * ((size_t)Q.nblk_pad + 64)));
+    }
     for (int k = 0; k < A; ++k) {
         { int rc = dalloc(c, &Q.J[k], (size_t)N + 16); if (rc) return rc; }
         CK(c, hipMemset(Q.J[k], 0, sizeof(int) * (size_t)N));
@@ -1079,6 +1129,11 @@ static int perm_pipe_ensure(bgmm_ctx *c) {
     CK(c, hipEventCreateWithFlags(&Q.ev_sweep, hipEventDisableTiming));
     CK(c, hipStreamCreateWithFlags(&Q.fin, hipStreamNonBlocking));
     CK(c, hipStreamCreateWithFlags(&Q.rawst, hipStreamNonBlocking));
+    try {
+        Q.worker = std::thread(perm_pipe_worker, c);
+    } catch (...) {
+        return fail(c, BGMM_EDEVICE, "could not start the permutations' worker thread");
+    }
     Q.built = true;
     return 0;
 }
@@ -1086,12 +1141,15 @@ static int perm_pipe_ensure(bgmm_ctx *c) {
 // a new era from a state the host knows (all three streams idle)
 static int perm_pipe_start_era(bgmm_ctx *c, const uint32_t *key624, int pos) {
     bgmm_ctx::PermPipe &Q = c->pp;
+    std::lock_guard<std::mutex> guard(Q.mu);        // (the worker is idle: drained, or never posted to)
     memcpy(Q.era_key_host, key624, sizeof(unsigned) * 624);
     CK(c, hipMemcpyAsync(Q.era_key, Q.era_key_host, sizeof(unsigned) * 624, hipMemcpyHostToDevice, Q.rawst));
     Q.era_pos = pos;
     Q.era_gen_words = 0;
     Q.off_exact = 0;
     Q.gen_next = Q.gen_queued;
+    Q.target = Q.gen_queued;
+    Q.full = false;
     CK(c, hipMemsetAsync(Q.goffs + (Q.gen_queued & 7), 0, sizeof(long long), c->perm_stream));
     Q.valid = true;
     return 0;
@@ -1124,14 +1182,14 @@ static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto) {
 }
 
 // queues one more generation; 1: the era has no room for it
-static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P) {
+// (the worker's: g = the generation, gen_next / off_exact / rounds as the stage calls had left them when it began)
+static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long long gen_next, long long off_exact, int rounds) {
     bgmm_ctx::PermPipe &Q = c->pp;
     constexpr int A = bgmm_ctx::PermPipe::kAhead;
     const long long N = c->d.N;
-    const long long g = Q.gen_queued;
     const int slot = (int)(g % A);
     // where it starts at the latest (every generation in front of it reads at most cap_words), what it may read
-    const long long hi = Q.off_exact + (g - Q.gen_next) * Q.cap_words;
+    const long long hi = off_exact + (g - gen_next) * Q.cap_words;
     const long long need = hi + Q.cap_words + 1248;
     if (need > Q.era_cap - 1248) return 1;
     int rc = perm_pipe_words(c, P, need + 2 * Q.cap_words);
@@ -1139,9 +1197,9 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P) {
     if (Q.era_gen_words < need) return 1;
     hipStream_t D = c->perm_stream;
     CK(c, hipStreamWaitEvent(D, Q.ev_raw, 0));
-    if (!launch_permutation_draws_chained(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
-                                          Q.J[slot], Q.cnt, Q.cnt0, Q.flags[slot], Q.out[slot], Q.keyout[slot],
-                                          (int *)(Q.keyout[slot] + 624), D))
+    if (!launch_permutation_draws_chained2(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
+                                           Q.J[slot], Q.cnt, Q.pre0, Q.zero[g & 1], Q.zero[(g + 1) & 1], Q.nblk_pad, Q.flags[slot],
+                                           Q.out[slot], Q.keyout[slot], (int *)(Q.keyout[slot] + 624), rounds, D))
         return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
     CK(c, hipEventRecord(Q.ev_draw[slot], D));
     // the swaps beside the next generation's draws; the order buffer they fill may be the one a sweep in flight still reads
@@ -1157,25 +1215,55 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P) {
     CK(c, hipMemcpyAsync(H, Q.keyout[slot], sizeof(unsigned) * 626, hipMemcpyDeviceToHost, F));            // key, pos, went through
     CK(c, hipMemcpyAsync(H + 627, P.changed, sizeof(int), hipMemcpyDeviceToHost, F));
     CK(c, hipMemcpyAsync(H + 628, Q.out[slot], sizeof(long long) * 2, hipMemcpyDeviceToHost, F));
-    CK(c, hipMemcpyAsync(H + 1280, Q.flags[slot], sizeof(int) * (size_t)(perm_rounds() + 2), hipMemcpyDeviceToHost, F));
+    CK(c, hipMemcpyAsync(H + 1280, Q.flags[slot], sizeof(int) * 64, hipMemcpyDeviceToHost, F));
     CK(c, hipEventRecord(Q.ev_fin[slot], F));
-    Q.gen_queued += 1;
     return 0;
 }
 
-static int perm_pipe_fill(bgmm_ctx *c, const PermPtrs &P) {
+static void perm_pipe_worker(bgmm_ctx *c) {
+    (void)hipSetDevice(c->device);
     bgmm_ctx::PermPipe &Q = c->pp;
-    while (Q.gen_queued - Q.gen_next < bgmm_ctx::PermPipe::kAhead) {
-        const int rc = perm_pipe_queue_one(c, P);
-        if (rc == 1) break;
-        if (rc) return rc;
+    std::unique_lock<std::mutex> lk(Q.mu);
+    for (;;) {
+        Q.cv.wait(lk, [&] { return Q.quit || (Q.gen_queued < Q.target && !Q.full && Q.wrc == 0); });
+        if (Q.quit) return;
+        const long long g = Q.gen_queued, gn = Q.gen_next, off = Q.off_exact;
+        const int rounds = Q.rounds_q;
+        Q.busy = true;
+        lk.unlock();
+        const int rc = perm_pipe_queue_one(c, Q.P, g, gn, off, rounds);
+        lk.lock();
+        Q.busy = false;
+        if (rc == 0) Q.gen_queued = g + 1;
+        else if (rc == 1) Q.full = true;
+        else Q.wrc = rc;
+        Q.cv.notify_all();
     }
+}
+
+// kAhead generations behind the one the next call takes: posted to the worker
+static int perm_pipe_fill(bgmm_ctx *c) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    {
+        std::lock_guard<std::mutex> g(Q.mu);
+        Q.target = Q.gen_next + bgmm_ctx::PermPipe::kAhead;
+    }
+    Q.cv.notify_all();
     return 0;
 }
 
-static void perm_note_rounds(bgmm_ctx *c, const unsigned *H) {
+// waits until the generation the next call takes has been queued -- or will not be (the era is full, the worker failed or
+// has nothing posted): true iff it has
+static bool perm_pipe_wait_queued(bgmm_ctx *c) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    std::unique_lock<std::mutex> lk(Q.mu);
+    Q.cv.wait(lk, [&] { return Q.gen_queued > Q.gen_next || Q.full || Q.wrc != 0 || (!Q.busy && Q.gen_queued >= Q.target); });
+    return Q.gen_queued > Q.gen_next;
+}
+
+static void perm_note_rounds(bgmm_ctx *c, const unsigned *H, int queued) {
     int r = 1;
-    while (r <= perm_rounds() && H[1280 + r] != 0) ++r;
+    while (r <= queued && H[1280 + r] != 0) ++r;
     c->perm_last_rounds = r;
     if (r > c->perm_max_rounds) c->perm_max_rounds = r;
 }
@@ -1195,30 +1283,55 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     if (piped && c->pp.built && c->pp.valid) {
         bgmm_ctx::PermPipe &Q = c->pp;
         const bool same = *pos == Q.expect_pos && memcmp(key624, Q.expect_key, sizeof(unsigned) * 624) == 0;
-        if (same && Q.gen_queued == Q.gen_next) {
-            // (the era ran out of room and the generations in it have all been taken: the next one from here)
-            rc = perm_pipe_drain(c);
-            if (rc == 0) rc = perm_pipe_start_era(c, key624, *pos);
-            if (rc == 0) rc = perm_pipe_fill(c, P);
-            if (rc) return rc;
+        bool queued = same && perm_pipe_wait_queued(c);
+        if (same && !queued) {
+            bool full;
+            { std::lock_guard<std::mutex> g(Q.mu); full = Q.full && Q.wrc == 0; }
+            if (full) {
+                // (the era ran out of room and the generations in it have all been taken: the next one from here)
+                rc = perm_pipe_drain(c);
+                if (rc == 0) rc = perm_pipe_start_era(c, key624, *pos);
+                if (rc == 0) rc = perm_pipe_fill(c);
+                if (rc) return rc;
+                queued = perm_pipe_wait_queued(c);
+            }
         }
-        if (same && Q.valid && Q.gen_queued > Q.gen_next) {
+        if (queued) {
             const int slot = (int)(Q.gen_next % bgmm_ctx::PermPipe::kAhead);
             CK(c, hipEventSynchronize(Q.ev_fin[slot]));
             const unsigned *H = Q.host[slot];
             long long out[2];
             memcpy(out, H + 628, sizeof(out));
+            std::lock_guard<std::mutex> g(Q.mu);
             if (H[625] == 1 && H[627] == 0 && out[1] == 0 && out[0] > 0) {
                 memcpy(key624, H, sizeof(unsigned) * 624);
                 *pos = (int32_t)H[624];
-                perm_note_rounds(c, H);
+                perm_note_rounds(c, H, 60);
+                // rounds queued per generation from here on: what the slowest generation so far needed (the round that
+                // changed nothing + the write pass behind it) and four to spare; one that needs more is repaired the old way
+                {
+                    int want = c->perm_max_rounds + 1 + 4;
+                    if (want < Q.rounds_floor) want = Q.rounds_floor;
+                    Q.rounds_q = Q.rounds_fixed ? Q.rounds_fixed : (want < 10 ? 10 : (want > 60 ? 60 : want));
+                }
                 std::swap(c->d_order, Q.ord[slot]);
                 std::swap(Q.ord[slot], Q.parked);
                 Q.off_exact += out[0];
                 Q.gen_next += 1;
                 c->perm_hits += 1;
                 hit = true;
+            } else {
+                // (it did not get through -- as a rule: not settled within the queued rounds; this one goes the old way)
+                Q.rounds_floor = Q.rounds_q + 8 > 60 ? 60 : Q.rounds_q + 8;
+                if (!Q.rounds_fixed) Q.rounds_q = Q.rounds_floor;
             }
+        }
+        if (!hit && getenv("BGMM_DEBUG_PERM")) {
+            const unsigned *H = Q.host[Q.gen_next % bgmm_ctx::PermPipe::kAhead];
+            long long out[2];
+            memcpy(out, H + 628, sizeof(out));
+            fprintf(stderr, "perm pipe miss: same %d queued %d full %d wrc %d gen_next %lld gen_queued %lld target %lld | went through %u changed %u out %lld %lld rounds_q %d\n",
+                    (int)same, (int)queued, (int)Q.full, Q.wrc, Q.gen_next, Q.gen_queued, Q.target, H[625], H[627], out[0], out[1], Q.rounds_q);
         }
         if (!hit) { rc = perm_pipe_drain(c); if (rc) return rc; }
     } else if (!piped && c->perm_ahead_valid) {
@@ -1256,10 +1369,11 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
         rc = perm_pipe_ensure(c);
         if (rc) return rc;
         bgmm_ctx::PermPipe &Q = c->pp;
+        Q.P = P;
         if (!Q.valid) { rc = perm_pipe_start_era(c, key624, *pos); if (rc) return rc; }
         memcpy(Q.expect_key, key624, sizeof(unsigned) * 624);
         Q.expect_pos = *pos;
-        return perm_pipe_fill(c, P);
+        return perm_pipe_fill(c);
     }
     if (c->mt_ahead_on) {
         // the next permutation, from the state just handed back, into the other buffer, beside the sweep about to be queued

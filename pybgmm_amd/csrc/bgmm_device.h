@@ -483,10 +483,11 @@ void launch_permutation_more(int n, const int *J, const int *pred, int *ptr, int
 void launch_perm_iota(int n, unsigned *iota, hipStream_t st);
 bool launch_permutation_swaps(int n, int *J, int *pred, int *ptr, unsigned *ks, unsigned *idx, unsigned *iota, void *temp,
                               size_t temp_bytes, int *changed, long long *order, hipStream_t st);
-bool launch_permutation_draws_chained(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
-                                      long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *cnt0, int *flags,
-                                      long long *out, unsigned *key_out, int *pos_out, hipStream_t st);
-void perm_guess(long long n_avail, int n, int *cnt_host);
+int perm_chain_guess(long long n_avail, int n, int *pre0_host);
+bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
+                                       long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *pre0, int *zero,
+                                       int *next_zero, int nblk_pad, int *flags_out, long long *out, unsigned *key_out, int *pos_out,
+                                       int rounds, hipStream_t st);
 static constexpr int kMtMaxMids = 8;      // sweeps a look-ahead request of the uniform generator may span
 struct MtMids { long long nb[kMtMaxMids]; int pos[kMtMaxMids]; int m; };
 void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos_out, unsigned *words, double *u, long long n,

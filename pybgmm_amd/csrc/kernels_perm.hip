@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 
 __device__ __forceinline__ unsigned perm_temper(unsigned y) {
@@ -70,18 +71,10 @@ static int perm_low(int n) { return n - 1 >= kPermTailLow ? kPermTailLow : n; }
 // since it last ran keeps its count without running again.  The round in which no count changed had every segment at its
 // true start; the round behind it writes the targets J[i] (i = 1 .. n-1) -- numpy's -- and out[0] = words consumed,
 // out[1] = 0 (by the segment in which step 1 is served), and the rounds behind that return at once.
-// goff (may be null): where this generation's words start in `raw`, left on the device by the generation in front of it
-// (pipelined generations, bgmm_api.hip "permutations in flight"); negative: that generation failed, and this one stands aside.
 __global__ __launch_bounds__(256) void perm_draw_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low, int round,
                                                         int rounds, int *cnt, int *__restrict__ seen, int *__restrict__ J,
-                                                        long long *__restrict__ out, int *__restrict__ flags,
-                                                        const long long *__restrict__ goff) {
+                                                        long long *__restrict__ out, int *__restrict__ flags) {
     __shared__ unsigned ws[4][kPermSeg];
-    if (goff) {
-        const long long off = *goff;
-        if (off < 0) return;
-        raw += off;
-    }
     // flags[r] = some count changed in round r.  The first round behind a round that changed nothing is the WRITE pass:
     // every segment runs from its (now true) start once more and leaves its targets in J; the rounds behind it return.
     const bool settled = round >= 2 && flags[round - 1] == 0;
@@ -167,15 +160,9 @@ __global__ void perm_reflag_kernel(int rounds, int *__restrict__ flags, long lon
 // The steps below `low` (the masks of at most 14 bits: 23 k words or so), one wavefront, strictly in order behind the rounds:
 // every one of these short ranges starts where the one before it ended, so rounds would need one launch per range.
 __global__ __launch_bounds__(64) void perm_tail_kernel(const unsigned *__restrict__ raw, long long n_avail, int n, int low,
-                                                       int *__restrict__ J, long long *__restrict__ out,
-                                                       const long long *__restrict__ goff) {
+                                                       int *__restrict__ J, long long *__restrict__ out) {
     __shared__ unsigned W[4096];
     const int lane = threadIdx.x;
-    if (goff) {
-        const long long off = *goff;
-        if (off < 0) return;
-        raw += off;
-    }
     const bool rounds_had_steps = n - 1 >= low;
     if (rounds_had_steps && out[3] != 0) return;           // (the rounds never reached `low`: the words ran out, or not settled yet)
     long long p = rounds_had_steps ? out[2] : 0;
@@ -312,25 +299,175 @@ __global__ void perm_state_kernel(const unsigned *__restrict__ key_in, const uns
     if (threadIdx.x == 0) pos_out[0] = (int)(g - 624 * nb);
 }
 
-// The same for a generation that reads its words at *goff_in of a longer stream (era_raw[k] = the k-th output behind
-// (era_key, era_pos)): the state behind it, and where the next generation starts (*goff_out; -1 when this one did not get
-// through -- its draws have not settled within the queued rounds, the words ran out, or the one in front of it failed).
-__global__ void perm_state_pipe_kernel(const unsigned *__restrict__ era_key, const unsigned *__restrict__ era_raw, int era_pos,
-                                       const long long *__restrict__ goff_in, const long long *__restrict__ out,
-                                       const int *__restrict__ written, unsigned *__restrict__ key_out, int *__restrict__ pos_out,
-                                       long long *__restrict__ goff_out) {
+// ---- a generation in flight: rounds, tail and state in the rounds' launches ------------------------------------------------
+// The draws of a generation that follows another one on the device (bgmm_api.hip "permutations in flight").  As
+// perm_draw_kernel, and:
+//   * a segment's start comes from block sums (64 segments each) + the counts of its own block: two loads per lane instead of
+//     up to sixty;
+//   * round 1 starts from the expected progress itself (pre0: its prefix, constant per N) and the counters a generation
+//     needs cleared (block sums, round flags) come in two alternating blocks, each cleared by the generation in front: no
+//     copy, no clearing launch between generations;
+//   * the rounds serve every step down to kPermChainLow = 256 (round = launch either way: a serial tail of 16 384 steps was
+//     84 us of ONE wavefront), and the wavefront that serves step 256 in the write pass walks the ~350 words that are left,
+//     writes the generator state behind the generation and where the next one starts (*goff_out).
+// zero: {block sums [nblk_pad], round flags [64]}; flags_out [64]: the round flags for the host's statistics.
+static constexpr int kPermChainLow = 256;
+
+__global__ __launch_bounds__(256) void perm_draw_chained_kernel(const unsigned *__restrict__ era_raw, long long n_avail, int n, int round,
+                                                                int rounds, const int *__restrict__ pre0, int *cnt, int *__restrict__ seen,
+                                                                int *zero, int *__restrict__ next_zero, int nblk_pad, int *__restrict__ J,
+                                                                long long *__restrict__ out, int *__restrict__ flags_out,
+                                                                const long long *__restrict__ goff_in, const unsigned *__restrict__ era_key,
+                                                                int era_pos, unsigned *__restrict__ key_out, int *__restrict__ pos_out,
+                                                                long long *__restrict__ goff_out) {
+    __shared__ unsigned ws[4][kPermSeg];
+    constexpr int low = kPermChainLow;
+    int *bsum = zero, *flags = zero + nblk_pad;
     const long long off = *goff_in;
-    const bool ok = off >= 0 && *written == 1 && out[1] == 0 && out[0] > 0;
-    const long long total = ok ? off + out[0] : 0;
+    if (round == 1 && blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < nblk_pad + 64; k += 256) next_zero[k] = 0;
+        // (failed until the wavefront that finishes the generation says otherwise)
+        if (threadIdx.x == 0) { pos_out[1] = 0; *goff_out = -1; out[0] = 0; out[1] = 1; }
+    }
+    if (off < 0) return;                                   // (the generation in front of this one failed)
+    const unsigned *__restrict__ raw = era_raw + off;
+    const bool settled = round >= 2 && flags[round - 1] == 0;
+    if (settled && round >= 3 && flags[round - 2] == 0) return;
+    const bool write_pass = settled;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = (int)blockIdx.x * 4 + wv;
+    const long long seg0 = (long long)t * kPermSeg;
+    if (seg0 >= n_avail) return;
+    const int len = (int)(seg0 + kPermSeg < n_avail ? kPermSeg : n_avail - seg0);
+    long long before;
+    if (round == 1) {
+        before = pre0[t];
+    } else {
+        const int blk = t >> 6;
+        int v = 0;
+        for (int b = lane; b < blk; b += 64) v += __hip_atomic_load(bsum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int k = (blk << 6) + lane;
+        if (k < t) v += __hip_atomic_load(cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        before = v;
+    }
+    const long long i0l = (long long)(n - 1) - before;
+    const int i0 = i0l > 0 ? (int)i0l : 0;
+    int *__restrict__ mine_seen = seen + 3 * (long long)t;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    unsigned *__restrict__ W = ws[wv];
+    int accepted = 0, end = -1;
+    if (round >= 2 && !write_pass && mine_seen[0] == i0) {
+        accepted = mine_seen[1];
+        end = mine_seen[2];
+    } else if (i0 >= low) {
+        for (int k = lane; k < len; k += 64) W[k] = perm_temper(raw[seg0 + k]);
+        int i = i0, p = 0;
+        while (i >= low && p < len) {
+            const unsigned mask = 0xffffffffu >> __builtin_clz((unsigned)i);
+            const int lowi = (int)(mask >> 1) + 1;
+            const int a = (p + lane < len) ? (int)(W[p + lane] & mask) : 0x7fffffff;
+            unsigned long long acc = __ballot(a <= i);
+            for (;;) {
+                const int c = __builtin_popcountll(acc & below);
+                const unsigned long long acc2 = __ballot(a <= i - c);
+                if (acc2 == acc) break;
+                acc = acc2;
+            }
+            const int c = __builtin_popcountll(acc & below);
+            const int sstep = i - c;
+            const bool mine = (acc >> lane) & 1ull;
+            const unsigned long long last = __ballot(mine && sstep == lowi);     // (low is a power of two: step `low` ends a range)
+            const int cut = last ? (int)__builtin_ctzll(last) + 1 : 64;
+            if (write_pass && mine && lane < cut) J[sstep] = a;
+            const unsigned long long used = cut == 64 ? acc : (acc & (~0ull >> (64 - cut)));
+            const int k = (int)__builtin_popcountll(used);
+            i -= k;
+            accepted += k;
+            p += cut;
+        }
+        if (i < low) end = p < len ? p : len;
+    }
+    if (lane == 0) {
+        mine_seen[0] = i0; mine_seen[1] = accepted; mine_seen[2] = end;
+        const int was = round == 1 ? 0 : __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (round == 1 || was != accepted) {
+            __hip_atomic_store(cnt + t, accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bsum + (t >> 6), accepted - was, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (round 1 is measured against the expected count the segments behind it started from)
+            const int expected = round == 1 ? pre0[t + 1] - pre0[t] : was;
+            if (!write_pass && expected != accepted) flags[round] = 1;
+        }
+    }
+    if (!(write_pass && accepted > 0 && before + accepted == (long long)(n - low) && end >= 0)) return;
+    // ---- this wavefront served step `low`: the steps low - 1 .. 1 from the word behind it, then the state behind them
+    long long p = seg0 + end;
+    int i = low - 1;
+    bool failed = false;
+    while (i >= 1) {
+        const long long base = p;
+        const int tl = (int)(base + kPermSeg < n_avail ? kPermSeg : n_avail - base);
+        if (tl < 64) { failed = true; break; }
+        for (int k = lane; k < tl; k += 64) W[k] = perm_temper(raw[base + k]);
+        int q = 0;
+        while (i >= 1 && q + 64 <= tl) {
+            const unsigned mask = 0xffffffffu >> __builtin_clz((unsigned)i);
+            const int lowi = (int)(mask >> 1) + 1;
+            const int a = (int)(W[q + lane] & mask);
+            unsigned long long acc = __ballot(a <= i);
+            for (;;) {
+                const int c = __builtin_popcountll(acc & below);
+                const unsigned long long acc2 = __ballot(a <= i - c);
+                if (acc2 == acc) break;
+                acc = acc2;
+            }
+            const int c = __builtin_popcountll(acc & below);
+            const int sstep = i - c;
+            const bool mine = (acc >> lane) & 1ull;
+            const unsigned long long last = __ballot(mine && sstep == lowi);
+            const int cut = last ? (int)__builtin_ctzll(last) + 1 : 64;
+            if (mine && lane < cut) J[sstep] = a;
+            const unsigned long long used = cut == 64 ? acc : (acc & (~0ull >> (64 - cut)));
+            i -= (int)__builtin_popcountll(used);
+            q += cut;
+        }
+        p = base + q;
+    }
+    const long long total = off + p;
     const long long g = (long long)era_pos + total;
     const long long nb = total > 0 ? (g - 1) / 624 : 0;
-    for (int k = threadIdx.x; k < 624; k += blockDim.x)
-        key_out[k] = nb == 0 ? era_key[k] : era_raw[624 * nb - era_pos + k];
-    if (threadIdx.x == 0) {
+    if (!failed)
+        for (int k = lane; k < 624; k += 64) key_out[k] = nb == 0 ? era_key[k] : era_raw[624 * nb - era_pos + k];
+    flags_out[lane] = (lane >= 1 && lane <= rounds) ? flags[lane] : 0;
+    if (lane == 0) {
+        out[0] = p; out[1] = failed ? 1 : 0;
         pos_out[0] = (int)(g - 624 * nb);
-        pos_out[1] = ok ? 1 : 0;
-        *goff_out = ok ? total : -1;
+        pos_out[1] = failed ? 0 : 1;
+        *goff_out = failed ? -1 : total;
     }
+}
+
+int perm_chain_low() { return kPermChainLow; }
+// pre0 [T + 1]: prefix of the expected counts (host); returns the block sums' padded length
+int perm_chain_guess(long long n_avail, int n, int *pre0_host) {
+    const int T = perm_segments(n_avail);
+    std::vector<int> g((size_t)T);
+    perm_guess_host(T, n_avail, n, kPermChainLow, g.data());
+    pre0_host[0] = 0;
+    for (int t = 0; t < T; ++t) pre0_host[t + 1] = pre0_host[t] + g[(size_t)t];
+    return 64 * ((T + 63) / 64 / 64 + 1);
+}
+// rounds <= 60 launches, the last of them long returned when the generation settles early
+bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
+                                       long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *pre0, int *zero,
+                                       int *next_zero, int nblk_pad, int *flags_out, long long *out, unsigned *key_out, int *pos_out,
+                                       int rounds, hipStream_t st) {
+    const int T = perm_segments(n_avail);
+    int *seen = cnt + 2 * (long long)T;
+    for (int r = 1; r <= rounds; ++r)
+        hipLaunchKernelGGL(perm_draw_chained_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, era_raw, n_avail, n, r, rounds, pre0, cnt,
+                           seen, zero, next_zero, nblk_pad, J, out, flags_out, goff_in, era_key, era_pos, key_out, pos_out, goff_out);
+    return hipGetLastError() == hipSuccess;
 }
 
 static unsigned perm_key_bits(int n) {
@@ -348,7 +485,7 @@ size_t perm_sort_temp_bytes(int n) {
 }
 
 static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int *J, int *cnt, int *flags, long long *out, int parity,
-                              hipStream_t st, const long long *goff = nullptr) {
+                              hipStream_t st) {
     const int T = perm_segments(n_avail);
     int *seen = cnt + 2 * (long long)T;              // [3 T]: perm_draw_kernel's memo (round 1 ignores what it holds)
     (void)parity;
@@ -357,8 +494,8 @@ static void queue_draw_rounds(const unsigned *raw, long long n_avail, int n, int
     const int low = perm_low(n);
     for (int r = 1; r <= rounds; ++r)
         hipLaunchKernelGGL(perm_draw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, raw, n_avail, n, low, r, rounds, cnt, seen, J, out,
-                           flags, goff);
-    hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out, goff);
+                           flags);
+    hipLaunchKernelGGL(perm_tail_kernel, dim3(1), dim3(64), 0, st, raw, n_avail, n, low, J, out);
 }
 
 // the swaps: sort by target, links, assembly
@@ -387,21 +524,6 @@ bool launch_permutation_tail(const unsigned *raw, int n, const unsigned *key_in,
     hipLaunchKernelGGL(perm_state_kernel, dim3(1), dim3(256), 0, st, key_in, raw, pos, out, key_out, pos_out);
     return hipGetLastError() == hipSuccess;
 }
-
-// A generation in flight behind another one (bgmm_api.hip "permutations in flight"): the draws of n steps from the words at
-// era_raw + *goff_in (n_avail of them), the state behind them and *goff_out.  cnt0: the expected counts (perm_guess_host for
-// n_avail words), device copy; cnt: [5 x perm_segments(n_avail)] scratch.
-bool launch_permutation_draws_chained(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
-                                      long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *cnt0, int *flags,
-                                      long long *out, unsigned *key_out, int *pos_out, hipStream_t st) {
-    const int T = perm_segments(n_avail);
-    if (hipMemcpyAsync(cnt, cnt0, sizeof(int) * (size_t)T, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    queue_draw_rounds(era_raw, n_avail, n, J, cnt, flags, out, 0, st, goff_in);
-    hipLaunchKernelGGL(perm_state_pipe_kernel, dim3(1), dim3(256), 0, st, era_key, era_raw, era_pos, goff_in, (const long long *)out,
-                       (const int *)(flags + perm_rounds_now() + 1), key_out, pos_out, goff_out);
-    return hipGetLastError() == hipSuccess;
-}
-void perm_guess(long long n_avail, int n, int *cnt_host) { perm_guess_host(perm_segments(n_avail), n_avail, n, perm_low(n), cnt_host); }
 
 // raw / n_avail: untempered words behind the caller's position.  Scratch (device): J, pred, ptr [n] ints; cnt [5 x
 // perm_segments] ints; flags [perm_rounds + 2] ints (flags[perm_rounds + 1] == 0 afterwards: the draws have not settled --

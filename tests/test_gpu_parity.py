@@ -1463,11 +1463,9 @@ def test_device_permutation_equals_numpy(N):
     ctx.close()
 
 
-def test_device_permutation_repairs_draws_that_have_not_settled():
-    """The rounds of the permutation's draws are queued blindly, a fixed number at a time; when they have not settled by
-    then, more rounds are queued and everything behind the draws runs again.  With the number of rounds cut to 5
-    (BGMM_PERM_ROUNDS, read when the library is loaded: a process of its own) that repair runs for every permutation --
-    which must still be numpy's, generator state included."""
+def _permutations_in_a_process(env, body):
+    """Runs `body` (python source; `ctx_for(N)` and numpy in scope) in a process of its own: the library reads BGMM_PERM_* when it
+    is loaded."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1476,27 +1474,63 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 from pybgmm_amd import _lib
 from pybgmm_amd.utils import gendata
-for N in (70000, 1000003):
+def ctx_for(N):
     X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(2)
     ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 12)
     ctx.set_assignments(zt)
+    return ctx
+def in_a_row(ctx, N, calls, disturb_at=()):
     host = np.random.RandomState(N)
     host.random_sample(33)
     key, pos = host.get_state()[1].copy(), int(host.get_state()[2])
-    for it in range(3):
+    for it in range(calls):
+        if it in disturb_at:
+            host.random_sample(3)          # (the caller draws something else from the stream: whatever is in flight is void)
+            key, pos = host.get_state()[1].copy(), int(host.get_state()[2])
         expect = host.permutation(N)
         key, pos = ctx.stage_permutation_mt19937(key, pos)
         assert np.array_equal(ctx.staged_order(), expect), (N, it)
-        assert np.array_equal(key, host.get_state()[1]) and pos == host.get_state()[2]
+        assert np.array_equal(key, host.get_state()[1]) and pos == host.get_state()[2], (N, it)
+%s
+print("PERMUTATIONS OK")
+""" % (root, body)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "PERMUTATIONS OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_device_permutation_repairs_draws_that_have_not_settled():
+    """The rounds of the permutation's draws are queued blindly, a fixed number at a time; when they have not settled by
+    then, more rounds are queued and everything behind the draws runs again.  With the number of rounds cut to 5
+    (BGMM_PERM_ROUNDS, read when the library is loaded: a process of its own; BGMM_PERM_PIPE=0: the route that generates one
+    permutation at a time) that repair runs for every permutation -- which must still be numpy's, generator state included."""
+    _permutations_in_a_process({"BGMM_PERM_ROUNDS": "5", "BGMM_PERM_PIPE": "0"}, """
+for N in (70000, 1000003):
+    ctx = ctx_for(N)
+    in_a_row(ctx, N, 3)
     st = ctx.permutation_stats()
     assert st["rounds_max"] <= 6, st          # (every batch of rounds is 5 long: the statistics count within a batch)
     ctx.close()
-print("REPAIRED OK")
-""" % root
-    env = dict(os.environ, BGMM_PERM_ROUNDS="5")
-    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "REPAIRED OK" in r.stdout, r.stdout[-2000:]
+""")
+
+
+@pytest.mark.parametrize("env,hits", [({}, True), ({"BGMM_PERM_ERA": "5"}, True), ({"BGMM_PERM_CHAIN_ROUNDS": "8"}, False)],
+                         ids=["as-shipped", "eras-of-five-generations", "never-settled-in-flight"])
+def test_device_permutations_in_flight(env, hits):
+    """bgmm_api.hip "permutations in flight": generations queued behind the one handed out, each taking its place in the word
+    stream from the one in front of it on the device.  Fourteen permutations in a row per N (the rings of slots, order buffers
+    and offsets all wrap), a caller that draws from the stream in between (twice), eras of five generations (the stream's
+    buffer starts over every few calls), and generations that cannot settle in the rounds queued for them (eight: every one
+    of them is dropped and drawn the old way): numpy's permutation and numpy's state behind it, every time."""
+    _permutations_in_a_process(env, """
+for N in (4096, 100003, 1000000):
+    ctx = ctx_for(N)
+    in_a_row(ctx, N, 14, disturb_at=(5, 6))
+    st = ctx.permutation_stats()
+    assert (st["lookahead_hits"] >= 10) == %r or N < 50000, st
+    ctx.close()
+""" % hits)
 
 
 def test_device_permutation_drives_the_pcrp_classes():
