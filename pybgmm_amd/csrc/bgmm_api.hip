@@ -138,9 +138,12 @@ struct bgmm_ctx {
         int rounds_floor = 0;               // ... never fewer than this (raised when a generation did not settle in rounds_q)
         int rounds_fixed = [] { const char *e = getenv("BGMM_PERM_CHAIN_ROUNDS"); const int v = e ? atoi(e) : 0;
                                 return v < 0 ? 0 : (v > 60 ? 60 : v); }();   // (for the test of that repair)
-        int *J[kAhead] = {}, *flags[kAhead] = {};
-        long long *out[kAhead] = {};
-        unsigned *keyout[kAhead] = {};      // [624 key | pos, went through]
+        int *J[kAhead] = {};
+        int *vblk[kAhead] = {};             // a generation's verdicts, laid out like perm_host: [624 key | pos | went through | - |
+                                            // swaps overflowed | out (2 x 64 bit) | ... | round flags at 1280], one copy to the host
+        int NB = 0;                         // the swaps by buckets of targets (kernels_perm.hip): their number (0: rocPRIM's sort),
+        int *bnd = nullptr, *cursor = nullptr;          // boundaries [NB + 1], fill counts [NB]
+        unsigned long long *slots = nullptr;            // [NB][perm_bucket_cap()] (target << 32 | step)
         long long *ord[kAhead] = {};
         long long *parked = nullptr;        // the order buffer released by the last call: written again one call later at the
                                             // earliest (a sweep begun and not yet ended may be redone from it: finish_pending)
@@ -1115,16 +1118,27 @@ static int perm_pipe_ensure(bgmm_ctx *c) {
     for (int k = 0; k < A; ++k) {
         { int rc = dalloc(c, &Q.J[k], (size_t)N + 16); if (rc) return rc; }
         CK(c, hipMemset(Q.J[k], 0, sizeof(int) * (size_t)N));
-        { int rc = dalloc(c, &Q.flags[k], (size_t)64); if (rc) return rc; }
-        { int rc = dalloc(c, &Q.out[k], (size_t)4); if (rc) return rc; }
-        { int rc = dalloc(c, &Q.keyout[k], (size_t)640); if (rc) return rc; }
+        { int rc = dalloc(c, &Q.vblk[k], (size_t)1344); if (rc) return rc; }
+        CK(c, hipMemset(Q.vblk[k], 0, sizeof(int) * 1344));
         { int rc = dalloc(c, &Q.ord[k], (size_t)N); if (rc) return rc; }
         CK(c, hipHostMalloc((void **)&Q.host[k], sizeof(unsigned) * 1344, hipHostMallocDefault));
         memset(Q.host[k], 0, sizeof(unsigned) * 1344);
-        CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], hipEventDisableTiming));
-        CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], hipEventDisableTiming));
+        const unsigned evf = getenv("BGMM_DEBUG_PERM") ? hipEventDefault : hipEventDisableTiming;
+        CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], evf));
+        CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], evf));
     }
     { int rc = dalloc(c, &Q.parked, (size_t)N); if (rc) return rc; }
+    {
+        std::vector<int> bnd;
+        Q.NB = perm_bucket_bounds((int)N, bnd);
+        if (Q.NB > 0) {
+            { int rc = dalloc(c, &Q.bnd, (size_t)Q.NB + 16); if (rc) return rc; }
+            { int rc = dalloc(c, &Q.cursor, (size_t)Q.NB + 16); if (rc) return rc; }
+            { int rc = dalloc(c, &Q.slots, (size_t)Q.NB * (size_t)perm_bucket_cap()); if (rc) return rc; }
+            CK(c, hipMemcpy(Q.bnd, bnd.data(), sizeof(int) * ((size_t)Q.NB + 1), hipMemcpyHostToDevice));
+            CK(c, hipMemset(Q.cursor, 0, sizeof(int) * (size_t)Q.NB));
+        }
+    }
     CK(c, hipEventCreateWithFlags(&Q.ev_raw, hipEventDisableTiming));
     CK(c, hipEventCreateWithFlags(&Q.ev_sweep, hipEventDisableTiming));
     CK(c, hipStreamCreateWithFlags(&Q.fin, hipStreamNonBlocking));
@@ -1197,9 +1211,10 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long
     if (Q.era_gen_words < need) return 1;
     hipStream_t D = c->perm_stream;
     CK(c, hipStreamWaitEvent(D, Q.ev_raw, 0));
+    int *V = Q.vblk[slot];
     if (!launch_permutation_draws_chained2(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
-                                           Q.J[slot], Q.cnt, Q.pre0, Q.zero[g & 1], Q.zero[(g + 1) & 1], Q.nblk_pad, Q.flags[slot],
-                                           Q.out[slot], Q.keyout[slot], (int *)(Q.keyout[slot] + 624), rounds, D))
+                                           Q.J[slot], Q.cnt, Q.pre0, Q.zero[g & 1], Q.zero[(g + 1) & 1], Q.nblk_pad, V + 1280,
+                                           (long long *)(V + 628), (unsigned *)V, V + 624, rounds, D))
         return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
     CK(c, hipEventRecord(Q.ev_draw[slot], D));
     // the swaps beside the next generation's draws; the order buffer they fill may be the one a sweep in flight still reads
@@ -1208,14 +1223,16 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long
     CK(c, hipEventRecord(Q.ev_sweep, c->stream));
     CK(c, hipStreamWaitEvent(F, Q.ev_sweep, 0));
     CK(c, hipStreamWaitEvent(F, Q.ev_draw[slot], 0));
-    if (!launch_permutation_swaps((int)N, Q.J[slot], P.pred, P.ptr, P.ks, P.idx, P.iota, c->perm_temp, c->perm_temp_bytes, P.changed,
-                                  Q.ord[slot], F))
-        return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
     unsigned *H = Q.host[slot];
-    CK(c, hipMemcpyAsync(H, Q.keyout[slot], sizeof(unsigned) * 626, hipMemcpyDeviceToHost, F));            // key, pos, went through
-    CK(c, hipMemcpyAsync(H + 627, P.changed, sizeof(int), hipMemcpyDeviceToHost, F));
-    CK(c, hipMemcpyAsync(H + 628, Q.out[slot], sizeof(long long) * 2, hipMemcpyDeviceToHost, F));
-    CK(c, hipMemcpyAsync(H + 1280, Q.flags[slot], sizeof(int) * 64, hipMemcpyDeviceToHost, F));
+    if (Q.NB > 0) {
+        if (!launch_permutation_swaps_bucketed((int)N, Q.NB, Q.bnd, Q.J[slot], Q.cursor, Q.slots, V + 627, P.pred, P.ptr, Q.ord[slot], F))
+            return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+    } else {
+        if (!launch_permutation_swaps((int)N, Q.J[slot], P.pred, P.ptr, P.ks, P.idx, P.iota, c->perm_temp, c->perm_temp_bytes, P.changed,
+                                      Q.ord[slot], F))
+            return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");
+    }
+    CK(c, hipMemcpyAsync(H, V, sizeof(int) * 1344, hipMemcpyDeviceToHost, F));
     CK(c, hipEventRecord(Q.ev_fin[slot], F));
     return 0;
 }
@@ -1302,6 +1319,23 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
             const unsigned *H = Q.host[slot];
             long long out[2];
             memcpy(out, H + 628, sizeof(out));
+            if (getenv("BGMM_DEBUG_PERM") && Q.gen_next > 8) {
+                // (device time from the end of the previous generation's draws to the end of this one's, and to its swaps')
+                static double sum_d = 0.0, sum_f = 0.0; static long cnt = 0;
+                const int prev = (int)((Q.gen_next - 1) % bgmm_ctx::PermPipe::kAhead);
+                float md = 0.f, mf = 0.f;
+                const hipError_t e1 = hipEventElapsedTime(&md, Q.ev_draw[prev], Q.ev_draw[slot]);
+                const hipError_t e2 = hipEventElapsedTime(&mf, Q.ev_draw[slot], Q.ev_fin[slot]);
+                if (e1 != hipSuccess || e2 != hipSuccess) {
+                    static int said = 0;
+                    if (said++ < 3) fprintf(stderr, "perm pipe: elapsed time failed (%d %d)\n", (int)e1, (int)e2);
+                    (void)hipGetLastError();
+                } else {
+                    sum_d += md; sum_f += mf; cnt += 1;
+                    if (cnt % 50 == 0) fprintf(stderr, "perm pipe: draws %.1f us per generation, swaps %.1f us behind them (%ld generations)\n",
+                                                1e3 * sum_d / cnt, 1e3 * sum_f / cnt, cnt);
+                }
+            }
             std::lock_guard<std::mutex> g(Q.mu);
             if (H[625] == 1 && H[627] == 0 && out[1] == 0 && out[0] > 0) {
                 memcpy(key624, H, sizeof(unsigned) * 624);

@@ -484,6 +484,10 @@ void launch_perm_iota(int n, unsigned *iota, hipStream_t st);
 bool launch_permutation_swaps(int n, int *J, int *pred, int *ptr, unsigned *ks, unsigned *idx, unsigned *iota, void *temp,
                               size_t temp_bytes, int *changed, long long *order, hipStream_t st);
 int perm_chain_guess(long long n_avail, int n, int *pre0_host);
+int perm_bucket_cap();
+int perm_bucket_bounds(int n, std::vector<int> &bnd);
+bool launch_permutation_swaps_bucketed(int n, int NB, const int *bnd, const int *J, int *cursor, unsigned long long *slots, int *overflow,
+                                       int *pred, int *ptr, long long *order, hipStream_t st);
 bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
                                        long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *pre0, int *zero,
                                        int *next_zero, int nblk_pad, int *flags_out, long long *out, unsigned *key_out, int *pos_out,

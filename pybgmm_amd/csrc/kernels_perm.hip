@@ -310,7 +310,8 @@ __global__ void perm_state_kernel(const unsigned *__restrict__ key_in, const uns
 //   * the rounds serve every step down to kPermChainLow = 256 (round = launch either way: a serial tail of 16 384 steps was
 //     84 us of ONE wavefront), and the wavefront that serves step 256 in the write pass walks the ~350 words that are left,
 //     writes the generator state behind the generation and where the next one starts (*goff_out).
-// zero: {block sums [nblk_pad], round flags [64]}; flags_out [64]: the round flags for the host's statistics.
+// zero: {block sums [nblk_pad], round flags [64]}; flags_out [64]: the round flags for the host's statistics;
+// pos_out [4]: {position, went through, -, the swaps' overflow flag (cleared here)}.
 static constexpr int kPermChainLow = 256;
 
 __global__ __launch_bounds__(256) void perm_draw_chained_kernel(const unsigned *__restrict__ era_raw, long long n_avail, int n, int round,
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void perm_draw_chained_kernel(const unsigned *
     if (round == 1 && blockIdx.x == 0) {
         for (int k = threadIdx.x; k < nblk_pad + 64; k += 256) next_zero[k] = 0;
         // (failed until the wavefront that finishes the generation says otherwise)
-        if (threadIdx.x == 0) { pos_out[1] = 0; *goff_out = -1; out[0] = 0; out[1] = 1; }
+        if (threadIdx.x == 0) { pos_out[1] = 0; pos_out[3] = 0; *goff_out = -1; out[0] = 0; out[1] = 1; }
     }
     if (off < 0) return;                                   // (the generation in front of this one failed)
     const unsigned *__restrict__ raw = era_raw + off;
@@ -467,6 +468,133 @@ bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *
     for (int r = 1; r <= rounds; ++r)
         hipLaunchKernelGGL(perm_draw_chained_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, era_raw, n_avail, n, r, rounds, pre0, cnt,
                            seen, zero, next_zero, nblk_pad, J, out, flags_out, goff_in, era_key, era_pos, key_out, pos_out, goff_out);
+    return hipGetLastError() == hipSuccess;
+}
+
+// ---- the swaps' links without a radix sort --------------------------------------------------------------------------------
+// pred / predV need, for every target, the steps that hit it in ascending order.  A full sort of the (target, step) pairs is
+// 21 launches of rocPRIM (156 us at N = 1e6); the generations in flight do it in two: the pairs are dealt into buckets of
+// targets whose EXPECTED load is equal -- the targets are not uniform (step i hits v <= i with probability 1 / (i + 1): v = 0
+// collects ln n hits, v = n - 1 hardly any), so the bucket boundaries are the quantiles of that law (perm_bucket_bounds, host,
+// once per N) and every bucket receives (n - 1) / NB +- a few dozen pairs, 2 048 at most on average in 3 072 slots -- and one
+// workgroup per bucket sorts its pairs in LDS (bitonic, 64-bit keys target << 32 | step) and writes the links.  A bucket that
+// overflows raises a flag and the generation is drawn again the old way (perm_final_kernel's input would be incomplete).
+static constexpr int kPermBucketCap = 3072;
+int perm_bucket_cap() { return kPermBucketCap; }
+// NB buckets (a power of two, <= 2048; 0: N too large for this route), bnd[NB + 1]: bucket b holds targets [bnd[b], bnd[b + 1])
+int perm_bucket_bounds(int n, std::vector<int> &bnd) {
+    int NB = 1;
+    while ((long long)NB * 2048 < (long long)n - 1) NB *= 2;
+    if (NB > 2048) return 0;
+    // rho[v] = sum_{i = max(v, 1)}^{n - 1} 1 / (i + 1): expected number of steps whose target is v
+    std::vector<double> cum((size_t)n + 1);
+    double suffix = 0.0;
+    std::vector<double> rho((size_t)n);
+    for (int i = n - 1; i >= 1; --i) { suffix += 1.0 / (double)(i + 1); rho[(size_t)i] = suffix; }
+    rho[0] = suffix;
+    cum[0] = 0.0;
+    for (int v = 0; v < n; ++v) cum[(size_t)v + 1] = cum[(size_t)v] + rho[(size_t)v];
+    bnd.assign((size_t)NB + 1, 0);
+    const double per = cum[(size_t)n] / (double)NB;
+    int v = 0;
+    for (int b = 1; b < NB; ++b) {
+        while (v < n && cum[(size_t)v + 1] < per * b) ++v;
+        bnd[(size_t)b] = v;
+    }
+    bnd[(size_t)NB] = n;
+    return NB;
+}
+
+// the pairs (J[i], i), i = 1 .. n - 1, into their buckets' slots (cursor[b]: pairs in bucket b so far; zero on entry)
+__global__ __launch_bounds__(256) void perm_bucket_scatter_kernel(int n, int NB, const int *__restrict__ bnd, const int *__restrict__ J,
+                                                                  int *__restrict__ cursor, unsigned long long *__restrict__ slots,
+                                                                  int *__restrict__ overflow) {
+    extern __shared__ int lds[];                   // [NB + 1] boundaries, [NB] counts, [NB] reserved bases
+    int *b_lo = lds, *cnt = lds + NB + 1, *base = cnt + NB;
+    constexpr int PER = 16;
+    for (int k = threadIdx.x; k <= NB; k += 256) b_lo[k] = bnd[k];
+    for (int k = threadIdx.x; k < NB; k += 256) cnt[k] = 0;
+    __syncthreads();
+    const int i0 = 1 + (int)blockIdx.x * 256 * PER;
+    int myb[PER], myr[PER], myv[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = i0 + t * 256 + (int)threadIdx.x;
+        myv[t] = i < n ? J[i] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        myb[t] = -1;
+        if (myv[t] >= 0) {
+            int lo = 0, hi = NB;                   // (the bucket: the last boundary <= v)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (b_lo[mid] <= myv[t]) lo = mid; else hi = mid;
+            }
+            myb[t] = lo;
+            myr[t] = atomicAdd(&cnt[lo], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NB; k += 256) base[k] = cnt[k] ? atomicAdd(&cursor[k], cnt[k]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+        if (myb[t] >= 0) {
+            const int at = base[myb[t]] + myr[t];
+            const int i = i0 + t * 256 + (int)threadIdx.x;
+            if (at < kPermBucketCap) slots[(long long)myb[t] * kPermBucketCap + at] = ((unsigned long long)(unsigned)myv[t] << 32) | (unsigned)i;
+            else *overflow = 1;
+        }
+}
+
+// one workgroup per bucket: its pairs sorted (target, then step), the links pred / ptr of perm_links_kernel for them -- and
+// the defaults perm_init_kernel would have set for the bucket's targets; the bucket's cursor cleared for the next generation
+__global__ __launch_bounds__(256) void perm_bucket_links_kernel(int n, const int *__restrict__ bnd, int *__restrict__ cursor,
+                                                                const unsigned long long *__restrict__ slots, int *__restrict__ pred,
+                                                                int *__restrict__ ptr) {
+    __shared__ unsigned long long key[4096];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    int m = cursor[b];
+    if (m > kPermBucketCap) m = kPermBucketCap;
+    int P2 = 64;
+    while (P2 < m) P2 <<= 1;
+    for (int e = tid; e < P2; e += 256) key[e] = e < m ? slots[(long long)b * kPermBucketCap + e] : ~0ull;
+    const int v_lo = bnd[b], v_hi = bnd[b + 1];
+    for (int v = v_lo + tid; v < v_hi; v += 256) ptr[v] = v;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < P2; e += 256) {
+                const int partner = e ^ j;
+                if (partner > e) {
+                    const unsigned long long a = key[e], c = key[partner];
+                    const bool up = (e & k) == 0;
+                    if ((a > c) == up) { key[e] = c; key[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int q = tid; q < m; q += 256) {
+        const unsigned v = (unsigned)(key[q] >> 32), i = (unsigned)key[q];
+        const bool next_same = q + 1 < m && (unsigned)(key[q + 1] >> 32) == v;
+        pred[i] = next_same ? (int)(unsigned)key[q + 1] : -1;
+        if (q == 0 || (unsigned)(key[q - 1] >> 32) != v) {
+            const int pv = (i != v) ? (int)i : (next_same ? (int)(unsigned)key[q + 1] : -1);
+            if (pv >= 0) ptr[v] = pv;
+        }
+    }
+    if (tid == 0) cursor[b] = 0;
+}
+
+// the swaps of a generation in flight: buckets, links, assembly (three launches)
+bool launch_permutation_swaps_bucketed(int n, int NB, const int *bnd, const int *J, int *cursor, unsigned long long *slots, int *overflow,
+                                       int *pred, int *ptr, long long *order, hipStream_t st) {
+    const unsigned gs = (unsigned)((n - 1 + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(perm_bucket_scatter_kernel, dim3(gs), dim3(256), (size_t)(3 * NB + 1) * sizeof(int), st, n, NB, bnd, J, cursor, slots,
+                       overflow);
+    hipLaunchKernelGGL(perm_bucket_links_kernel, dim3((unsigned)NB), dim3(256), 0, st, n, bnd, cursor, slots, pred, ptr);
+    hipLaunchKernelGGL(perm_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, J, (const int *)pred, (const int *)ptr, order);
     return hipGetLastError() == hipSuccess;
 }
 
