@@ -479,12 +479,12 @@ bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *
 // once per N) and every bucket receives (n - 1) / NB +- a few dozen pairs, 2 048 at most on average in 3 072 slots -- and one
 // workgroup per bucket sorts its pairs in LDS (bitonic, 64-bit keys target << 32 | step) and writes the links.  A bucket that
 // overflows raises a flag and the generation is drawn again the old way (perm_final_kernel's input would be incomplete).
-static constexpr int kPermBucketCap = 3072;
+static constexpr int kPermBucketCap = 2048;
 int perm_bucket_cap() { return kPermBucketCap; }
-// NB buckets (a power of two, <= 2048; 0: N too large for this route), bnd[NB + 1]: bucket b holds targets [bnd[b], bnd[b + 1])
+// NB buckets (<= 2048; 0: N too large for this route), bnd[NB + 1]: bucket b holds targets [bnd[b], bnd[b + 1])
 int perm_bucket_bounds(int n, std::vector<int> &bnd) {
-    int NB = 1;
-    while ((long long)NB * 2048 < (long long)n - 1) NB *= 2;
+    // (1 536 pairs per bucket on average: 2 048 -- the size the buckets' sort is built for -- is thirteen standard deviations away)
+    const int NB = (int)(((long long)n - 1 + 1535) / 1536);
     if (NB > 2048) return 0;
     // rho[v] = sum_{i = max(v, 1)}^{n - 1} 1 / (i + 1): expected number of steps whose target is v
     std::vector<double> cum((size_t)n + 1);
@@ -553,25 +553,29 @@ __global__ __launch_bounds__(256) void perm_bucket_scatter_kernel(int n, int NB,
 __global__ __launch_bounds__(256) void perm_bucket_links_kernel(int n, const int *__restrict__ bnd, int *__restrict__ cursor,
                                                                 const unsigned long long *__restrict__ slots, int *__restrict__ pred,
                                                                 int *__restrict__ ptr) {
-    __shared__ unsigned long long key[4096];
+    constexpr int P2 = kPermBucketCap;
+    __shared__ unsigned long long key[P2];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
     int m = cursor[b];
     if (m > kPermBucketCap) m = kPermBucketCap;
-    int P2 = 64;
-    while (P2 < m) P2 <<= 1;
-    for (int e = tid; e < P2; e += 256) key[e] = e < m ? slots[(long long)b * kPermBucketCap + e] : ~0ull;
+#pragma unroll
+    for (int t = 0; t < P2 / 256; ++t) {
+        const int e = tid + t * 256;
+        key[e] = e < m ? slots[(long long)b * kPermBucketCap + e] : ~0ull;
+    }
     const int v_lo = bnd[b], v_hi = bnd[b + 1];
     for (int v = v_lo + tid; v < v_hi; v += 256) ptr[v] = v;
     __syncthreads();
+    // bitonic network, every thread a PAIR per step (lower index: bit log2(j) of the pair number inserted as 0)
     for (int k = 2; k <= P2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < P2; e += 256) {
-                const int partner = e ^ j;
-                if (partner > e) {
-                    const unsigned long long a = key[e], c = key[partner];
-                    const bool up = (e & k) == 0;
-                    if ((a > c) == up) { key[e] = c; key[partner] = a; }
-                }
+#pragma unroll
+            for (int t = 0; t < P2 / 512; ++t) {
+                const int pr = tid + t * 256;
+                const int e = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));
+                const unsigned long long a = key[e], c = key[e | j];
+                const bool up = (e & k) == 0;
+                if ((a > c) == up) { key[e] = c; key[e | j] = a; }
             }
             __syncthreads();
         }
