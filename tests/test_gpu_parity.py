@@ -574,7 +574,7 @@ def test_burnin_against_c_oracle(N, D, K, sep):
 
 
 @pytest.mark.parametrize("N,D,K,sep,flip,budget", [(100000, 16, 100, 1.0, 0, 0.0), (100000, 16, 100, 1.0, 0, 1.0),
-                                                   (100000, 64, 40, 0.5, 0, 0.0), (100000, 64, 40, 4.0, 200, 0.0),
+                                                   (60000, 64, 40, 0.5, 0, 0.0), (60000, 64, 40, 4.0, 200, 0.0),
                                                    (10000, 128, 20, 0.28, 0, 0.0)],
                          ids=["D16-5pct-movers", "D16-5pct-movers-budget-1.0", "D64-0.6pct-movers", "D64-200-wrong-labels",
                               "D128-overlapping"])
@@ -831,14 +831,14 @@ def test_c3_full_size_against_c_oracle():
 
 @pytest.mark.slow
 def test_c4_quarter_size_against_c_oracle():
-    """BASELINE's C4 shape (D = 64, K = 200) at N = 1.6e5 against the C port of the reference: the truth
+    """BASELINE's C4 shape (D = 64, K = 200) at N = 1.2e5 against the C port of the reference: the truth
     with 400 wrong labels, one whole sweep in the default configuration and in the benchmarked mode -- the largest C4-shaped
-    problem the oracle finishes in about a minute and a half of host time (0.4 ms per visit)."""
+    problem the oracle finishes in about a minute of host time (0.4 ms per visit)."""
     from divergence import assert_same_labels, first_divergence
     from oracle import c_oracle
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
-    N, D, K, flip = 160000, 64, 200, 400
+    N, D, K, flip = 120000, 64, 200, 400
     X, zt = gendata.synth_mixture(N, D, K, seed=1)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     rs = np.random.RandomState(64)
