@@ -1086,16 +1086,17 @@ static int perm_pipe_drain(bgmm_ctx *c) {
     return 0;
 }
 
-static int perm_pipe_ensure(bgmm_ctx *c) {
+static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
     bgmm_ctx::PermPipe &Q = c->pp;
     if (Q.built) return 0;
+    Q.P = P;                            // (the worker's copy: set before it exists, never written again)
     constexpr int A = bgmm_ctx::PermPipe::kAhead;
     const long long N = c->d.N;
     Q.cap_words = 2 * N + 1248;
     const int T = perm_segments(Q.cap_words);
-    // the era: 64 generations' worth of words, within 1 GiB, never less than what kAhead + 2 generations may read
+    // the era: 32 generations' worth of words, within 1 GiB, never less than what kAhead + 2 generations may read
     // (BGMM_PERM_ERA: generations' worth, for the test that walks through several eras)
-    static const int era_gens = [] { const char *e = getenv("BGMM_PERM_ERA"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();
+    static const int era_gens = [] { const char *e = getenv("BGMM_PERM_ERA"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
     long long cap = era_gens * Q.cap_words;
     if (cap > (1ll << 28)) cap = 1ll << 28;
     if (cap < (A + 3) * Q.cap_words) cap = (A + 3) * Q.cap_words;
@@ -1400,10 +1401,9 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     c->cur_order = c->d_order;
     if (piped) {
         // the generations behind this one, from the state just handed back
-        rc = perm_pipe_ensure(c);
+        rc = perm_pipe_ensure(c, P);
         if (rc) return rc;
         bgmm_ctx::PermPipe &Q = c->pp;
-        Q.P = P;
         if (!Q.valid) { rc = perm_pipe_start_era(c, key624, *pos); if (rc) return rc; }
         memcpy(Q.expect_key, key624, sizeof(unsigned) * 624);
         Q.expect_pos = *pos;
