@@ -1533,6 +1533,20 @@ for N in (4096, 100003, 1000000):
 """ % hits)
 
 
+def test_device_permutations_in_flight_soak():
+    """The same over many calls (tools/permsoak.py is the long version): 1 500 permutations of 4 097 points in a row from one
+    context, eras of three generations (the word stream's buffer starts over every other call), the caller drawing from the
+    stream at 45 random moments -- every permutation and every state numpy's."""
+    _permutations_in_a_process({"BGMM_PERM_ERA": "3"}, """
+dice = np.random.RandomState(7)
+ctx = ctx_for(4097)
+in_a_row(ctx, 4097, 1500, disturb_at=set(dice.randint(0, 1500, size=45).tolist()))
+st = ctx.permutation_stats()
+assert st["lookahead_hits"] >= 1300, st
+ctx.close()
+""")
+
+
 def test_device_permutation_drives_the_pcrp_classes():
     """PCRPMM with the visiting order drawn on the device equals the same run with the order drawn by numpy on the host
     (N < 4096 is the host's: a twin run with a monkey-patched helper gives the host route at the same N)."""
