@@ -1213,7 +1213,7 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long
     hipStream_t D = c->perm_stream;
     CK(c, hipStreamWaitEvent(D, Q.ev_raw, 0));
     int *V = Q.vblk[slot];
-    if (!launch_permutation_draws_chained2(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
+    if (!launch_permutation_draws_chained(Q.era_raw, Q.era_key, Q.era_pos, Q.goffs + (g & 7), Q.goffs + ((g + 1) & 7), Q.cap_words, (int)N,
                                            Q.J[slot], Q.cnt, Q.pre0, Q.zero[g & 1], Q.zero[(g + 1) & 1], Q.nblk_pad, V + 1280,
                                            (long long *)(V + 628), (unsigned *)V, V + 624, rounds, D))
         return fail(c, BGMM_EDEVICE, "permutation kernels failed to launch");

@@ -488,7 +488,7 @@ int perm_bucket_cap();
 int perm_bucket_bounds(int n, std::vector<int> &bnd);
 bool launch_permutation_swaps_bucketed(int n, int NB, const int *bnd, const int *J, int *cursor, unsigned long long *slots, int *overflow,
                                        int *pred, int *ptr, long long *order, hipStream_t st);
-bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
+bool launch_permutation_draws_chained(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
                                        long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *pre0, int *zero,
                                        int *next_zero, int nblk_pad, int *flags_out, long long *out, unsigned *key_out, int *pos_out,
                                        int rounds, hipStream_t st);

@@ -448,7 +448,6 @@ __global__ __launch_bounds__(256) void perm_draw_chained_kernel(const unsigned *
     }
 }
 
-int perm_chain_low() { return kPermChainLow; }
 // pre0 [T + 1]: prefix of the expected counts (host); returns the block sums' padded length
 int perm_chain_guess(long long n_avail, int n, int *pre0_host) {
     const int T = perm_segments(n_avail);
@@ -459,7 +458,7 @@ int perm_chain_guess(long long n_avail, int n, int *pre0_host) {
     return 64 * ((T + 63) / 64 / 64 + 1);
 }
 // rounds <= 60 launches, the last of them long returned when the generation settles early
-bool launch_permutation_draws_chained2(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
+bool launch_permutation_draws_chained(const unsigned *era_raw, const unsigned *era_key, int era_pos, const long long *goff_in,
                                        long long *goff_out, long long n_avail, int n, int *J, int *cnt, const int *pre0, int *zero,
                                        int *next_zero, int nblk_pad, int *flags_out, long long *out, unsigned *key_out, int *pos_out,
                                        int rounds, hipStream_t st) {
