@@ -1533,6 +1533,43 @@ for N in (4096, 100003, 1000000):
 """ % hits)
 
 
+def test_device_permutations_with_the_lookahead_switched_off_and_on_again():
+    """bgmm_set_mt_lookahead between permutations: with generations in flight the switch to 0 leaves them behind (every
+    permutation is then drawn on the spot), the switch back starts a new era from the caller's state; uniforms staged in
+    between (the other generator's look-ahead shares the jump tables with the permutations' word stream).  numpy's
+    permutations and states throughout."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N = 50000
+    X, zt = gendata.synth_mixture(N, 2, 3, seed=1)
+    ctx = _lib.Context(X, *gendata.demo_prior_params(2), 1.0, 12)
+    ctx.set_assignments(zt)
+    host = np.random.RandomState(12)
+    key, pos = host.get_state()[1].copy(), int(host.get_state()[2])
+    r = random.Random(3)
+    st = r.getstate()
+    mkey, mpos = np.array(st[1][:624], dtype=np.uint32), int(st[1][624])
+    for it in range(16):
+        if it == 5:
+            ctx.set_mt_lookahead(0)
+        if it == 9:
+            ctx.set_mt_lookahead(-1)
+        if it == 12:
+            ctx.set_mt_lookahead(2)
+        expect = host.permutation(N)
+        key, pos = ctx.stage_permutation_mt19937(key, pos)
+        npt.assert_array_equal(ctx.staged_order(), expect, err_msg="permutation %d" % it)
+        npt.assert_array_equal(key, host.get_state()[1])
+        assert pos == host.get_state()[2]
+        mkey, mpos = ctx.stage_mt19937(mkey, mpos, None)
+        u = ctx.staged_uniforms()
+        npt.assert_array_equal(u, np.array([r.random() for _ in range(N)]))
+    stats = ctx.permutation_stats()
+    assert stats["lookahead_hits"] >= 8 and stats["generated_on_the_spot"] >= 5, stats
+    ctx.close()
+
+
 def test_device_permutations_in_flight_soak():
     """The same over many calls (tools/permsoak.py is the long version): 1 500 permutations of 4 097 points in a row from one
     context, eras of three generations (the word stream's buffer starts over every other call), the caller drawing from the
