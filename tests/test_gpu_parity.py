@@ -1570,6 +1570,18 @@ def test_device_permutations_with_the_lookahead_switched_off_and_on_again():
     ctx.close()
 
 
+def test_device_permutations_in_flight_beyond_the_bucketed_links():
+    """N > 3.1e6: more than 2 048 buckets of targets -- the generations in flight sort their (target, step) pairs with
+    rocPRIM instead (kernels_perm.hip perm_bucket_bounds returns 0).  Six in a row, one foreign draw."""
+    _permutations_in_a_process({}, """
+ctx = ctx_for(3200000)
+in_a_row(ctx, 3200000, 6, disturb_at=(3,))
+st = ctx.permutation_stats()
+assert st["lookahead_hits"] >= 3, st
+ctx.close()
+""")
+
+
 def test_device_permutations_in_flight_soak():
     """The same over many calls (tools/permsoak.py is the long version): 1 500 permutations of 4 097 points in a row from one
     context, eras of three generations (the word stream's buffer starts over every other call), the caller drawing from the
