@@ -5,7 +5,9 @@ The parallel restatement of numpy's legacy shuffle that pybgmm_amd/csrc/kernels_
   * the DRAWS: which 32-bit words a step consumes (masked rejection) resolved 64 words at a time by the fixed-point
     iteration  acc <- [(w & mask) <= i - #accepted below]  with a cut behind the step that ends a mask's range;
   * the SWAPS: final[i] from pred / predV links (a stable sort of the steps by target) and pointer jumping;
-  * the generator state left behind = the block of the stream the last consumed word lies in.
+  * the generator state left behind = the block of the stream the last consumed word lies in;
+  * (round 5) the same links from BUCKETS of targets whose boundaries are the quantiles of the targets' law: one sort per
+    bucket of ~1 536 pairs instead of one over all of them (what the generations in flight do on the device).
 The GPU test (tests/test_gpu_parity.py::test_device_permutation_equals_numpy) checks the kernels against numpy directly.
 """
 import numpy as np
@@ -84,3 +86,68 @@ def test_parallel_restatement_of_the_legacy_shuffle(n, seed):
     r3.randint(0, 2 ** 32, size=used, dtype=np.uint32)             # (numpy consumed exactly `used` words)
     assert np.array_equal(r3.get_state()[1], after[1]) and r3.get_state()[2] == after[2]
     assert used <= 2 * n + 64
+
+
+# ---- round 5: the links by buckets of targets (kernels_perm.hip perm_bucket_bounds / perm_bucket_links_kernel) -----------
+def bucket_bounds(n, per=1536):
+    """Bucket b holds the targets [bnd[b], bnd[b + 1]); the boundaries are the quantiles of the law of the targets (step i hits
+    v <= i with probability 1 / (i + 1), so v expects rho(v) = sum_{i >= max(v, 1)} 1 / (i + 1) hits): equal EXPECTED load."""
+    NB = max(1, (n - 1 + per - 1) // per)
+    inv = 1.0 / (np.arange(n, dtype=np.float64) + 1.0)
+    suffix = np.cumsum(inv[::-1])[::-1]                      # suffix[i] = sum_{j >= i} 1 / (j + 1)
+    rho = suffix.copy()
+    rho[0] = suffix[1] if n > 1 else 0.0
+    cum = np.concatenate([[0.0], np.cumsum(rho)])
+    bnd = np.searchsorted(cum[1:], cum[-1] / NB * np.arange(1, NB), side="left")
+    return np.concatenate([[0], bnd, [n]]).astype(np.int64)
+
+
+def links_by_buckets(J, n, bnd):
+    """pred / ptr of permutation_from_targets, bucket by bucket: the (target, step) pairs of a bucket sorted as ONE key
+    (target << 32 | step -- steps are distinct, so no stability is asked of the sort), links from neighbours in that order."""
+    pred = np.full(n, -1, dtype=np.int64)
+    ptr = np.arange(n, dtype=np.int64)
+    steps = np.arange(1, n, dtype=np.int64)
+    which = np.searchsorted(bnd, J[1:], side="right") - 1
+    loads = np.bincount(which, minlength=len(bnd) - 1)
+    for b in np.unique(which):
+        i = steps[which == b]
+        key = np.sort((J[i].astype(np.int64) << 32) | i)
+        v, st = key >> 32, key & 0xffffffff
+        same_next = np.zeros(len(key), bool)
+        same_next[:-1] = v[1:] == v[:-1]
+        pred[st[:-1][same_next[:-1]]] = st[1:][same_next[:-1]]
+        first = np.ones(len(key), bool)
+        first[1:] = v[1:] != v[:-1]
+        q = np.nonzero(first)[0]
+        nxt = np.where(same_next[q], st[np.minimum(q + 1, len(key) - 1)], -1)
+        pv = np.where(st[q] != v[q], st[q], nxt)
+        ptr[v[q][pv >= 0]] = pv[pv >= 0]
+    return pred, ptr, loads
+
+
+@pytest.mark.parametrize("n", [4096, 4097, 65537, 300000])
+def test_links_by_buckets_of_equal_expected_load(n):
+    rs = np.random.RandomState(n % 97)
+    st = rs.get_state()
+    ref = rs.permutation(n)
+    r2 = np.random.RandomState()
+    r2.set_state(st)
+    words = r2.randint(0, 2 ** 32, size=2 * n + 1248, dtype=np.uint32)
+    J, _ = draws_by_runs_of_64(words, n)
+    bnd = bucket_bounds(n)
+    assert bnd[0] == 0 and bnd[-1] == n and np.all(np.diff(bnd) >= 0)
+    pred, ptr, loads = links_by_buckets(J, n, bnd)
+    # the buckets' loads: (n - 1) / NB on average, far from the 2 048 slots a bucket has on the device
+    assert loads.sum() == n - 1 and loads.max() <= 2048 and loads.max() < 1.25 * (n - 1) / len(loads) + 64
+    # the same permutation as the sort-based links give (and numpy)
+    while True:
+        nxt = ptr[ptr]
+        if np.array_equal(nxt, ptr):
+            break
+        ptr = nxt
+    final = np.empty(n, dtype=np.int64)
+    final[0] = ptr[0]
+    i, j = np.arange(1, n), J[1:]
+    final[1:] = np.where(j == i, ptr[i], np.where(pred[i] >= 0, ptr[np.maximum(pred[i], 0)], j))
+    assert np.array_equal(final, ref)
