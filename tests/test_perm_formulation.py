@@ -14,9 +14,10 @@ import numpy as np
 import pytest
 
 
-def draws_by_runs_of_64(words, n):
-    J = np.zeros(n, dtype=np.int64)
-    i, p = n - 1, 0
+def draws_by_runs_of_64(words, n, i=None, p=0, J=None):
+    """The steps i .. 1 (default: all of them, n - 1 .. 1) from words[p:]; returns (targets, index behind the last word used)."""
+    J = np.zeros(n, dtype=np.int64) if J is None else J
+    i = n - 1 if i is None else i
     while i >= 1:
         mask = (1 << int(i).bit_length()) - 1
         lowi = (mask >> 1) + 1
@@ -151,3 +152,68 @@ def test_links_by_buckets_of_equal_expected_load(n):
     i, j = np.arange(1, n), J[1:]
     final[1:] = np.where(j == i, ptr[i], np.where(pred[i] >= 0, ptr[np.maximum(pred[i], 0)], j))
     assert np.array_equal(final, ref)
+
+
+# ---- the rounds across segments (kernels_perm.hip perm_draw_kernel / perm_draw_chained_kernel) ---------------------------
+def segment_run(words, seg0, seg_len, i0, low, J=None):
+    """One segment (one wavefront on the device): the steps served by words[seg0 : seg0 + seg_len] when the first of them
+    meets step i0; stops behind step `low`.  Returns (accepted, words used if step `low` was served here else -1)."""
+    i, p, accepted = i0, 0, 0
+    while i >= low and p < seg_len:
+        mask = (1 << int(i).bit_length()) - 1
+        lowi = (mask >> 1) + 1
+        a = (words[seg0 + p:seg0 + min(p + 64, seg_len)] & mask).astype(np.int64)
+        acc = a <= i
+        for _ in range(70):
+            c = np.concatenate([[0], np.cumsum(acc)[:-1]])
+            acc2 = a <= i - c
+            if np.array_equal(acc2, acc):
+                break
+            acc = acc2
+        c = np.concatenate([[0], np.cumsum(acc)[:-1]])
+        s = i - c
+        last = np.nonzero(acc & (s == lowi))[0]
+        cut = last[0] + 1 if last.size else len(a)
+        use = acc[:cut]
+        if J is not None:
+            J[s[:cut][use]] = a[:cut][use]
+        k = int(use.sum())
+        i -= k
+        accepted += k
+        p += cut
+    return accepted, (p if i < low else -1)
+
+
+@pytest.mark.parametrize("n,seg,low", [(20000, 1024, 256), (65537, 1024, 256), (65537, 512, 4096)])
+def test_rounds_over_segments_settle_on_the_sequential_draws(n, seg, low):
+    """The stream cut into segments, every segment's start taken from the counts of the segments in front of it as the
+    previous round left them (here: all at once, i.e. the device's rounds without their in-place reads), starting from a guess
+    that is wrong everywhere: the round in which no count changes has every segment at its true start, and the targets written
+    from there -- plus the serial tail below `low` -- are the sequential ones (draws_by_runs_of_64)."""
+    rs = np.random.RandomState(5)
+    words = rs.randint(0, 2 ** 32, size=2 * n + 1248, dtype=np.uint32)
+    J_ref, used_ref = draws_by_runs_of_64(words, n)
+    T = (len(words) + seg - 1) // seg
+    lens = [min(seg, len(words) - t * seg) for t in range(T)]
+    cnt = np.full(T, int(0.7 * seg), dtype=np.int64)             # (a guess: 70 % of the words accepted, everywhere)
+    for rounds in range(1, 200):
+        before = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        new = np.array([segment_run(words, t * seg, lens[t], max(n - 1 - int(before[t]), 0), low)[0] if n - 1 - before[t] >= low else 0
+                        for t in range(T)], dtype=np.int64)
+        if np.array_equal(new, cnt):
+            break
+        cnt = new
+    assert rounds < 60, rounds
+    J = np.zeros(n, dtype=np.int64)
+    before = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    tail_from = None
+    for t in range(T):
+        i0 = n - 1 - int(before[t])
+        if i0 >= low:
+            acc, end = segment_run(words, t * seg, lens[t], i0, low, J)
+            if end >= 0 and before[t] + acc == n - low:
+                tail_from = t * seg + end
+    assert tail_from is not None
+    _, p = draws_by_runs_of_64(words, n, i=low - 1, p=tail_from, J=J)     # (the serial tail: one wavefront behind the rounds)
+    assert np.array_equal(J[1:], J_ref[1:])
+    assert p == used_ref
