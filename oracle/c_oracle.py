@@ -47,8 +47,36 @@ def lib():
         L.go_log_post_pred.argtypes = [ctypes.c_void_p, ctypes.c_int64, _f64p]
         L.go_probe_visit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _f64p]
         L.go_probe_visit.restype = ctypes.c_int64
+        L.go_set_threads.argtypes = [ctypes.c_int]
+        L.go_get_threads.restype = ctypes.c_int
+        L.go_set_threads(default_threads())
         _lib = L
     return _lib
+
+
+def default_threads():
+    """Threads the K loop of a visit is shared over (bit-identical floats for any count: every component is still
+    scored by the scalar code on one thread).  GIBBS_ORACLE_THREADS overrides; default = the cores this process may
+    use, at most 32."""
+    env = os.environ.get("GIBBS_ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(32, n))
+
+
+def set_threads(t):
+    """Process-wide (the library keeps one setting).  Returns the count in force."""
+    L = lib()
+    L.go_set_threads(int(t))
+    return int(L.go_get_threads())
+
+
+def get_threads():
+    return int(lib().go_get_threads())
 
 
 def host_tables(v_0, N):

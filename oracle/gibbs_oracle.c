@@ -1,7 +1,8 @@
 /*
  * ORACLE (test infrastructure, not product code) -- plain-C restatement of the
  * reference's collapsed-Gibbs reassignment path (CRP / pCRP Gaussian mixture,
- * NIW prior; full covariance, and -- SURVEY 8f rank 1 -- diagonal covariance).  Scalar, single threaded, one visit at a time,
+ * NIW prior; full covariance, and -- SURVEY 8f rank 1 -- diagonal covariance).  Scalar, one visit at a time (the K evaluations of
+ * a visit optionally shared out over threads, see go_set_threads),
  * with the reference's algorithmic structure: component statistics cached and
  * restored around every visit, covariance log-determinant and inverse rebuilt
  * FROM SCRATCH (LU with partial pivoting) on every removal and every move, a
@@ -31,6 +32,33 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads (round 6).  A visit's K predictive evaluations are independent of each other, and so are the D columns of
+ * the inverse: both loops are shared out over go_set_threads(T) threads.  Every component's (and every column's)
+ * arithmetic is the scalar code below, untouched, on its own scratch -- the floats are bit-identical for every T; the
+ * maximum, the log-sum-exp and the u -= p scan stay serial in label order.  T = 1 (the default) is the single-threaded
+ * port bench.py's cpu_baseline also times. */
+static int go_threads = 1;
+#define GO_MAX_THREADS 64
+void go_set_threads(int t) {
+    if (t < 1) t = 1;
+    if (t > GO_MAX_THREADS) t = GO_MAX_THREADS;
+#ifndef _OPENMP
+    t = 1;
+#endif
+    go_threads = t;
+}
+int go_get_threads(void) { return go_threads; }
+static inline int go_tid(void) {
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
+}
 
 typedef struct {
     int64_t N, D, K_max, K;
@@ -56,7 +84,9 @@ typedef struct {
 #define LOG_PI 1.1447298858494001741434273513530587116472948129153
 
 /* LU with partial pivoting in place; returns sign, fills piv. */
+static int lu_factor_team(double *a, int64_t n, int64_t *piv);
 static int lu_factor(double *a, int64_t n, int64_t *piv) {
+    if (go_threads > 1 && n >= 96) return lu_factor_team(a, n, piv);
     int sign = 1;
     for (int64_t j = 0; j < n; ++j) {
         int64_t p = j;
@@ -84,6 +114,43 @@ static int lu_factor(double *a, int64_t n, int64_t *piv) {
     return sign;
 }
 
+/* The same elimination with the rows below the pivot shared out over the team: the pivot search and the row swap stay
+ * with one thread, every row's update is the serial loop's arithmetic on that row (rows are independent of each other
+ * within a column step) -- bit-identical to lu_factor for every thread count. */
+static int lu_factor_team(double *a, int64_t n, int64_t *piv) {
+    int sign = 1;
+#pragma omp parallel num_threads(go_threads)
+    for (int64_t j = 0; j < n; ++j) {
+#pragma omp single
+        {
+            int64_t p = j;
+            double best = fabs(a[j * n + j]);
+            for (int64_t i = j + 1; i < n; ++i) {
+                double v = fabs(a[i * n + j]);
+                if (v > best) { best = v; p = i; }
+            }
+            piv[j] = p;
+            if (p != j) {
+                for (int64_t c = 0; c < n; ++c) {
+                    double t = a[j * n + c]; a[j * n + c] = a[p * n + c]; a[p * n + c] = t;
+                }
+                sign = -sign;
+            }
+        }   /* (implicit barrier) */
+        double d = a[j * n + j];
+        if (d != 0.0) {
+#pragma omp for schedule(static)
+            for (int64_t i = j + 1; i < n; ++i) {
+                double l = a[i * n + j] / d;
+                a[i * n + j] = l;
+                if (l != 0.0)
+                    for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
+            }   /* (implicit barrier) */
+        }
+    }
+    return sign;
+}
+
 static double lu_logabsdet(const double *lu, int64_t n) {
     double s = 0.0;
     for (int64_t j = 0; j < n; ++j) s += log(fabs(lu[j * n + j]));
@@ -91,8 +158,10 @@ static double lu_logabsdet(const double *lu, int64_t n) {
 }
 
 /* inverse from the factorisation: solve A x = e_c for every column c */
-static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col) {
+static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col_all) {
+#pragma omp parallel for schedule(static) num_threads(go_threads) if (go_threads > 1 && n >= 16)
     for (int64_t c = 0; c < n; ++c) {
+        double *col = col_all + (int64_t)go_tid() * n;      /* (scratch per thread) */
         for (int64_t i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
         for (int64_t j = 0; j < n; ++j) {
             int64_t p = piv[j];
@@ -319,14 +388,14 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     for (int64_t i = 0; i < N; ++i) g->z[i] = -1;
     g->log_prior = (double *)malloc(sizeof(double) * N);
     g->lu = (double *)malloc(sizeof(double) * D * D);
-    g->col = (double *)malloc(sizeof(double) * D);
+    g->col = (double *)malloc(sizeof(double) * D * GO_MAX_THREADS);
     g->piv = (int64_t *)malloc(sizeof(int64_t) * D);
     g->lp = (double *)malloc(sizeof(double) * (K_max + 1));
     g->save_m = (double *)malloc(sizeof(double) * D);
     g->save_S = (double *)malloc(sizeof(double) * D * D);
     g->save_inv = (double *)malloc(sizeof(double) * D * D);
-    g->delta = (double *)malloc(sizeof(double) * D);
-    g->tmp = (double *)malloc(sizeof(double) * D);
+    g->delta = (double *)malloc(sizeof(double) * D * GO_MAX_THREADS);
+    g->tmp = (double *)malloc(sizeof(double) * D * GO_MAX_THREADS);
 
     if (diag == 2) {            /* gaussian_components_fixedvar.py:205-212: N(mu_0, precision_0) */
         double lp = 0.0;
@@ -408,17 +477,19 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         if (lik_evals) *lik_evals += K;
         const double *x = g->X + i * D;
         double top = -INFINITY;
+#pragma omp parallel for schedule(static) num_threads(go_threads) if (go_threads > 1 && K * g->SD >= 4096)
         for (int64_t k = 0; k < K; ++k) {
+            double *delta = g->delta + (int64_t)go_tid() * D, *tmp = g->tmp + (int64_t)go_tid() * D;
             double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
             int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
             if (g->diag == 2) {
-                for (int64_t a = 0; a < D; ++a) g->tmp[a] = g->m[k * D + a] / g->S[k * D + a];
-                g->lp[k] = w + student_t(g, x, g->tmp, 1.0, g->logdet[k], g->inv + k * D, 0, g->delta);
+                for (int64_t a = 0; a < D; ++a) tmp[a] = g->m[k * D + a] / g->S[k * D + a];
+                g->lp[k] = w + student_t(g, x, tmp, 1.0, g->logdet[k], g->inv + k * D, 0, delta);
             } else
             g->lp[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
-                                     g->inv + k * g->SD, nu, g->delta);
-            if (g->lp[k] > top) top = g->lp[k];
+                                     g->inv + k * g->SD, nu, delta);
         }
+        for (int64_t k = 0; k < K; ++k) if (g->lp[k] > top) top = g->lp[k];
         g->lp[K] = log_alpha + g->log_prior[i];
         if (g->lp[K] > top) top = g->lp[K];
         double s = 0.0;

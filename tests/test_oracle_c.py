@@ -56,3 +56,32 @@ def test_probe_visit_reproduces_the_references_first_visit_probabilities():
         p, _ = _cdf(lp)
         npt.assert_allclose(p, p_ref, rtol=1e-10, atol=1e-14)
         assert _draw(p, u) == k
+
+
+@pytest.mark.parametrize("case", ["c4twin_crpmm_64d", "c3rand_pcrpmm_16d", "c4rand_crpmm_64d", "diag_crpmm_256d"])
+def test_threads_do_not_change_a_single_float(case):
+    """Round 6: a visit's K evaluations (and the D columns of the inverse) shared out over OpenMP threads.  Every
+    component is still scored by the scalar code on one thread, the maximum / log-sum-exp / u -= p scan stay serial in
+    label order (gaussian_components.py:228-251, utils.py:15-20): the captured trajectories are reproduced with the
+    same floats -- log marginals and final statistics compared with == between 1 and several threads."""
+    from golden_util import ALL_CASES, DIAG_CASES, FIXED_CASES
+    if case not in ALL_CASES + DIAG_CASES + FIXED_CASES:
+        pytest.skip("no such fixture")
+    g = Golden(case)
+    before = c_oracle.get_threads()
+    try:
+        runs = []
+        for t in (1, 3, 8):
+            assert c_oracle.set_threads(t) == t
+            o, out = c_oracle.run_chain(g)
+            runs.append((out, o.stats()))
+        for it in range(g.n_iter):
+            npt.assert_array_equal(runs[0][0]["z"][it], g.z[it])
+        for out, st in runs[1:]:
+            for it in range(g.n_iter):
+                npt.assert_array_equal(out["z"][it], runs[0][0]["z"][it])
+                assert out["log_marg"][it] == runs[0][0]["log_marg"][it]
+            for a, b in zip(st, runs[0][1]):
+                npt.assert_array_equal(a, b)
+    finally:
+        c_oracle.set_threads(before)
