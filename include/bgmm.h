@@ -175,6 +175,14 @@ BGMM_API int bgmm_get_staged_order(bgmm_ctx *ctx, int64_t *order_out);
 /* out4 = {permutations served by the look-ahead, generated on the spot, rounds of draws the last one took to settle, the
  * most any took so far} (kernels_perm.hip: the rounds are queued blindly, a fixed number at a time). */
 BGMM_API int bgmm_get_permutation_stats(bgmm_ctx *ctx, int64_t *out4);
+/* The permutations in flight (three generations of np.random.permutation queued ahead on three streams): out4 = {set up,
+ * switched off for this context, generations in a row its worker thread could not queue, bytes of its word stream}.  Its
+ * memory (the word stream: 32 generations of 2 N + 1248 words, at most 1 GiB and at most a twentieth of the memory free
+ * when it is set up; 3 target arrays + 4 order buffers of N; pinned verdict blocks) is taken at the first staged
+ * permutation.  When that fails -- or the worker fails three times in a row -- everything it took is released, the state
+ * is latched "off" and the stage calls go on with the single look-ahead (one permutation ahead, one stream): a slower
+ * route to the same bits, not an error. */
+BGMM_API int bgmm_get_permutation_pipe_state(bgmm_ctx *ctx, int64_t *out4);
 
 /* Bench / multi-sweep form: make the inputs of n_sweeps sweeps resident in HBM at once
  * (u_all[n_sweeps][N]; order_all[n_sweeps][N] or NULL), then run sweep `index` of them with no

@@ -49,6 +49,7 @@ SIGNATURES = {
     "bgmm_stage_permutation_mt19937": (ctypes.c_int, [_vp, _vp, _vp]),
     "bgmm_get_staged_order": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_permutation_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_permutation_pipe_state": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
     "bgmm_sweep_staged_begin": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
@@ -258,6 +259,11 @@ class Context(object):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_permutation_stats(self.h, _ptr(out)))
         return {"lookahead_hits": int(out[0]), "generated_on_the_spot": int(out[1]), "rounds_last": int(out[2]), "rounds_max": int(out[3])}
+
+    def permutation_pipe_state(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_permutation_pipe_state(self.h, _ptr(out)))
+        return {"built": bool(out[0]), "off": bool(out[1]), "worker_failures_in_a_row": int(out[2]), "word_stream_bytes": int(out[3])}
 
     def staged_order(self):
         o = np.empty(self.N, dtype=np.int64)

@@ -39,6 +39,9 @@ void launch_export_stats(const Dev &d, int K, double *m_out, double *S_out, doub
                          double *inv_out, hipStream_t st);
 
 static thread_local std::string g_create_error;
+// The permutations' worker thread (PermPipe::worker) reports through a string of its own: bgmm_ctx::err belongs to the
+// thread that drives the context.  CK / fail write to err_of(ctx).
+static thread_local std::string *g_err_sink = nullptr;
 
 // Chains side by side on one GPU (bgmm_group_sweep_staged) keep one stream each busy.  The HIP runtime maps a process's
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; streams that share a queue run one behind the other).  The
@@ -163,6 +166,15 @@ struct bgmm_ctx {
         long long target = 0;
         bool busy = false, quit = false, full = false;     // full: the era has no room for another generation
         int wrc = 0;
+        std::string werr;                   // the worker's last error text (written under mu, never bgmm_ctx::err)
+        int wfails = 0;                     // generations in a row the worker could not queue
+        bool w_jump = true;                 // what the worker may read of the context, posted with the target (under mu)
+        unsigned *w_coef = nullptr;
+        // Set-up is all or nothing: what perm_pipe_build made so far is released when a step fails, `off` is latched and the
+        // context stays on the single look-ahead of round 3 (INTEGRATION.md "memory of the permutations in flight").
+        bool off = false;
+        std::string off_why;
+        std::vector<void *> dev_allocs;
     } pp;
     // bgmm_sweep_staged_begin / _end: a sweep whose first batch of launches is in the queue and has not been waited for
     bool async_pending = false, async_short = false;
@@ -257,11 +269,12 @@ constexpr double kSafeRun = 65536.0;
 constexpr double kSafeDenseRate = 0.25;
 constexpr double kSafeWalkShare = 0.25;
 
+static inline std::string &err_of(bgmm_ctx *c) { return g_err_sink ? *g_err_sink : c->err; }
 #define CK(ctx, call)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) {                                                             \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            err_of(ctx) = std::string(#call) + ": " + hipGetErrorString(e_);               \
             return BGMM_EDEVICE;                                                            \
         }                                                                                   \
     } while (0)
@@ -271,7 +284,7 @@ static int dalloc(bgmm_ctx *c, T **p, size_t count) {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
     if (e != hipSuccess) {
-        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        err_of(c) = std::string("hipMalloc: ") + hipGetErrorString(e);
         return BGMM_EDEVICE;
     }
     c->allocs.push_back(q);
@@ -290,7 +303,7 @@ static int finish_pending(bgmm_ctx *c);
 #define SETTLE(c) do { if ((c)->async_pending) { const int rc_ = finish_pending(c); if (rc_) return rc_; } } while (0)
 
 static int fail(bgmm_ctx *c, int code, const std::string &msg) {
-    if (c) c->err = msg;
+    if (c) err_of(c) = msg;
     else g_create_error = msg;
     return code;
 }
@@ -376,6 +389,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (c->pp.ev_sweep) (void)hipEventDestroy(c->pp.ev_sweep);
     if (c->pp.era_raw) (void)hipFree(c->pp.era_raw);
     if (c->pp.era_key_host) (void)hipHostFree(c->pp.era_key_host);
+    for (void *p : c->pp.dev_allocs) (void)hipFree(p);
     if (c->perm_done) (void)hipEventDestroy(c->perm_done);
     if (c->perm_words) (void)hipFree(c->perm_words);
     if (c->perm_seeds) (void)hipFree(c->perm_seeds);
@@ -737,8 +751,11 @@ extern "C" int bgmm_stage_sweep_inputs(bgmm_ctx *c, const int64_t *order, const 
 }
 
 // jump polynomials / chain seeds for requests of up to `chains` chains (grown on demand, never while a generation runs)
+static int perm_pipe_drain(bgmm_ctx *c);
 static int mt_ensure_tables(bgmm_ctx *c, int chains) {
     if (chains < 2 || c->mt_chains >= chains) return 0;
+    // (the permutations in flight read the coefficient table that is about to be replaced)
+    { const int rc = perm_pipe_drain(c); if (rc) return rc; }
     std::vector<unsigned> coef;
     const bool have = mt19937_jump_coefficients(chains, coef);
     if (c->mt_coef) { (void)hipFree(c->mt_coef); c->mt_coef = nullptr; }
@@ -1035,6 +1052,15 @@ extern "C" int bgmm_get_permutation_stats(bgmm_ctx *c, int64_t *out4) {
     return 0;
 }
 
+extern "C" int bgmm_get_permutation_pipe_state(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    bgmm_ctx::PermPipe &Q = c->pp;
+    std::lock_guard<std::mutex> g(Q.mu);
+    out4[0] = Q.built ? 1 : 0; out4[1] = Q.off ? 1 : 0; out4[2] = Q.wfails;
+    out4[3] = Q.built ? (int64_t)Q.era_cap * (int64_t)sizeof(unsigned) : 0;
+    return 0;
+}
+
 // queues the look-ahead permutation from the state noted in perm_host[640 ..) / perm_ahead_pos_in
 static int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
     int rc = perm_queue(c, P, c->perm_host + 640, c->perm_ahead_pos_in, c->d_order_ahead, c->perm_stream);
@@ -1081,61 +1107,114 @@ static int perm_pipe_drain(bgmm_ctx *c) {
     std::lock_guard<std::mutex> g(Q.mu);
     Q.valid = false;
     Q.full = false;
-    Q.wrc = 0;
+    if (Q.wrc != 0) {
+        // the worker could not queue a generation: the stage call goes the old way for this one -- and after three in a row
+        // for good (a device call that keeps failing would otherwise be queued and dropped at every stage call)
+        if (++Q.wfails >= 3 && !Q.off) {
+            Q.off = true;
+            Q.off_why = Q.werr;
+        }
+        Q.wrc = 0;
+    }
     Q.gen_next = Q.gen_queued;          // (whatever was in flight is dropped)
     return 0;
 }
 
-static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
+// device memory of the pipe: on a list of its own (released as a whole when set-up fails, freed with the context otherwise)
+template <typename T>
+static int pp_alloc(bgmm_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    if (e != hipSuccess) {
+        err_of(c) = std::string("hipMalloc (permutations in flight): ") + hipGetErrorString(e);
+        return BGMM_EDEVICE;
+    }
+    c->pp.dev_allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+static void perm_pipe_release(bgmm_ctx *c) {
     bgmm_ctx::PermPipe &Q = c->pp;
-    if (Q.built) return 0;
+    constexpr int A = bgmm_ctx::PermPipe::kAhead;
+    if (Q.fin) { (void)hipStreamSynchronize(Q.fin); (void)hipStreamDestroy(Q.fin); Q.fin = nullptr; }
+    if (Q.rawst) { (void)hipStreamSynchronize(Q.rawst); (void)hipStreamDestroy(Q.rawst); Q.rawst = nullptr; }
+    for (int k = 0; k < A; ++k) {
+        if (Q.ev_draw[k]) { (void)hipEventDestroy(Q.ev_draw[k]); Q.ev_draw[k] = nullptr; }
+        if (Q.ev_fin[k]) { (void)hipEventDestroy(Q.ev_fin[k]); Q.ev_fin[k] = nullptr; }
+        if (Q.host[k]) { (void)hipHostFree(Q.host[k]); Q.host[k] = nullptr; }
+        Q.J[k] = nullptr; Q.vblk[k] = nullptr; Q.ord[k] = nullptr;
+    }
+    if (Q.ev_raw) { (void)hipEventDestroy(Q.ev_raw); Q.ev_raw = nullptr; }
+    if (Q.ev_sweep) { (void)hipEventDestroy(Q.ev_sweep); Q.ev_sweep = nullptr; }
+    if (Q.era_raw) { (void)hipFree(Q.era_raw); Q.era_raw = nullptr; }
+    if (Q.era_key_host) { (void)hipHostFree(Q.era_key_host); Q.era_key_host = nullptr; }
+    for (void *q : Q.dev_allocs) (void)hipFree(q);
+    Q.dev_allocs.clear();
+    Q.era_key = nullptr; Q.goffs = nullptr; Q.cnt = nullptr; Q.pre0 = nullptr; Q.zero[0] = Q.zero[1] = nullptr;
+    Q.parked = nullptr; Q.bnd = nullptr; Q.cursor = nullptr; Q.slots = nullptr;
+    Q.NB = 0;
+}
+
+static int perm_pipe_build(bgmm_ctx *c, const PermPtrs &P) {
+    bgmm_ctx::PermPipe &Q = c->pp;
     Q.P = P;                            // (the worker's copy: set before it exists, never written again)
     constexpr int A = bgmm_ctx::PermPipe::kAhead;
     const long long N = c->d.N;
     Q.cap_words = 2 * N + 1248;
     const int T = perm_segments(Q.cap_words);
-    // the era: 32 generations' worth of words, within 1 GiB, never less than what kAhead + 2 generations may read
-    // (BGMM_PERM_ERA: generations' worth, for the test that walks through several eras)
+    // the era: 32 generations' worth of words, within 1 GiB AND within a twentieth of the memory that is free now (32 chains
+    // side by side at N = 1e6 would otherwise take 8 GB for look-ahead alone), never less than what kAhead + 2 generations
+    // may read (BGMM_PERM_ERA: generations' worth, for the test that walks through several eras)
     static const int era_gens = [] { const char *e = getenv("BGMM_PERM_ERA"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
     long long cap = era_gens * Q.cap_words;
     if (cap > (1ll << 28)) cap = 1ll << 28;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const long long share = (long long)(free_b / 20 / sizeof(unsigned));
+            if (cap > share) cap = share;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (cap < (A + 3) * Q.cap_words) cap = (A + 3) * Q.cap_words;
     Q.era_cap = 624 * ((cap + 623) / 624) + 1248;
     CK(c, hipMalloc((void **)&Q.era_raw, sizeof(unsigned) * (size_t)Q.era_cap));
     CK(c, hipHostMalloc((void **)&Q.era_key_host, sizeof(unsigned) * 640, hipHostMallocDefault));
-    { int rc = dalloc(c, &Q.era_key, (size_t)640); if (rc) return rc; }
-    { int rc = dalloc(c, &Q.goffs, (size_t)8); if (rc) return rc; }
-    { int rc = dalloc(c, &Q.cnt, 5 * (size_t)T + 16); if (rc) return rc; }
+    { int rc = pp_alloc(c, &Q.era_key, (size_t)640); if (rc) return rc; }
+    { int rc = pp_alloc(c, &Q.goffs, (size_t)8); if (rc) return rc; }
+    { int rc = pp_alloc(c, &Q.cnt, 5 * (size_t)T + 16); if (rc) return rc; }
     CK(c, hipMemset(Q.cnt, 0, sizeof(int) * 5 * (size_t)T));
     std::vector<int> pre((size_t)T + 1);
     Q.nblk_pad = perm_chain_guess(Q.cap_words, (int)N, pre.data());
     if (Q.rounds_fixed) Q.rounds_q = Q.rounds_fixed;
-    { int rc = dalloc(c, &Q.pre0, (size_t)T + 16); if (rc) return rc; }
+    { int rc = pp_alloc(c, &Q.pre0, (size_t)T + 16); if (rc) return rc; }
     CK(c, hipMemcpy(Q.pre0, pre.data(), sizeof(int) * ((size_t)T + 1), hipMemcpyHostToDevice));
     for (int k = 0; k < 2; ++k) {
-        { int rc = dalloc(c, &Q.zero[k], (size_t)Q.nblk_pad + 64); if (rc) return rc; }
+        { int rc = pp_alloc(c, &Q.zero[k], (size_t)Q.nblk_pad + 64); if (rc) return rc; }
         CK(c, hipMemset(Q.zero[k], 0, sizeof(int) * ((size_t)Q.nblk_pad + 64)));
     }
     for (int k = 0; k < A; ++k) {
-        { int rc = dalloc(c, &Q.J[k], (size_t)N + 16); if (rc) return rc; }
+        { int rc = pp_alloc(c, &Q.J[k], (size_t)N + 16); if (rc) return rc; }
         CK(c, hipMemset(Q.J[k], 0, sizeof(int) * (size_t)N));
-        { int rc = dalloc(c, &Q.vblk[k], (size_t)1344); if (rc) return rc; }
+        { int rc = pp_alloc(c, &Q.vblk[k], (size_t)1344); if (rc) return rc; }
         CK(c, hipMemset(Q.vblk[k], 0, sizeof(int) * 1344));
-        { int rc = dalloc(c, &Q.ord[k], (size_t)N); if (rc) return rc; }
+        { int rc = pp_alloc(c, &Q.ord[k], (size_t)N); if (rc) return rc; }
         CK(c, hipHostMalloc((void **)&Q.host[k], sizeof(unsigned) * 1344, hipHostMallocDefault));
         memset(Q.host[k], 0, sizeof(unsigned) * 1344);
         const unsigned evf = getenv("BGMM_DEBUG_PERM") ? hipEventDefault : hipEventDisableTiming;
         CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], evf));
         CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], evf));
     }
-    { int rc = dalloc(c, &Q.parked, (size_t)N); if (rc) return rc; }
+    { int rc = pp_alloc(c, &Q.parked, (size_t)N); if (rc) return rc; }
     {
         std::vector<int> bnd;
         Q.NB = perm_bucket_bounds((int)N, bnd);
         if (Q.NB > 0) {
-            { int rc = dalloc(c, &Q.bnd, (size_t)Q.NB + 16); if (rc) return rc; }
-            { int rc = dalloc(c, &Q.cursor, (size_t)Q.NB + 16); if (rc) return rc; }
-            { int rc = dalloc(c, &Q.slots, (size_t)Q.NB * (size_t)perm_bucket_cap()); if (rc) return rc; }
+            { int rc = pp_alloc(c, &Q.bnd, (size_t)Q.NB + 16); if (rc) return rc; }
+            { int rc = pp_alloc(c, &Q.cursor, (size_t)Q.NB + 16); if (rc) return rc; }
+            { int rc = pp_alloc(c, &Q.slots, (size_t)Q.NB * (size_t)perm_bucket_cap()); if (rc) return rc; }
             CK(c, hipMemcpy(Q.bnd, bnd.data(), sizeof(int) * ((size_t)Q.NB + 1), hipMemcpyHostToDevice));
             CK(c, hipMemset(Q.cursor, 0, sizeof(int) * (size_t)Q.NB));
         }
@@ -1149,8 +1228,34 @@ static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
     } catch (...) {
         return fail(c, BGMM_EDEVICE, "could not start the permutations' worker thread");
     }
-    Q.built = true;
     return 0;
+}
+
+// 0: the pipe stands; 1: it does not and will not (set-up failed -- as a rule: memory --, everything it had taken is
+// released, PermPipe::off is latched): the caller goes on with the single look-ahead, no error.
+// BGMM_PERM_PIPE_FAIL=1 makes the set-up fail after its allocations (the test of this path).
+static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
+    bgmm_ctx::PermPipe &Q = c->pp;
+    if (Q.built) return 0;
+    if (Q.off) return 1;
+    std::string why;
+    g_err_sink = &why;                  // (a failed set-up is not the caller's error: bgmm_ctx::err stays what it was)
+    int rc = perm_pipe_build(c, P);
+    if (rc == 0 && getenv("BGMM_PERM_PIPE_FAIL")) {
+        { std::lock_guard<std::mutex> g(Q.mu); Q.quit = true; }
+        Q.cv.notify_all();
+        if (Q.worker.joinable()) Q.worker.join();
+        Q.quit = false;
+        why = "BGMM_PERM_PIPE_FAIL";
+        rc = BGMM_EDEVICE;
+    }
+    g_err_sink = nullptr;
+    if (rc == 0) { Q.built = true; return 0; }
+    (void)hipGetLastError();
+    perm_pipe_release(c);
+    Q.off = true;
+    Q.off_why = why;
+    return 1;
 }
 
 // a new era from a state the host knows (all three streams idle)
@@ -1171,7 +1276,7 @@ static int perm_pipe_start_era(bgmm_ctx *c, const uint32_t *key624, int pos) {
 }
 
 // more words of the era on the words' stream, until `upto` of them are queued
-static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto) {
+static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto, const unsigned *coef) {
     bgmm_ctx::PermPipe &Q = c->pp;
     if (upto > Q.era_cap) upto = Q.era_cap;
     const long long chunk = 624 * ((Q.cap_words + 623) / 624);
@@ -1186,7 +1291,7 @@ static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto) {
         if (n_words < 624) break;
         const unsigned *key_in = first ? Q.era_key : Q.era_raw + Q.era_gen_words - 624;
         const int chains = mt19937_chains_for_words(pos, n_words);
-        launch_mt19937_raw(key_in, pos, Q.era_raw + Q.era_gen_words, n_words, (c->mt_jump_on && chains >= 2) ? c->mt_coef : nullptr, chains,
+        launch_mt19937_raw(key_in, pos, Q.era_raw + Q.era_gen_words, n_words, chains >= 2 ? coef : nullptr, chains,
                            P.draw, c->perm_seeds, P.dspare, P.dspare_pos, Q.rawst);
         CK(c, hipGetLastError());
         Q.era_gen_words += n_words;
@@ -1198,7 +1303,9 @@ static int perm_pipe_words(bgmm_ctx *c, const PermPtrs &P, long long upto) {
 
 // queues one more generation; 1: the era has no room for it
 // (the worker's: g = the generation, gen_next / off_exact / rounds as the stage calls had left them when it began)
-static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long long gen_next, long long off_exact, int rounds) {
+// (coef: the jump polynomials as the posting stage call saw them, nullptr = chains one after the other)
+static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long long gen_next, long long off_exact, int rounds,
+                               const unsigned *coef) {
     bgmm_ctx::PermPipe &Q = c->pp;
     constexpr int A = bgmm_ctx::PermPipe::kAhead;
     const long long N = c->d.N;
@@ -1207,7 +1314,7 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long
     const long long hi = off_exact + (g - gen_next) * Q.cap_words;
     const long long need = hi + Q.cap_words + 1248;
     if (need > Q.era_cap - 1248) return 1;
-    int rc = perm_pipe_words(c, P, need + 2 * Q.cap_words);
+    int rc = perm_pipe_words(c, P, need + 2 * Q.cap_words, coef);
     if (rc) return rc;
     if (Q.era_gen_words < need) return 1;
     hipStream_t D = c->perm_stream;
@@ -1241,20 +1348,25 @@ static int perm_pipe_queue_one(bgmm_ctx *c, const PermPtrs &P, long long g, long
 static void perm_pipe_worker(bgmm_ctx *c) {
     (void)hipSetDevice(c->device);
     bgmm_ctx::PermPipe &Q = c->pp;
+    std::string my_err;
+    g_err_sink = &my_err;               // (CK / fail on this thread never touch bgmm_ctx::err)
     std::unique_lock<std::mutex> lk(Q.mu);
     for (;;) {
         Q.cv.wait(lk, [&] { return Q.quit || (Q.gen_queued < Q.target && !Q.full && Q.wrc == 0); });
         if (Q.quit) return;
         const long long g = Q.gen_queued, gn = Q.gen_next, off = Q.off_exact;
         const int rounds = Q.rounds_q;
+        const bool jump = Q.w_jump;
+        unsigned *const coef = Q.w_coef;
         Q.busy = true;
         lk.unlock();
-        const int rc = perm_pipe_queue_one(c, Q.P, g, gn, off, rounds);
+        my_err.clear();
+        const int rc = perm_pipe_queue_one(c, Q.P, g, gn, off, rounds, jump ? coef : nullptr);
         lk.lock();
         Q.busy = false;
         if (rc == 0) Q.gen_queued = g + 1;
         else if (rc == 1) Q.full = true;
-        else Q.wrc = rc;
+        else { Q.wrc = rc; Q.werr = my_err; }
         Q.cv.notify_all();
     }
 }
@@ -1265,6 +1377,8 @@ static int perm_pipe_fill(bgmm_ctx *c) {
     {
         std::lock_guard<std::mutex> g(Q.mu);
         Q.target = Q.gen_next + bgmm_ctx::PermPipe::kAhead;
+        Q.w_jump = c->mt_jump_on;
+        Q.w_coef = c->mt_coef;
     }
     Q.cv.notify_all();
     return 0;
@@ -1296,7 +1410,7 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     int rc = perm_ensure(c, P);
     if (rc) return rc;
     unsigned *key_in_pinned = c->perm_host + 640;                 // [640, 1264): the state a generation starts from
-    const bool piped = c->mt_ahead_on && perm_pipe_wanted();
+    bool piped = c->mt_ahead_on && perm_pipe_wanted() && !c->pp.off;
     bool hit = false;
     if (piped && c->pp.built && c->pp.valid) {
         bgmm_ctx::PermPipe &Q = c->pp;
@@ -1354,6 +1468,7 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
                 Q.off_exact += out[0];
                 Q.gen_next += 1;
                 c->perm_hits += 1;
+                Q.wfails = 0;
                 hit = true;
             } else {
                 // (it did not get through -- as a rule: not settled within the queued rounds; this one goes the old way)
@@ -1399,10 +1514,15 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
     c->order_is_perm = true;
     c->have_order = true;
     c->cur_order = c->d_order;
+    if (piped && c->pp.off) piped = false;               // (the worker kept failing: latched by the drain above)
     if (piped) {
-        // the generations behind this one, from the state just handed back
+        // the generations behind this one, from the state just handed back; a pipe that cannot be set up (memory) is not an
+        // error: the single look-ahead below serves from here on
         rc = perm_pipe_ensure(c, P);
-        if (rc) return rc;
+        if (rc < 0) return rc;
+        if (rc == 1) piped = false;
+    }
+    if (piped) {
         bgmm_ctx::PermPipe &Q = c->pp;
         if (!Q.valid) { rc = perm_pipe_start_era(c, key624, *pos); if (rc) return rc; }
         memcpy(Q.expect_key, key624, sizeof(unsigned) * 624);

@@ -33,8 +33,14 @@
 //   * every wavefront (64 rows of the block, 16 at a time) has the next tiles on their way while the current one
 //     is in the matrix pipe (three of them up to D = 32); records a block ahead, issued before the block's row loads;
 //     the visit's uniform is fetched only when its draw depends on it;
-//   * a block that straddles two homes (or holds unassigned rows) takes the general path: factor tiles from L2
-//     through a register ring, home by home.
+//   * the evaluation order comes padded (bucket_prefix_kernel: every home's run of rows fills whole 256-row blocks), so a
+//     block has ONE home -- or is a block of the unassigned bin, whose rows go on the residual list as they always did.
+//     (Until round 5 a block could straddle two homes and took a "general path" here -- factor tiles from L2 through a
+//     register ring, home by home; with the padded order that path only ever saw unassigned rows, computed nothing for
+//     them, and cost the hot loop 25 registers, 2 of them spilled.  Round 6: a block that is not one home's passes its
+//     rows on, whatever they are.)
+//   * SAFE (template): the proof pass of a safe-stay window (kernels_safe.hip) is its own instantiation -- its tail, its
+//     tables and its constants are not live in the kernel that decides a chain at rest.
 // Per wavefront lane = row for everything scalar (the record, the tail); quadratic forms and distances meet their
 // rows' lanes through LDS.  The tail is short on purpose: FP64 VALU instructions queue behind the other
 // wavefronts' MFMAs (the same pipe), so a visit whose new table weighs less than 2^-53 of its home is decided
@@ -71,7 +77,10 @@ __host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_d
 // D = 64, one above (at two the D = 128 kernel spills, and a scratch access waits for every row load in flight)
 __host__ __device__ constexpr int home_waves_per_simd(int NJ) {
     const int by_lds = (160 * 1024) / home_lds_bytes(NJ * 16);
-    const int want = NJ <= 4 ? 2 : 1;
+#ifndef BGMM_HOME_W1
+#define BGMM_HOME_W1 2
+#endif
+    const int want = NJ == 1 ? BGMM_HOME_W1 : (NJ <= 4 ? 2 : 1);
     return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
 }
 
@@ -108,19 +117,18 @@ __device__ __forceinline__ double home_row_sum4(const double (&a)[4], int lane) 
 }
 
 // WHOLE: D is a multiple of 16 (no padded columns: every 16-byte piece of a tile lies inside its row)
-template <int NJ, bool WHOLE>
+template <int NJ, bool WHOLE, bool SAFE>
 __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev d) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = d.ctrl;
-    if (!job_is_pruned(d, c->job.mode, c->job.prune) || (d.safe_mode && c->safe_epoch_valid)) return;
+    if (!job_is_pruned(d, c->job.mode, c->job.prune) || (SAFE && c->safe_epoch_valid)) return;
     // (a short step queued neither the table kernels nor -- short_step 1 -- the bucket sort: without them there is
     // nothing sound to do here, and apply_kernel will refuse the step)
     if (d.short_step && (!c->tables_valid || (d.short_step == 1 && !c->skip_sort))) return;
     constexpr int Dp = NJ * 16, NF = 2 * NJ * (NJ + 1), NKK = NJ * 4, NJ8 = NJ * 2;
-    constexpr int PFK = pick_ring(NF, 4);                             // factor tiles in flight from L2 (general path)
-    constexpr int LRING = pick_ring(NF, 4);                           // ... from LDS
+    constexpr int LRING = pick_ring(NF, 4);                           // factor tiles in flight from LDS
     constexpr int NS = home_slots(NJ);
-    constexpr int NB = WHOLE ? home_nbr(NJ * 16) : 0;                 // neighbours of the home scored exactly (D = 16, 32)
+    constexpr int NB = (WHOLE && !SAFE) ? home_nbr(NJ * 16) : 0;     // neighbours of the home scored exactly (D = 16, 32)
     const long long nrows = c->n_sorted_pad;                          // (every home's run padded to whole blocks: bucket_prefix_kernel)
     // the records were written for this very window (bucket_scatter_kernel ran in front): they carry the visits' uniforms
     const bool u_in_rec = !c->skip_sort;
@@ -168,11 +176,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     //  far below -- so the wide margin there, and the rows in between go to the pruning kernel, whose draw kernel
     //  sums the alternatives exactly.)
     const double margin = keep_caches ? kHomeFar : 38.0 + fm_log((double)K + 1.0);
-    // where lane (lr, lk) finds its entry of permuted fragment kk in a factor stored in the standard order
-    // (Wfrag: fragment kk, lane (ln, lk) = column 4 kk + lk): source fragment 2 (kk / 2) + (lk >> 1) of the block,
-    // source k-lane (2 lk + (kk & 1)) & 3
-    const int src_lane[2] = {lr + 16 * ((2 * lk) & 3), lr + 16 * ((2 * lk + 1) & 3)};
-    const int src_frag = lk >> 1;
 
     // lane rho's row of the current block and of the next one (record, window row, uniform: a block ahead),
     // the homes of the block's first and last row
@@ -225,6 +228,32 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             }                                                                              \
         }                                                                                  \
     }
+    // One tile FURTHER ahead than the register slots reach, rows are only pulled into the XCD's L2 (round 6): one dword per
+    // 128-byte line of the tile -- 16 NJ lines, a single load instruction and one register up to D = 64 -- so that the
+    // real loads of that tile, a tile later, are served by L2 instead of paying the gather's memory latency with only
+    // one tile per wavefront in flight (SQ counters of round 5's kernel: 62 % of the wavefront cycles in s_waitcnt,
+    // the matrix pipe 52 % busy, HBM at 4.4 TB/s -- neither floor reached).  The value is consumed a tile later by an
+    // empty asm, where the older row loads have been waited for anyway.  WHOLE only (rows are whole lines there).
+#ifndef BGMM_HOME_PFD
+#define BGMM_HOME_PFD 1
+#endif
+    constexpr bool PFD = WHOLE && BGMM_HOME_PFD != 0 && NJ != 5;      // (D = 80: the extra register would cost the second wavefront per SIMD)
+    constexpr int PFN = PFD ? (16 * NJ + 63) / 64 : 1;
+    int pfv[PFN];
+#pragma unroll
+    for (int q = 0; q < PFN; ++q) pfv[q] = 0;
+#define HOME_PREFETCH(XO, TN)                                                              \
+    if (PFD) {                                                                             \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q) {                                  \
+            const int idx_ = q * 64 + lane;                                                \
+            const int row_ = idx_ / NJ < 16 ? idx_ / NJ : 15, line_ = idx_ % NJ;           \
+            const int src_ = 16 * (TN) + row_;                                             \
+            const long long o_ = ((long long)__shfl((int)((XO) >> 32), src_) << 32) | (unsigned int)__shfl((int)(XO), src_); \
+            pfv[q] = __builtin_nontemporal_load((const int *)(d.X + o_) + 32 * line_);     \
+        }                                                                                  \
+    }
+#define HOME_PREFETCH_DONE()                                                               \
+    if (PFD) { _Pragma("unroll") for (int q = 0; q < PFN; ++q) asm volatile("" :: "v"(pfv[q])); }
     // (element offset of the lane's row in X: one 64-bit multiply per record)
     // of the current block's rows, of the next block's (wanted NS - 1 tiles before that block starts: its record
     // index is fetched a block earlier than the rest of the record)
@@ -236,6 +265,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) HOME_ISSUE(xt[t], xo_cur, t)
+    if (NS - 1 < 4) { HOME_PREFETCH(xo_cur, NS - 1) }
     unsigned n_mfma = 0, n_homes = 0;
     int cur_home = -1;
 #ifdef BGMM_HOME_PROF
@@ -254,11 +284,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         const bool ok_after = b + 2 < b1 && k_after < nrows;
         i_after = d.wrec[ok_after ? k_after : 0].i;
         const int hf = __builtin_amdgcn_readfirstlane(hf_cur), hl = __builtin_amdgcn_readfirstlane(hl_cur);
-#ifdef HX_NOGENERAL
-        const bool one_home = hf >= 0;
-#else
         const bool one_home = hf == hl && hf >= 0;                    // (the same decision in all four wavefronts)
-#endif
         HP(6)
         if (one_home && hf != cur_home) {
             __syncthreads();                                          // everybody is done with the previous home
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             };
             copy_factor(hf, Bf);
             const int a = d.label_of_slot[hf];
-            if (NB > 0 && !d.safe_mode) {
+            if (NB > 0) {
                 // the home's neighbours (prune_ftable_kernel): factor, cvec, the constants of the as-is predictive
                 const int *__restrict__ nl = d.nbr + (long long)a * 4;
                 int nn = 0;
@@ -327,8 +353,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const int col = 16 * (e >> 4) + home_col((e >> 2) & 3, e & 3);     // e = 4 kk + lk
                 hmu[e] = col < D ? d.mu[(long long)hf * D + col] : 0.0;
             }
-            if (tid < 64) hft[tid] = (d.safe_mode ? d.ftabR : d.ftab)[(long long)a * 64 + tid];
-            if (d.safe_mode && tid >= 128 && tid < 136) hsr[tid - 128] = d.rtab[(long long)a * 8 + (tid - 128)];
+            if (tid < 64) hft[tid] = (SAFE ? d.ftabR : d.ftab)[(long long)a * 64 + tid];
+            if (SAFE && tid >= 128 && tid < 136) hsr[tid - 128] = d.rtab[(long long)a * 8 + (tid - 128)];
             if (tid == 64) {
                 const SlotConst sc = d.sc[hf];
                 hsc[0] = sc.A; hsc[1] = sc.half_vd; hsc[2] = sc.inv_cv; hsc[3] = sc.A1; hsc[4] = sc.half_vd1;
@@ -349,8 +375,11 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double (&xf)[NKK] = xt[t % NS];
                 HP(0)
                 // tile t + NS - 1 sets off into the slot tile t - 1 has left (beyond the block: the next block's rows)
+                HOME_PREFETCH_DONE()
                 if (t + NS - 1 < 4) { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_cur, t + NS - 1) }
                 else { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_next, t + NS - 1 - 4) }
+                if (t + NS < 4) { HOME_PREFETCH(xo_cur, t + NS) }
+                else if (t + NS - 4 < 4) { HOME_PREFETCH(xo_next, t + NS - 4) }
                 HP(1)
                 {
                 // ---- every row of the tile under the block's home: factor and constants from LDS
@@ -365,10 +394,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     // (the distance to the home's mean, one block of 16 columns per block row: four constants live at a
                     //  time instead of D/4, and the FP64 VALU work spread between the MFMAs)
                     asm volatile("" ::: "memory");
-#ifndef HX_NODPART
 #pragma unroll
                     for (int kk = 4 * J; kk < 4 * J + 4; ++kk) { const double tq = xf[kk] - hmu[4 * kk + lk]; dpart = fma(tq, tq, dpart); }
-#endif
                     const double cj = hcv[16 * J + lr];
                     v4d acc = (v4d){cj, cj, cj, cj};
 #pragma unroll
@@ -391,7 +418,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 dpart += __shfl_xor(dpart, 16);
                 dpart += __shfl_xor(dpart, 32);
                 if (lk == 0) sideRho[r0 + lr] = dpart;
-                if (NB > 0 && !d.safe_mode) {
+                if (NB > 0) {
                     // ---- the same rows under the home's neighbours (their as-is forms: nobody is removed from them)
                     const int nn = __builtin_amdgcn_readfirstlane(ncand[0]);
                     // (a neighbour's fragments come into registers in one batch, the next neighbour's while this one's
@@ -424,68 +451,9 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 HP(3)
             }
         } else {
-            // ---- the general path (a block that straddles homes, or holds unassigned rows): tile by tile with its
-            // own loads -- the prefetched slots are left alone and refilled for the next block afterwards
-#pragma unroll 1
-            for (int t = 0; t < 4; ++t) {
-                const int r0 = 16 * t;
-                double xf[NKK];
-                HOME_ISSUE(xf, xo_cur, t)
-                // the homes present in the tile, one after the other; factor tiles from L2 (standard order: every lane
-                // fetches the entry the permutation assigns to it)
-                {
-                const int hd = sideH[r0 + lr];
-                unsigned long long pending = __ballot(lane >= r0 && lane < r0 + 16 && hmine >= 0);
-#pragma unroll 1
-                while (pending) {
-                    const int first = __ffsll((long long)pending) - 1;
-                    const int s = __builtin_amdgcn_readlane(hmine, first);
-                    pending &= ~__ballot(hmine == s);
-                    const double *__restrict__ wfs = d.Wfrag + (long long)s * (NF * 64) + src_frag * 64;
-                    // (permuted fragment f = 2 J (J + 1) + kk: the parities of f and kk agree)
-#define HOME_BSRC(F) wfs[((F) & ~1) * 64 + src_lane[(F) & 1]]
-                    double ringk[PFK];
-#pragma unroll
-                    for (int i = 0; i < PFK; ++i) ringk[i] = HOME_BSRC(i);
-                    const double *__restrict__ cvp = d.cvec + (long long)s * d.Dp + lr;
-                    const double *__restrict__ mup = d.mu + (long long)s * D;
-                    double dpart = 0.0;
-                    double qp[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int J = 0; J < NJ; ++J) {
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int kk = 4 * J; kk < 4 * J + 4; ++kk) {
-                            const int l = 16 * J + home_col(kk & 3, lk);
-                            const double m = l < D ? mup[l] : 0.0;
-                            const double tq = xf[kk] - m;
-                            dpart = fma(tq, tq, dpart);
-                        }
-                        const double cj = cvp[16 * J];
-                        v4d acc = (v4d){cj, cj, cj, cj};
-#pragma unroll
-                        for (int kk = 0; kk < 4 * (J + 1); ++kk) {
-                            const int f = 2 * J * (J + 1) + kk;
-                            const double bfr = ringk[f % PFK];
-                            if (f + PFK < NF) ringk[f % PFK] = HOME_BSRC(f + PFK);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], bfr, acc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qp[r] = fma(acc[r], acc[r], qp[r]);
-                    }
-#undef HOME_BSRC
-                    n_mfma += NF;
-                    n_homes += 1;
-                    {
-                        const double v = home_row_sum4(qp, lane);
-                        if (lr < 4 && sideH[r0 + lk + 4 * lr] == s) sideQ[r0 + lk + 4 * lr] = v;
-                    }
-                    dpart += __shfl_xor(dpart, 16);
-                    dpart += __shfl_xor(dpart, 32);
-                    if (lk == 0 && hd == s) sideRho[r0 + lr] = dpart;
-                }
-                }
-            }
+            // ---- not one home's block (the unassigned bin; any block, should the order ever come unpadded): its live rows
+            // go on the residual list below, where every label they cannot exclude is scored exactly (kernels_prune.hip).
+            // The slots in flight hold this block's first rows: refilled with the next block's.
 #pragma unroll
             for (int t = 0; t < NS - 1; ++t) HOME_ISSUE(xt[t], xo_next, t)
             HP(3)
@@ -494,7 +462,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         // ---- the scalar tail: lane = row
         const bool live = imine >= 0;
         bool easy = false;
-        if (d.safe_mode) {
+        if (SAFE) {
             // ---- proof pass of a safe-stay window (kernels_safe.hip): does the visit stay under the frozen state AND
             // every state the window's budget allows?  Nothing is drawn here; the rows left unproven are walked in order
             // by the frozen-factor resolver.
@@ -502,15 +470,9 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #ifdef BGMM_SAFE_DEBUG
             int why = live ? 1 : 0;
 #endif
-            if (live && hmine >= 0) {
+            if (live && hmine >= 0 && one_home) {
                 const double q_t = sideQ[lane], rho2_t = sideRho[lane];
-                const int a = rcur.home_label;
-                double lb0, hv1m, okf, ik0, finv_a;
-                if (one_home) { lb0 = hsr[4]; hv1m = hsr[5]; okf = hsr[6]; ik0 = hsr[3]; finv_a = hsc[12]; }
-                else {
-                    const double *__restrict__ g = d.rtab + (long long)a * 8;
-                    lb0 = g[4]; hv1m = g[5]; okf = g[6]; ik0 = g[3]; finv_a = d.finv[a];
-                }
+                const double lb0 = hsr[4], hv1m = hsr[5], okf = hsr[6], ik0 = hsr[3], finv_a = hsc[12];
                 const double *__restrict__ gg = d.rtab + (long long)(d.nslots - 1) * 8;
                 const double chi = (q_t + ik0) * gg[1];                 // c_0(x, x) e^cap
                 if (okf > 0.5 && q_t >= 0.0 && chi < 1.0) {
@@ -518,7 +480,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                     const double rad = sqrt(rho2_t * (1.0 + 1e-9)) * (1.0 + 1e-9);
                     const double jf = rad * finv_a;
                     double bound = INFINITY;
-                    if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftabR[(long long)a * 64 + (int)jf + 1];
+                    if (jf < 62.0) bound = hft[(int)jf + 1];
                     // everything but the home, relative to it: the other labels (together below `bound`), the new table
                     // (exact); a component opened inside the window ends it (kernels_gram.hip)
                     const double R = (exp(bound - lb) + exp(rcur.mlb0 - lb)) * (1.0 + 1e-6);
@@ -542,24 +504,12 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #endif
             if (live) d.cert[wrow_cur] = safe ? 1 : 0;
             easy = !resid;
-#ifdef HX_NOTAIL
-        } else if (live && hmine >= 0) {
-            easy = sideQ[lane] + sideRho[lane] > -1.0;
-#endif
-        } else if (live && hmine >= 0) {
+        } else if (live && hmine >= 0 && one_home) {
             const double q_t = sideQ[lane], rho2_t = sideRho[lane];
             const int a = rcur.home_label;
-            int nh, ver;
-            double a1, coef1, half_vd1, base1, finv_a;
-            if (one_home) {
-                LDS_AS const int *hi = (LDS_AS const int *)(hsc + 13);
-                nh = hi[0]; ver = hi[1];
-                a1 = hsc[6]; coef1 = hsc[5]; half_vd1 = hsc[4]; base1 = hsc[9] + hsc[3]; finv_a = hsc[12];
-            } else {
-                nh = d.n[hmine]; ver = d.mu_ver[hmine];
-                const SlotConst sc = d.sc[hmine];
-                a1 = sc.a1; coef1 = sc.coef1; half_vd1 = sc.half_vd1; base1 = sc.logseat1 + sc.A1; finv_a = d.finv[a];
-            }
+            LDS_AS const int *hi = (LDS_AS const int *)(hsc + 13);
+            const int nh = hi[0], ver = hi[1];
+            const double a1 = hsc[6], coef1 = hsc[5], half_vd1 = hsc[4], base1 = hsc[9] + hsc[3], finv_a = hsc[12];
             if (keep_caches) {
                 // per-point cache for certify_kernel (bgmm_device.h: PCache)
                 PCache pc;
@@ -574,7 +524,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             // vnew < vh_lb - 37.5 and every other component below vh_lb - margin is exactly a row the exact tail lets stay
             // without its uniform (dv < -37 there): the same decision, nothing else is left behind when the caches are off.
             bool all_fast = false;
-            if (NB == 0 && one_home && !keep_caches && nh >= 2) {
+            if (NB == 0 && !keep_caches && nh >= 2) {
                 const double den = 1.0 - a1 * q_t;
                 const double t_ub = coef1 * q_t * __builtin_amdgcn_rcp(den) * (1.0 + 1e-6);
                 const double vh_lb = base1 - half_vd1 * t_ub;
@@ -594,8 +544,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double rad = sqrt(rho2_t * (1.0 + 1e-9)) * (1.0 + 1e-9);
                 const double jf = rad * finv_a;
                 double bound = INFINITY;
-                if (jf < 62.0) bound = one_home ? hft[(int)jf + 1] : d.ftab[(long long)a * 64 + (int)jf + 1];
-                if (NB > 0 && one_home) {
+                if (jf < 62.0) bound = hft[(int)jf + 1];
+                if (NB > 0) {
                     // ---- D = 16 / 32: ONE draw for every row (a wavefront executes both sides of a branch its lanes split
                     // over, and here nearly every wavefront has rows of both kinds): the candidates are the home, the new
                     // table and -- for a row the first table cannot settle -- the home's neighbours, scored exactly; everyone
@@ -731,6 +681,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #endif
 #undef HOME_LOAD_REC
 #undef HOME_ISSUE
+#undef HOME_PREFETCH
+#undef HOME_PREFETCH_DONE
     if (lane == 0) {
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_homes);
         atomicAdd(&d.pr_counts[512 + (blockIdx.x & 255)], (unsigned long long)n_mfma);
@@ -750,15 +702,20 @@ static int home_cu_count() {
     return cus[dev];
 }
 
-template <int NJ, bool WHOLE>
-static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
+template <int NJ, bool WHOLE, bool SAFE>
+static void launch_home_ts(const Dev &d, long long max_rows, hipStream_t st) {
     const long long want = (max_rows + 255) / 256 + d.nslots + 1;     // (+ the pads of the evaluation order: at most one block per bin)
     const long long cap = (long long)home_waves_per_simd(NJ) * home_cu_count();      // (a workgroup = one wavefront per SIMD)
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     constexpr int lds = home_lds_bytes(NJ * 16);
     static PerDeviceLds attr;
-    attr.ensure((const void *)home_kernel<NJ, WHOLE>, lds);
-    hipLaunchKernelGGL((home_kernel<NJ, WHOLE>), dim3(gx), dim3(256), lds, st, d);
+    attr.ensure((const void *)home_kernel<NJ, WHOLE, SAFE>, lds);
+    hipLaunchKernelGGL((home_kernel<NJ, WHOLE, SAFE>), dim3(gx), dim3(256), lds, st, d);
+}
+template <int NJ, bool WHOLE>
+static void launch_home_t(const Dev &d, long long max_rows, hipStream_t st) {
+    if (d.safe_mode) launch_home_ts<NJ, WHOLE, true>(d, max_rows, st);
+    else launch_home_ts<NJ, WHOLE, false>(d, max_rows, st);
 }
 
 void launch_home(const Dev &d, long long max_rows, hipStream_t st) {

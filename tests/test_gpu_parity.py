@@ -1533,6 +1533,31 @@ for N in (4096, 100003, 1000000):
 """ % hits)
 
 
+def test_permutations_in_flight_that_cannot_be_set_up_leave_the_single_lookahead():
+    """set-up of the permutations in flight is all or nothing.  BGMM_PERM_PIPE_FAIL makes it fail after all its
+    allocations: everything it took is released, the state is latched off (bgmm_get_permutation_pipe_state), no stage call
+    returns an error, and the single look-ahead of round 3 serves from there -- numpy's permutations and states, ten in a
+    row with a foreign draw, and look-ahead hits among them."""
+    _permutations_in_a_process({"BGMM_PERM_PIPE_FAIL": "1"}, """
+for N in (4096, 200000):
+    ctx = ctx_for(N)
+    in_a_row(ctx, N, 10, disturb_at=(4,))
+    ps = ctx.permutation_pipe_state()
+    assert ps["off"] and not ps["built"] and ps["word_stream_bytes"] == 0, ps
+    st = ctx.permutation_stats()
+    assert st["lookahead_hits"] >= 6, st
+    ctx.close()
+""")
+    # ... and as shipped it is set up, within its share of the free memory
+    _permutations_in_a_process({}, """
+ctx = ctx_for(200000)
+in_a_row(ctx, 200000, 4, disturb_at=())
+ps = ctx.permutation_pipe_state()
+assert ps["built"] and not ps["off"] and 0 < ps["word_stream_bytes"] <= (1 << 30) + 8192, ps
+ctx.close()
+""")
+
+
 def test_device_permutations_with_the_lookahead_switched_off_and_on_again():
     """bgmm_set_mt_lookahead between permutations: with generations in flight the switch to 0 leaves them behind (every
     permutation is then drawn on the spot), the switch back starts a new era from the caller's state; uniforms staged in
