@@ -293,6 +293,14 @@ BGMM_API int bgmm_get_safe_stats(bgmm_ctx *ctx, int64_t *out6);
  * pass (every (visit, label) pair of a stretch through the likelihood kernel: chains whose clusters overlap, where the tables
  * prove nothing).  Which one runs never changes the chain, only its cost. */
 BGMM_API int bgmm_get_proof_pass_stats(bgmm_ctx *ctx, int64_t *out2);
+/* Frozen-factor windows of a chain on its own are PIPELINED by default (gram_finish of window w - 1 and the cross forms of
+ * window w + 1 on a second stream beside the walk of window w, window w - 1's rank-1 terms carried into window w's cross
+ * forms -- kernels_gram.hip): the same chain as plain windows, label for label (the reference's loop, igmm/crpmm.py:57-88,
+ * knows neither).  bgmm_set_window_pipeline(ctx, 0) runs plain windows (tests A/B the two); the stats: out4 = {pipelined
+ * batches queued, chains broken on the device (a window that ended early, opened or deleted a component, or failed: the
+ * host reads the control block and runs two plain batches first), the mode, plain batches still to go}. */
+BGMM_API int bgmm_set_window_pipeline(bgmm_ctx *ctx, int32_t enabled);
+BGMM_API int bgmm_get_window_pipeline_stats(bgmm_ctx *ctx, int64_t *out4);
 /* Which proof pass the next batches of safe-stay windows run: -1 = the chain decides (the default; BGMM_SAFE_DENSE in the
  * environment sets the initial value), 0 = always the per-home tables, 1 = always the dense pass.  May be changed between
  * sweeps (the tests switch kinds on one chain); it never changes the trajectory. */

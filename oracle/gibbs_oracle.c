@@ -28,37 +28,95 @@
  *   draw (inside go_sweep) ........... pybgmm/utils/utils.py:15-20
  *   go_log_marg ...................... pybgmm/igmm/igmm.py:199-215, gaussian_components.py:253-289
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#ifdef _OPENMP
-#include <omp.h>
-#endif
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
+#include <unistd.h>
 
 /* Threads (round 6).  A visit's K predictive evaluations are independent of each other, and so are the D columns of
  * the inverse: both loops are shared out over go_set_threads(T) threads.  Every component's (and every column's)
  * arithmetic is the scalar code below, untouched, on its own scratch -- the floats are bit-identical for every T; the
- * maximum, the log-sum-exp and the u -= p scan stay serial in label order.  T = 1 (the default) is the single-threaded
- * port bench.py's cpu_baseline also times. */
-static int go_threads = 1;
+ * maximum, the log-sum-exp and the u -= p scan stay serial in label order.  T = 1 (the default of the library; the
+ * loader picks more for the tests) is the single-threaded port bench.py's cpu_baseline times.
+ *
+ * The team is a pool of its own: workers that SPIN on a generation counter between the regions of a visit (two or three
+ * per visit, tens of microseconds each -- an OpenMP runtime whose workers sleep between regions, which is what a
+ * process that has already loaded torch's gets, made the D = 128 cases slower on a 256-core box, not faster), static
+ * contiguous shares; once nothing has come for a while a worker polls every 50 us, after 10 ms every millisecond. */
 #define GO_MAX_THREADS 64
+typedef void (*go_job_fn)(void *arg, int64_t lo, int64_t hi, int tid);
+static int go_threads = 1;
+static struct {
+    pthread_t th[GO_MAX_THREADS];
+    int started;                        /* workers that exist (ids 1 .. started) */
+    _Atomic uint64_t gen;
+    _Atomic int done;
+    go_job_fn fn;
+    void *arg;
+    int64_t n;
+    int nt;
+} go_pool;
+
+static void *go_worker(void *p) {
+    const int tid = (int)(intptr_t)p;
+    uint64_t seen = 0;
+    for (;;) {
+        uint64_t g;
+        int idle = 0;
+        while ((g = atomic_load_explicit(&go_pool.gen, memory_order_acquire)) == seen) {
+            if (++idle <= (1 << 16)) { if ((idle & 1023) == 0) sched_yield(); else __builtin_ia32_pause(); }
+            else if (idle <= (1 << 16) + 200) usleep(50);
+            else { usleep(1000); idle = (1 << 16) + 200; }           /* (nothing for 10 ms: the sweep is over) */
+        }
+        seen = g;
+        if (tid < go_pool.nt) {
+            const int64_t lo = go_pool.n * tid / go_pool.nt, hi = go_pool.n * (tid + 1) / go_pool.nt;
+            if (hi > lo) go_pool.fn(go_pool.arg, lo, hi, tid);
+            atomic_fetch_add_explicit(&go_pool.done, 1, memory_order_release);
+        }
+    }
+    return NULL;
+}
+
+/* fn over [0, n) in nt contiguous shares; share 0 on the calling thread.  Returns when all of them are done. */
+static void go_parallel_for(go_job_fn fn, void *arg, int64_t n, int nt) {
+    if (nt > go_pool.started + 1) nt = go_pool.started + 1;
+    if (nt > n) nt = (int)n;
+    if (nt <= 1) { fn(arg, 0, n, 0); return; }
+    go_pool.fn = fn; go_pool.arg = arg; go_pool.n = n; go_pool.nt = nt;
+    atomic_store_explicit(&go_pool.done, 0, memory_order_relaxed);
+    atomic_fetch_add_explicit(&go_pool.gen, 1, memory_order_release);
+    fn(arg, 0, n / nt, 0);
+    for (int spin = 0; atomic_load_explicit(&go_pool.done, memory_order_acquire) < nt - 1; ++spin) {
+        if ((spin & 1023) == 1023) sched_yield();
+        else __builtin_ia32_pause();
+    }
+}
+
 void go_set_threads(int t) {
     if (t < 1) t = 1;
     if (t > GO_MAX_THREADS) t = GO_MAX_THREADS;
-#ifndef _OPENMP
-    t = 1;
-#endif
-    go_threads = t;
+    {   /* never more threads than cores this process may run on: the team spins, an oversubscribed team crawls */
+        cpu_set_t set;
+        int cores = 1;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+        if (cores < 1) cores = 1;
+        if (t > cores) t = cores;
+    }
+    while (go_pool.started + 1 < t) {
+        const int tid = go_pool.started + 1;
+        if (pthread_create(&go_pool.th[tid], NULL, go_worker, (void *)(intptr_t)tid) != 0) break;
+        pthread_detach(go_pool.th[tid]);
+        go_pool.started = tid;
+    }
+    go_threads = t < go_pool.started + 1 ? t : go_pool.started + 1;
 }
 int go_get_threads(void) { return go_threads; }
-static inline int go_tid(void) {
-#ifdef _OPENMP
-    return omp_get_thread_num();
-#else
-    return 0;
-#endif
-}
 
 typedef struct {
     int64_t N, D, K_max, K;
@@ -83,10 +141,22 @@ typedef struct {
 
 #define LOG_PI 1.1447298858494001741434273513530587116472948129153
 
-/* LU with partial pivoting in place; returns sign, fills piv. */
-static int lu_factor_team(double *a, int64_t n, int64_t *piv);
+/* LU with partial pivoting in place; returns sign, fills piv.  The rows below the pivot are independent of each other
+ * within a column step: from n = 64 on they are shared out (every row's update is the serial loop's arithmetic on that
+ * row: bit-identical for any thread count); the pivot search and the row swap stay with the calling thread. */
+typedef struct { double *a; int64_t n, j; double d; } lu_job_t;
+static void lu_rows(void *argp, int64_t lo, int64_t hi, int tid) {
+    (void)tid;
+    const lu_job_t *J = (const lu_job_t *)argp;
+    double *a = J->a; const int64_t n = J->n, j = J->j; const double d = J->d;
+    for (int64_t i = j + 1 + lo; i < j + 1 + hi; ++i) {
+        double l = a[i * n + j] / d;
+        a[i * n + j] = l;
+        if (l != 0.0)
+            for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
+    }
+}
 static int lu_factor(double *a, int64_t n, int64_t *piv) {
-    if (go_threads > 1 && n >= 96) return lu_factor_team(a, n, piv);
     int sign = 1;
     for (int64_t j = 0; j < n; ++j) {
         int64_t p = j;
@@ -104,49 +174,11 @@ static int lu_factor(double *a, int64_t n, int64_t *piv) {
         }
         double d = a[j * n + j];
         if (d == 0.0) continue;
-        for (int64_t i = j + 1; i < n; ++i) {
-            double l = a[i * n + j] / d;
-            a[i * n + j] = l;
-            if (l != 0.0)
-                for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
-        }
-    }
-    return sign;
-}
-
-/* The same elimination with the rows below the pivot shared out over the team: the pivot search and the row swap stay
- * with one thread, every row's update is the serial loop's arithmetic on that row (rows are independent of each other
- * within a column step) -- bit-identical to lu_factor for every thread count. */
-static int lu_factor_team(double *a, int64_t n, int64_t *piv) {
-    int sign = 1;
-#pragma omp parallel num_threads(go_threads)
-    for (int64_t j = 0; j < n; ++j) {
-#pragma omp single
-        {
-            int64_t p = j;
-            double best = fabs(a[j * n + j]);
-            for (int64_t i = j + 1; i < n; ++i) {
-                double v = fabs(a[i * n + j]);
-                if (v > best) { best = v; p = i; }
-            }
-            piv[j] = p;
-            if (p != j) {
-                for (int64_t c = 0; c < n; ++c) {
-                    double t = a[j * n + c]; a[j * n + c] = a[p * n + c]; a[p * n + c] = t;
-                }
-                sign = -sign;
-            }
-        }   /* (implicit barrier) */
-        double d = a[j * n + j];
-        if (d != 0.0) {
-#pragma omp for schedule(static)
-            for (int64_t i = j + 1; i < n; ++i) {
-                double l = a[i * n + j] / d;
-                a[i * n + j] = l;
-                if (l != 0.0)
-                    for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
-            }   /* (implicit barrier) */
-        }
+        lu_job_t J = {a, n, j, d};
+        const int64_t rows = n - j - 1;
+        int nt = n >= 64 ? go_threads : 1;
+        while (nt > 1 && (rows / nt) * rows < 1500) --nt;        /* (a share worth a hand-over) */
+        go_parallel_for(lu_rows, &J, rows, nt);
     }
     return sign;
 }
@@ -157,11 +189,13 @@ static double lu_logabsdet(const double *lu, int64_t n) {
     return s;
 }
 
-/* inverse from the factorisation: solve A x = e_c for every column c */
-static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col_all) {
-#pragma omp parallel for schedule(static) num_threads(go_threads) if (go_threads > 1 && n >= 16)
-    for (int64_t c = 0; c < n; ++c) {
-        double *col = col_all + (int64_t)go_tid() * n;      /* (scratch per thread) */
+/* inverse from the factorisation: solve A x = e_c for every column c (columns [lo, hi) on thread tid's scratch) */
+typedef struct { const double *lu; const int64_t *piv; int64_t n; double *out, *col_all; } inv_job_t;
+static void lu_inverse_cols(void *argp, int64_t lo, int64_t hi, int tid) {
+    const inv_job_t *J = (const inv_job_t *)argp;
+    const double *lu = J->lu; const int64_t *piv = J->piv; const int64_t n = J->n; double *out = J->out;
+    double *col = J->col_all + (int64_t)tid * n;
+    for (int64_t c = lo; c < hi; ++c) {
         for (int64_t i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
         for (int64_t j = 0; j < n; ++j) {
             int64_t p = piv[j];
@@ -179,6 +213,13 @@ static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *
         }
         for (int64_t i = 0; i < n; ++i) out[i * n + c] = col[i];
     }
+}
+static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col_all) {
+    inv_job_t J = {lu, piv, n, out, col_all};
+    /* (a column is ~2 n^2 flop: shared out only where a share is worth a hand-over) */
+    int nt = go_threads;
+    while (nt > 1 && (n / nt) * n * n < 20000) --nt;
+    go_parallel_for(lu_inverse_cols, &J, n, nt);
 }
 
 static double slogdet_of(go_t *g, const double *a) {
@@ -453,6 +494,25 @@ int go_set_assignments(void *h, const int64_t *z) {
     return 0;
 }
 
+/* labels [lo, hi) of a visit's predictive (gaussian_components.py:228-251 + the seating weight), on thread tid's scratch */
+typedef struct { go_t *g; const double *x; int use_power; double power; } score_job_t;
+static void score_labels(void *argp, int64_t lo, int64_t hi, int tid) {
+    const score_job_t *J = (const score_job_t *)argp;
+    go_t *g = J->g;
+    const int64_t D = g->D;
+    double *delta = g->delta + (int64_t)tid * D, *tmp = g->tmp + (int64_t)tid * D;
+    for (int64_t k = lo; k < hi; ++k) {
+        double w = J->use_power ? log(pow((double)g->n[k], J->power)) : log((double)g->n[k]);
+        int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
+        if (g->diag == 2) {
+            for (int64_t a = 0; a < D; ++a) tmp[a] = g->m[k * D + a] / g->S[k * D + a];
+            g->lp[k] = w + student_t(g, J->x, tmp, 1.0, g->logdet[k], g->inv + k * D, 0, delta);
+        } else
+            g->lp[k] = w + student_t(g, J->x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
+                                     g->inv + k * g->SD, nu, delta);
+    }
+}
+
 /* One sweep.  order==NULL: visit 0..N-1.  use_power: weights log(pow(n, power)).
  * n_visits <= N visits are performed (u[t] consumed at visit t).
  * lik_evals (may be NULL) accumulates sum over visits of K_at_visit.
@@ -477,17 +537,12 @@ int go_sweep(void *h, const int64_t *order, const double *u, int use_power, doub
         if (lik_evals) *lik_evals += K;
         const double *x = g->X + i * D;
         double top = -INFINITY;
-#pragma omp parallel for schedule(static) num_threads(go_threads) if (go_threads > 1 && K * g->SD >= 4096)
-        for (int64_t k = 0; k < K; ++k) {
-            double *delta = g->delta + (int64_t)go_tid() * D, *tmp = g->tmp + (int64_t)go_tid() * D;
-            double w = use_power ? log(pow((double)g->n[k], power)) : log((double)g->n[k]);
-            int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;
-            if (g->diag == 2) {
-                for (int64_t a = 0; a < D; ++a) tmp[a] = g->m[k * D + a] / g->S[k * D + a];
-                g->lp[k] = w + student_t(g, x, tmp, 1.0, g->logdet[k], g->inv + k * D, 0, delta);
-            } else
-            g->lp[k] = w + student_t(g, x, g->m + k * D, g->k0 + (double)g->n[k], g->logdet[k],
-                                     g->inv + k * g->SD, nu, delta);
+        {
+            score_job_t J = {g, x, use_power, power};
+            /* (a component is ~2 SD flop: shared out only where a share is worth a hand-over) */
+            int nt = go_threads;
+            while (nt > 1 && (K / nt) * g->SD < 12000) --nt;
+            go_parallel_for(score_labels, &J, K, nt);
         }
         for (int64_t k = 0; k < K; ++k) if (g->lp[k] > top) top = g->lp[k];
         g->lp[K] = log_alpha + g->log_prior[i];

@@ -50,6 +50,8 @@ SIGNATURES = {
     "bgmm_get_staged_order": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_permutation_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_permutation_pipe_state": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_set_window_pipeline": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_get_window_pipeline_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
     "bgmm_sweep_staged_begin": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
@@ -260,6 +262,14 @@ class Context(object):
         self._ck(self.L.bgmm_get_permutation_stats(self.h, _ptr(out)))
         return {"lookahead_hits": int(out[0]), "generated_on_the_spot": int(out[1]), "rounds_last": int(out[2]), "rounds_max": int(out[3])}
 
+    def set_window_pipeline(self, enabled):
+        self._ck(self.L.bgmm_set_window_pipeline(self.h, 1 if enabled else 0))
+
+    def window_pipeline_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_window_pipeline_stats(self.h, _ptr(out)))
+        return {"batches": int(out[0]), "breaks": int(out[1]), "mode": int(out[2]), "hold": int(out[3])}
+
     def permutation_pipe_state(self):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_permutation_pipe_state(self.h, _ptr(out)))
@@ -462,10 +472,11 @@ class Context(object):
         self._ck(self.L.bgmm_synchronize(self.h))
 
 
-def group_sweep_staged(ctxs, powers=None):
+def group_sweep_staged(ctxs, powers=None, raise_errors=True):
     """``bgmm_group_sweep_staged``: the staged sweeps of several contexts of ONE device side by side (small-D chains: one
     workgroup each, two launches for all).  ``powers[i]``: chain i's pCRP exponent or None.  Raises for the first
-    chain that failed."""
+    chain that failed -- or, with ``raise_errors=False``, returns the chains' status codes (a caller that treats them
+    chain by chain: BGMM_EKMAX of a chain whose slots grow on demand)."""
     n = len(ctxs)
     L = ctxs[0].L
     handles = (_vp * n)(*[c.h for c in ctxs])
@@ -474,10 +485,12 @@ def group_sweep_staged(ctxs, powers=None):
     pw = np.array([1.0 if p is None else float(p) for p in powers], dtype=np.float64)
     rcs = np.zeros(n, dtype=np.int32)
     rc_all = L.bgmm_group_sweep_staged(handles, n, _ptr(up), _ptr(pw), _ptr(rcs))
-    for c, rc in zip(ctxs, rcs):
-        c._ck(int(rc))
-    if rc_all != 0:                     # (refused as a whole: e.g. a context twice in the group)
+    if raise_errors:
+        for c, rc in zip(ctxs, rcs):
+            c._ck(int(rc))
+    if rc_all != 0 and (raise_errors or not np.any(rcs)):       # (refused as a whole: e.g. a context twice in the group)
         raise BGMMError(rc_all, "; ".join(filter(None, ((L.bgmm_last_error(c.h) or b"").decode() for c in ctxs))) or "group sweep refused")
+    return [int(rc) for rc in rcs]
 
 
 class Comm(object):

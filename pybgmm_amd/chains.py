@@ -134,19 +134,25 @@ class _Lockstep(object):
         self.models = list(models)
         self.powers = [None] * len(self.models)
         self.error = None
+        self.rcs = [0] * len(self.models)
         self.barrier = threading.Barrier(len(self.models), action=self._sweep_all)
 
     def _sweep_all(self):
         try:
-            self._lib.group_sweep_staged([m.components._ctx for m in self.models], self.powers)
+            self.rcs = self._lib.group_sweep_staged([m.components._ctx for m in self.models], self.powers, raise_errors=False)
         except Exception as e:          # (raised again in every chain's thread below)
             self.error = e
 
     def sweep(self, model, power):
-        self.powers[self.models.index(model)] = power
+        """Chain ``model``'s part of the round.  A status of its OWN sweep is raised in its own thread only (the others
+        finished theirs): IGMM._sweep treats BGMM_EKMAX of a chain whose slots grow on demand as the solo path does."""
+        idx = self.models.index(model)
+        self.powers[idx] = power
         self.barrier.wait()
         if self.error is not None:
             raise self.error
+        if self.rcs[idx] != 0:
+            model.components._ctx._ck(self.rcs[idx])
 
     def leave(self):
         self.barrier.abort()

@@ -2114,7 +2114,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 c->ctrl_host->gram_stall = 0;
                 CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
             }
-            if (h.error != 0 || h.job.mode == MODE_DONE) { d.safe_mode = 0; break; }
+            if (h.error != 0 || h.job.mode == MODE_DONE) { d.safe_mode = 0; d.use_certify = use_certify ? 1 : 0; break; }
             if (h.job.pos == pos && !stalled) safe_skip = true;
             if (c->resolver_mode == 0 && h.safe_windows - w0 >= 16 && h.job.pos > pos) {
                 // Did these windows pay?  Where movers are few and far between, the per-mover kernel chain (~0.2 ms per
@@ -2138,6 +2138,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             batch_pos0 = pos; batch_moves0 = h.n_moves;
             d.safe_mode = 0;
             d.safe_dense = 0;
+            d.use_certify = use_certify ? 1 : 0;      // (the safe batch ran without certificates: what follows does not)
             c->tables_robust = true;
             continue;
         }
@@ -2256,7 +2257,8 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         d.use_home = (d.cov_type == COV_FULL && c->kind == KERNEL_MFMA && c->home_pass) ? 1 : 0;
         // (a short residual list -- D <= 32: clusters a dozen sigma apart leave home_kernel a fraction of a per cent -- is settled
         //  by one dense launch; with certified stays on the sparse draw kernel also feeds the certificates, so not then)
-        d.resid_dense = (d.use_home && !d.use_certify && d.Dp <= 32 && resid_dense_lds_bytes(d) <= 150 * 1024) ? 1 : 0;
+        d.use_certify = use_certify ? 1 : 0;
+        d.resid_dense = (d.use_home && !use_certify && d.Dp <= 32 && resid_dense_lds_bytes(d) <= 150 * 1024) ? 1 : 0;
         if ((pmode != 2 && !(pmode == 1 && c->home_mode == 3)) || !first_batch || !d.use_home || lean) short_step = false;
         d.short_step = short_step ? (d.order ? 2 : 1) : 0;
         d.publish = (lean || short_step) ? 1 : 0;
@@ -2898,6 +2900,19 @@ extern "C" int bgmm_set_mt_jump(bgmm_ctx *c, int32_t enabled) {
     if (!c) return BGMM_EINVAL;
     SETTLE(c);
     c->mt_jump_on = enabled != 0;
+    return 0;
+}
+
+extern "C" int bgmm_set_window_pipeline(bgmm_ctx *c, int32_t enabled) {
+    if (!c) return BGMM_EINVAL;
+    SETTLE(c);
+    c->pipe_mode = enabled ? 1 : 0;
+    return 0;
+}
+
+extern "C" int bgmm_get_window_pipeline_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    out4[0] = c->pipe_batches; out4[1] = c->pipe_breaks; out4[2] = c->pipe_mode; out4[3] = c->pipe_hold;
     return 0;
 }
 

@@ -77,21 +77,23 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
 // Sum over the 16 lanes of a DPP row without touching the LDS crossbar: quad_perm [1,0,3,2],
 // quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after the four steps every lane of the
 // row holds the row total.
-template <int NJ, int RB, int MINW>
+// PROOF: the dense proof pass of a safe-stay stretch (skip_pruned_jobs 2) is an instantiation of its own -- with its label split
+// as a run-time variable in the one kernel, the windows' instantiation spilled four A fragments and reloaded them in every
+// slot iteration (mode `full` 52.6 -> 43.8 sweeps/s between rounds 3 and 4).
+template <int NJ, int RB, int MINW, bool PROOF>
 __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
                                                             double *__restrict__ q, long long qstride,
                                                             int col_override, int skip_pruned_jobs) {
     const JobView job = load_job(jobp);
-    // (skip_pruned_jobs 2: the dense proof pass of a safe-stay stretch -- runs whatever the window's kind, but only in front of
-    // a stretch whose proofs are to be made, kernels_safe.hip)
-    if (job.mode == MODE_DONE || (skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
-        (skip_pruned_jobs == 2 && d.ctrl->safe_epoch_valid)) return;
+    // (PROOF: runs whatever the window's kind, but only in front of a stretch whose proofs are to be made, kernels_safe.hip)
+    if (job.mode == MODE_DONE || (!PROOF && skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
+        (PROOF && d.ctrl->safe_epoch_valid)) return;
     constexpr int ROWS_W_ = 16 * RB;
     const int chunk = blockIdx.y;
     // (the dense proof pass covers a few thousand rows: its launch brings its own, finer split of the labels -- grid.y --
     // so that every compute unit holds two or three workgroups and a wavefront's factor loads hide behind its neighbours')
     int nchunks = job.chunks;
-    if (skip_pruned_jobs == 2) {
+    if (PROOF) {
         // ~1 400 workgroups whatever the stretch's length (measured: 197 ms per sweep at 0.5 % movers against 207 with 700, 240
         // with 400), at most one label chunk per grid row
         const long long rb = (job.win_hi - job.pos + 4 * ROWS_W_ - 1) / (4 * ROWS_W_);
@@ -198,8 +200,14 @@ static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstri
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
     // (skip_pruned_jobs 2 = the dense proof pass of a safe-stay stretch, a few thousand rows: up to 64 label chunks)
     const unsigned gy = skip_pruned_jobs == 2 ? 64 : kMaxChunks;      // (the kernel picks its split from the stretch's real length)
-    hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, (NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1))>), dim3(gx, gy), dim3(256), 0, st, d, job, q,
-                       qstride, col_override, skip_pruned_jobs);
+    constexpr int W = NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1);
+    // (the proof pass is ~1 400 workgroups: two per SIMD is all it fills, and at three its label split costs D = 64 32 spills)
+    constexpr int WP = NJ == 4 ? 2 : W;
+    if (skip_pruned_jobs == 2)
+        hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, WP, true>), dim3(gx, gy), dim3(256), 0, st, d, job, q, qstride, col_override, 2);
+    else
+        hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, W, false>), dim3(gx, gy), dim3(256), 0, st, d, job, q, qstride, col_override,
+                           skip_pruned_jobs);
 }
 
 void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,

@@ -401,8 +401,10 @@ __global__ __launch_bounds__(TPB) void gram_finish_kernel(Dev d) { gram_finish_b
 // (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
 // (three workgroups per compute unit: G x ~90 slots per window want the room; what that costs -- spills on the rare
 // from-scratch route -- the single-chain kernel above does not pay)
+// (D > 64: the factor's LDS -- 138 KB at D = 128 -- admits ONE workgroup per compute unit whatever the registers say; asking
+// for three there bought 368 spilled registers and 804 bytes of scratch per lane and nothing else -- round 6)
 template <int SREGS>
-__global__ __launch_bounds__(TPB, 3) void gram_finish_group_kernel(const Dev *__restrict__ group) {
+__global__ __launch_bounds__(TPB, SREGS <= 16 ? 3 : 1) void gram_finish_group_kernel(const Dev *__restrict__ group) {
     const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
     gram_finish_body<SREGS>(d);
 }

@@ -172,11 +172,11 @@ class IGMM(GMM):
         if not staged:
             ctx.stage(_rng.take_uniforms(self.N, self._rng), order)
         step = getattr(self, "_lockstep", None)
-        if step is not None:            # one of several chains on this device (chains.run_chains_on_device)
-            step.sweep(self, power)
-            return
         try:
-            ctx.sweep_staged(power)
+            if step is not None:        # one of several chains on this device (chains.run_chains_on_device)
+                step.sweep(self, power)
+            else:
+                ctx.sweep_staged(power)
         except _lib.BGMMError as e:
             # ``K_max=None`` means "as many components as the chain opens, up to N" (reference
             # gaussian_components.py:81-83); the slots are grown on demand instead of set aside up front
