@@ -78,8 +78,9 @@ def test_lockstep_rendezvous_of_sampler_loops_without_a_gpu(monkeypatch):
                 self.rounds += 1
             return {"rounds": self.rounds}, None
 
-    def fake_group_sweep(ctxs, powers):
+    def fake_group_sweep(ctxs, powers, raise_errors=True):
         calls.append((len(ctxs), tuple(powers), threading.current_thread().name))
+        return [0] * len(ctxs)
     monkeypatch.setattr(_lib, "group_sweep_staged", fake_group_sweep)
     out = chains.run_chains_on_device(Model, None, None, 1.0, 6, 5, seed=3)
     assert len(out) == 6 and all(rec["rounds"] == 5 for _, rec in out)
