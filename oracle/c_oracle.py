@@ -55,17 +55,13 @@ def lib():
 
 
 def default_threads():
-    """Threads the K loop of a visit is shared over (bit-identical floats for any count: every component is still
-    scored by the scalar code on one thread).  GIBBS_ORACLE_THREADS overrides; default = the cores this process may
-    use, at most 32."""
+    """Threads a visit's K loop (and the LU / inverse of a rebuild) is shared over.  ONE unless GIBBS_ORACLE_THREADS says
+    otherwise: the floats are the same for any count, but a hand-over between cores costs ~20 us on the GPU box's 256-core
+    host (measured, profiles/r06/oracle_threads.txt: D = 64, K = 200 407 us per visit on one thread, 271 on 32; D = 128 no
+    gain at all) -- the tests get their parallelism from running the heavy cases' oracles side by side instead
+    (tests/oracle_pool.py)."""
     env = os.environ.get("GIBBS_ORACLE_THREADS")
-    if env:
-        return max(1, int(env))
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(32, n))
+    return max(1, int(env)) if env else 1
 
 
 def set_threads(t):

@@ -50,10 +50,20 @@
  * contiguous shares; once nothing has come for a while a worker polls every 50 us, after 10 ms every millisecond. */
 #define GO_MAX_THREADS 64
 typedef void (*go_job_fn)(void *arg, int64_t lo, int64_t hi, int tid);
+/* The three hot loops are compiled twice, for AVX2 and for the baseline ISA, and picked at load time (the shared object is
+ * built in one container and run in another).  Wider vectors hold more INDEPENDENT sums side by side; no sum is reordered
+ * (-fno-fast-math) and no product is fused into its sum (-ffp-contract=off, and the clones do not enable FMA). */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define GO_HOT __attribute__((target_clones("avx2", "default")))
+#else
+#define GO_HOT
+#endif
 static int go_threads = 1;
 static struct {
     pthread_t th[GO_MAX_THREADS];
     int started;                        /* workers that exist (ids 1 .. started) */
+    uint64_t seen0[GO_MAX_THREADS];
+    atomic_flag busy;                   /* one region at a time: a second caller (another oracle on another thread) runs its own serially */
     _Atomic uint64_t gen;
     _Atomic int done;
     go_job_fn fn;
@@ -64,7 +74,7 @@ static struct {
 
 static void *go_worker(void *p) {
     const int tid = (int)(intptr_t)p;
-    uint64_t seen = 0;
+    uint64_t seen = go_pool.seen0[tid];       /* (the generation when it was made: regions before that are not its business) */
     for (;;) {
         uint64_t g;
         int idle = 0;
@@ -77,8 +87,11 @@ static void *go_worker(void *p) {
         if (tid < go_pool.nt) {
             const int64_t lo = go_pool.n * tid / go_pool.nt, hi = go_pool.n * (tid + 1) / go_pool.nt;
             if (hi > lo) go_pool.fn(go_pool.arg, lo, hi, tid);
-            atomic_fetch_add_explicit(&go_pool.done, 1, memory_order_release);
         }
+        /* EVERY worker answers every region, with or without a share: a worker that merely skipped one could otherwise still
+         * be looking at the region's description when the next one is written over it, take a share of that one, and take it
+         * again when it notices the new generation (seen as labels that differed from run to run while this was so). */
+        atomic_fetch_add_explicit(&go_pool.done, 1, memory_order_release);
     }
     return NULL;
 }
@@ -87,15 +100,16 @@ static void *go_worker(void *p) {
 static void go_parallel_for(go_job_fn fn, void *arg, int64_t n, int nt) {
     if (nt > go_pool.started + 1) nt = go_pool.started + 1;
     if (nt > n) nt = (int)n;
-    if (nt <= 1) { fn(arg, 0, n, 0); return; }
+    if (nt <= 1 || atomic_flag_test_and_set_explicit(&go_pool.busy, memory_order_acquire)) { fn(arg, 0, n, 0); return; }
     go_pool.fn = fn; go_pool.arg = arg; go_pool.n = n; go_pool.nt = nt;
     atomic_store_explicit(&go_pool.done, 0, memory_order_relaxed);
     atomic_fetch_add_explicit(&go_pool.gen, 1, memory_order_release);
     fn(arg, 0, n / nt, 0);
-    for (int spin = 0; atomic_load_explicit(&go_pool.done, memory_order_acquire) < nt - 1; ++spin) {
+    for (int spin = 0; atomic_load_explicit(&go_pool.done, memory_order_acquire) < go_pool.started; ++spin) {
         if ((spin & 1023) == 1023) sched_yield();
         else __builtin_ia32_pause();
     }
+    atomic_flag_clear_explicit(&go_pool.busy, memory_order_release);
 }
 
 void go_set_threads(int t) {
@@ -108,13 +122,16 @@ void go_set_threads(int t) {
         if (cores < 1) cores = 1;
         if (t > cores) t = cores;
     }
+    while (atomic_flag_test_and_set_explicit(&go_pool.busy, memory_order_acquire)) sched_yield();     /* (no region meanwhile) */
     while (go_pool.started + 1 < t) {
         const int tid = go_pool.started + 1;
+        go_pool.seen0[tid] = atomic_load_explicit(&go_pool.gen, memory_order_acquire);
         if (pthread_create(&go_pool.th[tid], NULL, go_worker, (void *)(intptr_t)tid) != 0) break;
         pthread_detach(go_pool.th[tid]);
         go_pool.started = tid;
     }
     go_threads = t < go_pool.started + 1 ? t : go_pool.started + 1;
+    atomic_flag_clear_explicit(&go_pool.busy, memory_order_release);
 }
 int go_get_threads(void) { return go_threads; }
 
@@ -145,15 +162,17 @@ typedef struct {
  * within a column step: from n = 64 on they are shared out (every row's update is the serial loop's arithmetic on that
  * row: bit-identical for any thread count); the pivot search and the row swap stay with the calling thread. */
 typedef struct { double *a; int64_t n, j; double d; } lu_job_t;
-static void lu_rows(void *argp, int64_t lo, int64_t hi, int tid) {
+GO_HOT static void lu_rows(void *argp, int64_t lo, int64_t hi, int tid) {
     (void)tid;
     const lu_job_t *J = (const lu_job_t *)argp;
     double *a = J->a; const int64_t n = J->n, j = J->j; const double d = J->d;
+    const double *restrict rj = a + j * n;
     for (int64_t i = j + 1 + lo; i < j + 1 + hi; ++i) {
-        double l = a[i * n + j] / d;
-        a[i * n + j] = l;
+        double *restrict ri = a + i * n;
+        double l = ri[j] / d;
+        ri[j] = l;
         if (l != 0.0)
-            for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
+            for (int64_t c = j + 1; c < n; ++c) ri[c] -= l * rj[c];
     }
 }
 static int lu_factor(double *a, int64_t n, int64_t *piv) {
@@ -189,33 +208,45 @@ static double lu_logabsdet(const double *lu, int64_t n) {
     return s;
 }
 
-/* inverse from the factorisation: solve A x = e_c for every column c (columns [lo, hi) on thread tid's scratch) */
-typedef struct { const double *lu; const int64_t *piv; int64_t n; double *out, *col_all; } inv_job_t;
-static void lu_inverse_cols(void *argp, int64_t lo, int64_t hi, int tid) {
+/* inverse from the factorisation: solve A x = e_c for every column c.  All right-hand sides of a share [lo, hi) go through
+ * the substitutions TOGETHER, row by row of the factor: Y[i][c] -= lu[i][t] * Y[t][c] for t ascending -- per entry the
+ * very subtractions, in the very order, of a column-at-a-time solve (s = col[i]; s -= lu[i][t] * col[t], t ascending), so
+ * the floats are those of the scalar loop; but c is the fastest index, contiguous in `out` (out[i * n + c] IS Y[i][c]). */
+typedef struct { const double *lu; const int64_t *piv; int64_t n; double *out; } inv_job_t;
+GO_HOT static void lu_inverse_cols(void *argp, int64_t lo, int64_t hi, int tid) {
+    (void)tid;
     const inv_job_t *J = (const inv_job_t *)argp;
-    const double *lu = J->lu; const int64_t *piv = J->piv; const int64_t n = J->n; double *out = J->out;
-    double *col = J->col_all + (int64_t)tid * n;
-    for (int64_t c = lo; c < hi; ++c) {
-        for (int64_t i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
-        for (int64_t j = 0; j < n; ++j) {
-            int64_t p = piv[j];
-            if (p != j) { double t = col[j]; col[j] = col[p]; col[p] = t; }
+    const double *lu = J->lu; const int64_t *piv = J->piv; const int64_t n = J->n; double *Y = J->out;
+    const int64_t w = hi - lo;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t c = lo; c < hi; ++c) Y[i * n + c] = (i == c) ? 1.0 : 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        int64_t p = piv[j];
+        if (p != j)
+            for (int64_t c = lo; c < hi; ++c) { double t = Y[j * n + c]; Y[j * n + c] = Y[p * n + c]; Y[p * n + c] = t; }
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        double *restrict yi = Y + i * n + lo;
+        for (int64_t t = 0; t < i; ++t) {
+            const double l = lu[i * n + t];
+            const double *restrict yt = Y + t * n + lo;
+            for (int64_t c = 0; c < w; ++c) yi[c] -= l * yt[c];
         }
-        for (int64_t i = 0; i < n; ++i) {
-            double s = col[i];
-            for (int64_t t = 0; t < i; ++t) s -= lu[i * n + t] * col[t];
-            col[i] = s;
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        double *restrict yi = Y + i * n + lo;
+        for (int64_t t = i + 1; t < n; ++t) {
+            const double l = lu[i * n + t];
+            const double *restrict yt = Y + t * n + lo;
+            for (int64_t c = 0; c < w; ++c) yi[c] -= l * yt[c];
         }
-        for (int64_t i = n - 1; i >= 0; --i) {
-            double s = col[i];
-            for (int64_t t = i + 1; t < n; ++t) s -= lu[i * n + t] * col[t];
-            col[i] = s / lu[i * n + i];
-        }
-        for (int64_t i = 0; i < n; ++i) out[i * n + c] = col[i];
+        const double d = lu[i * n + i];
+        for (int64_t c = 0; c < w; ++c) yi[c] = yi[c] / d;
     }
 }
 static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col_all) {
-    inv_job_t J = {lu, piv, n, out, col_all};
+    (void)col_all;
+    inv_job_t J = {lu, piv, n, out};
     /* (a column is ~2 n^2 flop: shared out only where a share is worth a hand-over) */
     int nt = go_threads;
     while (nt > 1 && (n / nt) * n * n < 20000) --nt;
@@ -347,7 +378,7 @@ static void unseat(go_t *g, int64_t i) {
     refresh_cov(g, k);
 }
 
-static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
+GO_HOT static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
                         double logdet, const double *inv, int64_t nu, double *delta) {
     int64_t D = g->D;
     if (g->diag == 2) {         /* product of univariate normals: gaussian_components_fixedvar.py:293-303;
@@ -368,13 +399,19 @@ static double student_t(const go_t *g, const double *x, const double *mu_num, do
         return (double)D * (g->tab_lgam[nu + 1] - g->tab_lgam[nu] - 0.5 * g->tab_log[nu] - 0.5 * LOG_PI)
                - 0.5 * logdet - ((double)nu + 1.) / 2. * acc;
     }
-    for (int64_t a = 0; a < D; ++a) delta[a] = mu_num[a] / k_N - x[a];
-    double q = 0.0;
-    for (int64_t a = 0; a < D; ++a) {
-        double r = 0.0;
-        for (int64_t b = 0; b < D; ++b) r += delta[b] * inv[b * D + a];
-        q += r * delta[a];
+    /* q = sum_a (sum_b delta[b] inv[b][a]) delta[a] -- the reference's einsum pair (gaussian_components.py:240-244).
+     * The inner sums run over b ascending for every a, as a scalar loop over a would have them: with b outermost the SAME
+     * additions happen in the SAME order per a (r[a] += delta[b] * inv[b][a], product and sum rounded separately), but
+     * the memory is walked row by row and the compiler may keep several a in one vector register.  delta[D .. 2D) is r. */
+    double *restrict r = delta + D;
+    for (int64_t a = 0; a < D; ++a) { delta[a] = mu_num[a] / k_N - x[a]; r[a] = 0.0; }
+    for (int64_t b = 0; b < D; ++b) {
+        const double db = delta[b];
+        const double *restrict row = inv + b * D;
+        for (int64_t a = 0; a < D; ++a) r[a] += db * row[a];
     }
+    double q = 0.0;
+    for (int64_t a = 0; a < D; ++a) q += r[a] * delta[a];
     double hd = (double)D / 2.;
     return g->tab_lgam[nu + D] - g->tab_lgam[nu] - hd * g->tab_log[nu] - hd * LOG_PI
            - 0.5 * logdet - (double)(nu + D) / 2. * log(1 + 1. / (double)nu * q);
@@ -435,7 +472,7 @@ void *go_create(int64_t N, int64_t D, int64_t K_max, const double *X, const doub
     g->save_m = (double *)malloc(sizeof(double) * D);
     g->save_S = (double *)malloc(sizeof(double) * D * D);
     g->save_inv = (double *)malloc(sizeof(double) * D * D);
-    g->delta = (double *)malloc(sizeof(double) * D * GO_MAX_THREADS);
+    g->delta = (double *)malloc(sizeof(double) * 2 * D * GO_MAX_THREADS);
     g->tmp = (double *)malloc(sizeof(double) * D * GO_MAX_THREADS);
 
     if (diag == 2) {            /* gaussian_components_fixedvar.py:205-212: N(mu_0, precision_0) */
@@ -500,7 +537,7 @@ static void score_labels(void *argp, int64_t lo, int64_t hi, int tid) {
     const score_job_t *J = (const score_job_t *)argp;
     go_t *g = J->g;
     const int64_t D = g->D;
-    double *delta = g->delta + (int64_t)tid * D, *tmp = g->tmp + (int64_t)tid * D;
+    double *delta = g->delta + (int64_t)tid * 2 * D, *tmp = g->tmp + (int64_t)tid * D;
     for (int64_t k = lo; k < hi; ++k) {
         double w = J->use_power ? log(pow((double)g->n[k], J->power)) : log((double)g->n[k]);
         int64_t nu = g->diag ? g->v0 + g->n[k] : g->v0 + g->n[k] - D + 1;

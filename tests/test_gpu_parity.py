@@ -16,6 +16,8 @@ import numpy as np
 import numpy.testing as npt
 import pytest
 
+from oracle_pool import with_oracle
+
 from golden_util import ALL_CASES, API_CASES, DIAG_CASES, FIXED_CASES, GOLDEN_DIR, Golden
 from pybgmm_amd.gaussian.gaussian_components import reference_tables
 
@@ -544,29 +546,35 @@ def test_full_size_burnin_two_mover_paths(N, D, K, pcrp):
     assert mva == mvb and abs(lma - lmb) <= 1e-9 * abs(lma)
 
 
-@pytest.mark.parametrize("N,D,K,sep", [(30000, 64, 200, 4.0), (10000, 128, 60, 4.0), (60000, 16, 100, 1.0)],
-                         ids=["D64-K200", "D128", "D16-overlapping"])
-def test_burnin_against_c_oracle(N, D, K, sep):
-    """Frozen-factor windows against the C port of the reference, two sweeps from a random start at the
-    BASELINE dimensions (every visit of the first sweep moves; components die and are born)."""
-    from oracle import c_oracle
-    from pybgmm_amd import _lib
+def _case_burnin(N, D, K, sep):
     from pybgmm_amd.utils import gendata
     X, _ = gendata.synth_mixture(N, D, K, seed=31 + D, mu_scale=sep)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     rs = np.random.RandomState(D)
     z0 = np.unique(rs.randint(0, K, N), return_inverse=True)[1]
-    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
-    ctx.set_assignments(z0)
-    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+    us = [rs.random_sample(N) for _ in range(2)]
+    return {"X": X, "prior": gendata.demo_prior_params(D), "z0": z0, "K_max": 4 * K, "sweeps": [(u,) for u in us]}
+
+
+_case_burnin.cost = lambda N, D, K, sep: 2 * N * (K + 2 * D) * D * D
+
+
+@pytest.mark.parametrize("N,D,K,sep", [(30000, 64, 200, 4.0), (10000, 128, 60, 4.0), (60000, 16, 100, 1.0)],
+                         ids=["D64-K200", "D128", "D16-overlapping"])
+@with_oracle(_case_burnin)
+def test_burnin_against_c_oracle(N, D, K, sep, oracle_ref):
+    """Frozen-factor windows against the C port of the reference, two sweeps from a random start at the
+    BASELINE dimensions (every visit of the first sweep moves; components die and are born)."""
+    from pybgmm_amd import _lib
+    case, ref = oracle_ref
+    m_0, k_0, v_0, S_0 = case["prior"]
+    ctx = _lib.Context(case["X"], m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(case["z0"])
     for it in range(2):
-        u = rs.random_sample(N)
-        ctx.sweep(u)
-        o.sweep(u)
+        ctx.sweep(case["sweeps"][it][0])
         z = ctx.assignments()
-        bad = np.nonzero(z != o.z)[0]
+        bad = np.nonzero(z != ref[it]["z"])[0]
         assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
-        lo = o.log_marg()
+        lo = ref[it]["log_marg"]
         assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
         if it == 0:
             assert ctx.path_stats()["frozen_windows"] > N // 80
@@ -612,40 +620,46 @@ def test_pipelined_windows_against_plain_ones(N, D, K_true, K_init):
     assert a[0][3] < len(np.unique(z0))          # (components died on the way)
 
 
-@pytest.mark.parametrize("N,D,K,sep,flip,budget", [(100000, 16, 100, 1.0, 0, 0.0), (100000, 16, 100, 1.0, 0, 1.0),
-                                                   (60000, 64, 40, 0.5, 0, 0.0), (60000, 64, 40, 4.0, 200, 0.0),
-                                                   (10000, 128, 20, 0.28, 0, 0.0)],
-                         ids=["D16-5pct-movers", "D16-5pct-movers-budget-1.0", "D64-0.6pct-movers", "D64-200-wrong-labels",
-                              "D128-overlapping"])
-def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget):
-    """The regime between "nothing moves" and "everything moves" (VERDICT r2 #1): clusters that overlap so that 0.5 - 5 %
-    of the visits move at equilibrium, and a chain at the truth with wrong labels sprinkled in.  Three sweeps against the
-    C port of the reference, labels identical; the safe-stay windows must have run and must have left most visits off
-    the resolver's chain."""
-    from oracle import c_oracle
-    from pybgmm_amd import _lib
+def _case_safe_stay(N, D, K, sep, flip):
     from pybgmm_amd.utils import gendata
     X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=sep)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     rs = np.random.RandomState(D + flip)
     z0 = zt.copy()
     if flip:
         idx = rs.choice(N, size=flip, replace=False)
         z0[idx] = rs.randint(0, K, size=flip)
-    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    us = [rs.random_sample(N) for _ in range(3)]
+    return {"X": X, "prior": gendata.demo_prior_params(D), "z0": z0, "K_max": 4 * K, "sweeps": [(u,) for u in us]}
+
+
+_case_safe_stay.cost = lambda N, D, K, sep, flip: 3 * N * K * D * D
+
+
+@pytest.mark.parametrize("N,D,K,sep,flip,budget", [(100000, 16, 100, 1.0, 0, 0.0), (100000, 16, 100, 1.0, 0, 1.0),
+                                                   (60000, 64, 40, 0.5, 0, 0.0), (60000, 64, 40, 4.0, 200, 0.0),
+                                                   (10000, 128, 20, 0.28, 0, 0.0)],
+                         ids=["D16-5pct-movers", "D16-5pct-movers-budget-1.0", "D64-0.6pct-movers", "D64-200-wrong-labels",
+                              "D128-overlapping"])
+@with_oracle(_case_safe_stay)
+def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget, oracle_ref):
+    """The regime between "nothing moves" and "everything moves" (VERDICT r2 #1): clusters that overlap so that 0.5 - 5 %
+    of the visits move at equilibrium, and a chain at the truth with wrong labels sprinkled in.  Three sweeps against the
+    C port of the reference, labels identical; the safe-stay windows must have run and must have left most visits off
+    the resolver's chain."""
+    from pybgmm_amd import _lib
+    case, ref = oracle_ref
+    m_0, k_0, v_0, S_0 = case["prior"]
+    ctx = _lib.Context(case["X"], m_0, k_0, v_0, S_0, 1.0, 4 * K)
     ctx.set_safe_budget(budget)
-    ctx.set_assignments(z0)
-    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
+    ctx.set_assignments(case["z0"])
     windows = walked = moved = 0
     for it in range(3):
-        u = rs.random_sample(N)
-        ctx.sweep(u)
+        ctx.sweep(case["sweeps"][it][0])
         moved += ctx.sweep_stats()["moves"]
-        o.sweep(u)
         z = ctx.assignments()
-        bad = np.nonzero(z != o.z)[0]
+        bad = np.nonzero(z != ref[it]["z"])[0]
         assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
-        lo = o.log_marg()
+        lo = ref[it]["log_marg"]
         assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
         ss = ctx.safe_stats()
         windows += ss["windows"]
@@ -721,10 +735,27 @@ def test_dense_and_table_proof_passes_give_the_same_chain():
     ctx.close()
 
 
+def _case_benchmarked_at_scale(N, D, K, flip, tail):
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=31 + D)
+    rs = np.random.RandomState(D + K)
+    z0 = zt.copy()
+    idx = rs.choice(N, size=flip, replace=False)
+    z0[idx] = rs.randint(0, K, size=flip)
+    n_sw = 2 if tail else 1
+    us = rs.random_sample((n_sw, N))
+    return {"X": X, "prior": gendata.demo_prior_params(D), "z0": z0, "K_max": 2 * K,
+            "sweeps": [(us[it], None, None, N if it == 0 else tail) for it in range(n_sw)]}
+
+
+_case_benchmarked_at_scale.cost = lambda N, D, K, flip, tail: (N + tail) * K * D * D
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("N,D,K,flip,tail", [(100000, 64, 200, 2000, 8000), (16000, 128, 40, 200, 0), (8000, 128, 200, 200, 0)],
                          ids=["D64-K200-2000-wrong-labels", "D128-K40-200-wrong-labels", "D128-K200-200-wrong-labels"])
-def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
+@with_oracle(_case_benchmarked_at_scale)
+def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail, oracle_ref):
     """the largest problems the C port of the reference finishes in about a minute per sweep, at
     BASELINE's D and K, the truth with wrong labels sprinkled in (the sweep repairs them: movers one per ~50 visits, then
     a chain at rest).  The default configuration AND the mode bench.py times (prune_mode 3) against ONE oracle run --
@@ -735,15 +766,11 @@ def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
     from divergence import assert_same_labels, first_divergence
     from oracle import c_oracle
     from pybgmm_amd import _lib
-    from pybgmm_amd.utils import gendata
-    X, zt = gendata.synth_mixture(N, D, K, seed=31 + D)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    rs = np.random.RandomState(D + K)
-    z0 = zt.copy()
-    idx = rs.choice(N, size=flip, replace=False)
-    z0[idx] = rs.randint(0, K, size=flip)
-    n_sw = 2 if tail else 1
-    us = rs.random_sample((n_sw, N))
+    case, ref = oracle_ref
+    X, z0 = case["X"], case["z0"]
+    m_0, k_0, v_0, S_0 = case["prior"]
+    n_sw = len(case["sweeps"])
+    us = np.stack([sw[0] for sw in case["sweeps"]])
     orders, powers = [None] * n_sw, [None] * n_sw
     mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 2 * K, scipy_tables=False)
 
@@ -752,13 +779,11 @@ def test_benchmarked_mode_against_c_oracle_at_scale(N, D, K, flip, tail):
         c.set_tuning(prune_mode=prune)
         c.set_assignments(z0)
         return c
-    o = mk_oracle()
     ctxs = {prune: mk_ctx(prune) for prune in (0, 3)}
     moved = 0
     for it in range(n_sw):
-        n_vis = N if it == 0 else tail
-        o.sweep(us[it], n_visits=n_vis)
-        zo, lo = o.z, o.log_marg()
+        n_vis = case["sweeps"][it][3]
+        zo, lo = ref[it]["z"], ref[it]["log_marg"]
         for prune, ctx in ctxs.items():
             ctx.set_sweep_visits(n_vis)
             ctx.sweep(us[it])
@@ -823,128 +848,92 @@ def test_crpmm_class_init_strings_reproduce_reference(case, mode, seed):
     assert Ks == list(g.K)
 
 
+def _case_wrong_labels(N, D, K, flip, seed, rs_seed, n_sweeps, pcrp):
+    """The truth with `flip` wrong labels; n_sweeps sweeps, pCRP ones with a fresh permutation each and powered weights from
+    the second on (igmm/pcrpmm.py:86-131)."""
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=seed)
+    rs = np.random.RandomState(rs_seed)
+    z0 = zt.copy()
+    idx = rs.choice(N, size=flip, replace=False)
+    z0[idx] = rs.randint(0, K, size=flip)
+    us = rs.random_sample((n_sweeps, N))
+    orders = [rs.permutation(N).astype(np.int64) if pcrp else None for _ in range(n_sweeps)]
+    powers = [1.01 if (pcrp and it > 0) else None for it in range(n_sweeps)]
+    return {"X": X, "prior": gendata.demo_prior_params(D), "z0": z0, "K_max": 2 * K,
+            "sweeps": [(us[it], orders[it], powers[it]) for it in range(n_sweeps)], "flip": flip}
+
+
+def _case_c4_full():
+    return _case_wrong_labels(1000000, 64, 200, 2000, seed=1, rs_seed=64, n_sweeps=1, pcrp=False)
+
+
+_case_c4_full.cost = lambda: 1000000 * 200 * 64 * 64
+
+
+def _case_c5_part():
+    return _case_wrong_labels(50000, 128, 200, 400, seed=2, rs_seed=128, n_sweeps=2, pcrp=True)
+
+
+_case_c5_part.cost = lambda: 2 * 50000 * 200 * 128 * 128
+
+
+def _case_c3_full():
+    return _case_wrong_labels(1000000, 16, 100, 2000, seed=1, rs_seed=16, n_sweeps=2, pcrp=True)
+
+
+_case_c3_full.cost = lambda: 2 * 1000000 * 100 * 16 * 16
+
+
+def _wrong_labels_against_the_oracle(case, ref):
+    from divergence import assert_same_labels
+    from pybgmm_amd import _lib
+    m_0, k_0, v_0, S_0 = case["prior"]
+    for prune in (0, 3):
+        ctx = _lib.Context(case["X"], m_0, k_0, v_0, S_0, 1.0, case["K_max"])
+        ctx.set_tuning(prune_mode=prune)
+        ctx.set_assignments(case["z0"])
+        moves = 0
+        for it, (u, order, power) in enumerate(case["sweeps"]):
+            ctx.sweep(u, order, power)
+            assert_same_labels(ctx.assignments(), ref[it]["z"], "prune_mode %d, sweep %d" % (prune, it))
+            assert abs(ctx.log_marg() - ref[it]["log_marg"]) <= 1e-9 * abs(ref[it]["log_marg"])
+            moves += ctx.sweep_stats()["moves"]
+        assert moves >= case["flip"] // 2
+        ctx.close()
+
+
 @pytest.mark.slow
-def test_c3_full_size_against_c_oracle():
+@with_oracle(_case_c4_full)
+def test_c4_full_size_against_c_oracle(oracle_ref):
+    """BASELINE's C4 at FULL size (N = 1e6, D = 64, K = 200) against the C port of the reference (VERDICT r5 #6): the truth
+    with 2 000 wrong labels, one whole sweep in the default configuration and in the benchmarked mode, every label and the
+    log marginal.  The oracle needs ~7 minutes of one host core for it (0.4 ms per visit: 6.5 MB of inverse covariances
+    streamed per visit); since round 6 the heavy cases' oracles all run side by side from the start of the session, each
+    on a core of its own (tests/oracle_pool.py), and this one is simply the last to finish.  Rounds 3 - 5 stopped at
+    N = 1.2e5 - 2.5e5."""
+    _wrong_labels_against_the_oracle(*oracle_ref)
+
+
+@pytest.mark.slow
+@with_oracle(_case_c3_full)
+def test_c3_full_size_against_c_oracle(oracle_ref):
     """BASELINE's C3 at FULL size against the C port of the reference: PCRPMM semantics, N = 1e6, D = 16,
     K = 100, the truth with 2 000 wrong labels, two sweeps (a fresh permutation each, powered weights in the second:
     pcrpmm.py:86-112).  The default configuration AND the mode bench.py times against ONE oracle run: labels identical
     after each sweep, log marginal to 1e-9.  The oracle costs ~12 us per visit at this shape: ~25 s of host time."""
-    from divergence import assert_same_labels, first_divergence
-    from oracle import c_oracle
-    from pybgmm_amd import _lib
-    from pybgmm_amd.utils import gendata
-    N, D, K, flip = 1000000, 16, 100, 2000
-    X, zt = gendata.synth_mixture(N, D, K, seed=1)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    rs = np.random.RandomState(16)
-    z0 = zt.copy()
-    idx = rs.choice(N, size=flip, replace=False)
-    z0[idx] = rs.randint(0, K, size=flip)
-    n_sw = 2
-    us = rs.random_sample((n_sw, N))
-    orders = [rs.permutation(N).astype(np.int64) for _ in range(n_sw)]
-    powers = [None, 1.01]
-    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
-
-    def mk_ctx(prune):
-        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
-        c.set_tuning(prune_mode=prune)
-        c.set_assignments(z0)
-        return c
-    o = mk_oracle()
-    ctxs = {prune: mk_ctx(prune) for prune in (0, 3)}
-    moved = 0
-    for it in range(n_sw):
-        o.sweep(us[it], orders[it], powers[it])
-        zo, lo = o.z, o.log_marg()
-        for prune, ctx in ctxs.items():
-            ctx.sweep(us[it], orders[it], powers[it])
-            assert_same_labels(ctx.assignments(), zo, "prune_mode %d, sweep %d" % (prune, it),
-                               lambda: first_divergence(lambda: mk_ctx(prune), mk_oracle, us, orders, powers, it))
-            assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
-        moved += ctxs[3].sweep_stats()["moves"]
-    assert moved >= flip // 2
-    for ctx in ctxs.values():
-        ctx.close()
+    _wrong_labels_against_the_oracle(*oracle_ref)
 
 
 @pytest.mark.slow
-def test_c4_full_size_against_c_oracle():
-    """BASELINE's C4 at FULL size (N = 1e6, D = 64, K = 200) against the C port of the reference (VERDICT r5 #6): the truth
-    with 2 000 wrong labels, one whole sweep in the default configuration and in the benchmarked mode, every label and the
-    log marginal.  Possible since round 6: the oracle shares a visit's K evaluations out over the box's host cores
-    (oracle/gibbs_oracle.c: go_set_threads -- every component scored by the scalar code on one thread, the floats
-    bit-identical for any thread count: tests/test_oracle_c.py); rounds 3 - 5 stopped at N = 1.2e5 - 2.5e5."""
-    from divergence import assert_same_labels, first_divergence
-    from oracle import c_oracle
-    from pybgmm_amd import _lib
-    from pybgmm_amd.utils import gendata
-    N, D, K, flip = 1000000, 64, 200, 2000
-    X, zt = gendata.synth_mixture(N, D, K, seed=1)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    rs = np.random.RandomState(64)
-    z0 = zt.copy()
-    idx = rs.choice(N, size=flip, replace=False)
-    z0[idx] = rs.randint(0, K, size=flip)
-    us = rs.random_sample((1, N))
-    mk_oracle = lambda: c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 2 * K, scipy_tables=False)
-
-    def mk_ctx(prune):
-        c = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 2 * K)
-        c.set_tuning(prune_mode=prune)
-        c.set_assignments(z0)
-        return c
-    o = mk_oracle()
-    o.sweep(us[0])
-    zo, lo = o.z, o.log_marg()
-    del o
-    for prune in (0, 3):
-        ctx = mk_ctx(prune)
-        ctx.sweep(us[0])
-        assert_same_labels(ctx.assignments(), zo, "prune_mode %d" % prune,
-                           lambda: first_divergence(lambda: mk_ctx(prune), mk_oracle, us, [None], [None], 0))
-        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
-        assert ctx.sweep_stats()["moves"] >= flip // 2
-        ctx.close()
-
-
-@pytest.mark.slow
-def test_c5_fifth_size_against_c_oracle():
-    """BASELINE's C5 shape (PCRPMM, D = 128, K = 200, full covariance) at N = 2e5 against the C port of the reference
-    (VERDICT r5 #6): the truth with 400 wrong labels, two pCRP sweeps -- a fresh permutation each, powered seating weights
-    from the second on (igmm/pcrpmm.py:86-131) -- in the default configuration and in the benchmarked mode."""
-    from divergence import assert_same_labels
-    from oracle import c_oracle
-    from pybgmm_amd import _lib
-    from pybgmm_amd.utils import gendata
-    N, D, K, flip = 200000, 128, 200, 400
-    X, zt = gendata.synth_mixture(N, D, K, seed=2)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    rs = np.random.RandomState(128)
-    z0 = zt.copy()
-    idx = rs.choice(N, size=flip, replace=False)
-    z0[idx] = rs.randint(0, K, size=flip)
-    us = rs.random_sample((2, N))
-    orders = [rs.permutation(N).astype(np.int64) for _ in range(2)]
-    powers = [None, 1.01]
-    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 2 * K, scipy_tables=False)
-    want = []
-    for it in range(2):
-        o.sweep(us[it], orders[it], powers[it])
-        want.append((o.z, o.log_marg()))
-    del o
-    for prune in (0, 3):
-        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 2 * K)
-        ctx.set_tuning(prune_mode=prune)
-        ctx.set_assignments(z0)
-        moves = 0
-        for it in range(2):
-            ctx.sweep(us[it], orders[it], powers[it])
-            assert_same_labels(ctx.assignments(), want[it][0], "prune_mode %d, sweep %d" % (prune, it))
-            assert abs(ctx.log_marg() - want[it][1]) <= 1e-9 * abs(want[it][1])
-            moves += ctx.sweep_stats()["moves"]
-        assert moves >= flip // 2
-        ctx.close()
+@with_oracle(_case_c5_part)
+def test_c5_shape_against_c_oracle(oracle_ref):
+    """BASELINE's C5 shape (PCRPMM, D = 128, K = 200, full covariance) at N = 5e4 against the C port of the reference
+    (rounds 4 - 5: N = 8 000 - 16 000): the truth with 400 wrong labels, two pCRP sweeps -- a fresh
+    permutation each, powered seating weights from the second on (igmm/pcrpmm.py:86-131) -- in the default configuration
+    and in the benchmarked mode.  3.6 ms per oracle visit: ~6 minutes of a host core, side by side with the others
+    (N = 2e5 would be 24 minutes: the session's limit is 20)."""
+    _wrong_labels_against_the_oracle(*oracle_ref)
 
 
 def test_first_divergence_diagnostic_finds_a_planted_divergence():
@@ -2672,48 +2661,61 @@ def test_k_max_none_grows_on_demand_for_chains_side_by_side_too():
         assert abs(mm.log_marg() - lo) <= 1e-9 * abs(lo)
 
 
-def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle():
+def _case_c5_device_generators():
+    import random
+    from pybgmm_amd.utils import gendata, rng as _rng
+    N, D, K = 10000, 128, 20
+    X, zt = gendata.synth_mixture(N, D, K, seed=59)
+    z0 = zt.copy()
+    rs = np.random.RandomState(4)
+    idx = rs.choice(N, size=300, replace=False)
+    z0[idx] = rs.randint(0, K, size=300)
+    host_r, host_np = random.Random(17), np.random.RandomState(17)
+    sweeps = []
+    for it in range(2):
+        order = host_np.permutation(N)
+        u = _rng.take_uniforms(N, host_r)
+        sweeps.append((u, order, 1.01 if it else None))
+    return {"X": X, "prior": gendata.demo_prior_params(D), "z0": z0, "K_max": 4 * K, "sweeps": sweeps,
+            "host_r": host_r, "host_np": host_np}
+
+
+_case_c5_device_generators.cost = lambda: 2 * 10000 * 20 * 128 * 128
+
+
+@with_oracle(_case_c5_device_generators)
+def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle(oracle_ref):
     """C5's shape (PCRPMM, D = 128, full covariance) driven the way the classes drive it -- every sweep's
     visiting order drawn ON THE DEVICE from a numpy RandomState (bgmm_stage_permutation_mt19937) and its uniforms from a
     random.Random (bgmm_stage_mt19937) -- against numpy / random themselves value for value, and label for label against
     the C oracle fed from twin generators on the host; powered weights from the second sweep on (pcrpmm.py:98-117).
     Wrong labels sprinkled in so that the sweeps move (the D = 128 mover paths behind a device-drawn permutation)."""
     import random
-    from oracle import c_oracle
     from pybgmm_amd import _lib
-    from pybgmm_amd.utils import gendata, rng as _rng
-    N, D, K = 10000, 128, 20
-    X, zt = gendata.synth_mixture(N, D, K, seed=59)
-    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
-    z0 = zt.copy()
-    rs = np.random.RandomState(4)
-    idx = rs.choice(N, size=300, replace=False)
-    z0[idx] = rs.randint(0, K, size=300)
-    dev_r, host_r = random.Random(17), random.Random(17)
-    dev_np, host_np = np.random.RandomState(17), np.random.RandomState(17)
-    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, 4 * K, scipy_tables=False)
-    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
-    ctx.set_assignments(z0)
+    from pybgmm_amd.utils import rng as _rng
+    case, ref = oracle_ref
+    N, K = case["X"].shape[0], 20
+    m_0, k_0, v_0, S_0 = case["prior"]
+    dev_r, dev_np = random.Random(17), np.random.RandomState(17)
+    ctx = _lib.Context(case["X"], m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    ctx.set_assignments(case["z0"])
     moved = 0
     for it in range(2):
-        order = host_np.permutation(N)
-        u = _rng.take_uniforms(N, host_r)
+        u, order, power = case["sweeps"][it]
         assert _rng.take_permutation_staged(ctx, N, dev_np) is _rng.STAGED
         npt.assert_array_equal(ctx.staged_order(), order, err_msg="device permutation differs from numpy's")
         assert _rng.stage_uniforms_on_device(ctx, None, dev_r)
         npt.assert_array_equal(ctx.staged_uniforms(), u, err_msg="device uniforms differ from random.random()")
-        power = 1.01 if it else None
         ctx.sweep_staged(power)
         moved += ctx.sweep_stats()["moves"]
-        o.sweep(u, order, power)
-        bad = np.nonzero(ctx.assignments() != o.z)[0]
+        bad = np.nonzero(ctx.assignments() != ref[it]["z"])[0]
         assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
-        lo = o.log_marg()
+        lo = ref[it]["log_marg"]
         assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
     assert moved >= 150, "the case is meant to repair its wrong labels"
-    assert dev_r.getstate() == host_r.getstate()
-    npt.assert_array_equal(dev_np.get_state()[1], host_np.get_state()[1])
-    assert dev_np.get_state()[2] == host_np.get_state()[2]
+    assert dev_r.getstate() == case["host_r"].getstate()
+    npt.assert_array_equal(dev_np.get_state()[1], case["host_np"].get_state()[1])
+    assert dev_np.get_state()[2] == case["host_np"].get_state()[2]
     ctx.close()
 
 
