@@ -80,12 +80,18 @@ __host__ __device__ constexpr int home_waves_per_simd(int NJ) {
 #ifndef BGMM_HOME_W1
 #define BGMM_HOME_W1 2
 #endif
-    const int want = NJ == 1 ? BGMM_HOME_W1 : (NJ <= 4 ? 2 : 1);
+#ifndef BGMM_HOME_W4
+#define BGMM_HOME_W4 2
+#endif
+    const int want = NJ == 1 ? BGMM_HOME_W1 : (NJ == 4 ? BGMM_HOME_W4 : (NJ <= 4 ? 2 : 1));
     return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
 }
 
 // register slots for tiles (one in the matrix pipe, the others on their way; 2 D/16 registers each)
-__host__ __device__ constexpr int home_slots(int NJ) { return NJ <= 2 ? 4 : 2; }
+#ifndef BGMM_HOME_S4
+#define BGMM_HOME_S4 2
+#endif
+__host__ __device__ constexpr int home_slots(int NJ) { return NJ <= 2 ? 4 : (NJ == 4 ? BGMM_HOME_S4 : 2); }
 
 // column of X (inside its block of 16) that k-lane lk holds in k-slice kq (0..3) of the block
 __host__ __device__ constexpr int home_col(int kq, int lk) { return 8 * (kq >> 1) + 2 * lk + (kq & 1); }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     // the matrix pipe 52 % busy, HBM at 4.4 TB/s -- neither floor reached).  The value is consumed a tile later by an
     // empty asm, where the older row loads have been waited for anyway.  WHOLE only (rows are whole lines there).
 #ifndef BGMM_HOME_PFD
-#define BGMM_HOME_PFD 1
+#define BGMM_HOME_PFD 0
 #endif
     constexpr bool PFD = WHOLE && BGMM_HOME_PFD != 0 && NJ != 5;      // (D = 80: the extra register would cost the second wavefront per SIMD)
     constexpr int PFN = PFD ? (16 * NJ + 63) / 64 : 1;

@@ -141,6 +141,7 @@ int main() {
     for (int bpc : {1, 2}) run<16, 1>(bpc, iters);
     for (int bpc : {1, 2, 4}) run<8, 2>(bpc, iters);
     for (int bpc : {1, 2}) run<16, 2>(bpc, iters);
+    run<1, 0>(1, iters);             // ONE dependent chain alone on a SIMD
     run<1, 0>(2, iters);
     run<2, 1>(1, iters);
     for (int bpc : {2, 8}) {
