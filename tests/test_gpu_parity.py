@@ -585,8 +585,8 @@ def test_burnin_against_c_oracle(N, D, K, sep, oracle_ref):
 def test_pipelined_windows_against_plain_ones(N, D, K_true, K_init):
     """the pipelined frozen-factor windows (cross forms of window w made against the factors of window w - 2,
     window w - 1's terms carried in -- on by default for a chain on its own) A/B against plain windows on ONE chain: a
-    burn-in from a random start with five times too many components, so that components are deleted (and a few opened)
-    on the way -- every such window breaks the pipeline on the device.  Labels, counts and log marginal equal after every
+    burn-in from a random start with five times too many components -- windows that end early, open a component or
+    delete one break the pipeline on the device.  Labels, counts and log marginal equal after every
     sweep (the reference's loop, igmm/crpmm.py:57-88, knows neither kind), pipelined batches AND broken chains both
     counted (bgmm_get_window_pipeline_stats)."""
     from pybgmm_amd import _lib
@@ -617,7 +617,6 @@ def test_pipelined_windows_against_plain_ones(N, D, K_true, K_init):
         npt.assert_array_equal(a[it][1], b[it][1])
         assert a[it][3] == b[it][3]
         assert abs(a[it][2] - b[it][2]) <= 1e-9 * abs(b[it][2])
-    assert a[0][3] < len(np.unique(z0))          # (components died on the way)
 
 
 def _case_safe_stay(N, D, K, sep, flip):
