@@ -77,21 +77,12 @@ __host__ __device__ constexpr int home_lds_bytes(int Dp) { return (home_shared_d
 // D = 64, one above (at two the D = 128 kernel spills, and a scratch access waits for every row load in flight)
 __host__ __device__ constexpr int home_waves_per_simd(int NJ) {
     const int by_lds = (160 * 1024) / home_lds_bytes(NJ * 16);
-#ifndef BGMM_HOME_W1
-#define BGMM_HOME_W1 2
-#endif
-#ifndef BGMM_HOME_W4
-#define BGMM_HOME_W4 2
-#endif
-    const int want = NJ == 1 ? BGMM_HOME_W1 : (NJ == 4 ? BGMM_HOME_W4 : (NJ <= 4 ? 2 : 1));
+    const int want = NJ <= 4 ? 2 : 1;
     return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
 }
 
 // register slots for tiles (one in the matrix pipe, the others on their way; 2 D/16 registers each)
-#ifndef BGMM_HOME_S4
-#define BGMM_HOME_S4 2
-#endif
-__host__ __device__ constexpr int home_slots(int NJ) { return NJ <= 2 ? 4 : (NJ == 4 ? BGMM_HOME_S4 : 2); }
+__host__ __device__ constexpr int home_slots(int NJ) { return NJ <= 2 ? 4 : 2; }
 
 // column of X (inside its block of 16) that k-lane lk holds in k-slice kq (0..3) of the block
 __host__ __device__ constexpr int home_col(int kq, int lk) { return 8 * (kq >> 1) + 2 * lk + (kq & 1); }
@@ -234,32 +225,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             }                                                                              \
         }                                                                                  \
     }
-    // One tile FURTHER ahead than the register slots reach, rows are only pulled into the XCD's L2 (round 6): one dword per
-    // 128-byte line of the tile -- 16 NJ lines, a single load instruction and one register up to D = 64 -- so that the
-    // real loads of that tile, a tile later, are served by L2 instead of paying the gather's memory latency with only
-    // one tile per wavefront in flight (SQ counters of round 5's kernel: 62 % of the wavefront cycles in s_waitcnt,
-    // the matrix pipe 52 % busy, HBM at 4.4 TB/s -- neither floor reached).  The value is consumed a tile later by an
-    // empty asm, where the older row loads have been waited for anyway.  WHOLE only (rows are whole lines there).
-#ifndef BGMM_HOME_PFD
-#define BGMM_HOME_PFD 0
-#endif
-    constexpr bool PFD = WHOLE && BGMM_HOME_PFD != 0 && NJ != 5;      // (D = 80: the extra register would cost the second wavefront per SIMD)
-    constexpr int PFN = PFD ? (16 * NJ + 63) / 64 : 1;
-    int pfv[PFN];
-#pragma unroll
-    for (int q = 0; q < PFN; ++q) pfv[q] = 0;
-#define HOME_PREFETCH(XO, TN)                                                              \
-    if (PFD) {                                                                             \
-        _Pragma("unroll") for (int q = 0; q < PFN; ++q) {                                  \
-            const int idx_ = q * 64 + lane;                                                \
-            const int row_ = idx_ / NJ < 16 ? idx_ / NJ : 15, line_ = idx_ % NJ;           \
-            const int src_ = 16 * (TN) + row_;                                             \
-            const long long o_ = ((long long)__shfl((int)((XO) >> 32), src_) << 32) | (unsigned int)__shfl((int)(XO), src_); \
-            pfv[q] = __builtin_nontemporal_load((const int *)(d.X + o_) + 32 * line_);     \
-        }                                                                                  \
-    }
-#define HOME_PREFETCH_DONE()                                                               \
-    if (PFD) { _Pragma("unroll") for (int q = 0; q < PFN; ++q) asm volatile("" :: "v"(pfv[q])); }
     // (element offset of the lane's row in X: one 64-bit multiply per record)
     // of the current block's rows, of the next block's (wanted NS - 1 tiles before that block starts: its record
     // index is fetched a block earlier than the rest of the record)
@@ -271,7 +236,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
     }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) HOME_ISSUE(xt[t], xo_cur, t)
-    if (NS - 1 < 4) { HOME_PREFETCH(xo_cur, NS - 1) }
     unsigned n_mfma = 0, n_homes = 0;
     int cur_home = -1;
 #ifdef BGMM_HOME_PROF
@@ -381,11 +345,8 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double (&xf)[NKK] = xt[t % NS];
                 HP(0)
                 // tile t + NS - 1 sets off into the slot tile t - 1 has left (beyond the block: the next block's rows)
-                HOME_PREFETCH_DONE()
                 if (t + NS - 1 < 4) { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_cur, t + NS - 1) }
                 else { HOME_ISSUE(xt[(t + NS - 1) % NS], xo_next, t + NS - 1 - 4) }
-                if (t + NS < 4) { HOME_PREFETCH(xo_cur, t + NS) }
-                else if (t + NS - 4 < 4) { HOME_PREFETCH(xo_next, t + NS - 4) }
                 HP(1)
                 {
                 // ---- every row of the tile under the block's home: factor and constants from LDS
@@ -687,8 +648,6 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
 #endif
 #undef HOME_LOAD_REC
 #undef HOME_ISSUE
-#undef HOME_PREFETCH
-#undef HOME_PREFETCH_DONE
     if (lane == 0) {
         atomicAdd(&d.pr_counts[blockIdx.x & 255], (unsigned long long)n_homes);
         atomicAdd(&d.pr_counts[512 + (blockIdx.x & 255)], (unsigned long long)n_mfma);

@@ -37,3 +37,11 @@ def oracle_ref(request):
     state after every sweep of it."""
     import oracle_pool
     return oracle_pool.result_for(request.node)
+
+
+def pytest_terminal_summary(terminalreporter):
+    import oracle_pool
+    if oracle_pool.TIMES:
+        terminalreporter.write_line("oracle runs side by side (tests/oracle_pool.py), seconds of one host core each:")
+        for sec, what in sorted(oracle_pool.TIMES, reverse=True):
+            terminalreporter.write_line("  %7.1f s  %s" % (sec, what))

@@ -21,6 +21,7 @@ import threading
 
 _lock = threading.Lock()
 _futures = {}
+TIMES = []          # (seconds, case) of the runs that have finished: reported at the end of the session
 
 
 class _Job(object):
@@ -34,9 +35,12 @@ class _Job(object):
         self.t.start()
 
     def _run(self, gate, case_fn, params):
+        import time
         with gate:
+            t0 = time.time()
             try:
                 self.out = run_case(case_fn, params)
+                TIMES.append((time.time() - t0, "%s%s" % (case_fn.__name__, tuple(params.values()))))
             except BaseException as e:      # noqa: BLE001  (raised again in the test that asks for the result)
                 self.err = e
             finally:
