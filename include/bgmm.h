@@ -301,6 +301,14 @@ BGMM_API int bgmm_get_proof_pass_stats(bgmm_ctx *ctx, int64_t *out2);
  * host reads the control block and runs two plain batches first), the mode, plain batches still to go}. */
 BGMM_API int bgmm_set_window_pipeline(bgmm_ctx *ctx, int32_t enabled);
 BGMM_API int bgmm_get_window_pipeline_stats(bgmm_ctx *ctx, int64_t *out4);
+/* The dense proof pass of the safe-stay windows takes the exact quadratic forms of its (visit, label) pairs from a
+ * LOOK-AHEAD: a second stream scores them a chunk of `chunk_visits` visits at a time (a power of two, default 8192; 0: off
+ * -- every stretch scores its own pairs on the chain's stream), every slot, beside the resolver; a stretch re-scores only
+ * the labels that took a rank-1 term since its chunk was requested (gaussian_components.py:154-205: a move touches two
+ * components).  Same proofs, same chain; stats: out4 = {stretches served from the ring, stretches that scored themselves in
+ * full, labels re-scored over the former, chunks requested} since the context was made. */
+BGMM_API int bgmm_set_proof_lookahead(bgmm_ctx *ctx, int32_t chunk_visits);
+BGMM_API int bgmm_get_proof_lookahead_stats(bgmm_ctx *ctx, int64_t *out4);
 /* Which proof pass the next batches of safe-stay windows run: -1 = the chain decides (the default; BGMM_SAFE_DENSE in the
  * environment sets the initial value), 0 = always the per-home tables, 1 = always the dense pass.  May be changed between
  * sweeps (the tests switch kinds on one chain); it never changes the trajectory. */

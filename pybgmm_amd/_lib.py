@@ -51,6 +51,8 @@ SIGNATURES = {
     "bgmm_get_permutation_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_permutation_pipe_state": (ctypes.c_int, [_vp, _vp]),
     "bgmm_set_window_pipeline": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_set_proof_lookahead": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "bgmm_get_proof_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_window_pipeline_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
@@ -261,6 +263,15 @@ class Context(object):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_permutation_stats(self.h, _ptr(out)))
         return {"lookahead_hits": int(out[0]), "generated_on_the_spot": int(out[1]), "rounds_last": int(out[2]), "rounds_max": int(out[3])}
+
+    def set_proof_lookahead(self, chunk_visits):
+        self._ck(self.L.bgmm_set_proof_lookahead(self.h, int(chunk_visits)))
+
+    def proof_lookahead_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_proof_lookahead_stats(self.h, _ptr(out)))
+        return {"stretches_from_the_ring": int(out[0]), "stretches_scored_in_full": int(out[1]),
+                "labels_rescored": int(out[2]), "chunks_requested": int(out[3])}
 
     def set_window_pipeline(self, enabled):
         self._ck(self.L.bgmm_set_window_pipeline(self.h, 1 if enabled else 0))

@@ -251,6 +251,10 @@ struct bgmm_ctx {
     long long proof_batches[2] = {0, 0};      // batches of safe-stay windows queued with a table / a dense proof pass
     double safe_cap_user = 0.0;      // bgmm_set_safe_budget: > 0 pins the per-component budget of a window (0: it follows the chain)
     long long safe_stats[6] = {0, 0, 0, 0, 0, 0};
+    // the look-ahead of the dense proof pass (kernels_safe.hip): its stream, a ring of event pairs (plan made / request served)
+    int ahead_chunk = 8192;          // visits per chunk (a power of two; 0: off -- bgmm_set_proof_lookahead)
+    hipStream_t ahead_stream = nullptr;
+    hipEvent_t ahead_ev[2][8] = {};
     int seq_cap = 0;                 // labels the one-workgroup sweep plans LDS for (0: as many as fit)
     bool home_pass = true;           // home_kernel in front of the pruning kernel (kernels_home.hip)
     int home_retry = 0;
@@ -403,6 +407,8 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     if (c->mt_seeds) (void)hipFree(c->mt_seeds);
     for (void *p : c->gram_mem) if (p) (void)hipFree(p);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
+    if (c->ahead_stream) { (void)hipStreamSynchronize(c->ahead_stream); (void)hipStreamDestroy(c->ahead_stream); }
+    for (auto &row : c->ahead_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     for (auto e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->true_dev) (void)hipFree(c->true_dev);
     if (c->table_dev) (void)hipFree(c->table_dev);
@@ -504,6 +510,12 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.ftab2, (size_t)d.nslots * 64);
         DALLOC(c, d.nbr, (size_t)d.nslots * 4);
     }
+    DALLOC(c, d.ah_job, 1);
+    DALLOC(c, d.resc_job, 1);
+    DALLOC(c, d.resc_list, ns);
+    DALLOC(c, d.touch_seq, ns);
+    CK(c, hipMemsetAsync(d.touch_seq, 0, sizeof(long long) * ns, c->stream));
+    d.ahead_C = 0; d.slot_list = nullptr;
     DALLOC(c, d.glist, (size_t)kSafeList + 1);
     DALLOC(c, d.ep_state, ns);
     DALLOC(c, d.rtab, ns * 8);
@@ -2090,9 +2102,19 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             const long long resid0 = hc.safe_resid_sum, sorted0 = hc.safe_sorted_sum;
             d.safe_cap = c->safe_cap_user;
             d.gram_K = hc.job.K;
+            // (a dense proof pass takes its forms from the look-ahead's ring: a second stream scores them a chunk at a time
+            //  beside the resolver -- kernels_safe.hip "look-ahead"; not while the launches are being timed one by one)
+            const bool ahead = d.safe_dense && c->ahead_chunk > 0 && !c->timing && d.qstride >= 2ll * c->ahead_chunk &&
+                               d.cov_type == COV_FULL && c->kind == KERNEL_MFMA;
+            d.ahead_C = ahead ? c->ahead_chunk : 0;
+            if (ahead && !c->ahead_stream) {
+                CK(c, hipStreamCreateWithFlags(&c->ahead_stream, hipStreamNonBlocking));
+                for (auto &row : c->ahead_ev) for (hipEvent_t &e : row) CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
             {   // launch grids: room for the stretch to double twice inside the batch
                 long long r = 4096;
                 while (r < 4ll * hc.safe_L && r < c->win_rows) r <<= 1;
+                if (ahead && r > c->ahead_chunk) r = c->ahead_chunk > 4096 ? c->ahead_chunk : 4096;     // (stretches end with their chunk)
                 if (r > c->win_rows) r = c->win_rows;
                 d.batch_rows = (int)r;
             }
@@ -2101,9 +2123,15 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             const long long w0 = hc.safe_windows, mv0 = hc.n_moves, rows0 = hc.safe_rows;
             const auto t_batch0 = std::chrono::steady_clock::now();
             launch_safe_open(d, st);
-            for (int t = 0; t < (int)Tg; ++t)
-                if (!launch_safe_step(d, c->gram_lds, d.batch_rows, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr))
+            for (int t = 0; t < (int)Tg; ++t) {
+                SafeAhead ah{c->ahead_stream, c->ahead_ev[0][t & 7], c->ahead_ev[1][t & 7]};
+                // (the request made by the step before has been served before this step's plan books it)
+                if (ahead && t > 0) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][(t - 1) & 7], 0));
+                if (!launch_safe_step(d, c->gram_lds, d.batch_rows, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr,
+                                      ahead ? &ah : nullptr))
                     return fail(c, BGMM_EDEVICE, "safe-stay window launch failed");
+            }
+            if (ahead) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][((int)Tg - 1) & 7], 0));       // (the second stream is idle when the batch ends)
             CK(c, hipGetLastError());
             int rc = fetch_ctrl(c);
             if (rc) return rc;
@@ -2114,7 +2142,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                 c->ctrl_host->gram_stall = 0;
                 CK(c, hipMemcpy(&d.ctrl->gram_stall, &c->ctrl_host->gram_stall, sizeof(int), hipMemcpyHostToDevice));
             }
-            if (h.error != 0 || h.job.mode == MODE_DONE) { d.safe_mode = 0; d.use_certify = use_certify ? 1 : 0; break; }
+            if (h.error != 0 || h.job.mode == MODE_DONE) { d.safe_mode = 0; d.ahead_C = 0; d.use_certify = use_certify ? 1 : 0; break; }
             if (h.job.pos == pos && !stalled) safe_skip = true;
             if (c->resolver_mode == 0 && h.safe_windows - w0 >= 16 && h.job.pos > pos) {
                 // Did these windows pay?  Where movers are few and far between, the per-mover kernel chain (~0.2 ms per
@@ -2138,6 +2166,7 @@ static int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             batch_pos0 = pos; batch_moves0 = h.n_moves;
             d.safe_mode = 0;
             d.safe_dense = 0;
+            d.ahead_C = 0;
             d.use_certify = use_certify ? 1 : 0;      // (the safe batch ran without certificates: what follows does not)
             c->tables_robust = true;
             continue;
@@ -2913,6 +2942,26 @@ extern "C" int bgmm_set_window_pipeline(bgmm_ctx *c, int32_t enabled) {
 extern "C" int bgmm_get_window_pipeline_stats(bgmm_ctx *c, int64_t *out4) {
     if (!c || !out4) return BGMM_EINVAL;
     out4[0] = c->pipe_batches; out4[1] = c->pipe_breaks; out4[2] = c->pipe_mode; out4[3] = c->pipe_hold;
+    return 0;
+}
+
+extern "C" int bgmm_set_proof_lookahead(bgmm_ctx *c, int32_t chunk_visits) {
+    if (!c || chunk_visits < 0) return BGMM_EINVAL;
+    SETTLE(c);
+    int v = 0;
+    if (chunk_visits > 0) { v = 1024; while (v < chunk_visits && v < (1 << 20)) v <<= 1; }
+    c->ahead_chunk = v;
+    return 0;
+}
+
+extern "C" int bgmm_get_proof_lookahead_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    SETTLE(c);
+    CK(c, hipSetDevice(c->device));
+    int rc = fetch_ctrl(c);
+    if (rc) return rc;
+    const Ctrl &h = *c->ctrl_host;
+    out4[0] = h.ah_served; out4[1] = h.ah_self; out4[2] = h.ah_dirty; out4[3] = h.ah_chunks;
     return 0;
 }
 

@@ -35,7 +35,9 @@
                                      cache instead of an LDS tile (score_diag*_kernel)                                       */
 #define BGMM_LOG_PI 1.1447298858494001741434273513530587116472948129153
 
-enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2 };
+enum { MODE_FRESH = 0, MODE_PARTIAL = 1, MODE_DONE = 2,
+       MODE_SLOTS = 3,        // the likelihood kernel's list is the slots 0 .. n_dirty - 1 themselves (the proof pass's look-ahead)
+       MODE_LIST = 4 };       // ... is Dev::slot_list[0 .. n_dirty)  (a stretch re-scored for the labels touched since)
 enum { KERNEL_AUTO = 0, KERNEL_VALU = 1, KERNEL_MFMA = 2 };
 enum { COV_FULL = 0, COV_DIAG = 1, COV_FIXED = 2 };
 // how a slot's derived state (mu, Winv, cvec, constants) follows a change of (n, m, S)
@@ -175,6 +177,17 @@ struct Ctrl {
     long long safe_resid_sum, safe_sorted_sum;   // this sweep, over the proof passes through the per-home tables: visits they had to leave to the exact forms / visits they looked at
     long long safe_windows, safe_scanned, safe_rows, safe_cuts;   // this sweep: windows, visits examined by the proof pass,
                                                                   // rows walked by the resolver, windows ended by the budget
+    // Look-ahead of the DENSE proof pass (kernels_safe.hip, "look-ahead"): the exact quadratic forms of every (visit, slot)
+    // pair are made a chunk of Dev::ahead_C visits at a time on a second stream, beside the resolver, into a ring of two
+    // chunks (q row = visit & (2 C - 1)); a stretch then re-scores only the labels that took a rank-1 term since its
+    // chunk's request.  Only the main stream's plan kernel writes these fields.
+    long long win_seq;                 // frozen-factor windows closed since the context was made
+    long long ah_chunk[2];             // per half of the ring: the chunk whose forms it holds (-1: none)
+    long long ah_seq[2];               // ... win_seq when that chunk's scoring was requested: a slot with touch_seq beyond it is dirty
+    long long ah_lo[2];                // ... first visit of the chunk that was scored
+    long long ah_req_chunk, ah_req_seq, ah_req_lo;   // the request the second stream is serving (-1: none)
+    long long ah_served, ah_self, ah_dirty, ah_chunks;   // this sweep: stretches re-scored from the ring / scored in full,
+                                                         // labels re-scored over the former, chunks requested
 };
 
 // One reassignment logged by a frozen-factor window, in visiting order: the finish kernel replays
@@ -352,6 +365,12 @@ struct Dev {
                                  // takes); 0: Ctrl::safe_cap, which follows the chain
     long long *glist;            // [kSafeList + 1] visit positions of the stretch's unproven visits, ascending
     struct SafeCol *ep_state;    // [nslots] per SLOT, since the proof pass: budget used, the counts the proofs allow
+    int ahead_C;                 // > 0: this batch's dense proof pass takes its forms from the look-ahead ring (a power of two;
+                                 // stretches end at multiples of it)
+    Job *ah_job, *resc_job;      // device: what the look-ahead scores next / what the stretch at hand re-scores
+    int *resc_list;              // [nslots] the dirty slots of resc_job
+    const int *slot_list;        // MODE_LIST: the list this launch's job indexes
+    long long *touch_seq;        // [nslots] per slot: win_seq of the last window that changed it
     double *rtab;                // [nslots][8] per label of the frozen state: robust constants (kernels_safe.hip)
     double *ftabR;               // [nslots][64] per home label: robust upper bound of every other label's score
     int prune_enabled;           // exact pruning of negligible components in fresh windows, per batch of
@@ -453,7 +472,10 @@ void launch_gram_finish(const Dev &d, hipStream_t st);
 void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st);
 bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, hipStream_t st);   // G chains, shared launches
 void launch_safe_open(const Dev &d, hipStream_t st);                     // kernels_safe.hip
-bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// (the look-ahead of a dense proof pass: its stream, the events "this step's plan is made" / "its request is served")
+struct SafeAhead { hipStream_t stream; hipEvent_t ev_plan, ev_done; };
+bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                      const SafeAhead *ah = nullptr);
 bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
 // pipelined windows: the pieces, queued by the host on two streams (bgmm_api.hip: gram_pipe_batch)
 bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st);   // cross forms (+ those with the window before) + weights

@@ -1041,6 +1041,7 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
         c->n_steps += 1;
         c->n_score_launches += 1;
         c->gram_windows += 1;
+        c->win_seq += 1;                               // (gram_finish stamps the slots this window touched with it: Dev::touch_seq)
         c->gram_rows_total += consumed;
         c->n_scored += (long long)nrows * (j.K + 1);
         c->n_pairs_exact += (unsigned long long)nrows * (unsigned long long)(j.K + 1);

@@ -45,7 +45,13 @@ __global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode == MODE_DONE) return;
     for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;      // (the bucket sort counts from zero)
-    if (threadIdx.x == 0) { c->safe_epoch_valid = 0; safe_open_window(d, c); }
+    if (threadIdx.x == 0) {
+        c->safe_epoch_valid = 0;
+        safe_open_window(d, c);
+        // (the look-ahead's ring starts empty with every batch: other kinds of windows may have changed the state in between)
+        c->ah_chunk[0] = c->ah_chunk[1] = -1;
+        c->ah_req_chunk = -1;
+    }
 }
 
 // Robust per-label constants (rtab[label][8]) for the frozen state:
@@ -326,6 +332,8 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
     const int K = c->job.K;
     const long long p = base + r;
     const long long i = d.order ? d.order[p] : p;
+    // (with the look-ahead the forms of visit p sit at ring row p & (2 C - 1), whoever scored them)
+    const long long rq = d.ahead_C > 0 ? (p & (2ll * d.ahead_C - 1)) : r;
     const int h = d.z[i];
     const int a = h >= 0 ? d.label_of_slot[h] : -1;
     const double *__restrict__ gg = d.rtab + (long long)(d.nslots - 1) * 8;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
     double lb = 0.0, R = 0.0;
     if (a >= 0 && a < K) {
         const double *__restrict__ rh = d.rtab + (long long)a * 8;
-        const double qh = d.q[(long long)h * d.qstride + r];
+        const double qh = d.q[(long long)h * d.qstride + rq];
         const double chi = (qh + rh[3]) * ecap;
         if (rh[6] > 0.5 && qh >= 0.0 && chi < 1.0) {
             ok = true;
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
                     const int t = t0 + 16 * k;
                     const double *__restrict__ rt = d.rtab + (long long)(t < K ? t : 0) * 8;
                     r0[k] = rt[0]; r1[k] = rt[1]; r3[k] = rt[3];
-                    qv[k] = d.q[(long long)sl[k] * d.qstride + r];
+                    qv[k] = d.q[(long long)sl[k] * d.qstride + rq];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -377,12 +385,109 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
     d.cert[r] = safe ? 1 : 0;
 }
 
+// ---- the look-ahead of the dense proof pass -------------------------------------------------------------------------------
+// A stretch's proof pass used to put every (visit, label) pair of the stretch through the likelihood kernel on the chain's
+// own stream: ~1 000 visits x 200 labels, a launch too small for the chip (106 us at C4's shape) in front of a resolver that
+// then walks a few dozen of those visits on ONE compute unit.  Nothing in those forms depends on the stretch: they depend
+// on the visits (fixed for the sweep) and on the components' factors -- and a window changes the factors of the handful of
+// labels it moves points between, nobody else's (gaussian_components.py:154-205: add_item / del_item touch one component).
+// So the forms are made a CHUNK of ahead_C visits at a time, for every slot, on a second stream, while the resolver of
+// an earlier stretch is at work -- one launch that fills the chip -- into a ring of two chunks (row = visit & (2 C - 1)).
+// A stretch then re-scores its rows for the labels that took a term since its chunk's request (Dev::touch_seq against
+// Ctrl::ah_seq), typically a tenth of them, and the verdict kernel reads the ring.  What is read is in every case an exact
+// form under the state the stretch starts from: either untouched since it was made, or re-made on the spot.
+//
+// safe_plan_kernel (one workgroup, main stream, behind safe_rtab_kernel) is the only writer of the look-ahead's state:
+//   * books the request the second stream has served since the last step (the host made this stream wait for it),
+//   * describes what this step's stretch re-scores (resc_job: the dirty labels; the whole stretch if its chunk is not in
+//     the ring; nothing while the stretch's proofs stand),
+//   * describes what the second stream scores next (ah_job: the chunk the chain is in, from the end of the stretch at
+//     hand, if the ring does not hold it; else the chunk after it; else nothing).
+__global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
+    __shared__ int n_dirty_s, hw_s;
+    Ctrl *c = d.ctrl;
+    const int tid = threadIdx.x;
+    const long long C = d.ahead_C;
+    if (tid == 0) { n_dirty_s = 0; hw_s = 0; }
+    __syncthreads();
+    if (c->error != 0 || c->job.mode == MODE_DONE) {
+        if (tid == 0) { d.ah_job->mode = MODE_DONE; d.resc_job->mode = MODE_DONE; c->ah_req_chunk = -1; }
+        return;
+    }
+    // (uniform reads of the state as the last step left it; thread 0 writes it back at the end)
+    long long ch0 = c->ah_chunk[0], ch1 = c->ah_chunk[1], sq0 = c->ah_seq[0], sq1 = c->ah_seq[1], lo0 = c->ah_lo[0], lo1 = c->ah_lo[1];
+    if (c->ah_req_chunk >= 0) {
+        if (c->ah_req_chunk & 1) { ch1 = c->ah_req_chunk; sq1 = c->ah_req_seq; lo1 = c->ah_req_lo; }
+        else { ch0 = c->ah_req_chunk; sq0 = c->ah_req_seq; lo0 = c->ah_req_lo; }
+    }
+    const Job &j = c->job;
+    const int K = j.K;
+    const long long a = j.win_base, b = j.win_hi;
+    const bool proving = !c->safe_epoch_valid && j.mode == MODE_FRESH;
+    const long long cur = (proving ? a : j.pos) / C;
+    const long long chc = (cur & 1) ? ch1 : ch0, sqc = (cur & 1) ? sq1 : sq0, loc = (cur & 1) ? lo1 : lo0;
+    const bool covered = proving && chc == cur && a >= loc;
+    // the dirty labels of a covered stretch; the highest slot in use (the look-ahead scores slots 0 .. hw - 1)
+    int hw = 0;
+    for (int t = tid; t < K; t += 256) {
+        const int s = d.perm[t];
+        hw = s + 1 > hw ? s + 1 : hw;
+        if (covered && d.touch_seq[s] > sqc) d.resc_list[atomicAdd(&n_dirty_s, 1)] = s;
+    }
+    atomicMax(&hw_s, hw);
+    __syncthreads();
+    if (tid != 0) return;
+    Job r;
+    r.pos = a; r.win_base = a & ~(2 * C - 1); r.win_hi = b; r.K = K; r.n_dirty = 0; r.dirty[0] = r.dirty[1] = 0; r.chunks = 1; r.prune = 0;
+    if (!proving) r.mode = MODE_DONE;
+    else if (!covered) { r.mode = MODE_FRESH; c->ah_self += 1; }
+    else {
+        r.n_dirty = n_dirty_s;
+        r.mode = n_dirty_s > 0 ? MODE_LIST : MODE_DONE;
+        c->ah_served += 1; c->ah_dirty += n_dirty_s;
+    }
+    *d.resc_job = r;
+    // the next request
+    long long want = -1, want_lo = 0;
+    const long long from = proving ? b : j.pos;                // (what this step's stretch scores itself is not asked for)
+    if (chc != cur && from < (cur + 1) * C && from < c->n_visits) { want = cur; want_lo = from; }
+    else {
+        const long long chn = ((cur + 1) & 1) ? ch1 : ch0;
+        if (chn != cur + 1 && (cur + 1) * C < c->n_visits) { want = cur + 1; want_lo = (cur + 1) * C; }
+    }
+    long long want_hi = want >= 0 ? (want + 1) * C : 0;
+    if (want_hi > c->n_visits) want_hi = c->n_visits;
+    Job q;
+    q.pos = want_lo; q.win_base = (want * C) & ~(2 * C - 1); q.win_hi = want_hi; q.K = hw_s; q.n_dirty = hw_s;
+    q.dirty[0] = q.dirty[1] = 0; q.chunks = 1; q.prune = 0;
+    if (want < 0 || want_lo >= want_hi || hw_s <= 0) { q.mode = MODE_DONE; want = -1; }
+    else { q.mode = MODE_SLOTS; c->ah_chunks += 1; }
+    *d.ah_job = q;
+    c->ah_chunk[0] = ch0; c->ah_chunk[1] = ch1; c->ah_seq[0] = sq0; c->ah_seq[1] = sq1; c->ah_lo[0] = lo0; c->ah_lo[1] = lo1;
+    c->ah_req_chunk = want; c->ah_req_seq = c->win_seq; c->ah_req_lo = want_lo;
+}
+
 void launch_safe_open(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(safe_open_kernel, dim3(1), dim3(256), 0, st, d);
 }
 
 // One safe-stay step.  The Dev of a safe batch has prune_enabled = 2, use_certify = 0, use_home = 1, safe_mode = 1.
-bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                      const SafeAhead *ah) {
+    if (d.safe_dense && ah && d.ahead_C > 0) {
+        // with the look-ahead: plan -> (second stream: the next chunk, every slot) || re-score the dirty labels -> verdicts
+        hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(safe_plan_kernel, dim3(1), dim3(256), 0, st, d);
+        if (hipEventRecord(ah->ev_plan, st) != hipSuccess || hipStreamWaitEvent(ah->stream, ah->ev_plan, 0) != hipSuccess) return false;
+        launch_score(d, KERNEL_MFMA, d.ah_job, d.q, d.qstride, -1, d.ahead_C, 3, ah->stream);
+        if (hipEventRecord(ah->ev_done, ah->stream) != hipSuccess) return false;
+        Dev dl = d;
+        dl.slot_list = d.resc_list;
+        launch_score(dl, KERNEL_MFMA, d.resc_job, d.q, d.qstride, -1, max_rows, 3, st);
+        hipLaunchKernelGGL(safe_dense_choice_kernel, dim3((unsigned)((max_rows + 15) / 16)), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(safe_compact_kernel, dim3(1), dim3(1024), 0, st, d);
+        return launch_gram_core(d, resolve_lds, st, ev0, ev1);
+    }
     if (d.safe_dense) {
         hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
         launch_score(d, KERNEL_MFMA, &d.ctrl->job, d.q, d.qstride, -1, max_rows, 2, st);   // every pair of the stretch, exactly

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
     const JobView job = load_job(jobp);
     // (PROOF: runs whatever the window's kind, but only in front of a stretch whose proofs are to be made, kernels_safe.hip)
     if (job.mode == MODE_DONE || (!PROOF && skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
-        (PROOF && d.ctrl->safe_epoch_valid)) return;
+        (PROOF && skip_pruned_jobs == 2 && d.ctrl->safe_epoch_valid)) return;      // (3: a job of the look-ahead's -- DONE when idle)
     constexpr int ROWS_W_ = 16 * RB;
     const int chunk = blockIdx.y;
     // (the dense proof pass covers a few thousand rows: its launch brings its own, finer split of the labels -- grid.y --
@@ -199,12 +199,13 @@ static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstri
                         long long max_rows, int skip_pruned_jobs, hipStream_t st) {
     const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
     // (skip_pruned_jobs 2 = the dense proof pass of a safe-stay stretch, a few thousand rows: up to 64 label chunks)
-    const unsigned gy = skip_pruned_jobs == 2 ? 64 : kMaxChunks;      // (the kernel picks its split from the stretch's real length)
+    const unsigned gy = skip_pruned_jobs >= 2 ? 64 : kMaxChunks;      // (the kernel picks its split from the stretch's real length)
     constexpr int W = NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1);
     // (the proof pass is ~1 400 workgroups: two per SIMD is all it fills, and at three its label split costs D = 64 32 spills)
     constexpr int WP = NJ == 4 ? 2 : W;
-    if (skip_pruned_jobs == 2)
-        hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, WP, true>), dim3(gx, gy), dim3(256), 0, st, d, job, q, qstride, col_override, 2);
+    if (skip_pruned_jobs >= 2)
+        hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, WP, true>), dim3(gx, gy), dim3(256), 0, st, d, job, q, qstride, col_override,
+                           skip_pruned_jobs);
     else
         hipLaunchKernelGGL((score_mfma_kernel<NJ, 2, W, false>), dim3(gx, gy), dim3(256), 0, st, d, job, q, qstride, col_override,
                            skip_pruned_jobs);

@@ -220,6 +220,8 @@ __device__ __forceinline__ void gram_finish_body(const Dev &d) {
     __shared__ double xs[BGMM_MAX_D], ms[BGMM_MAX_D], wide_scan[256];
     if ((int)blockIdx.x >= d.gfin[0]) return;
     const int s = d.gtouched[blockIdx.x];
+    // (the look-ahead of the dense proof pass re-scores a label iff a window closed after its chunk's request changed it)
+    if (threadIdx.x == 0 && d.touch_seq) d.touch_seq[s] = d.ctrl->win_seq;
     if (d.pipe) {              // (the slot's count behind this window: the resolver left it on the list, see there)
         if (threadIdx.x == 0) d.n[s] = d.gfin[16 + blockIdx.x];
         __syncthreads();

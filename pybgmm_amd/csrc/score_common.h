@@ -42,6 +42,8 @@ __device__ __forceinline__ JobView load_job(const Job *__restrict__ j) {
 }
 // entry t of the job's list -> slot
 __device__ __forceinline__ int job_slot(const Dev &d, const JobView &job, int t) {
+    if (job.mode == MODE_SLOTS) return t;
+    if (job.mode == MODE_LIST) return d.slot_list[t];
     return job.mode == MODE_FRESH ? d.perm[t] : (t == 0 ? job.dirty0 : job.dirty1);
 }
 

@@ -471,6 +471,10 @@ __device__ inline void safe_open_window(const Dev &d, Ctrl *c) {
     if (w > d.batch_rows) w = d.batch_rows;
     long long hi = j.pos + w;
     if (hi > c->n_visits) hi = c->n_visits;
+    if (d.safe_dense && d.ahead_C > 0) {          // (the look-ahead's ring holds whole chunks: a stretch lies inside one)
+        const long long chunk_end = (j.pos / d.ahead_C + 1) * (long long)d.ahead_C;
+        if (hi > chunk_end) hi = chunk_end;
+    }
     j.win_base = j.pos;
     j.win_hi = hi;
     j.mode = MODE_FRESH;

@@ -671,6 +671,49 @@ def test_safe_stay_windows_against_c_oracle(N, D, K, sep, flip, budget, oracle_r
     ctx.close()
 
 
+@pytest.mark.parametrize("chunk", [2048, 8192], ids=["chunks-of-2048", "chunks-of-8192"])
+def test_proof_lookahead_gives_the_same_chain(chunk):
+    """Round 6: the dense proof pass takes its exact forms from a LOOK-AHEAD -- a second stream scores a chunk of visits
+    for every slot beside the resolver, a stretch re-scores only the labels that took a rank-1 term since (kernels_safe.hip).
+    A/B on one overlapping chain with the proof pass pinned dense: look-ahead off (every stretch scores its own pairs) against
+    on -- labels, counts, log marginal, windows, walked visits and budget cuts identical after every sweep (the same proofs
+    from the same forms: which stream made them changes the cost, never the chain, igmm/crpmm.py:57-88), and the stats
+    show that stretches were served from the ring and labels were re-scored."""
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K = 60000, 64, 40
+    X, zt = gendata.synth_mixture(N, D, K, seed=141, mu_scale=0.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    us = np.random.RandomState(8).random_sample((3, N))
+    out = []
+    for ahead in (0, chunk):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        ctx.set_proof_pass(1)
+        ctx.set_proof_lookahead(ahead)
+        ctx.set_assignments(zt)
+        per = []
+        for it in range(3):
+            ctx.sweep(us[it])
+            st = ctx.safe_stats()
+            per.append((ctx.assignments(), ctx.counts(), ctx.log_marg(), st["windows"], st["unproven_walked"], st["budget_cuts"],
+                        ctx.sweep_stats()["moves"]))
+        out.append((per, ctx.proof_lookahead_stats(), ctx.proof_pass_stats()))
+        ctx.close()
+    (a, sa, pa), (b, sb, pb) = out
+    assert pa["dense_batches"] > 0 and pb["dense_batches"] > 0 and pa["table_batches"] == 0
+    assert sum(x[6] for x in a) > 50, "the case is meant to have movers"
+    assert sa["stretches_from_the_ring"] == 0 and sa["chunks_requested"] == 0, sa
+    assert sb["stretches_from_the_ring"] > 10 and sb["labels_rescored"] > 0 and sb["chunks_requested"] >= 3, sb
+    assert sb["stretches_from_the_ring"] > 3 * sb["stretches_scored_in_full"], sb
+    for it in range(3):
+        bad = np.nonzero(a[it][0] != b[it][0])[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        npt.assert_array_equal(a[it][1], b[it][1])
+        assert abs(a[it][2] - b[it][2]) <= 1e-12 * abs(a[it][2])
+        # (the look-ahead ends stretches at chunk boundaries: more windows of the same walk)
+        assert a[it][6] == b[it][6]
+
+
 def test_dense_and_table_proof_passes_give_the_same_chain():
     """Safe-stay windows prove which visits stay in two ways: through the per-home bound tables + the pruning kernel's exact
     forms, or DENSELY (every (visit, label) pair of a stretch through the likelihood kernel, bgmm_get_proof_pass_stats).

@@ -77,6 +77,8 @@ def chain(a, quiet=False):
     ctx.set_home_pass(a.home)
     if a.budget:
         ctx.set_safe_budget(a.budget)
+    if a.ahead >= 0:
+        ctx.set_proof_lookahead(a.ahead)
     if a.seq_plan:
         ctx.set_seq_plan(a.seq_plan)
     ctx.set_assignments(z0)
@@ -116,6 +118,7 @@ def chain(a, quiet=False):
         if not ok:
             break
     print("proof passes of the safe-stay windows so far: %(table_batches)d batches through the per-home tables, %(dense_batches)d dense" % ctx.proof_pass_stats())
+    print("look-ahead of the dense proof pass: %s" % ctx.proof_lookahead_stats())
     if a.timing:
         n, ms = ctx.kernel_timing()
         print("last sweep: %d timed launches, avg %.4f ms" % (n, ms / max(n, 1)))
@@ -330,6 +333,7 @@ def parser():
     c.add_argument("--oracle", action="store_true")
     c.add_argument("--timing", action="store_true")
     c.add_argument("--prof", action="store_true")
+    c.add_argument("--ahead", type=int, default=-1, help="bgmm_set_proof_lookahead: visits per chunk of the dense proof pass's look-ahead (0: off)")
     c.add_argument("--lib", default="", help="load libbgmm_hip_<name>.so (tools/build_variant.sh)")
     sub.add_parser("safe-check")
     k = sub.add_parser("classes")
