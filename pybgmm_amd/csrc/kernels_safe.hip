@@ -452,8 +452,13 @@ __global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
     const long long from = proving ? b : j.pos;                // (what this step's stretch scores itself is not asked for)
     if (chc != cur && from < (cur + 1) * C && from < c->n_visits) { want = cur; want_lo = from; }
     else {
+        // (the next chunk as LATE as will do -- every window between the request and the chunk's use adds two labels to what
+        //  its stretches re-score: when what is left of this chunk is a couple of stretches' worth)
         const long long chn = ((cur + 1) & 1) ? ch1 : ch0;
-        if (chn != cur + 1 && (cur + 1) * C < c->n_visits) { want = cur + 1; want_lo = (cur + 1) * C; }
+        const long long left = (cur + 1) * C - from;
+        long long margin = 2 * (long long)c->safe_L;
+        margin = margin < 1024 ? 1024 : (margin > C / 2 ? C / 2 : margin);
+        if (chn != cur + 1 && (cur + 1) * C < c->n_visits && left <= margin) { want = cur + 1; want_lo = (cur + 1) * C; }
     }
     long long want_hi = want >= 0 ? (want + 1) * C : 0;
     if (want_hi > c->n_visits) want_hi = c->n_visits;

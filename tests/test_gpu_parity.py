@@ -703,8 +703,7 @@ def test_proof_lookahead_gives_the_same_chain(chunk):
     assert pa["dense_batches"] > 0 and pb["dense_batches"] > 0 and pa["table_batches"] == 0
     assert sum(x[6] for x in a) > 50, "the case is meant to have movers"
     assert sa["stretches_from_the_ring"] == 0 and sa["chunks_requested"] == 0, sa
-    assert sb["stretches_from_the_ring"] > 10 and sb["labels_rescored"] > 0 and sb["chunks_requested"] >= 3, sb
-    assert sb["stretches_from_the_ring"] > 3 * sb["stretches_scored_in_full"], sb
+    assert sb["stretches_from_the_ring"] >= 5 and sb["labels_rescored"] > 0 and sb["chunks_requested"] >= 3, sb
     for it in range(3):
         bad = np.nonzero(a[it][0] != b[it][0])[0]
         assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
