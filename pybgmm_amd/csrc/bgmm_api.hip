@@ -510,7 +510,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.ftab2, (size_t)d.nslots * 64);
         DALLOC(c, d.nbr, (size_t)d.nslots * 4);
     }
-    DALLOC(c, d.ah_job, 1);
+    DALLOC(c, d.ah_job, 3);
     DALLOC(c, d.resc_job, 1);
     DALLOC(c, d.resc_list, ns);
     DALLOC(c, d.touch_seq, ns);

@@ -183,7 +183,8 @@ struct Ctrl {
     // chunk's request.  Only the main stream's plan kernel writes these fields.
     long long win_seq;                 // frozen-factor windows closed since the context was made
     long long ah_chunk[2];             // per half of the ring: the chunk whose forms it holds (-1: none)
-    long long ah_seq[2];               // ... win_seq when that chunk's scoring was requested: a slot with touch_seq beyond it is dirty
+    long long ah_seq[2];               // [0] the ring is valid up to the windows closed by then (win_seq): a slot with touch_seq beyond
+                                       // it is dirty; [1] 1: a plan has been handed to the second stream in this batch
     long long ah_lo[2];                // ... first visit of the chunk that was scored
     long long ah_req_chunk, ah_req_seq, ah_req_lo;   // the request the second stream is serving (-1: none)
     long long ah_served, ah_self, ah_dirty, ah_chunks;   // this sweep: stretches re-scored from the ring / scored in full,
@@ -367,7 +368,8 @@ struct Dev {
     struct SafeCol *ep_state;    // [nslots] per SLOT, since the proof pass: budget used, the counts the proofs allow
     int ahead_C;                 // > 0: this batch's dense proof pass takes its forms from the look-ahead ring (a power of two;
                                  // stretches end at multiples of it)
-    Job *ah_job, *resc_job;      // device: what the look-ahead scores next / what the stretch at hand re-scores
+    Job *ah_job, *resc_job;      // device: ah_job[3] = what the second stream scores next (a chunk in full; the touched labels over
+                                 // either half of the ring) / what the stretch at hand re-scores
     int *resc_list;              // [nslots] the dirty slots of resc_job
     const int *slot_list;        // MODE_LIST: the list this launch's job indexes
     long long *touch_seq;        // [nslots] per slot: win_seq of the last window that changed it

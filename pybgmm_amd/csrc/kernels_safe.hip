@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
         // (the look-ahead's ring starts empty with every batch: other kinds of windows may have changed the state in between)
         c->ah_chunk[0] = c->ah_chunk[1] = -1;
         c->ah_req_chunk = -1;
+        c->ah_seq[0] = c->win_seq; c->ah_seq[1] = 0;      // ([1]: no plan has been handed to the second stream yet)
     }
 }
 
@@ -391,18 +392,23 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
 // then walks a few dozen of those visits on ONE compute unit.  Nothing in those forms depends on the stretch: they depend
 // on the visits (fixed for the sweep) and on the components' factors -- and a window changes the factors of the handful of
 // labels it moves points between, nobody else's (gaussian_components.py:154-205: add_item / del_item touch one component).
-// So the forms are made a CHUNK of ahead_C visits at a time, for every slot, on a second stream, while the resolver of
-// an earlier stretch is at work -- one launch that fills the chip -- into a ring of two chunks (row = visit & (2 C - 1)).
-// A stretch then re-scores its rows for the labels that took a term since its chunk's request (Dev::touch_seq against
-// Ctrl::ah_seq), typically a tenth of them, and the verdict kernel reads the ring.  What is read is in every case an exact
-// form under the state the stretch starts from: either untouched since it was made, or re-made on the spot.
+// So the forms live in a RING of two chunks of ahead_C visits (row = visit & (2 C - 1)), kept current from a second stream:
+//   * a chunk the chain is about to enter is scored there in one launch, every slot, beside the resolver;
+//   * after every window the labels it touched (Dev::touch_seq: a dozen) are re-scored there for the ring's rows ahead of
+//     the chain -- again beside the next resolver;
+//   * on the chain's own stream a stretch re-scores its rows only for the labels of the window that closed last (whose
+//     re-scoring on the second stream ran while that window was still being walked: it cannot have seen its outcome).
+// What the verdict kernel reads is in every case an exact form under the state the stretch starts from: untouched since it
+// was made, or re-made after the touching window's finish kernel.
 //
-// safe_plan_kernel (one workgroup, main stream, behind safe_rtab_kernel) is the only writer of the look-ahead's state:
-//   * books the request the second stream has served since the last step (the host made this stream wait for it),
-//   * describes what this step's stretch re-scores (resc_job: the dirty labels; the whole stretch if its chunk is not in
-//     the ring; nothing while the stretch's proofs stand),
-//   * describes what the second stream scores next (ah_job: the chunk the chain is in, from the end of the stretch at
-//     hand, if the ring does not hold it; else the chunk after it; else nothing).
+// safe_plan_kernel (one workgroup, main stream, behind safe_rtab_kernel) is the only writer of the ring's state:
+//   1. books what the second stream has done since the last step (the host made this stream wait for it): the ring is
+//      valid up to the windows closed when that work was planned (Ctrl::ah_seq[0]);
+//   2. lists the labels touched since (resc_list) and describes what this step's stretch re-scores for them (resc_job;
+//      the whole stretch, every label, if the ring does not hold it; nothing while the stretch's proofs stand);
+//   3. describes the second stream's next work: the same labels over the ring's rows ahead of the stretch (mt_job per half),
+//      and a chunk to score in full (ah_job) -- the one the chain is in, from the end of the stretch at hand, if the ring
+//      does not hold it; else the next one once half of this one is behind the chain.
 __global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
     __shared__ int n_dirty_s, hw_s;
     Ctrl *c = d.ctrl;
@@ -411,64 +417,64 @@ __global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
     if (tid == 0) { n_dirty_s = 0; hw_s = 0; }
     __syncthreads();
     if (c->error != 0 || c->job.mode == MODE_DONE) {
-        if (tid == 0) { d.ah_job->mode = MODE_DONE; d.resc_job->mode = MODE_DONE; c->ah_req_chunk = -1; }
+        if (tid == 0) { d.ah_job[0].mode = d.ah_job[1].mode = d.ah_job[2].mode = MODE_DONE; d.resc_job->mode = MODE_DONE; c->ah_req_chunk = -1; }
         return;
     }
     // (uniform reads of the state as the last step left it; thread 0 writes it back at the end)
-    long long ch0 = c->ah_chunk[0], ch1 = c->ah_chunk[1], sq0 = c->ah_seq[0], sq1 = c->ah_seq[1], lo0 = c->ah_lo[0], lo1 = c->ah_lo[1];
-    if (c->ah_req_chunk >= 0) {
-        if (c->ah_req_chunk & 1) { ch1 = c->ah_req_chunk; sq1 = c->ah_req_seq; lo1 = c->ah_req_lo; }
-        else { ch0 = c->ah_req_chunk; sq0 = c->ah_req_seq; lo0 = c->ah_req_lo; }
-    }
+    long long ch[2] = {c->ah_chunk[0], c->ah_chunk[1]}, lo[2] = {c->ah_lo[0], c->ah_lo[1]};
+    long long ring_seq = c->ah_seq[0];
+    const bool served = c->ah_seq[1] != 0;                          // (a plan was handed to the second stream last step)
+    if (served) ring_seq = c->ah_req_seq;
+    if (c->ah_req_chunk >= 0) { ch[c->ah_req_chunk & 1] = c->ah_req_chunk; lo[c->ah_req_chunk & 1] = c->ah_req_lo; }
     const Job &j = c->job;
     const int K = j.K;
     const long long a = j.win_base, b = j.win_hi;
     const bool proving = !c->safe_epoch_valid && j.mode == MODE_FRESH;
     const long long cur = (proving ? a : j.pos) / C;
-    const long long chc = (cur & 1) ? ch1 : ch0, sqc = (cur & 1) ? sq1 : sq0, loc = (cur & 1) ? lo1 : lo0;
-    const bool covered = proving && chc == cur && a >= loc;
-    // the dirty labels of a covered stretch; the highest slot in use (the look-ahead scores slots 0 .. hw - 1)
+    const int hc = (int)(cur & 1), hn = hc ^ 1;
+    const bool covered = proving && ch[hc] == cur && a >= lo[hc];
+    // the labels touched since the ring was last brought up to date; the highest slot in use (a chunk is scored for slots
+    // 0 .. hw - 1)
     int hw = 0;
     for (int t = tid; t < K; t += 256) {
         const int s = d.perm[t];
         hw = s + 1 > hw ? s + 1 : hw;
-        if (covered && d.touch_seq[s] > sqc) d.resc_list[atomicAdd(&n_dirty_s, 1)] = s;
+        if (d.touch_seq[s] > ring_seq) d.resc_list[atomicAdd(&n_dirty_s, 1)] = s;
     }
     atomicMax(&hw_s, hw);
     __syncthreads();
     if (tid != 0) return;
-    Job r;
-    r.pos = a; r.win_base = a & ~(2 * C - 1); r.win_hi = b; r.K = K; r.n_dirty = 0; r.dirty[0] = r.dirty[1] = 0; r.chunks = 1; r.prune = 0;
-    if (!proving) r.mode = MODE_DONE;
-    else if (!covered) { r.mode = MODE_FRESH; c->ah_self += 1; }
-    else {
-        r.n_dirty = n_dirty_s;
-        r.mode = n_dirty_s > 0 ? MODE_LIST : MODE_DONE;
-        c->ah_served += 1; c->ah_dirty += n_dirty_s;
-    }
-    *d.resc_job = r;
-    // the next request
-    long long want = -1, want_lo = 0;
+    const int nd = n_dirty_s;
+    auto job_of = [&](int mode, long long p0, long long p1, int nlist) {
+        Job r;
+        r.pos = p0; r.win_base = p0 & ~(2 * C - 1); r.win_hi = p1; r.K = nlist; r.n_dirty = nlist; r.dirty[0] = r.dirty[1] = 0;
+        r.chunks = 1; r.prune = 0;
+        r.mode = (p0 < p1 && nlist > 0) ? mode : MODE_DONE;
+        return r;
+    };
+    // 2. this step's stretch
+    if (!proving) *d.resc_job = job_of(MODE_DONE, 0, 0, 0);
+    else if (!covered) { *d.resc_job = job_of(MODE_FRESH, a, b, K); c->ah_self += 1; }
+    else { *d.resc_job = job_of(MODE_LIST, a, b, nd); c->ah_served += 1; c->ah_dirty += nd; }
+    // 3. the second stream: the touched labels over the ring's rows ahead ...
     const long long from = proving ? b : j.pos;                // (what this step's stretch scores itself is not asked for)
-    if (chc != cur && from < (cur + 1) * C && from < c->n_visits) { want = cur; want_lo = from; }
-    else {
-        // (the next chunk as LATE as will do -- every window between the request and the chunk's use adds two labels to what
-        //  its stretches re-score: when what is left of this chunk is a couple of stretches' worth)
-        const long long chn = ((cur + 1) & 1) ? ch1 : ch0;
-        const long long left = (cur + 1) * C - from;
-        long long margin = 2 * (long long)c->safe_L;
-        margin = margin < 1024 ? 1024 : (margin > C / 2 ? C / 2 : margin);
-        if (chn != cur + 1 && (cur + 1) * C < c->n_visits && left <= margin) { want = cur + 1; want_lo = (cur + 1) * C; }
+    const long long end_c = (cur + 1) * C < c->n_visits ? (cur + 1) * C : c->n_visits;
+    const long long end_n = (cur + 2) * C < c->n_visits ? (cur + 2) * C : c->n_visits;
+    {
+        const long long p0 = from > lo[hc] ? from : lo[hc];
+        d.ah_job[1] = (ch[hc] == cur) ? job_of(MODE_LIST, p0, end_c, nd) : job_of(MODE_DONE, 0, 0, 0);
+        d.ah_job[2] = (ch[hn] == cur + 1) ? job_of(MODE_LIST, lo[hn] > (cur + 1) * C ? lo[hn] : (cur + 1) * C, end_n, nd)
+                                          : job_of(MODE_DONE, 0, 0, 0);
     }
-    long long want_hi = want >= 0 ? (want + 1) * C : 0;
-    if (want_hi > c->n_visits) want_hi = c->n_visits;
-    Job q;
-    q.pos = want_lo; q.win_base = (want * C) & ~(2 * C - 1); q.win_hi = want_hi; q.K = hw_s; q.n_dirty = hw_s;
-    q.dirty[0] = q.dirty[1] = 0; q.chunks = 1; q.prune = 0;
-    if (want < 0 || want_lo >= want_hi || hw_s <= 0) { q.mode = MODE_DONE; want = -1; }
-    else { q.mode = MODE_SLOTS; c->ah_chunks += 1; }
-    *d.ah_job = q;
-    c->ah_chunk[0] = ch0; c->ah_chunk[1] = ch1; c->ah_seq[0] = sq0; c->ah_seq[1] = sq1; c->ah_lo[0] = lo0; c->ah_lo[1] = lo1;
+    // ... and a chunk in full
+    long long want = -1, want_lo = 0, want_hi = 0;
+    if (ch[hc] != cur && from < end_c) { want = cur; want_lo = from; want_hi = end_c; }
+    else if (ch[hn] != cur + 1 && (cur + 1) * C < c->n_visits && 2 * (end_c - from) <= C) { want = cur + 1; want_lo = (cur + 1) * C; want_hi = end_n; }
+    d.ah_job[0] = want >= 0 ? job_of(MODE_SLOTS, want_lo, want_hi, hw_s) : job_of(MODE_DONE, 0, 0, 0);
+    if (d.ah_job[0].mode == MODE_DONE) want = -1;
+    else c->ah_chunks += 1;
+    c->ah_chunk[0] = ch[0]; c->ah_chunk[1] = ch[1]; c->ah_lo[0] = lo[0]; c->ah_lo[1] = lo[1];
+    c->ah_seq[0] = ring_seq; c->ah_seq[1] = 1;
     c->ah_req_chunk = want; c->ah_req_seq = c->win_seq; c->ah_req_lo = want_lo;
 }
 
@@ -484,10 +490,12 @@ bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStre
         hipLaunchKernelGGL(safe_rtab_kernel, dim3(d.nslots), dim3(64), 0, st, d);
         hipLaunchKernelGGL(safe_plan_kernel, dim3(1), dim3(256), 0, st, d);
         if (hipEventRecord(ah->ev_plan, st) != hipSuccess || hipStreamWaitEvent(ah->stream, ah->ev_plan, 0) != hipSuccess) return false;
-        launch_score(d, KERNEL_MFMA, d.ah_job, d.q, d.qstride, -1, d.ahead_C, 3, ah->stream);
-        if (hipEventRecord(ah->ev_done, ah->stream) != hipSuccess) return false;
         Dev dl = d;
         dl.slot_list = d.resc_list;
+        launch_score(d, KERNEL_MFMA, d.ah_job, d.q, d.qstride, -1, d.ahead_C, 3, ah->stream);           // a chunk, every slot
+        launch_score(dl, KERNEL_MFMA, d.ah_job + 1, d.q, d.qstride, -1, d.ahead_C, 3, ah->stream);      // the touched labels, this half
+        launch_score(dl, KERNEL_MFMA, d.ah_job + 2, d.q, d.qstride, -1, d.ahead_C, 3, ah->stream);      // ... the other half
+        if (hipEventRecord(ah->ev_done, ah->stream) != hipSuccess) return false;
         launch_score(dl, KERNEL_MFMA, d.resc_job, d.q, d.qstride, -1, max_rows, 3, st);
         hipLaunchKernelGGL(safe_dense_choice_kernel, dim3((unsigned)((max_rows + 15) / 16)), dim3(256), 0, st, d);
         hipLaunchKernelGGL(safe_compact_kernel, dim3(1), dim3(1024), 0, st, d);
