@@ -1094,14 +1094,6 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                 c->safe_epoch_valid = 0;
                 long long L = next_pos >= c->gl_stretch_end && S.cut == 0 ? 2ll * (c->gl_stretch_end - c->safe_epoch_pos0)
                                                                           : 2ll * (next_pos - c->safe_epoch_pos0) + 64;
-                if (d.safe_dense && d.ahead_C > 0) {
-                    // (with the look-ahead's ring a proof pass costs a verdict kernel, not a likelihood launch: what a step costs
-                    //  is the window's fixed part -- cross forms, weights, finish, ten launches -- so the stretch is sized to FILL
-                    //  its window: as many visits as leave about a window's worth unproven, at this stretch's density of them)
-                    const long long span = c->gl_stretch_end - c->safe_epoch_pos0, tot = c->gl_total;
-                    if (tot > 0 && span > 0) L = (kGramRows - 2) * span / tot;
-                    if (L > d.ahead_C) L = d.ahead_C;
-                }
                 if (L < 1024) L = 1024;
                 if (L > (1ll << 22)) L = 1ll << 22;
                 c->safe_L = (int)L;
