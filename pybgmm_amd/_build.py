@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgmm_hip.so")
-SOURCES = ["bgmm_api.hip", "kernels_state.hip", "kernels_score.hip", "kernels_prune.hip", "kernels_choice.hip",
+SOURCES = ["api_context.hip", "api_inputs.hip", "api_perm.hip", "api_sweep.hip", "api_group.hip", "api_comm.hip", "kernels_state.hip", "kernels_score.hip", "kernels_prune.hip", "kernels_choice.hip",
            "kernels_resolve.hip", "kernels_rng.hip", "kernels_seq.hip", "kernels_gram.hip", "kernels_home.hip", "kernels_safe.hip",
            "kernels_perm.hip", "kernels_resid.hip"]
 # every header next to the sources + the public one: editing any of them rebuilds every object

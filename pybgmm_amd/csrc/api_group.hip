@@ -1,0 +1,284 @@
+// Chains side by side on one device: the rendezvous of their host threads, the shared frozen-factor launches, and
+// bgmm_group_sweep_staged.
+#include "api_internal.h"
+
+// Chains of one group call that are in the frozen-factor regime TOGETHER (burn-in from a random start) share their
+// launches: the hardware runs about four kernels of different streams side by side, whatever the number of streams, so
+// eight chains with four small launches per window each queue up behind one another -- while one launch whose grid is
+// (x, chain) runs the eight resolvers truly side by side (kernels_gram.hip: *_group_kernel).  The chains' host threads meet
+// here.  Every thread declares, once per batch of its sweep loop, either "a batch of frozen-factor windows" (submit: it
+// waits) or "something else" (pass: the others do not wait for it); when nobody is undeclared, one of the waiting threads
+// is made leader and queues the batch for all waiting chains of its shape on its own stream, behind an event of each
+// member's stream; the members' streams wait for the leader's.  Same kernels, same per-chain control blocks: the
+// trajectories are those of separate sweeps.
+struct GramCombiner {
+    enum { UNKNOWN = 0, WAITING = 1, BUSY = 2, DONE = 3 };
+    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int result = 0; hipEvent_t ev = nullptr; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot> slots;
+    int leader = -1;
+    long long shared_batches = 0, shared_members = 0;
+
+    void elect_locked() {
+        if (leader >= 0) return;
+        int first = -1;
+        for (size_t k = 0; k < slots.size(); ++k) {
+            if (slots[k].state == UNKNOWN) return;
+            if (slots[k].state == WAITING && first < 0) first = (int)k;
+        }
+        if (first >= 0) { leader = first; cv.notify_all(); }
+    }
+    void declare(int i, int state) {
+        std::lock_guard<std::mutex> lk(mu);
+        slots[(size_t)i].state = state;
+        elect_locked();
+    }
+};
+
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
+
+// Returns 0: the batch has been queued with the group's (the chain's stream waits for it); 1: queue it yourself; < 0: error.
+void combiner_declare_busy(bgmm_ctx *c) { c->combiner->declare(c->combiner_slot, GramCombiner::BUSY); }
+
+int combiner_submit(bgmm_ctx *c, int T) {
+    GramCombiner &G = *c->combiner;
+    const int me = c->combiner_slot;
+    // (a chain that cannot take part queues its batch itself -- and says so, or the others would wait for its declaration)
+    if (!c->grp_ev_in) {
+        if (hipEventCreateWithFlags(&c->grp_ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->grp_ev_out, hipEventDisableTiming) != hipSuccess) {
+            G.declare(me, GramCombiner::BUSY);
+            return 1;
+        }
+    }
+    if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) { G.declare(me, GramCombiner::BUSY); return 1; }
+    std::unique_lock<std::mutex> lk(G.mu);
+    GramCombiner::Slot &S = G.slots[(size_t)me];
+    S.state = GramCombiner::WAITING; S.T = T; S.result = 1; S.ev = nullptr;
+    G.elect_locked();
+    G.cv.wait(lk, [&] { return S.state != GramCombiner::WAITING || G.leader == me; });
+    if (S.state == GramCombiner::WAITING) {
+        // leader: the waiting chains of this chain's shape (device, D, column plan)
+        std::vector<int> members;
+        int Tmax = 0;
+        for (size_t k = 0; k < G.slots.size(); ++k) {
+            const GramCombiner::Slot &o = G.slots[k];
+            if (o.state != GramCombiner::WAITING) continue;
+            if (o.c->device == c->device && o.c->d.D == c->d.D && o.c->d.gcols == c->d.gcols && o.c->gram_lds == c->gram_lds) {
+                members.push_back((int)k);
+                if (o.T > Tmax) Tmax = o.T;
+            }
+        }
+        int rc = 1;
+        std::vector<hipEvent_t> ev_of;                  // per member: the event its stream waits for (its sub-group's)
+        if (members.size() >= 2) {
+            lk.unlock();
+            rc = gram_group_launch(G, members, Tmax, ev_of);
+            lk.lock();
+            if (rc == 0) { G.shared_batches += 1; G.shared_members += (long long)members.size(); }
+        }
+        // everybody who waited goes on: the members with the shared batch (or, if it could not be queued, on their own),
+        // the chains of other shapes on their own
+        for (size_t k = 0; k < G.slots.size(); ++k) {
+            GramCombiner::Slot &o = G.slots[k];
+            if (o.state != GramCombiner::WAITING) continue;
+            const auto it = std::find(members.begin(), members.end(), (int)k);
+            const bool member = it != members.end() && members.size() >= 2;
+            o.result = member ? rc : 1;
+            o.ev = (member && rc == 0) ? ev_of[(size_t)(it - members.begin())] : nullptr;
+            o.state = GramCombiner::UNKNOWN;
+        }
+        G.leader = -1;
+        G.cv.notify_all();
+    }
+    const int result = S.result;
+    hipEvent_t ev = S.ev;
+    lk.unlock();
+    if (result == 0 && ev && ev != c->grp_ev_out) {       // (a sub-group's leader queued the batch on its own stream)
+        if (hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess) return BGMM_EDEVICE;
+    }
+    return result;
+}
+
+// The shared batch is queued as a few SUB-GROUPS, each on the stream of its first member: the one-workgroup resolvers of
+// one sub-group run beside the wide kernels (cross forms, rebuilds) of the others -- with every chain in ONE launch
+// sequence the chip idles through each window's resolver phase and the resolvers wait through its wide phases (eight
+// C4 chains: 201 + 132 us per window whatever runs beside them).  One stream per chain, the other extreme, keeps only
+// about four kernels in flight and stretches every one of them.  BGMM_GROUP_SPLIT
+// overrides the number of sub-groups (1: one launch sequence for all).
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of) {
+    bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
+    const int m = (int)members.size();
+    ev_of.assign((size_t)m, nullptr);
+    if (hipSetDevice(lead->device) != hipSuccess) return 1;
+    if (lead->grp_devs_cap < m) {
+        if (lead->grp_devs) (void)hipFree(lead->grp_devs);
+        lead->grp_devs = nullptr; lead->grp_devs_cap = 0;
+        if (hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m) != hipSuccess) return 1;
+        lead->grp_devs_cap = m;
+    }
+    static const int split_env = [] { const char *e = getenv("BGMM_GROUP_SPLIT"); return e ? atoi(e) : 0; }();
+    int n_sub = split_env > 0 ? split_env : (m >= 4 ? 2 : 1);
+    if (n_sub > m / 2) n_sub = m / 2 > 0 ? m / 2 : 1;
+    std::vector<Dev> views((size_t)m);
+    std::vector<int> reach_of((size_t)n_sub, 0), lo_of((size_t)n_sub + 1, 0);
+    for (int g = 0; g <= n_sub; ++g) lo_of[(size_t)g] = (int)((long long)m * g / n_sub);
+    for (int g = 0; g < n_sub; ++g) {
+        bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+        for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k) {
+            bgmm_ctx *o = G.slots[(size_t)members[(size_t)k]].c;
+            views[(size_t)k] = o->d;
+            const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
+            if (r > reach_of[(size_t)g]) reach_of[(size_t)g] = r;
+            // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
+            if (o != sl && hipStreamWaitEvent(sl->stream, o->grp_ev_in, 0) != hipSuccess) return 1;
+            ev_of[(size_t)k] = sl->grp_ev_out;
+        }
+    }
+    // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
+    // have been waited for by every one of its members)
+    if (hipMemcpy(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    // (from here on a failure is an error for every member, not a reason to queue their batches separately: part of the shared
+    // batch may already be in the queue, and separate launches would run beside it on the same chains)
+    // window by window across the sub-groups, so that the host queues them at the same pace
+    for (int t = 0; t < T; ++t)
+        for (int g = 0; g < n_sub; ++g) {
+            bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+            if (!launch_gram_group_step(sl->d, lead->grp_devs + lo_of[(size_t)g], lo_of[(size_t)g + 1] - lo_of[(size_t)g],
+                                        reach_of[(size_t)g], sl->gram_lds, sl->stream)) return BGMM_EDEVICE;
+        }
+    if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
+    for (int g = 0; g < n_sub; ++g) {
+        bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+        if (hipEventRecord(sl->grp_ev_out, sl->stream) != hipSuccess) return BGMM_EDEVICE;
+    }
+    return 0;
+}
+
+// Sweeps of several chains that live on ONE device, side by side.  Chains that can take the one-workgroup sweep (D <= 4,
+// full covariance, automatic tuning, labels within the LDS plan) are opened and swept by two launches for all of them
+// -- one workgroup, one compute unit per chain -- instead of two launches and a host round trip each; every other chain
+// is swept on its own as bgmm_sweep_staged would.  Same trajectories as separate calls.
+extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const int32_t *use_power, const double *power,
+                                       int32_t *rc_out) {
+    if (!ctxs || n < 1 || !rc_out) return BGMM_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return BGMM_EINVAL;
+        rc_out[i] = 0;
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctxs[i], BGMM_EINVAL, "a context appears twice in the group");
+    }
+    std::vector<int> deferred;
+    int worst = 0;
+    // Chains that can never take the one-workgroup sweep (D > 4, diagonal / fixed covariance) run their whole sweep as
+    // bgmm_sweep_staged would -- but CONCURRENTLY, each on its own stream, each driven by its own host thread (a context is
+    // one host thread's at a time; distinct contexts share nothing).  What bounds such a sweep while the chain still moves is
+    // a latency chain that keeps ONE workgroup busy (kernels_gram.hip: the resolver); G chains side by side keep G of them
+    // busy, and the wide kernels of one chain (cross forms, rebuilds) run beside the resolvers of the others.
+    std::vector<std::thread> workers;
+    std::vector<int> threaded;
+    for (int i = 0; i < n; ++i)
+        if (!seq_shape(ctxs[i])) threaded.push_back(i);
+    GramCombiner comb;
+    if (threaded.size() >= 2) {
+        comb.slots.resize(threaded.size());
+        for (size_t k = 0; k < threaded.size(); ++k) {
+            comb.slots[k].c = ctxs[threaded[k]];
+            ctxs[threaded[k]]->combiner_slot = (int)k;
+        }
+        // (std::thread's constructor may throw -- no exception may cross the C ABI, least of all with joinable workers
+        //  behind it: the chains whose thread could not be started are declared DONE for the rendezvous, so that nobody
+        //  waits for them, and swept on this thread)
+        size_t started = 0;
+        try {
+            workers.reserve(threaded.size());
+            for (int i : threaded) {
+                const int up = use_power ? use_power[i] : 0;
+                const double pw = (up && power) ? power[i] : 1.0;
+                workers.emplace_back([=, &comb]() {
+                    ctxs[i]->combiner = &comb;
+                    rc_out[i] = sweep_impl(ctxs[i], up, pw, 0);
+                    comb.declare(ctxs[i]->combiner_slot, GramCombiner::DONE);
+                    ctxs[i]->combiner = nullptr;
+                });
+                ++started;
+            }
+        } catch (...) {
+        }
+        for (size_t k = started; k < threaded.size(); ++k) comb.declare((int)k, GramCombiner::DONE);
+        for (size_t k = started; k < threaded.size(); ++k) {
+            const int i = threaded[k];
+            const int up = use_power ? use_power[i] : 0;
+            rc_out[i] = sweep_impl(ctxs[i], up, (up && power) ? power[i] : 1.0, 0);
+        }
+    } else {
+        threaded.clear();
+    }
+    for (int i = 0; i < n; ++i) {
+        if (std::find(threaded.begin(), threaded.end(), i) != threaded.end()) continue;
+        const int up = use_power ? use_power[i] : 0;
+        const int rc = sweep_impl(ctxs[i], up, (up && power) ? power[i] : 1.0, 1);
+        if (rc == 1) deferred.push_back(i);
+        else { rc_out[i] = rc; if (rc < 0 && worst == 0) worst = rc; }
+    }
+    // one pair of launches per (device, D, LDS plan) among the chains that wait
+    std::vector<char> done(deferred.size(), 0);
+    for (size_t a = 0; a < deferred.size(); ++a) {
+        if (done[a]) continue;
+        bgmm_ctx *lead = ctxs[deferred[a]];
+        std::vector<int> grp;
+        for (size_t b = a; b < deferred.size(); ++b) {
+            bgmm_ctx *o = ctxs[deferred[b]];
+            if (!done[b] && o->device == lead->device && o->d.D == lead->d.D && o->grp_cap == lead->grp_cap) {
+                grp.push_back(deferred[b]);
+                done[b] = 1;
+            }
+        }
+        const int m = (int)grp.size();
+        hipError_t e = hipSetDevice(lead->device);
+        if (e == hipSuccess && lead->grp_devs_cap < m) {
+            if (lead->grp_devs) (void)hipFree(lead->grp_devs);
+            lead->grp_devs = nullptr; lead->grp_devs_cap = 0;
+            e = hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m);
+            if (e == hipSuccess) lead->grp_devs_cap = m;
+        }
+        std::vector<Dev> views((size_t)m);
+        for (int k = 0; k < m && e == hipSuccess; ++k) {
+            views[(size_t)k] = ctxs[grp[(size_t)k]]->d;
+            // (what phase 1 queued on the chain's own stream -- a new seating table, stale factors rebuilt -- has to be there)
+            e = hipStreamSynchronize(ctxs[grp[(size_t)k]]->stream);
+        }
+        hipStream_t st = lead->stream;
+        if (e == hipSuccess) e = hipMemcpyAsync(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            launch_sweep_begin(lead->d, st, lead->grp_devs, m);
+            if (!launch_sweep_seq(lead->d, lead->grp_cap, st, lead->grp_devs, m)) e = hipErrorLaunchFailure;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        for (int k = 0; k < m && e == hipSuccess; ++k) {
+            bgmm_ctx *o = ctxs[grp[(size_t)k]];
+            e = hipMemcpyAsync(o->ctrl_host, o->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);      // (views is pageable: the copy above has been staged by now)
+        for (int k = 0; k < m; ++k) {
+            bgmm_ctx *o = ctxs[grp[(size_t)k]];
+            int rc;
+            if (e != hipSuccess) {
+                o->err = std::string("group sweep: ") + hipGetErrorString(e);
+                rc = BGMM_EDEVICE;
+            } else {
+                rc = sweep_impl(o, o->d.use_power, o->d.power, 2);
+            }
+            rc_out[grp[(size_t)k]] = rc;
+            if (rc < 0 && worst == 0) worst = rc;
+        }
+    }
+    for (auto &w : workers) w.join();
+    if (getenv("BGMM_DEBUG_GROUP") && !threaded.empty())
+        fprintf(stderr, "[bgmm] group sweep: %zu chains on threads, %lld shared batches of frozen-factor windows, %.1f chains each\n",
+                threaded.size(), comb.shared_batches, comb.shared_batches ? (double)comb.shared_members / (double)comb.shared_batches : 0.0);
+    for (int i : threaded)
+        if (rc_out[i] < 0 && worst == 0) worst = rc_out[i];
+    return worst;
+}

@@ -479,7 +479,7 @@ struct SafeAhead { hipStream_t stream; hipEvent_t ev_plan, ev_done; };
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                       const SafeAhead *ah = nullptr);
 bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);   // gram + weights + resolve + finish
-// pipelined windows: the pieces, queued by the host on two streams (bgmm_api.hip: gram_pipe_batch)
+// pipelined windows: the pieces, queued by the host on two streams (api_sweep.hip: gram_pipe_batch)
 bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st);   // cross forms (+ those with the window before) + weights
 void launch_gram_carry(const Dev &d, hipStream_t st);
 bool launch_gram_resolve_only(const Dev &d, int resolve_lds, hipStream_t st);

@@ -300,7 +300,7 @@ __global__ void perm_state_kernel(const unsigned *__restrict__ key_in, const uns
 }
 
 // ---- a generation in flight: rounds, tail and state in the rounds' launches ------------------------------------------------
-// The draws of a generation that follows another one on the device (bgmm_api.hip "permutations in flight").  As
+// The draws of a generation that follows another one on the device (api_perm.hip "permutations in flight").  As
 // perm_draw_kernel, and:
 //   * a segment's start comes from block sums (64 segments each) + the counts of its own block: two loads per lane instead of
 //     up to sixty;

@@ -64,7 +64,7 @@ __device__ __forceinline__ double log1p_lower(double t) {
 // lower bound, their total weight relative to the home is < e^-38 = 3e-17 < 2^-53: the reference's
 // normaliser rounds to the home's score, p_home = exp(0) = 1 exactly, everything before it in the
 // scan subtracts < 3e-17 from a uniform that is at least 2^-53 (an exact zero disables pruning for
-// the sweep, bgmm_api.hip), and `u - 1 < 0` returns the home.
+// the sweep, api_inputs.hip), and `u - 1 < 0` returns the home.
 // One thread per window row, in visiting order; the rows it certifies are left out of the bucket
 // sort and of everything behind it.
 // ------------------------------------------------------------------------------------------

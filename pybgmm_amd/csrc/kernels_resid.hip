@@ -141,7 +141,7 @@ static void launch_resid_t(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL((resid_dense_kernel<NJ>), dim3(kResidDenseMax / 16), dim3(512), lds, st, d);
 }
 
-// Queued behind home_kernel when Dev::resid_dense is set (bgmm_api.hip: full covariance, D <= 32, certified stays off,
+// Queued behind home_kernel when Dev::resid_dense is set (api_sweep.hip: full covariance, D <= 32, certified stays off,
 // the log scores of all labels fit LDS).
 void launch_resid_dense(const Dev &d, hipStream_t st) {
     if (!d.resid_dense) return;

@@ -70,7 +70,7 @@ static constexpr int kJumpSplits = 16, kJumpTargets = 4; // coefficient range pe
 // chain `p` of a sweep: seed = block p * kChainBlocks of the stream (key_in for p = 0, a jumped state otherwise);
 // emits the blocks (p kChainBlocks, (p + 1) kChainBlocks] that the request [pos, E) reaches into -- chain 0 also what is
 // left of block 0 -- and, if the request ends in its range, the generator state the caller gets back.
-// `mids`: a request that spans several sweeps (the look-ahead, bgmm_api.hip) also wants the generator state at every
+// `mids`: a request that spans several sweeps (the look-ahead, api_inputs.hip) also wants the generator state at every
 // sweep boundary inside it: mids.nb[j] / mids.pos[j] = the block that boundary lies in and the position in it; the chain
 // that regenerates that block leaves it in key_mid[j] (blocks >= 1 only: such requests are long).
 __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__restrict__ key_in, const unsigned *__restrict__ seeds,

@@ -86,4 +86,4 @@ constexpr int pick_pf(int nf) {
 
 // MINW = waves per SIMD the register budget is planned for: 3 up to D = 64 (168 VGPRs with a
 // 10..12-deep ring), 2 at D = 80, 1 for D = 96..128 (2 x 16 rows of A fragments alone are
-// 96..128 VGPRs).  bgmm_api.hip sizes the grid (label chunks) to a whole number of residency rounds.
+// 96..128 VGPRs).  api_context.hip (resolve_kind) sizes the grid (label chunks) to a whole number of residency rounds.

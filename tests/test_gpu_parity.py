@@ -1629,7 +1629,7 @@ for N in (70000, 1000003):
 @pytest.mark.parametrize("env,hits", [({}, True), ({"BGMM_PERM_ERA": "5"}, True), ({"BGMM_PERM_CHAIN_ROUNDS": "8"}, False)],
                          ids=["as-shipped", "eras-of-five-generations", "never-settled-in-flight"])
 def test_device_permutations_in_flight(env, hits):
-    """bgmm_api.hip "permutations in flight": generations queued behind the one handed out, each taking its place in the word
+    """api_perm.hip "permutations in flight": generations queued behind the one handed out, each taking its place in the word
     stream from the one in front of it on the device.  Fourteen permutations in a row per N (the rings of slots, order buffers
     and offsets all wrap), a caller that draws from the stream in between (twice), eras of five generations (the stream's
     buffer starts over every few calls), and generations that cannot settle in the rounds queued for them (eight: every one
@@ -2762,7 +2762,7 @@ def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle(or
 
 def test_thirty_two_chains_burn_in_side_by_side_and_equal_their_solo_runs():
     """G = 32 chains of one shape from the reference's "rand" start in ONE group call -- their frozen-factor
-    windows shared in two sub-groups of launches on two streams (bgmm_api.hip: gram_group_launch), a host thread each --
+    windows shared in two sub-groups of launches on two streams (api_group.hip: gram_group_launch), a host thread each --
     every chain label for label its solo run, two sweeps."""
     import random
     from pybgmm_amd import _lib

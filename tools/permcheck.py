@@ -1,4 +1,4 @@
-"""Device permutations in a row against numpy (the generations in flight of bgmm_api.hip), with a caller that draws from the
+"""Device permutations in a row against numpy (the generations in flight of api_perm.hip), with a caller that draws from the
 stream in between, and the time per call:  python tools/permcheck.py [N] [calls]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
