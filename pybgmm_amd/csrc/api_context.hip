@@ -5,6 +5,28 @@
 thread_local std::string g_create_error;
 thread_local std::string *g_err_sink = nullptr;
 
+int bgmm_dev_option(const char *name, int dflt) {
+    // parsed once (C++11 static initialisation is thread safe); unknown names are ignored, malformed values read as 0
+    static const std::vector<std::pair<std::string, int>> opts = [] {
+        std::vector<std::pair<std::string, int>> v;
+        const char *e = getenv("BGMM_DEV_OPTIONS");
+        std::string s = e ? e : "";
+        size_t i = 0;
+        while (i < s.size()) {
+            size_t j = s.find(',', i);
+            if (j == std::string::npos) j = s.size();
+            const std::string item = s.substr(i, j - i);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos && eq > 0) v.emplace_back(item.substr(0, eq), atoi(item.c_str() + eq + 1));
+            i = j + 1;
+        }
+        return v;
+    }();
+    for (const auto &kv : opts)
+        if (kv.first == name) return kv.second;
+    return dflt;
+}
+
 extern "C" const char *bgmm_version(void) { return "bgmm-hip 0.1 gfx950"; }
 
 extern "C" const char *bgmm_last_error(const bgmm_ctx *ctx) {

@@ -105,7 +105,7 @@ int combiner_submit(bgmm_ctx *c, int T) {
 // one sub-group run beside the wide kernels (cross forms, rebuilds) of the others -- with every chain in ONE launch
 // sequence the chip idles through each window's resolver phase and the resolvers wait through its wide phases (eight
 // C4 chains: 201 + 132 us per window whatever runs beside them).  One stream per chain, the other extreme, keeps only
-// about four kernels in flight and stretches every one of them.  BGMM_GROUP_SPLIT
+// about four kernels in flight and stretches every one of them.  BGMM_DEV_OPTIONS group_split
 // overrides the number of sub-groups (1: one launch sequence for all).
 static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of) {
     bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
@@ -118,7 +118,7 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
         if (hipMalloc((void **)&lead->grp_devs, sizeof(Dev) * (size_t)m) != hipSuccess) return 1;
         lead->grp_devs_cap = m;
     }
-    static const int split_env = [] { const char *e = getenv("BGMM_GROUP_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int split_env = bgmm_dev_option("group_split", 0);
     int n_sub = split_env > 0 ? split_env : (m >= 4 ? 2 : 1);
     if (n_sub > m / 2) n_sub = m / 2 > 0 ? m / 2 : 1;
     std::vector<Dev> views((size_t)m);
@@ -275,9 +275,6 @@ extern "C" int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const i
         }
     }
     for (auto &w : workers) w.join();
-    if (getenv("BGMM_DEBUG_GROUP") && !threaded.empty())
-        fprintf(stderr, "[bgmm] group sweep: %zu chains on threads, %lld shared batches of frozen-factor windows, %.1f chains each\n",
-                threaded.size(), comb.shared_batches, comb.shared_batches ? (double)comb.shared_members / (double)comb.shared_batches : 0.0);
     for (int i : threaded)
         if (rc_out[i] < 0 && worst == 0) worst = rc_out[i];
     return worst;

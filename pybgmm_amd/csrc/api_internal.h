@@ -146,7 +146,7 @@ struct bgmm_ctx {
         int nblk_pad = 0;
         int rounds_q = 36;                  // rounds queued per generation (follows what the slowest generation so far needed)
         int rounds_floor = 0;               // ... never fewer than this (raised when a generation did not settle in rounds_q)
-        int rounds_fixed = [] { const char *e = getenv("BGMM_PERM_CHAIN_ROUNDS"); const int v = e ? atoi(e) : 0;
+        int rounds_fixed = [] { const int v = bgmm_dev_option("perm_chain_rounds", 0);
                                 return v < 0 ? 0 : (v > 60 ? 60 : v); }();   // (for the test of that repair)
         int *J[kAhead] = {};
         int *vblk[kAhead] = {};             // a generation's verdicts, laid out like perm_host: [624 key | pos | went through | - |
@@ -238,7 +238,7 @@ struct bgmm_ctx {
     // next, events between the two
     hipStream_t pipe_stream = nullptr;
     std::vector<hipEvent_t> pipe_ev;
-    int pipe_mode = [] { const char *e = getenv("BGMM_GRAM_PIPE"); return e ? atoi(e) : 1; }();   // 0: never (plain windows)
+    int pipe_mode = 1;               // 0: never (plain windows) -- bgmm_set_window_pipeline
     long long pipe_batches = 0, pipe_breaks = 0;
     int pipe_hold = 0;               // plain batches to go before pipelined ones are tried again (after a break)
     int gram_lds = 0;
@@ -251,8 +251,8 @@ struct bgmm_ctx {
     // safe-stay windows (kernels_safe.hip)
     // safe-stay windows: which kind of proof pass the next batch runs (Dev::safe_dense).  -1: the chain decides (dense once the
     // per-home tables left more than half of a batch's visits to the exact forms; looked at again every eighth sweep);
-    // 0 / 1: pinned (BGMM_SAFE_DENSE in the environment, for experiments and tests)
-    int safe_dense_pin = [] { const char *e = getenv("BGMM_SAFE_DENSE"); return e ? atoi(e) : -1; }();
+    // 0 / 1: pinned (bgmm_set_proof_pass, for experiments and tests)
+    int safe_dense_pin = -1;         // (bgmm_set_proof_pass)
     bool safe_dense_on = false;
     int safe_dense_age = 0;
     long long proof_batches[2] = {0, 0};      // batches of safe-stay windows queued with a table / a dense proof pass

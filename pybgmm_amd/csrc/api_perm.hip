@@ -134,7 +134,7 @@ int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
 // ---- permutations in flight ---------------------------------------------------------------------------------------------
 // One generation is a chain of ~0.64 ms at N = 1e6 (words 100 us, 30 rounds of draws 250, the serial tail 84, the swaps 190,
 // verdicts) in front of a pCRP sweep of 0.23 ms -- and the next generation needs only TWO things from it: where its words
-// end, and that they were generated.  So (BGMM_PERM_PIPE=0: the single look-ahead of round 3):
+// end, and that they were generated.  So (BGMM_DEV_OPTIONS perm_pipe=0: the single look-ahead of round 3):
 //   * the words are one long stream (an "era": era_raw[k] = the k-th output behind the state the era began at), generated in
 //     chunks on their own stream far ahead of the draws -- a chunk continues from the last block of the one before it, which
 //     IS the generator's state there;
@@ -148,7 +148,7 @@ int perm_schedule(bgmm_ctx *c, const PermPtrs &P) {
 static void perm_pipe_worker(bgmm_ctx *c);
 
 static bool perm_pipe_wanted() {
-    static const bool on = [] { const char *e = getenv("BGMM_PERM_PIPE"); return !(e && atoi(e) == 0); }();
+    static const bool on = bgmm_dev_option("perm_pipe", 1) != 0;
     return on;
 }
 
@@ -225,8 +225,8 @@ static int perm_pipe_build(bgmm_ctx *c, const PermPtrs &P) {
     const int T = perm_segments(Q.cap_words);
     // the era: 32 generations' worth of words, within 1 GiB AND within a twentieth of the memory that is free now (32 chains
     // side by side at N = 1e6 would otherwise take 8 GB for look-ahead alone), never less than what kAhead + 2 generations
-    // may read (BGMM_PERM_ERA: generations' worth, for the test that walks through several eras)
-    static const int era_gens = [] { const char *e = getenv("BGMM_PERM_ERA"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
+    // may read (BGMM_DEV_OPTIONS perm_era: generations' worth, for the test that walks through several eras)
+    static const int era_gens = [] { const int v = bgmm_dev_option("perm_era", 32); return v < 1 ? 1 : v; }();
     long long cap = era_gens * Q.cap_words;
     if (cap > (1ll << 28)) cap = 1ll << 28;
     {
@@ -263,9 +263,8 @@ static int perm_pipe_build(bgmm_ctx *c, const PermPtrs &P) {
         { int rc = pp_alloc(c, &Q.ord[k], (size_t)N); if (rc) return rc; }
         CK(c, hipHostMalloc((void **)&Q.host[k], sizeof(unsigned) * 1344, hipHostMallocDefault));
         memset(Q.host[k], 0, sizeof(unsigned) * 1344);
-        const unsigned evf = getenv("BGMM_DEBUG_PERM") ? hipEventDefault : hipEventDisableTiming;
-        CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], evf));
-        CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], evf));
+        CK(c, hipEventCreateWithFlags(&Q.ev_draw[k], hipEventDisableTiming));
+        CK(c, hipEventCreateWithFlags(&Q.ev_fin[k], hipEventDisableTiming));
     }
     { int rc = pp_alloc(c, &Q.parked, (size_t)N); if (rc) return rc; }
     {
@@ -293,7 +292,7 @@ static int perm_pipe_build(bgmm_ctx *c, const PermPtrs &P) {
 
 // 0: the pipe stands; 1: it does not and will not (set-up failed -- as a rule: memory --, everything it had taken is
 // released, PermPipe::off is latched): the caller goes on with the single look-ahead, no error.
-// BGMM_PERM_PIPE_FAIL=1 makes the set-up fail after its allocations (the test of this path).
+// BGMM_DEV_OPTIONS perm_pipe_fail=1 makes the set-up fail after its allocations (the test of this path).
 static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
     bgmm_ctx::PermPipe &Q = c->pp;
     if (Q.built) return 0;
@@ -301,12 +300,12 @@ static int perm_pipe_ensure(bgmm_ctx *c, const PermPtrs &P) {
     std::string why;
     g_err_sink = &why;                  // (a failed set-up is not the caller's error: bgmm_ctx::err stays what it was)
     int rc = perm_pipe_build(c, P);
-    if (rc == 0 && getenv("BGMM_PERM_PIPE_FAIL")) {
+    if (rc == 0 && bgmm_dev_option("perm_pipe_fail", 0)) {
         { std::lock_guard<std::mutex> g(Q.mu); Q.quit = true; }
         Q.cv.notify_all();
         if (Q.worker.joinable()) Q.worker.join();
         Q.quit = false;
-        why = "BGMM_PERM_PIPE_FAIL";
+        why = "perm_pipe_fail (BGMM_DEV_OPTIONS)";
         rc = BGMM_EDEVICE;
     }
     g_err_sink = nullptr;
@@ -494,23 +493,6 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
             const unsigned *H = Q.host[slot];
             long long out[2];
             memcpy(out, H + 628, sizeof(out));
-            if (getenv("BGMM_DEBUG_PERM") && Q.gen_next > 8) {
-                // (device time from the end of the previous generation's draws to the end of this one's, and to its swaps')
-                static double sum_d = 0.0, sum_f = 0.0; static long cnt = 0;
-                const int prev = (int)((Q.gen_next - 1) % bgmm_ctx::PermPipe::kAhead);
-                float md = 0.f, mf = 0.f;
-                const hipError_t e1 = hipEventElapsedTime(&md, Q.ev_draw[prev], Q.ev_draw[slot]);
-                const hipError_t e2 = hipEventElapsedTime(&mf, Q.ev_draw[slot], Q.ev_fin[slot]);
-                if (e1 != hipSuccess || e2 != hipSuccess) {
-                    static int said = 0;
-                    if (said++ < 3) fprintf(stderr, "perm pipe: elapsed time failed (%d %d)\n", (int)e1, (int)e2);
-                    (void)hipGetLastError();
-                } else {
-                    sum_d += md; sum_f += mf; cnt += 1;
-                    if (cnt % 50 == 0) fprintf(stderr, "perm pipe: draws %.1f us per generation, swaps %.1f us behind them (%ld generations)\n",
-                                                1e3 * sum_d / cnt, 1e3 * sum_f / cnt, cnt);
-                }
-            }
             std::lock_guard<std::mutex> g(Q.mu);
             if (H[625] == 1 && H[627] == 0 && out[1] == 0 && out[0] > 0) {
                 memcpy(key624, H, sizeof(unsigned) * 624);
@@ -535,13 +517,6 @@ extern "C" int bgmm_stage_permutation_mt19937(bgmm_ctx *c, uint32_t *key624, int
                 Q.rounds_floor = Q.rounds_q + 8 > 60 ? 60 : Q.rounds_q + 8;
                 if (!Q.rounds_fixed) Q.rounds_q = Q.rounds_floor;
             }
-        }
-        if (!hit && getenv("BGMM_DEBUG_PERM")) {
-            const unsigned *H = Q.host[Q.gen_next % bgmm_ctx::PermPipe::kAhead];
-            long long out[2];
-            memcpy(out, H + 628, sizeof(out));
-            fprintf(stderr, "perm pipe miss: same %d queued %d full %d wrc %d gen_next %lld gen_queued %lld target %lld | went through %u changed %u out %lld %lld rounds_q %d\n",
-                    (int)same, (int)queued, (int)Q.full, Q.wrc, Q.gen_next, Q.gen_queued, Q.target, H[625], H[627], out[0], out[1], Q.rounds_q);
         }
         if (!hit) { rc = perm_pipe_drain(c); if (rc) return rc; }
     } else if (!piped && c->perm_ahead_valid) {

@@ -571,9 +571,6 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         if (pos > batch_pos0) recent_rate = (double)(h.n_moves - batch_moves0) / (double)(pos - batch_pos0);
         batch_pos0 = pos; batch_moves0 = h.n_moves;
     }
-    if (getenv("BGMM_DEBUG_PIPE"))
-        fprintf(stderr, "[bgmm] pipelined batches so far %lld, chains broken %lld; this sweep %lld windows\n", c->pipe_batches, c->pipe_breaks,
-                (long long)c->ctrl_host->gram_windows);
     c->last_move_rate = (double)c->ctrl_host->n_moves / (double)(N > 0 ? N : 1);
     const Ctrl &h = *c->ctrl_host;
     c->stats[0] = h.lik_evals; c->stats[1] = h.n_moves; c->stats[2] = h.n_windows;

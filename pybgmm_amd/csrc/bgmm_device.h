@@ -434,6 +434,11 @@ struct PerDeviceLds {
     }
 };
 
+// The ONE gateway to the process environment (api_context.hip): development switches of the tests and tools, read once per
+// process from BGMM_DEV_OPTIONS="name=value,name=value" -- perm_pipe, perm_era, perm_chain_rounds, perm_pipe_fail, perm_rounds,
+// perm_tail_log2, group_split.  Everything a user may want to set has an entry point (include/bgmm.h: bgmm_set_*).
+int bgmm_dev_option(const char *name, int dflt);
+
 // ---- host-side launchers (each defined next to its kernels) -------------------------------
 void launch_init_stats(const Dev &d, const int *members, const long long *offsets, int K_init,
                        hipStream_t st);

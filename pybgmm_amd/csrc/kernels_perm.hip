@@ -45,17 +45,16 @@ __device__ __forceinline__ unsigned perm_temper(unsigned y) {
 }
 
 static constexpr int kPermRoundsDefault = 30;   // rounds of draws queued at a time (those behind the write pass return at once)
-// (BGMM_PERM_ROUNDS in the environment, 3 .. 56: for the test that drives the "not settled yet, more rounds" repair)
+// (BGMM_DEV_OPTIONS perm_rounds, 3 .. 56: for the test that drives the "not settled yet, more rounds" repair)
 static int perm_rounds_now() {
     static const int r = [] {
-        const char *e = getenv("BGMM_PERM_ROUNDS");
-        const int v = e ? atoi(e) : kPermRoundsDefault;
+        const int v = bgmm_dev_option("perm_rounds", kPermRoundsDefault);
         return v < 3 ? 3 : (v > 56 ? 56 : v);
     }();
     return r;
 }
-// steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel); BGMM_PERM_TAIL_LOG2 overrides (10 .. 16)
-static const int kPermTailLow = [] { const char *e = getenv("BGMM_PERM_TAIL_LOG2"); const int v = e ? atoi(e) : 14;
+// steps below this are served by ONE wavefront behind the rounds (perm_tail_kernel); BGMM_DEV_OPTIONS perm_tail_log2 overrides (10 .. 16)
+static const int kPermTailLow = [] { const int v = bgmm_dev_option("perm_tail_log2", 14);
                                      return 1 << (v < 10 ? 10 : (v > 16 ? 16 : v)); }();
 static constexpr int kPermSeg = 1024;      // words per segment (one wavefront, 4 KB of LDS)
 int perm_segments(long long n_avail) { return (int)((n_avail + kPermSeg - 1) / kPermSeg); }

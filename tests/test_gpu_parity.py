@@ -717,7 +717,7 @@ def test_dense_and_table_proof_passes_give_the_same_chain():
     """Safe-stay windows prove which visits stay in two ways: through the per-home bound tables + the pruning kernel's exact
     forms, or DENSELY (every (visit, label) pair of a stretch through the likelihood kernel, bgmm_get_proof_pass_stats).
     On overlapping clusters the chain picks the dense pass by itself after its first batch; pinned to either kind
-    (BGMM_SAFE_DENSE, read when the context is made) the labels, the log marginal, the windows and the visits left on the
+    (bgmm_set_proof_pass) the labels, the log marginal, the windows and the visits left on the
     resolver's chain are the same -- which kind runs changes the cost, never the chain."""
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
@@ -726,28 +726,18 @@ def test_dense_and_table_proof_passes_give_the_same_chain():
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     us = np.random.RandomState(8).random_sample((3, N))
     out = {}
-    old = os.environ.get("BGMM_SAFE_DENSE")
-    try:
-        for pin in ("0", "1", None):
-            if pin is None:
-                os.environ.pop("BGMM_SAFE_DENSE", None)
-            else:
-                os.environ["BGMM_SAFE_DENSE"] = pin
-            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
-            ctx.set_assignments(zt)
-            zs, ss = [], []
-            for it in range(3):
-                ctx.sweep(us[it])
-                zs.append(ctx.assignments())
-                st = ctx.safe_stats()
-                ss.append((st["windows"], st["unproven_walked"], st["budget_cuts"], ctx.sweep_stats()["moves"]))
-            out[pin] = (zs, ss, ctx.log_marg(), ctx.proof_pass_stats())
-            ctx.close()
-    finally:
-        if old is None:
-            os.environ.pop("BGMM_SAFE_DENSE", None)
-        else:
-            os.environ["BGMM_SAFE_DENSE"] = old
+    for pin in ("0", "1", None):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        ctx.set_proof_pass(-1 if pin is None else int(pin))
+        ctx.set_assignments(zt)
+        zs, ss = [], []
+        for it in range(3):
+            ctx.sweep(us[it])
+            zs.append(ctx.assignments())
+            st = ctx.safe_stats()
+            ss.append((st["windows"], st["unproven_walked"], st["budget_cuts"], ctx.sweep_stats()["moves"]))
+        out[pin] = (zs, ss, ctx.log_marg(), ctx.proof_pass_stats())
+        ctx.close()
     assert sum(s[0] for s in out["0"][1]) > 0, "the case is meant to run safe-stay windows"
     assert sum(s[3] for s in out["0"][1]) > 50, "the case is meant to have movers"
     assert out["0"][3]["dense_batches"] == 0 and out["0"][3]["table_batches"] > 0
@@ -1575,7 +1565,7 @@ def test_device_permutation_equals_numpy(N):
 
 
 def _permutations_in_a_process(env, body):
-    """Runs `body` (python source; `ctx_for(N)` and numpy in scope) in a process of its own: the library reads BGMM_PERM_* when it
+    """Runs `body` (python source; `ctx_for(N)` and numpy in scope) in a process of its own: the library reads BGMM_DEV_OPTIONS when it
     is loaded."""
     import subprocess
     import sys
@@ -1614,9 +1604,9 @@ print("PERMUTATIONS OK")
 def test_device_permutation_repairs_draws_that_have_not_settled():
     """The rounds of the permutation's draws are queued blindly, a fixed number at a time; when they have not settled by
     then, more rounds are queued and everything behind the draws runs again.  With the number of rounds cut to 5
-    (BGMM_PERM_ROUNDS, read when the library is loaded: a process of its own; BGMM_PERM_PIPE=0: the route that generates one
-    permutation at a time) that repair runs for every permutation -- which must still be numpy's, generator state included."""
-    _permutations_in_a_process({"BGMM_PERM_ROUNDS": "5", "BGMM_PERM_PIPE": "0"}, """
+    (BGMM_DEV_OPTIONS perm_rounds, read when the library is loaded: a process of its own; perm_pipe=0: the route that generates
+    one permutation at a time) that repair runs for every permutation -- which must still be numpy's, generator state included."""
+    _permutations_in_a_process({"BGMM_DEV_OPTIONS": "perm_rounds=5,perm_pipe=0"}, """
 for N in (70000, 1000003):
     ctx = ctx_for(N)
     in_a_row(ctx, N, 3)
@@ -1626,7 +1616,7 @@ for N in (70000, 1000003):
 """)
 
 
-@pytest.mark.parametrize("env,hits", [({}, True), ({"BGMM_PERM_ERA": "5"}, True), ({"BGMM_PERM_CHAIN_ROUNDS": "8"}, False)],
+@pytest.mark.parametrize("env,hits", [({}, True), ({"BGMM_DEV_OPTIONS": "perm_era=5"}, True), ({"BGMM_DEV_OPTIONS": "perm_chain_rounds=8"}, False)],
                          ids=["as-shipped", "eras-of-five-generations", "never-settled-in-flight"])
 def test_device_permutations_in_flight(env, hits):
     """api_perm.hip "permutations in flight": generations queued behind the one handed out, each taking its place in the word
@@ -1645,11 +1635,11 @@ for N in (4096, 100003, 1000000):
 
 
 def test_permutations_in_flight_that_cannot_be_set_up_leave_the_single_lookahead():
-    """set-up of the permutations in flight is all or nothing.  BGMM_PERM_PIPE_FAIL makes it fail after all its
+    """set-up of the permutations in flight is all or nothing.  BGMM_DEV_OPTIONS perm_pipe_fail=1 makes it fail after all its
     allocations: everything it took is released, the state is latched off (bgmm_get_permutation_pipe_state), no stage call
     returns an error, and the single look-ahead of round 3 serves from there -- numpy's permutations and states, ten in a
     row with a foreign draw, and look-ahead hits among them."""
-    _permutations_in_a_process({"BGMM_PERM_PIPE_FAIL": "1"}, """
+    _permutations_in_a_process({"BGMM_DEV_OPTIONS": "perm_pipe_fail=1"}, """
 for N in (4096, 200000):
     ctx = ctx_for(N)
     in_a_row(ctx, N, 10, disturb_at=(4,))
@@ -1722,7 +1712,7 @@ def test_device_permutations_in_flight_soak():
     """The same over many calls (tools/permsoak.py is the long version): 1 500 permutations of 4 097 points in a row from one
     context, eras of three generations (the word stream's buffer starts over every other call), the caller drawing from the
     stream at 45 random moments -- every permutation and every state numpy's."""
-    _permutations_in_a_process({"BGMM_PERM_ERA": "3"}, """
+    _permutations_in_a_process({"BGMM_DEV_OPTIONS": "perm_era=3"}, """
 dice = np.random.RandomState(7)
 ctx = ctx_for(4097)
 in_a_row(ctx, 4097, 1500, disturb_at=set(dice.randint(0, 1500, size=45).tolist()))

@@ -1,6 +1,6 @@
 """Soak of the device permutations in flight against numpy: many calls in a row, the caller drawing from the stream at random
 moments, every permutation and every state compared:  python tools/permsoak.py N calls [seed]
-(BGMM_PERM_ERA=3 in the environment makes the word stream's buffer start over every couple of calls.)"""
+(BGMM_DEV_OPTIONS=perm_era=3 in the environment makes the word stream's buffer start over every couple of calls.)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
