@@ -830,9 +830,12 @@ def main():
     if dist is not None:
         dist.broadcast_object_list(ident, src=0)
     comm = _lib.Comm(rank, world, ident[0], device=local_rank)
-    z_abi = ctx.gather_labels(comm, world)
-    comm.close()
+    t_comm_create = time.time() - t0                 # (librccl loaded + ncclCommInitRank: once per process, ~6 s)
+    z_abi = ctx.gather_labels(comm, world)           # (first collective on the communicator)
+    t0 = time.time()
+    z_abi = ctx.gather_labels(comm, world)           # the gather itself, communicator in hand -- what a run pays per gather
     t_gather_abi = time.time() - t0
+    comm.close()
     if not np.array_equal(z_abi, z_all):
         raise SystemExit("bench.py: bgmm_gather_labels and chains.gather_chains disagree on rank %d" % rank)
     ctx.close()
@@ -951,6 +954,7 @@ def main():
                       "roofline_other_modes": extra_rooflines or None,
                       "label_gather_s": round(t_gather, 4),
                       "label_gather_c_abi_s": round(t_gather_abi, 4),
+                      "label_gather_c_abi_comm_create_s": round(t_comm_create, 3),
                       "label_gathers_agree": True,
                       "sweeps_per_s_per_rank": per_rank_rate,
                       "gathered_shape": list(z_all.shape)},
