@@ -92,9 +92,11 @@ def prior_for(cov, D):
 
 
 def cpu_baseline(D, K, seed, budget_visits, cov="full", threads=1):
-    """C oracle (oracle/gibbs_oracle.c, scalar arithmetic; `threads` = 1: the single-core port, > 1: a visit's K
-    evaluations shared over that many host threads, bit-identical floats) on a down-sized twin of the
-    workload: same D, K, prior, init-at-truth; per-visit cost does not depend on N."""
+    """C oracle (oracle/gibbs_oracle.c: the reference's algorithm one visit at a time, its inner loops walked row-wise so
+    that gcc vectorises them -- the same additions in the same order) on ONE thread, on a down-sized twin of the workload:
+    same D, K, prior, init-at-truth; per-visit cost does not depend on N.  (The oracle can share a visit's K evaluations
+    over threads with the same floats, but on the GPU box's 256-core host a hand-over between cores costs ~20 us and 32
+    threads run the C4 shape three times SLOWER than one -- profiles/r06/oracle_threads.txt: no threaded leg.)"""
     from oracle import c_oracle
     from pybgmm_amd.utils import gendata
     c_oracle.set_threads(threads)
@@ -871,15 +873,6 @@ def main():
                "us_per_visit": round(per_visit * 1e6, 2),
                "lik_evals_per_s": round(cpu_lik / (per_visit * args.cpu_visits), 1),
                "reference_python_us_per_visit_survey_container": REFERENCE_US_PER_VISIT.get(args.workload)}
-        n_host = len(os.sched_getaffinity(0))
-        if n_host > 1:
-            # the same port with a visit's K evaluations shared over the box's host cores (the K loop of
-            # gaussian_components.py:228-251 is the reference's one vectorised step: what a multi-threaded BLAS would spread)
-            nt = min(32, n_host)
-            pv_t, _, _, _ = cpu_baseline(D, K, args.seed + 7, args.cpu_visits, args.cov, threads=nt)
-            cpu["threaded"] = {"value": round(1.0 / (pv_t * N), 8), "unit": "sweeps/s", "cores": nt, "kind": "port",
-                               "us_per_visit": round(pv_t * 1e6, 2),
-                               "sample": "the same %d visits, K loop + inverse columns over %d OpenMP threads" % (args.cpu_visits, nt)}
         if args.numpy_visits > 0 and args.cov == "full":
             npv, n_np = cpu_baseline_numpy(D, K, args.seed + 7, args.numpy_visits)
             cpu["numpy_restatement"] = {

@@ -903,10 +903,13 @@ _case_c4_full.cost = lambda: 1000000 * 200 * 64 * 64
 
 
 def _case_c5_part():
-    return _case_wrong_labels(50000, 128, 200, 400, seed=2, rs_seed=128, n_sweeps=2, pcrp=True)
+    case = _case_wrong_labels(200000, 128, 200, 800, seed=2, rs_seed=128, n_sweeps=2, pcrp=True)
+    u, order, power = case["sweeps"][1]
+    case["sweeps"][1] = (u, order, power, 40000)          # (the second sweep -- powered weights -- for its first 40 000 visits)
+    return case
 
 
-_case_c5_part.cost = lambda: 2 * 50000 * 200 * 128 * 128
+_case_c5_part.cost = lambda: 240000 * 200 * 128 * 128
 
 
 def _case_c3_full():
@@ -925,7 +928,10 @@ def _wrong_labels_against_the_oracle(case, ref):
         ctx.set_tuning(prune_mode=prune)
         ctx.set_assignments(case["z0"])
         moves = 0
-        for it, (u, order, power) in enumerate(case["sweeps"]):
+        for it, sw in enumerate(case["sweeps"]):
+            u, order, power, n_vis = (tuple(sw) + (None,))[:4]
+            if n_vis is not None:
+                ctx.set_sweep_visits(n_vis)
             ctx.sweep(u, order, power)
             assert_same_labels(ctx.assignments(), ref[it]["z"], "prune_mode %d, sweep %d" % (prune, it))
             assert abs(ctx.log_marg() - ref[it]["log_marg"]) <= 1e-9 * abs(ref[it]["log_marg"])
@@ -939,10 +945,10 @@ def _wrong_labels_against_the_oracle(case, ref):
 def test_c4_full_size_against_c_oracle(oracle_ref):
     """BASELINE's C4 at FULL size (N = 1e6, D = 64, K = 200) against the C port of the reference: the truth
     with 2 000 wrong labels, one whole sweep in the default configuration and in the benchmarked mode, every label and the
-    log marginal.  The oracle needs ~7 minutes of one host core for it (0.4 ms per visit: 6.5 MB of inverse covariances
-    streamed per visit); since round 6 the heavy cases' oracles all run side by side from the start of the session, each
-    on a core of its own (tests/oracle_pool.py), and this one is simply the last to finish.  Rounds 3 - 5 stopped at
-    N = 1.2e5 - 2.5e5."""
+    log marginal.  The oracle needs ~3 minutes of one host core for it (0.17 ms per visit since its loops walk the 6.5 MB of
+    inverse covariances row-wise); since round 6 the heavy cases' oracles all run side by side from the start of the
+    session, each on a core of its own (tests/oracle_pool.py), and this one is simply among the last to finish.  Rounds
+    3 - 5 stopped at N = 1.2e5 - 2.5e5."""
     _wrong_labels_against_the_oracle(*oracle_ref)
 
 
@@ -959,11 +965,11 @@ def test_c3_full_size_against_c_oracle(oracle_ref):
 @pytest.mark.slow
 @with_oracle(_case_c5_part)
 def test_c5_shape_against_c_oracle(oracle_ref):
-    """BASELINE's C5 shape (PCRPMM, D = 128, K = 200, full covariance) at N = 5e4 against the C port of the reference
-    (rounds 4 - 5: N = 8 000 - 16 000): the truth with 400 wrong labels, two pCRP sweeps -- a fresh
-    permutation each, powered seating weights from the second on (igmm/pcrpmm.py:86-131) -- in the default configuration
-    and in the benchmarked mode.  3.6 ms per oracle visit: ~6 minutes of a host core, side by side with the others
-    (N = 2e5 would be 24 minutes: the session's limit is 20)."""
+    """BASELINE's C5 shape (PCRPMM, D = 128, K = 200, full covariance) at N = 2e5 against the C port of the reference
+    (rounds 4 - 5: N = 8 000 - 16 000): the truth with 800 wrong labels, a whole pCRP sweep and the first
+    40 000 visits of a second one -- a fresh permutation each, powered seating weights in the second
+    (igmm/pcrpmm.py:86-131) -- in the default configuration and in the benchmarked mode.  0.78 ms per oracle visit:
+    ~3 minutes of a host core, side by side with the others."""
     _wrong_labels_against_the_oracle(*oracle_ref)
 
 
