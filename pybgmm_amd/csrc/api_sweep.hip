@@ -289,10 +289,7 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         }
         // (beside other chains of a group call: a batch of frozen-factor windows is queued together with theirs -- declared
         // when it is submitted; any other kind of batch is this chain's own business, and nobody waits for it meanwhile)
-        // (BGMM_DEV_OPTIONS group_own=1: the chains of a group call do not share launches -- each pipelines its windows on its
-        //  own two streams, as a chain on its own does; an experiment against the shared launches)
-        static const bool group_own = bgmm_dev_option("group_own", 0) != 0;
-        if (c->combiner && (group_own || !(use_gram && !c->timing))) combiner_declare_busy(c);
+        if (c->combiner && !(use_gram && !c->timing)) combiner_declare_busy(c);
         if (use_safe) {
             const Ctrl &hc = *c->ctrl_host;
             // windows still needed: from the visits a window has covered on average so far in this sweep
@@ -401,14 +398,14 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             first_batch = false;
             // (chains of a group call that are here together share the launches: GramCombiner above)
             int own = 1;
-            if (c->combiner && !c->timing && !group_own) {
+            if (c->combiner && !c->timing) {
                 own = combiner_submit(c, (int)Tg);
                 if (own < 0) return fail(c, BGMM_EDEVICE, "shared frozen-factor launch failed");
             }
             // (a chain on its own, far inside the mover-dense regime: the windows pipelined -- gram_finish and the next cross
             //  forms on a second stream beside the resolver; after a break of the chain a couple of plain batches first)
             bool piped = false;
-            if (own && c->pipe_mode && (!c->combiner || group_own) && !c->timing && c->resolver_mode != 1 && remaining >= 4 * kGramRows &&
+            if (own && c->pipe_mode && !c->combiner && !c->timing && c->resolver_mode != 1 && remaining >= 4 * kGramRows &&
                 (was_first || hc.job.pos == pos)) {
                 if (c->pipe_hold > 0) c->pipe_hold -= 1;
                 else {
