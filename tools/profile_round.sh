@@ -9,7 +9,7 @@
 # 4. kernel trace of the burn-in regime alone (C4 from a random start, two sweeps),
 # 5. the other BASELINE shapes' bench lines.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -43,4 +43,7 @@ for WL in C3 C5 C2; do
     python bench.py --workload $WL --steps 300 --keep-pmc "$OUT" > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
     tail -c 300 "$OUT/bench_$WL.json"
 done
+# 6. SQ counters of home_kernel at rest (C4, C3) and the FP64 matrix pipe's sustained rate
+for WL in C4 C3; do bash tools/pmc_home.sh $WL > "$OUT/pmc_sq_home_$WL.txt" 2>&1; done
+[ -x tools/mfma_f64_peak ] && tools/mfma_f64_peak > "$OUT/mfma_f64_peak.txt" 2>&1
 rm -rf "$OUT/kt" "$OUT/ktb" "$OUT/ktm" "$OUT/pmcm" "$OUT/kt3" "$OUT/ktb5"
