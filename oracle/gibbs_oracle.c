@@ -193,6 +193,15 @@ static int lu_factor(double *a, int64_t n, int64_t *piv) {
         }
         double d = a[j * n + j];
         if (d == 0.0) continue;
+        if (n < 8) {            /* (tiny n: in place, no hand-over) */
+            for (int64_t i = j + 1; i < n; ++i) {
+                double l = a[i * n + j] / d;
+                a[i * n + j] = l;
+                if (l != 0.0)
+                    for (int64_t c = j + 1; c < n; ++c) a[i * n + c] -= l * a[j * n + c];
+            }
+            continue;
+        }
         lu_job_t J = {a, n, j, d};
         const int64_t rows = n - j - 1;
         int nt = n >= 64 ? go_threads : 1;
@@ -244,8 +253,28 @@ GO_HOT static void lu_inverse_cols(void *argp, int64_t lo, int64_t hi, int tid) 
         for (int64_t c = 0; c < w; ++c) yi[c] = yi[c] / d;
     }
 }
-static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col_all) {
-    (void)col_all;
+static void lu_inverse(const double *lu, const int64_t *piv, int64_t n, double *out, double *col) {
+    if (n < 8) {                /* (tiny n: a column at a time -- the same subtractions in the same order) */
+        for (int64_t c = 0; c < n; ++c) {
+            for (int64_t i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+            for (int64_t j = 0; j < n; ++j) {
+                int64_t p = piv[j];
+                if (p != j) { double t = col[j]; col[j] = col[p]; col[p] = t; }
+            }
+            for (int64_t i = 0; i < n; ++i) {
+                double s = col[i];
+                for (int64_t t = 0; t < i; ++t) s -= lu[i * n + t] * col[t];
+                col[i] = s;
+            }
+            for (int64_t i = n - 1; i >= 0; --i) {
+                double s = col[i];
+                for (int64_t t = i + 1; t < n; ++t) s -= lu[i * n + t] * col[t];
+                col[i] = s / lu[i * n + i];
+            }
+            for (int64_t i = 0; i < n; ++i) out[i * n + c] = col[i];
+        }
+        return;
+    }
     inv_job_t J = {lu, piv, n, out};
     /* (a column is ~2 n^2 flop: shared out only where a share is worth a hand-over) */
     int nt = go_threads;
@@ -378,7 +407,7 @@ static void unseat(go_t *g, int64_t i) {
     refresh_cov(g, k);
 }
 
-GO_HOT static double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
+GO_HOT static double student_t_wide(const go_t *g, const double *x, const double *mu_num, double k_N,
                         double logdet, const double *inv, int64_t nu, double *delta) {
     int64_t D = g->D;
     if (g->diag == 2) {         /* product of univariate normals: gaussian_components_fixedvar.py:293-303;
@@ -403,18 +432,82 @@ GO_HOT static double student_t(const go_t *g, const double *x, const double *mu_
      * The inner sums run over b ascending for every a, as a scalar loop over a would have them: with b outermost the SAME
      * additions happen in the SAME order per a (r[a] += delta[b] * inv[b][a], product and sum rounded separately), but
      * the memory is walked row by row and the compiler may keep several a in one vector register.  delta[D .. 2D) is r. */
-    double *restrict r = delta + D;
-    for (int64_t a = 0; a < D; ++a) { delta[a] = mu_num[a] / k_N - x[a]; r[a] = 0.0; }
-    for (int64_t b = 0; b < D; ++b) {
-        const double db = delta[b];
-        const double *restrict row = inv + b * D;
-        for (int64_t a = 0; a < D; ++a) r[a] += db * row[a];
-    }
     double q = 0.0;
-    for (int64_t a = 0; a < D; ++a) q += r[a] * delta[a];
+    if (D < 8) {                /* (tiny D: the plain column loop -- the same sums; vector set-up would cost more than it saves) */
+        for (int64_t a = 0; a < D; ++a) delta[a] = mu_num[a] / k_N - x[a];
+        for (int64_t a = 0; a < D; ++a) {
+            double r = 0.0;
+            for (int64_t b = 0; b < D; ++b) r += delta[b] * inv[b * D + a];
+            q += r * delta[a];
+        }
+    } else {
+        double *restrict r = delta + D;
+        for (int64_t a = 0; a < D; ++a) { delta[a] = mu_num[a] / k_N - x[a]; r[a] = 0.0; }
+        for (int64_t b = 0; b < D; ++b) {
+            const double db = delta[b];
+            const double *restrict row = inv + b * D;
+            for (int64_t a = 0; a < D; ++a) r[a] += db * row[a];
+        }
+        for (int64_t a = 0; a < D; ++a) q += r[a] * delta[a];
+    }
     double hd = (double)D / 2.;
     return g->tab_lgam[nu + D] - g->tab_lgam[nu] - hd * g->tab_log[nu] - hd * LOG_PI
            - 0.5 * logdet - (double)(nu + D) / 2. * log(1 + 1. / (double)nu * q);
+}
+
+static double student_t_plain(const go_t *g, const double *x, const double *mu_num, double k_N,
+                        double logdet, const double *inv, int64_t nu, double *delta) {
+    int64_t D = g->D;
+    if (g->diag == 2) {         /* product of univariate normals: gaussian_components_fixedvar.py:293-303;
+                                   mu_num / k_N is the mean (callers pass k_N = 1 and a ready mean) */
+        double acc = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double dl = x[a] - mu_num[a] / k_N;
+            acc += (dl * dl) * inv[a];
+        }
+        return -0.5 * (double)D * log(2. * 3.14159265358979323846) + 0.5 * logdet - 0.5 * acc;
+    }
+    if (g->diag) {              /* product of univariate Student-t: gaussian_components_diag.py:340-354 */
+        double acc = 0.0;
+        for (int64_t a = 0; a < D; ++a) {
+            double dl = x[a] - mu_num[a] / k_N;
+            acc += log(1. + 1. / (double)nu * (dl * dl) * inv[a]);
+        }
+        return (double)D * (g->tab_lgam[nu + 1] - g->tab_lgam[nu] - 0.5 * g->tab_log[nu] - 0.5 * LOG_PI)
+               - 0.5 * logdet - ((double)nu + 1.) / 2. * acc;
+    }
+    /* q = sum_a (sum_b delta[b] inv[b][a]) delta[a] -- the reference's einsum pair (gaussian_components.py:240-244).
+     * The inner sums run over b ascending for every a, as a scalar loop over a would have them: with b outermost the SAME
+     * additions happen in the SAME order per a (r[a] += delta[b] * inv[b][a], product and sum rounded separately), but
+     * the memory is walked row by row and the compiler may keep several a in one vector register.  delta[D .. 2D) is r. */
+    double q = 0.0;
+    if (D < 8) {                /* (tiny D: the plain column loop -- the same sums; vector set-up would cost more than it saves) */
+        for (int64_t a = 0; a < D; ++a) delta[a] = mu_num[a] / k_N - x[a];
+        for (int64_t a = 0; a < D; ++a) {
+            double r = 0.0;
+            for (int64_t b = 0; b < D; ++b) r += delta[b] * inv[b * D + a];
+            q += r * delta[a];
+        }
+    } else {
+        double *restrict r = delta + D;
+        for (int64_t a = 0; a < D; ++a) { delta[a] = mu_num[a] / k_N - x[a]; r[a] = 0.0; }
+        for (int64_t b = 0; b < D; ++b) {
+            const double db = delta[b];
+            const double *restrict row = inv + b * D;
+            for (int64_t a = 0; a < D; ++a) r[a] += db * row[a];
+        }
+        for (int64_t a = 0; a < D; ++a) q += r[a] * delta[a];
+    }
+    double hd = (double)D / 2.;
+    return g->tab_lgam[nu + D] - g->tab_lgam[nu] - hd * g->tab_log[nu] - hd * LOG_PI
+           - 0.5 * logdet - (double)(nu + D) / 2. * log(1 + 1. / (double)nu * q);
+}
+
+/* (the vector clones pay from D = 8 on; below, the baseline build of the same function) */
+static inline double student_t(const go_t *g, const double *x, const double *mu_num, double k_N,
+                               double logdet, const double *inv, int64_t nu, double *delta) {
+    return g->D < 8 ? student_t_plain(g, x, mu_num, k_N, logdet, inv, nu, delta)
+                    : student_t_wide(g, x, mu_num, k_N, logdet, inv, nu, delta);
 }
 
 /* ------------------------------------------------------------------------- */
