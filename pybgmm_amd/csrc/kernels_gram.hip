@@ -1094,6 +1094,9 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
                 c->safe_epoch_valid = 0;
                 long long L = next_pos >= c->gl_stretch_end && S.cut == 0 ? 2ll * (c->gl_stretch_end - c->safe_epoch_pos0)
                                                                           : 2ll * (next_pos - c->safe_epoch_pos0) + 64;
+                // (one window per stretch with the look-ahead -- kernels_safe.hip: safe_compact_kernel: a cut says nothing about
+                //  how far the next window's worth of unproven visits reaches; the stretch keeps its length)
+                if (d.safe_dense && d.ahead_C > 0 && S.cut != 0 && L < c->safe_L) L = c->safe_L;
                 if (L < 1024) L = 1024;
                 if (L > (1ll << 22)) L = 1ll << 22;
                 c->safe_L = (int)L;

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long base = c->job.win_base;
     const int nrows = (int)(c->job.win_hi - base);
+    // With the look-ahead's ring a proof pass is a verdict kernel, not a likelihood launch, and what a step costs is its
+    // window's fixed part (cross forms, weights, finish, ten launches): the stretch then ends right behind the visits that
+    // FILL one window -- the list holds kGramRows of them, the next stretch starts at the one after -- instead of carrying
+    // a list whose last window is a partial one.
+    const int cap = (d.safe_dense && d.ahead_C > 0) ? kGramRows : kSafeList;
     const int per = ((nrows + 1023) / 1024 + 15) & ~15;             // (16-byte pieces)
     const int lo = threadIdx.x * per, hi = lo + per < nrows ? lo + per : nrows;
     int cnt = 0;
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
     int total = 0;
     for (int k = 0; k < 16; ++k) total += wsum[k];
     if (threadIdx.x == 0) {
-        c->gl_total = total < kSafeList ? total : kSafeList;
-        if (total <= kSafeList) c->gl_stretch_end = base + nrows;
+        c->gl_total = total < cap ? total : cap;
+        if (total <= cap) c->gl_stretch_end = base + nrows;
         c->gl_off = 0;
         c->safe_epoch_pos0 = base;
         c->safe_scanned += nrows;
@@ -244,10 +249,10 @@ __global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
         c->safe_epoch_built = d.safe_dense ? -1 : c->state_epoch;
         c->safe_cap_built = safe_cap_now(d, c);         // (the budget the resolver enforces: kernels_gram.hip)
     }
-    if (cnt > 0 && rank <= kSafeList) {
-        for (int r = lo; r < hi && rank <= kSafeList; ++r) {
+    if (cnt > 0 && rank <= cap) {
+        for (int r = lo; r < hi && rank <= cap; ++r) {
             if (d.cert[r]) continue;
-            if (rank < kSafeList) d.glist[rank] = base + r;
+            if (rank < cap) d.glist[rank] = base + r;
             else c->gl_stretch_end = base + r;                        // the first visit the list has no room for
             ++rank;
         }
