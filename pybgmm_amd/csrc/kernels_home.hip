@@ -113,6 +113,14 @@ __device__ __forceinline__ double home_row_sum4(const double (&a)[4], int lane) 
     return c;
 }
 
+// minorant of log(1 + t), t >= 0 (kernels_prune.hip: log1p_lower): 1 + t = m 2^e, the chord of log over [0.5, 1]
+__device__ __forceinline__ double home_log1p_lower(double t) {
+    const double y = 1.0 + t;
+    const double m = __builtin_amdgcn_frexp_mant(y);
+    const int e = __builtin_amdgcn_frexp_exp(y);
+    return 0.6931471805599453 * ((double)(e - 2) + 2.0 * m);
+}
+
 // WHOLE: D is a multiple of 16 (no padded columns: every 16-byte piece of a tile lies inside its row)
 template <int NJ, bool WHOLE, bool SAFE>
 __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev d) {
@@ -490,14 +498,33 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
             // radius from above by the hardware square root rounded up (the table grows with the radius).  A row with
             // vnew < vh_lb - 37.5 and every other component below vh_lb - margin is exactly a row the exact tail lets stay
             // without its uniform (dv < -37 there): the same decision, nothing else is left behind when the caches are off.
+            // Round 6, D = 16 / 32 too (SQ counters: ~1 600 VALU instructions per 64 rows there, the software logarithms and
+            // exponentials of up to six candidates per row, the matrix pipe 26 % busy): where the first table does not exclude
+            // everybody, the neighbours' EXACT forms are at hand (sideQn) and bound their scores from above without a
+            // logarithm -- log(1 + t) >= t - t^2 / 2 for small t (their components are large: t = q / v ~ 0.01, the bound is
+            // tight to 1e-6 nats), the frexp chord beyond -- and the second table excludes the rest.
             bool all_fast = false;
-            if (NB == 0 && !keep_caches && nh >= 2) {
+            if (!keep_caches && nh >= 2) {
                 const double den = 1.0 - a1 * q_t;
                 const double t_ub = coef1 * q_t * __builtin_amdgcn_rcp(den) * (1.0 + 1e-6);
                 const double vh_lb = base1 - half_vd1 * t_ub;
                 const double jf_ub = __builtin_amdgcn_sqrt(rho2_t) * (1.0 + 1e-6) * finv_a;
-                const bool fast = den > 0.5 && q_t >= 0.0 && jf_ub < 62.0 && rcur.mlb0 < vh_lb - 37.5 &&
-                                  hft[(int)jf_ub + 1] < vh_lb - margin;
+                bool fast = den > 0.5 && q_t >= 0.0 && jf_ub < 62.0 && rcur.mlb0 < vh_lb - 37.5;
+                const int jt = jf_ub < 62.0 ? (int)jf_ub + 1 : 63;
+                bool others = hft[jt] < vh_lb - margin;
+                if (NB > 0 && !others) {
+                    others = hft2[jt] < vh_lb - margin;
+                    const int nn = ncand[0];
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) {
+                        if (m >= nn) continue;
+                        double t = sideQn[m * 64 + lane] * nsc[m * 8 + 2];
+                        t = t > 0.0 ? t : 0.0;
+                        const double lo = t < 0.25 ? t * (1.0 - 0.5 * t) : home_log1p_lower(t);
+                        others = others && (nsc[m * 8] - nsc[m * 8 + 1] * lo < vh_lb - margin);
+                    }
+                }
+                fast = fast && others;
                 all_fast = __ballot(!fast) == 0ull;
             }
             if (all_fast) {
