@@ -509,7 +509,12 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 const double t_ub = coef1 * q_t * __builtin_amdgcn_rcp(den) * (1.0 + 1e-6);
                 const double vh_lb = base1 - half_vd1 * t_ub;
                 const double jf_ub = __builtin_amdgcn_sqrt(rho2_t) * (1.0 + 1e-6) * finv_a;
-                bool fast = den > 0.5 && q_t >= 0.0 && jf_ub < 62.0 && rcur.mlb0 < vh_lb - 37.5;
+                // (the new table: below e^-37.5 of the home it does not exist for the draw; up to e^-20 = 2.1e-9 of it, it takes
+                //  the visit only for a uniform beyond 1 - 2.1e-9 -- the reference's scan, utils.py:15-20, subtracts the home's
+                //  probability >= 1 - 2.1e-9 from u minus at most 3e-17: negative for every u <= 1 - 1e-8.  At D = 16 the prior
+                //  predictive sits 24 - 45 nats below a point's own component: 70 % pass the first test, all the second.)
+                bool fast = den > 0.5 && q_t >= 0.0 && jf_ub < 62.0 &&
+                            (rcur.mlb0 < vh_lb - 37.5 || (u_in_rec && rcur.mlb0 < vh_lb - 20.0 && rcur.u <= 1.0 - 1e-8));
                 const int jt = jf_ub < 62.0 ? (int)jf_ub + 1 : 63;
                 bool others = hft[jt] < vh_lb - margin;
                 if (NB > 0 && !others) {
