@@ -531,6 +531,20 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
                 }
                 fast = fast && others;
                 all_fast = __ballot(!fast) == 0ull;
+#ifdef BGMM_HOME_PROF
+                {   // (why a wavefront takes the exact tail: rows failing the new-table test / the tables + neighbours / the rest)
+                    const bool f_new = rcur.mlb0 < vh_lb - 37.5 || (u_in_rec && rcur.mlb0 < vh_lb - 20.0 && rcur.u <= 1.0 - 1e-8);
+                    const unsigned long long m0 = __ballot(true), m1 = __ballot(!f_new), m2 = __ballot(!others), m3 = __ballot(!fast);
+                    if (lane == __ffsll((long long)m0) - 1) {
+                        atomicAdd((unsigned long long *)&c->prof[8], 1ull);
+                        atomicAdd((unsigned long long *)&c->prof[9], all_fast ? 1ull : 0ull);
+                        atomicAdd((unsigned long long *)&c->prof[10], (unsigned long long)__popcll(m1));
+                        atomicAdd((unsigned long long *)&c->prof[11], (unsigned long long)__popcll(m2));
+                        atomicAdd((unsigned long long *)&c->prof[12], (unsigned long long)__popcll(m3));
+                        atomicAdd((unsigned long long *)&c->prof[13], (unsigned long long)__popcll(m0));
+                    }
+                }
+#endif
             }
             if (all_fast) {
                 easy = true;

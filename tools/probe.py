@@ -131,6 +131,9 @@ def chain(a, quiet=False):
         tot = float(pc[:8].sum())
         for k in range(8):
             print("  %-12s %8.0f cycles per tile-wave  %5.1f %%" % (names[k], pc[k] / (N / 16.0), 100.0 * pc[k] / tot))
+        if pc[8] > 0:
+            print("  log-free tail: %d of %d wavefront-blocks; rows failing: new table %d, tables / neighbours %d, any %d of %d" % (
+                pc[9], pc[8], pc[10], pc[11], pc[12], pc[13]))
     elif a.prof and D <= 4:                          # sweep_seq_kernel's clocks (-DBGMM_SEQ_PROF)
         names = ["ring read", "home lookup", "evaluate", "stats", "commit", "rebuild", "barrier 1", "barrier 2"]
         tot = float(pc[:8].sum())
