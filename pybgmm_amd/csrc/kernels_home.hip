@@ -50,6 +50,11 @@
 #include "fast_math.h"
 
 #define LDS_AS __attribute__((address_space(3)))
+#ifdef BGMM_HOME_TEMPORAL
+#define HOME_ROW_LOAD(p) (*(p))
+#else
+#define HOME_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 
 #ifdef BGMM_HOME_PROF
 #define HP(k) { const long long tk1_ = clock64(); pf[k] += tk1_ - tk0; tk0 = tk1_; }
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, home_waves_per_simd(NJ)) void home_kernel(Dev 
         if (WHOLE) {                                                                       \
             const home_d2 *__restrict__ xrow = (const home_d2 *)(d.X + o_ + 2 * lk);       \
             _Pragma("unroll") for (int j = 0; j < NJ8; ++j) {                              \
-                const home_d2 v_ = __builtin_nontemporal_load(xrow + 4 * j);               \
+                const home_d2 v_ = HOME_ROW_LOAD(xrow + 4 * j);                            \
                 DST[2 * j] = v_.x; DST[2 * j + 1] = v_.y;                                  \
             }                                                                              \
         } else {                                                                           \
