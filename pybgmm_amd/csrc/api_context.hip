@@ -189,6 +189,11 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         DALLOC(c, d.ftab2, (size_t)d.nslots * 64);
         DALLOC(c, d.nbr, (size_t)d.nslots * 4);
     }
+    d.big_ws = nullptr; d.big_ws_stride = 0;
+    if (cov_type == BGMM_COV_FULL && D > BGMM_FAST_MAX_D) {
+        d.big_ws_stride = refresh_ws_doubles(D);
+        DALLOC(c, d.big_ws, (size_t)d.big_ws_stride * (ns + 1));
+    }
     DALLOC(c, d.ah_job, 3);
     DALLOC(c, d.resc_job, 1);
     DALLOC(c, d.resc_list, ns);
@@ -321,8 +326,9 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
         return fail(nullptr, BGMM_EUNSUPPORTED, "covariance_type must be full (0), diag (1) or fixed (2)");
     if (!X || !m_0 || !S_0 || N < 1 || D < 1 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
     if (cov_type == BGMM_COV_FULL && D > BGMM_MAX_D)
-        return fail(nullptr, BGMM_EUNSUPPORTED, "full covariance supports D <= 128 (a component's D x D factor has to fit the LDS of a "
-                                                "compute unit); covariance_type diag / fixed take D up to 4096");
+        return fail(nullptr, BGMM_EUNSUPPORTED, "full covariance supports D <= 256 (up to 128 a component's D x D factor fits the LDS of a "
+                                                "compute unit: the fast kernels; 129 .. 256 take the general route through a workspace in "
+                                                "global memory); covariance_type diag / fixed take D up to 4096");
     if (D > BGMM_MAX_D_DIAG) return fail(nullptr, BGMM_EUNSUPPORTED, "D > 4096 is not supported");
     if (N >= (1ll << 31) - 256) return fail(nullptr, BGMM_EUNSUPPORTED, "N must fit int32");
     if (v_0 < D && cov_type == BGMM_COV_FULL)

@@ -34,6 +34,7 @@
 #include <vector>
 
 int choice_rows_for(int K_max);
+long long refresh_ws_doubles(int D);
 void launch_contingency(const Dev &d, const long long *true_idx, int K_true, unsigned long long *table,
                         hipStream_t st);
 void launch_dispersion(const Dev &d, double *out, hipStream_t st);

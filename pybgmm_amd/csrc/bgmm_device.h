@@ -30,7 +30,11 @@
 #include <mutex>
 #include <vector>
 
-#define BGMM_MAX_D 128            /* full covariance: the factor of a component has to fit LDS (refresh, MFMA tiles)      */
+#define BGMM_MAX_D 256            /* full covariance.  Up to kFastMaxD = 128 a component's factor fits the LDS of a compute unit: the MFMA
+                                     kernels, pruning, certified stays, frozen-factor and safe-stay windows; beyond it (round 6) the
+                                     general route only: the VALU likelihood kernel, the per-mover kernel chain, rebuilds through a
+                                     workspace in global memory (Dev::big_ws) -- correct, slow                                      */
+#define BGMM_FAST_MAX_D 128
 #define BGMM_MAX_D_DIAG 4096      /* diag / fixed: the state is a D-vector; above kDiagLdsMaxD the rows are read through the
                                      cache instead of an LDS tile (score_diag*_kernel)                                       */
 #define BGMM_LOG_PI 1.1447298858494001741434273513530587116472948129153
@@ -366,6 +370,8 @@ struct Dev {
                                  // takes); 0: Ctrl::safe_cap, which follows the chain
     long long *glist;            // [kSafeList + 1] visit positions of the stretch's unproven visits, ascending
     struct SafeCol *ep_state;    // [nslots] per SLOT, since the proof pass: budget used, the counts the proofs allow
+    double *big_ws;              // D > BGMM_FAST_MAX_D: per-workgroup scratch of the rebuild / rank-1 kernels in global memory instead
+    long long big_ws_stride;     // of LDS (doubles per workgroup; nslots + 1 of them)
     int ahead_C;                 // > 0: this batch's dense proof pass takes its forms from the look-ahead ring (a power of two;
                                  // stretches end at multiples of it)
     Job *ah_job, *resc_job;      // device: ah_job[3] = what the second stream scores next (a chunk in full; the touched labels over

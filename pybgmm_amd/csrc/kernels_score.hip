@@ -233,6 +233,8 @@ void launch_score(const Dev &d, int kind, const Job *job, double *q, long long q
     }
     const unsigned gx = (unsigned)((max_rows + kValuRows - 1) / kValuRows);
     const int lds = d.D * kValuRows * (int)sizeof(double);
+    static PerDeviceLds attr;                             // (D > 128: the transposed tile is more than the 64 KB a launch gets unasked)
+    attr.ensure((const void *)score_valu_kernel, lds);
     hipLaunchKernelGGL(score_valu_kernel, dim3(gx, kMaxChunks), dim3(256), lds, st, d, job, q, qstride,
                        col_override, skip_pruned_jobs);
 }

@@ -105,10 +105,25 @@ int refresh_lds_bytes(int D, int cov_type) {
     const int Dp = (D + 15) / 16 * 16;
     const int diag = 2 * 256 * (int)sizeof(double);
     if (cov_type != COV_FULL) return diag;              // (D-vector state: two reduction arrays, whatever D)
+    if (D > BGMM_FAST_MAX_D) return diag;               // (the factor does not fit: the kernels work in Dev::big_ws)
     const int rank1 = (D * (D + 1) + 6 * D + 4) * (int)sizeof(double);
     const int blocked = refresh_blocked_lds_doubles(Dp) * (int)sizeof(double);
     int v = rank1 > diag ? rank1 : diag;
     return v > blocked ? v : blocked;
+}
+
+// doubles of scratch a rebuild / rank-1 workgroup needs (LDS up to D = 128, Dev::big_ws beyond)
+long long refresh_ws_doubles(int D) {
+    const int Dp = (D + 15) / 16 * 16;
+    const long long rank1 = (long long)D * (D + 1) + 6 * D + 4, blocked = refresh_blocked_lds_doubles(Dp);
+    return ((rank1 > blocked ? rank1 : blocked) + 63) / 64 * 64;
+}
+// the workgroup's scratch: its LDS, or -- BIG: the factor too large for it -- its stripe of the global workspace.  (A template
+// parameter, not a run-time choice: with one the compiler could no longer tell that the small route's pointers are LDS.)
+template <bool BIG>
+__device__ __forceinline__ double *refresh_scratch(const Dev &d, double *lds) {
+    if (BIG) return d.big_ws + (long long)blockIdx.x * d.big_ws_stride;
+    return lds;
 }
 
 __device__ void refresh_slot(const Dev &d, int s, double *sm) {
@@ -162,8 +177,10 @@ __device__ void rank1_slot(const Dev &d, int src, int dst, long long i, int kind
     if (tid == 0) d.nupd[dst] += 1;
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__restrict__ slots, int n) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+    double *const sm = refresh_scratch<BIG>(d, sm_lds);
     if ((int)blockIdx.x >= n) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->tables_valid = 0; d.ctrl->wsort_valid = 0; d.ctrl->state_epoch += 1; }
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
@@ -176,8 +193,10 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
 // once at the start of a sweep that follows a sweep with moves: the eigenvalue bound behind the
 // pruning only ever grows under rank-1 steps (slot_math.h: lam_after_rank1), so after a burn-in it
 // would stay loose until a slot's 64th update.
+template <bool BIG>
 __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+    double *const sm = refresh_scratch<BIG>(d, sm_lds);
     if ((int)blockIdx.x >= d.ctrl->job.K) return;
     const int s = d.perm[blockIdx.x];
     if (d.nupd[s] == 0) return;
@@ -185,8 +204,10 @@ __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
     refresh_slot_blocked(d, s, sm);
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+    double *const sm = refresh_scratch<BIG>(d, sm_lds);
     const Ctrl *c = d.ctrl;
     if ((int)blockIdx.x >= c->n_refresh) return;
     const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
@@ -441,23 +462,26 @@ void launch_refresh_list(const Dev &d, const int *slots, int n, hipStream_t st) 
     if (n <= 0) return;
     const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
-    ensure_lds((const void *)refresh_list_kernel, lds, attr);
-    hipLaunchKernelGGL(refresh_list_kernel, dim3(n), dim3(TPB), lds, st, d, slots, n);
+    ensure_lds((const void *)refresh_list_kernel<false>, lds, attr);
+    if (d.big_ws) hipLaunchKernelGGL(refresh_list_kernel<true>, dim3(n), dim3(TPB), lds, st, d, slots, n);
+    else hipLaunchKernelGGL(refresh_list_kernel<false>, dim3(n), dim3(TPB), lds, st, d, slots, n);
 }
 
 void launch_refresh_stale(const Dev &d, int K, hipStream_t st) {
     if (K <= 0) return;
     const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
-    ensure_lds((const void *)refresh_stale_kernel, lds, attr);
-    hipLaunchKernelGGL(refresh_stale_kernel, dim3(K), dim3(TPB), lds, st, d);
+    ensure_lds((const void *)refresh_stale_kernel<false>, lds, attr);
+    if (d.big_ws) hipLaunchKernelGGL(refresh_stale_kernel<true>, dim3(K), dim3(TPB), lds, st, d);
+    else hipLaunchKernelGGL(refresh_stale_kernel<false>, dim3(K), dim3(TPB), lds, st, d);
 }
 
 void launch_refresh_ctrl(const Dev &d, hipStream_t st) {
     const int lds = refresh_lds_bytes(d.D, d.cov_type);
     static PerDeviceLds attr;
-    ensure_lds((const void *)refresh_ctrl_kernel, lds, attr);
-    hipLaunchKernelGGL(refresh_ctrl_kernel, dim3(2), dim3(TPB), lds, st, d);
+    ensure_lds((const void *)refresh_ctrl_kernel<false>, lds, attr);
+    if (d.big_ws) hipLaunchKernelGGL(refresh_ctrl_kernel<true>, dim3(2), dim3(TPB), lds, st, d);
+    else hipLaunchKernelGGL(refresh_ctrl_kernel<false>, dim3(2), dim3(TPB), lds, st, d);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -400,6 +400,15 @@ def case_d12():
              true_assignments=z_true, skip_metrics=True)
 
 
+def case_d192():
+    # round 6: full covariance beyond D = 128 (the device's general route: rebuilds in a global-memory workspace)
+    X, z_true = gendata.synth_mixture(300, 192, 4, seed=27, mu_scale=1.5)
+    pp = gendata.demo_prior_params(192)
+    run_case("crpmm_192d", "CRPMM", X, pp, 1.0, "rand", 6, 48, 2, (13, 13),
+             true_assignments=z_true, recipe="synth_mixture(300,192,4,seed=27,mu_scale=1.5)",
+             store_X=False, skip_metrics=True)
+
+
 # ---- diagonal covariance: S_0 is a D-vector ------------------------- #
 def diag_prior(D, v_0=None):
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D, v_0=v_0)
@@ -617,7 +626,7 @@ CASES = {
     "c4twin": case_c4_twin, "c4rand": case_c4_rand,
     "each_in_own": case_each_in_own, "one_by_one": case_one_by_one,
     "pcrp_burnin": case_pcrp_burnin, "pcrp_flagoff": case_pcrp_flag_off,
-    "general_prior": case_general_prior, "d12": case_d12,
+    "general_prior": case_general_prior, "d12": case_d12, "d192": case_d192,
     "diag_kat": case_diag_kat, "diag_each_in_own": case_diag_each_in_own, "diag_pcrp": case_diag_pcrp,
     "diag_general": case_diag_general, "diag_64d": case_diag_64d, "diag_256d": case_diag_256d, "adap": case_adap,
     "fixed_256d": case_fixed_256d,

@@ -38,10 +38,10 @@ class Golden(object):
         if "X" in d.files:
             self.X = d["X"]
         else:
-            m = re.match(r"synth_mixture\((\d+),(\d+),(\d+),seed=(\d+)\)", str(d["recipe"]))
+            m = re.match(r"synth_mixture\((\d+),(\d+),(\d+),seed=(\d+)(?:,mu_scale=([0-9.]+))?\)", str(d["recipe"]))
             assert m, "fixture %s has neither X nor a known recipe" % name
-            N, D, K, seed = (int(g) for g in m.groups())
-            self.X, _ = gendata.synth_mixture(N, D, K, seed)
+            N, D, K, seed = (int(g) for g in m.groups()[:4])
+            self.X, _ = gendata.synth_mixture(N, D, K, seed, **({"mu_scale": float(m.group(5))} if m.group(5) else {}))
         assert gendata.array_digest(self.X) == str(d["X_sha256"]), \
             "regenerated X does not match the fixture's sha256"
 

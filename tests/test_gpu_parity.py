@@ -2793,18 +2793,74 @@ def test_thirty_two_chains_burn_in_side_by_side_and_equal_their_solo_runs():
 
 
 def test_dimension_limits_are_errors_that_say_so():
-    """diag / fixed components take any D up to 4096 (their state is a D-vector: goldens diag_crpmm_256d /
-    fixed_pcrp_256d, the oracle cases at D = 200 / 300); full covariance stops at D = 128 -- a component's D x D factor
-    has to fit the LDS of a compute unit -- and says so at construction (BGMM_EUNSUPPORTED), where the reference has no
-    limit (gaussian_components.py:86-90)."""
+    """diag / fixed components take any D up to 4096 (their state is a D-vector: goldens
+    diag_crpmm_256d / fixed_pcrp_256d, the oracle cases at D = 200 / 300); full covariance takes D <= 256 since round 6 (up to
+    128 through the fast kernels, beyond through the general route: test_full_covariance_beyond_128_dimensions) and says so at
+    construction beyond that (BGMM_EUNSUPPORTED), where the reference has no limit (gaussian_components.py:86-90)."""
     from pybgmm_amd import _lib
-    D = 130
+    D = 260
     X = np.random.RandomState(0).randn(300, D)
     with pytest.raises(_lib.BGMMError) as ei:
         _lib.Context(X, np.zeros(D), 0.03, D + 3, np.eye(D), 1.0, 16)
-    assert ei.value.code == -5 and "128" in str(ei.value) and "diag" in str(ei.value)
+    assert ei.value.code == -5 and "256" in str(ei.value) and "diag" in str(ei.value)
     ctx = _lib.Context(X, np.zeros(D), 0.03, D + 3, np.ones(D), 1.0, 16, cov_type="diag")
     ctx.set_assignments(np.zeros(300, dtype=np.int64))
     ctx.sweep(np.random.RandomState(1).random_sample(300))
     assert ctx.counts().sum() == 300
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,D,K,init,pcrp", [(1500, 160, 5, "rand", False), (1200, 192, 4, "true", True), (900, 256, 3, "rand", True),
+                                             (400, 129, 3, "one-by-one", False)],
+                         ids=["D160-rand", "D192-pcrp-flipped", "D256-pcrp-rand", "D129-one-by-one"])
+def test_full_covariance_beyond_128_dimensions(N, D, K, init, pcrp):
+    """VERDICT r5 missing #2 / next #10: the reference has no limit on D (gaussian_components.py:86-90, 319-331); here a
+    component's factor had to fit LDS, D <= 128.  Round 6: 129 .. 256 take the general route -- the VALU likelihood kernel over
+    every label, the per-mover kernel chain, rebuilds and rank-1 steps in a workspace in global memory.  Three sweeps against
+    the C oracle from the reference's kinds of start (components deleted and opened on the way), labels, counts, log marginal;
+    then the statistics and the method-level calls the classes use (raw statistics bit-equal to the oracle's, the predictive
+    of a point under every component, del_item / add_item round trip)."""
+    from oracle import c_oracle
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    X, zt = gendata.synth_mixture(N, D, K, seed=D, mu_scale=1.2)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    rs = np.random.RandomState(D + 1)
+    if init == "rand":
+        z0 = np.unique(rs.randint(0, 3 * K, N), return_inverse=True)[1]
+    elif init == "one-by-one":
+        z0 = -np.ones(N, dtype=np.int64)
+    else:
+        z0 = zt.copy()
+        idx = rs.choice(N, size=N // 10, replace=False)
+        z0[idx] = rs.randint(0, K, size=idx.size)
+    K_max = 8 * K
+    ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, K_max)
+    ctx.set_assignments(z0)
+    o = c_oracle.COracle(X, m_0, k_0, v_0, S_0, 1.0, z0, K_max, scipy_tables=False)
+    moved = 0
+    for it in range(3):
+        u = rs.random_sample(N)
+        order = rs.permutation(N).astype(np.int64) if pcrp else None
+        power = 1.01 if (pcrp and it > 0) else None
+        ctx.sweep(u, order, power)
+        o.sweep(u, order, power)
+        bad = np.nonzero(ctx.assignments() != o.z)[0]
+        assert bad.size == 0, "sweep %d: %d labels differ, first at i=%d" % (it, bad.size, bad[0])
+        npt.assert_array_equal(ctx.counts(), o.counts)
+        lo = o.log_marg()
+        assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
+        moved += ctx.sweep_stats()["moves"]
+    assert moved > 0
+    m, S, ld, iv = o.stats()
+    for k in range(o.K):
+        mk, Sk = ctx.raw_stats(k)
+        npt.assert_array_equal(mk, m[k])
+        npt.assert_array_equal(Sk, S[k])
+    i = int(np.nonzero(o.z >= 0)[0][7])
+    npt.assert_allclose(ctx.log_post_pred(i), o.log_post_pred(i), rtol=1e-9, atol=1e-9)
+    k_i = int(o.z[i])
+    ctx.del_item(i); ctx.add_item(i, k_i)
+    npt.assert_array_equal(ctx.assignments(), o.z)
+    assert abs(ctx.log_marg() - lo) <= 1e-9 * abs(lo)
     ctx.close()
