@@ -186,6 +186,7 @@ __global__ __launch_bounds__(TPB) void refresh_list_kernel(Dev d, const int *__r
     const int s = slots ? slots[blockIdx.x] : (int)blockIdx.x;
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
+    else if (BIG) refresh_slot(d, s, sm);              // (the blocked rebuild holds its columns in registers: 8 blocks at most)
     else refresh_slot_blocked(d, s, sm);
 }
 
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(TPB) void refresh_stale_kernel(Dev d) {
     const int s = d.perm[blockIdx.x];
     if (d.nupd[s] == 0) return;
     if (threadIdx.x == 0) { d.ctrl->tables_valid = 0; atomicAdd((unsigned long long *)&d.ctrl->state_epoch, 1ull); }   // (means and bounds change; the homes do not)
-    refresh_slot_blocked(d, s, sm);
+    if (BIG) refresh_slot(d, s, sm);
+    else refresh_slot_blocked(d, s, sm);
 }
 
 template <bool BIG>
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(TPB) void refresh_ctrl_kernel(Dev d) {
     const int s = c->refresh[blockIdx.x], kind = c->refresh_kind[blockIdx.x];
     if (d.cov_type == COV_DIAG) refresh_diag_slot<TPB>(d, s, sm, threadIdx.x);
     else if (d.cov_type == COV_FIXED) refresh_fixed_slot<TPB>(d, s, sm, threadIdx.x);
-    else if (kind == REFRESH_SCRATCH) refresh_slot_blocked(d, s, sm);
+    else if (kind == REFRESH_SCRATCH) { if (BIG) refresh_slot(d, s, sm); else refresh_slot_blocked(d, s, sm); }
     else rank1_slot(d, kind == REFRESH_NEW ? d.K_max : s, s, c->refresh_i, kind, sm);
 }
 
