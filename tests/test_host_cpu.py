@@ -236,3 +236,46 @@ def test_mt19937_jump_polynomials_against_numpy():
             acc ^= x[i:i + 624]
         np.testing.assert_array_equal(acc[1:], x[J + 1:J + 624])
         assert ((acc[0] ^ x[J]) >> np.uint32(31)) == 0
+
+
+def test_oracle_pool_runs_cases_side_by_side_and_serves_a_test_run_on_its_own():
+    """tests/oracle_pool.py (round 6): a decorated test's case function is called with the test's own parameters (the ones it
+    names), its sweeps go through the C oracle on a thread of their own, the result is handed out once -- and a test whose
+    case was never prefetched (pytest -k, ORACLE_POOL=0) gets the same through the same path.  Items with a case sort behind
+    the others, the cheapest oracle first."""
+    import numpy as np
+    import oracle_pool
+    from pybgmm_amd.utils import gendata
+
+    def case(N, D):
+        X, zt = gendata.synth_mixture(N, D, 3, seed=N)
+        us = np.random.RandomState(D).random_sample((2, N))
+        return {"X": X, "prior": gendata.demo_prior_params(D), "z0": zt, "K_max": 12, "sweeps": [(us[0],), (us[1], None, None, N // 2)]}
+    case.cost = lambda N, D: N * D
+
+    class Spec(object):
+        def __init__(self, params):
+            self.params = params
+
+    class Item(object):
+        def __init__(self, nodeid, fn, params):
+            self.nodeid, self.function, self.callspec = nodeid, fn, Spec(params)
+
+    @oracle_pool.with_oracle(case)
+    def decorated():
+        pass
+
+    def plain():
+        pass
+    items = [Item("t::big", decorated, {"N": 300, "D": 3, "budget": 1.0}), Item("t::plain", plain, {}),
+             Item("t::small", decorated, {"N": 120, "D": 2, "budget": 0.0})]
+    assert oracle_pool.cost_of(items[0]) == 900 and oracle_pool.cost_of(items[2]) == 240
+    oracle_pool.prefetch(items)
+    c_big, r_big = oracle_pool.result_for(items[0])
+    c_small, r_small = oracle_pool.result_for(items[2])
+    assert c_big["X"].shape == (300, 3) and c_small["X"].shape == (120, 2)
+    assert len(r_big) == 2 and r_big[0]["z"].shape == (300,) and isinstance(r_big[1]["log_marg"], float)
+    # handed out once; asked again (or never prefetched), the case is run on the spot with the same outcome
+    c2, r2 = oracle_pool.result_for(items[2])
+    assert np.array_equal(r2[1]["z"], r_small[1]["z"]) and r2[1]["log_marg"] == r_small[1]["log_marg"]
+    assert any("case" in what for _, what in oracle_pool.TIMES)
