@@ -5,6 +5,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 import ctypes
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -24,34 +25,46 @@ def build(force=False):
     return _SO
 
 
+_lock = threading.Lock()
+
+
 def lib():
+    """The loaded library (built first if its source is newer).  Thread safe: the heavy GPU tests' oracles start together,
+    each on a thread of its own (tests/oracle_pool.py)."""
     global _lib
-    if _lib is None:
-        L = ctypes.CDLL(build())
-        L.go_create.restype = ctypes.c_void_p
-        L.go_create.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _f64p, _f64p,
-                                ctypes.c_double, ctypes.c_int64, _f64p, ctypes.c_double,
-                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        L.go_destroy.argtypes = [ctypes.c_void_p]
-        L.go_set_assignments.argtypes = [ctypes.c_void_p, _i64p]
-        L.go_sweep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _f64p, ctypes.c_int,
-                               ctypes.c_double, ctypes.c_int64, ctypes.c_void_p]
-        L.go_log_marg.restype = ctypes.c_double
-        L.go_log_marg.argtypes = [ctypes.c_void_p]
-        L.go_K.restype = ctypes.c_int64
-        L.go_K.argtypes = [ctypes.c_void_p]
-        L.go_get_assignments.argtypes = [ctypes.c_void_p, _i64p]
-        L.go_get_counts.argtypes = [ctypes.c_void_p, _i64p]
-        L.go_get_log_prior.argtypes = [ctypes.c_void_p, _f64p]
-        L.go_get_stats.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
-        L.go_log_post_pred.argtypes = [ctypes.c_void_p, ctypes.c_int64, _f64p]
-        L.go_probe_visit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _f64p]
-        L.go_probe_visit.restype = ctypes.c_int64
-        L.go_set_threads.argtypes = [ctypes.c_int]
-        L.go_get_threads.restype = ctypes.c_int
-        L.go_set_threads(default_threads())
-        _lib = L
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            _lib = _load()
     return _lib
+
+
+def _load():
+    L = ctypes.CDLL(build())
+    L.go_create.restype = ctypes.c_void_p
+    L.go_create.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _f64p, _f64p,
+                            ctypes.c_double, ctypes.c_int64, _f64p, ctypes.c_double,
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.go_destroy.argtypes = [ctypes.c_void_p]
+    L.go_set_assignments.argtypes = [ctypes.c_void_p, _i64p]
+    L.go_sweep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _f64p, ctypes.c_int,
+                           ctypes.c_double, ctypes.c_int64, ctypes.c_void_p]
+    L.go_log_marg.restype = ctypes.c_double
+    L.go_log_marg.argtypes = [ctypes.c_void_p]
+    L.go_K.restype = ctypes.c_int64
+    L.go_K.argtypes = [ctypes.c_void_p]
+    L.go_get_assignments.argtypes = [ctypes.c_void_p, _i64p]
+    L.go_get_counts.argtypes = [ctypes.c_void_p, _i64p]
+    L.go_get_log_prior.argtypes = [ctypes.c_void_p, _f64p]
+    L.go_get_stats.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
+    L.go_log_post_pred.argtypes = [ctypes.c_void_p, ctypes.c_int64, _f64p]
+    L.go_probe_visit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _f64p]
+    L.go_probe_visit.restype = ctypes.c_int64
+    L.go_set_threads.argtypes = [ctypes.c_int]
+    L.go_get_threads.restype = ctypes.c_int
+    L.go_set_threads(default_threads())
+    return L
 
 
 def default_threads():
