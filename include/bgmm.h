@@ -69,6 +69,12 @@ BGMM_API const char *bgmm_last_error(const bgmm_ctx *ctx);
 BGMM_API int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
                 const double *X, const double *m_0, double k_0, int64_t v_0, const double *S_0,
                 double alpha, const double *lgamma_tab, const double *log_tab);
+/* A context over the SAME data matrix as `parent` (same device, N, D, covariance type): it borrows the parent's device copy
+ * of X instead of uploading one -- chains side by side over one data set (the reference builds every sampler object over
+ * the caller's one X array, igmm/igmm.py:68-76) hold it once: 8 chains at C5's shape 2 GB instead of 16.  Prior and K_max are
+ * its own.  The copy lives until the last context using it is destroyed, in any order. */
+BGMM_API int bgmm_create_shared(bgmm_ctx **out, bgmm_ctx *parent, int32_t K_max, const double *m_0, double k_0, int64_t v_0,
+                                const double *S_0, double alpha, const double *lgamma_tab, const double *log_tab);
 
 BGMM_API void bgmm_destroy(bgmm_ctx *ctx);
 

@@ -5,6 +5,7 @@ There is NO CPU fallback: if the shared object is missing, cannot be built, or
 no HIP device is visible, the calls raise.  ``oracle/`` is never imported here.
 """
 import ctypes
+import threading
 import os
 
 # Chains side by side on one GPU keep one stream each busy, and the HIP runtime maps a process's streams onto
@@ -34,6 +35,7 @@ SIGNATURES = {
                                    ctypes.c_int32, ctypes.c_int32, _vp, _vp, ctypes.c_double,
                                    ctypes.c_int64, _vp, ctypes.c_double, _vp, _vp]),
     "bgmm_destroy": (None, [_vp]),
+    "bgmm_create_shared": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, ctypes.c_int32, _vp, ctypes.c_double, ctypes.c_int64, _vp, ctypes.c_double, _vp, _vp]),
     "bgmm_set_assignments": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_stage_sweep_inputs": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -142,10 +144,33 @@ def mt19937_jump_poly(chain):
     return out
 
 
+_share_default = threading.local()
+
+
+class share_x_with(object):
+    """``with share_x_with(ctx): ...`` -- contexts made inside the block over the very array ``ctx`` was made over borrow its
+    device copy of X (chains.run_chains_on_device builds its chains' model objects this way: the classes keep the
+    reference's signatures)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_share_default, "ctx", None)
+        _share_default.ctx = self.ctx
+        return self
+
+    def __exit__(self, *exc):
+        _share_default.ctx = self.prev
+        return False
+
+
 class Context(object):
     """One chain on one GPU.  Thin, argument-checked wrapper over the C-ABI."""
 
-    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, device=0, tables=None, cov_type="full"):
+    def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, device=0, tables=None, cov_type="full", share_with=None):
+        """``share_with``: a Context over the same X (same device and covariance type) whose device copy of the data this
+        one borrows (bgmm_create_shared) -- chains side by side hold X once."""
         L = load()
         self.L = L
         self.X = np.ascontiguousarray(X, dtype=np.float64)
@@ -167,10 +192,20 @@ class Context(object):
             tg = np.ascontiguousarray(tables[1], dtype=np.float64)
             assert tl.shape == (int(v_0) + self.N + 2,) and tg.shape == tl.shape
         h = _vp()
-        rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max,
-                           {"full": 0, "diag": 1, "fixed": 2}[cov_type],
-                           _ptr(self.X), _ptr(m_0), float(k_0), int(v_0), _ptr(S_0), float(alpha),
-                           _ptr(tl), _ptr(tg))
+        if share_with is None:
+            dflt = getattr(_share_default, "ctx", None)
+            if (dflt is not None and getattr(dflt, "h", None) and dflt.cov_type == cov_type and dflt.X.shape == self.X.shape
+                    and np.shares_memory(dflt.X, self.X)):
+                share_with = dflt
+        if share_with is not None:
+            assert share_with.X.shape == self.X.shape and share_with.cov_type == cov_type, "shared contexts are over one data set"
+            rc = L.bgmm_create_shared(ctypes.byref(h), share_with.h, self.K_max, _ptr(m_0), float(k_0), int(v_0), _ptr(S_0),
+                                      float(alpha), _ptr(tl), _ptr(tg))
+        else:
+            rc = L.bgmm_create(ctypes.byref(h), int(device), self.N, self.D, self.K_max,
+                               {"full": 0, "diag": 1, "fixed": 2}[cov_type],
+                               _ptr(self.X), _ptr(m_0), float(k_0), int(v_0), _ptr(S_0), float(alpha),
+                               _ptr(tl), _ptr(tg))
         if rc != 0:
             raise BGMMError(rc, (L.bgmm_last_error(None) or b"").decode())
         self.h = h

@@ -90,8 +90,11 @@ class ChainGroup(object):
     def __init__(self, X, m_0, k_0, v_0, S_0, alpha, K_max, n_chains, seed=0, device=0, cov_type="full"):
         from . import _lib
         self._lib = _lib
-        self.ctxs = [_lib.Context(X, m_0, k_0, v_0, S_0, alpha, K_max, device=device, cov_type=cov_type)
-                     for _ in range(int(n_chains))]
+        # (one copy of X on the device for the whole group: the chains after the first borrow the first one's)
+        self.ctxs = []
+        for _ in range(int(n_chains)):
+            self.ctxs.append(_lib.Context(X, m_0, k_0, v_0, S_0, alpha, K_max, device=device, cov_type=cov_type,
+                                          share_with=self.ctxs[0] if self.ctxs else None))
         self.rngs = [random.Random(seed + c) for c in range(int(n_chains))]
         self._keys = []
         for r in self.rngs:
@@ -169,10 +172,13 @@ def run_chains_on_device(model_cls, X, prior, alpha, n_chains, n_iter, seed=0, d
     any dimension while the chains still move (burn-in, overlapping clusters); chains at rest at D >= 12 fill the GPU alone.
     """
     models = []
+    from . import _lib
+    X = np.ascontiguousarray(X, dtype=np.float64)          # (one array, so that the chains' contexts can share its device copy)
     for c in range(int(n_chains)):
         rng, nprng = chain_rngs(seed, c)
-        models.append(model_cls(X, prior, alpha, None, assignments=assignments, K=K, K_max=K_max,
-                                covariance_type=covariance_type, device=device_index, rng=rng, nprng=nprng))
+        with _lib.share_x_with(models[0].components._ctx if models else None):
+            models.append(model_cls(X, prior, alpha, None, assignments=assignments, K=K, K_max=K_max,
+                                    covariance_type=covariance_type, device=device_index, rng=rng, nprng=nprng))
     step = _Lockstep(models)
     out = [None] * len(models)
     errors = []

@@ -50,6 +50,11 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->xshare && c->xshare->refs.fetch_sub(1) == 1) {       // (the last context that used this copy of X)
+        if (c->xshare->p) (void)hipFree(c->xshare->p);
+        delete c->xshare;
+    }
+    c->xshare = nullptr;
     if (c->mt_stream) { (void)hipStreamSynchronize(c->mt_stream); (void)hipStreamDestroy(c->mt_stream); }
     for (auto &b : c->mt_b) {
         if (b.done) (void)hipEventDestroy(b.done);
@@ -99,10 +104,11 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     delete c;
 }
 
+// (share: a context whose device copy of X this one borrows instead of uploading its own -- X is then not read)
 static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_max, int32_t cov_type,
                        const double *X, const double *m_0, double k_0, int64_t v_0,
                        const double *S_0, double alpha, const double *lgamma_tab,
-                       const double *log_tab) {
+                       const double *log_tab, bgmm_ctx *share = nullptr) {
     c->device = device;
     CK(c, hipSetDevice(device));
     CK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -122,7 +128,16 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     const size_t DD = fixed ? (size_t)2 * D : diag ? (size_t)D : (size_t)D * D, ns = (size_t)d.nslots;   // second-moment block
     const size_t WW = diag ? 1 : (size_t)D * D;                                   // factor block (full only)
     double *dX, *dtl, *dtg, *dpm, *dpS, *dtG, *dtC, *dtS;
-    DALLOC(c, dX, (size_t)N * D);
+    if (share) {
+        c->xshare = share->xshare;
+        c->xshare->refs.fetch_add(1);
+        dX = c->xshare->p;
+    } else {
+        void *q = nullptr;
+        CK(c, hipMalloc(&q, sizeof(double) * (size_t)N * D + 64));
+        c->xshare = new SharedX();
+        c->xshare->p = dX = (double *)q;
+    }
     DALLOC(c, d.log_prior, (size_t)N);
     DALLOC(c, d.z, (size_t)N);
     DALLOC(c, dtl, (size_t)d.tab_len);
@@ -224,7 +239,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
         d.fv_mu0 = dmu0;
     }
     c->tabSeat = dtS;
-    CK(c, hipMemcpyAsync(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
+    if (!share) CK(c, hipMemcpyAsync(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
 
     // tables: the reference's n = [1, 1, 2, ..., v_0+N+1] (gaussian_components.py:120-122)
     std::vector<double> tl(d.tab_len), tg(d.tab_len);
@@ -341,6 +356,31 @@ extern "C" int bgmm_create(bgmm_ctx **out, int device, int64_t N, int32_t D, int
     if (device < 0 || device >= ndev) return fail(nullptr, BGMM_EINVAL, "device index out of range");
     bgmm_ctx *c = new bgmm_ctx();
     const int rc = create_impl(c, device, N, D, K_max, cov_type, X, m_0, k_0, v_0, S_0, alpha, lgamma_tab, log_tab);
+    if (rc != 0) {
+        g_create_error = c->err;
+        bgmm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return BGMM_OK;
+}
+
+extern "C" int bgmm_create_shared(bgmm_ctx **out, bgmm_ctx *parent, int32_t K_max, const double *m_0, double k_0, int64_t v_0,
+                                  const double *S_0, double alpha, const double *lgamma_tab, const double *log_tab) {
+    if (!out) return BGMM_EINVAL;
+    *out = nullptr;
+    if (!parent || !parent->xshare || !m_0 || !S_0 || K_max < 1) return fail(nullptr, BGMM_EINVAL, "bad shape or null pointer");
+    const Dev &pd = parent->d;
+    if (v_0 < pd.D && pd.cov_type == COV_FULL) return fail(nullptr, BGMM_EINVAL, "v_0 must be larger or equal to dimension of data");
+    if (v_0 < 1) return fail(nullptr, BGMM_EINVAL, "v_0 must be positive");
+    if (!(k_0 > 0) || !(alpha > 0)) return fail(nullptr, BGMM_EINVAL, "k_0 and alpha must be positive");
+    {   // (whatever the parent still has in its queue -- its own upload of X among it -- comes first)
+        if (hipSetDevice(parent->device) != hipSuccess || hipStreamSynchronize(parent->stream) != hipSuccess)
+            return fail(nullptr, BGMM_EDEVICE, "the parent context's device is not available");
+    }
+    bgmm_ctx *c = new bgmm_ctx();
+    const int rc = create_impl(c, parent->device, pd.N, pd.D, K_max, pd.cov_type, nullptr, m_0, k_0, v_0, S_0, alpha, lgamma_tab, log_tab,
+                               parent);
     if (rc != 0) {
         g_create_error = c->err;
         bgmm_destroy(c);

@@ -64,8 +64,16 @@ struct PermPtrs {
     long long n_words_cap;
 };
 
+// The device copy of X may serve several contexts (bgmm_create_shared: chains side by side over one data set): it is freed by
+// whoever lets go of it last.
+struct SharedX {
+    double *p = nullptr;
+    std::atomic<int> refs{1};
+};
+
 struct bgmm_ctx {
     int device = 0;
+    SharedX *xshare = nullptr;       // the data matrix on the device (owned through its reference count)
     hipStream_t stream = nullptr;
     Dev d{};
     std::string err;

@@ -2756,6 +2756,57 @@ def test_c5_shape_pcrp_sweeps_fed_by_the_device_generators_against_the_oracle(or
     ctx.close()
 
 
+def test_contexts_over_one_data_set_share_its_device_copy():
+    """VERDICT r5 #2 (second half): bgmm_create_shared -- chains side by side hold X once.  (i) a context made over its
+    parent's copy runs the same chain as one with a copy of its own (two sweeps, labels and log marginal equal), with its own
+    prior and K_max; (ii) the copy outlives the parent (destroyed first) for as long as a child uses it; (iii) four
+    contexts over a 102-MB X take little more device memory than one with its working buffers; (iv) ChainGroup and
+    run_chains_on_device build their chains that way."""
+    import torch
+    from pybgmm_amd import _lib, chains
+    from pybgmm_amd.igmm import CRPMM
+    from pybgmm_amd.prior import NIW
+    from pybgmm_amd.utils import gendata
+    N, D, K = 200000, 64, 12
+    X, zt = gendata.synth_mixture(N, D, K, seed=3)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+    us = np.random.RandomState(1).random_sample((2, N))
+    z0 = zt.copy(); z0[::97] = (z0[::97] + 1) % K
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    parent = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+    parent.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    kids = [_lib.Context(X, m_0, 2.0 * k_0, v_0 + 3, S_0, 0.7, 3 * K, share_with=parent) for _ in range(3)]
+    own = _lib.Context(X, m_0, 2.0 * k_0, v_0 + 3, S_0, 0.7, 3 * K)
+    for c in kids + [own]:
+        c.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    x_bytes = X.nbytes
+    per_own = free1 - free0                              # a context with its own copy
+    assert per_own > x_bytes
+    used_by_four = free1 - free2                         # three borrowers + one with its own copy
+    assert used_by_four < 4 * per_own - 2.5 * x_bytes, (per_own, used_by_four, x_bytes)
+    for c in (kids[0], own):
+        c.set_assignments(z0)
+    parent.close()                                       # (ii): the children keep the copy alive
+    for it in range(2):
+        kids[0].sweep(us[it]); own.sweep(us[it])
+        npt.assert_array_equal(kids[0].assignments(), own.assignments())
+        assert kids[0].log_marg() == own.log_marg()
+    assert kids[0].sweep_stats()["moves"] + 1 > 0
+    for c in kids + [own]:
+        c.close()
+    # (iv)
+    grp = chains.ChainGroup(X[:6000], m_0, k_0, v_0, S_0, 1.0, 4 * K, n_chains=3, seed=5)
+    assert all(c.h for c in grp.ctxs)
+    grp.set_assignments([zt[:6000]] * 3)
+    grp.sweep()
+    grp.close()
+    out = chains.run_chains_on_device(CRPMM, X[:6000], NIW(m_0, k_0, v_0, S_0), 1.0, 3, 2, seed=2, assignments="rand", K=K)
+    assert len(out) == 3 and all(m.components.K >= 1 for m, _ in out)
+
+
 def test_thirty_two_chains_burn_in_side_by_side_and_equal_their_solo_runs():
     """G = 32 chains of one shape from the reference's "rand" start in ONE group call -- their frozen-factor
     windows shared in two sub-groups of launches on two streams (api_group.hip: gram_group_launch), a host thread each --
