@@ -2762,7 +2762,7 @@ def test_contexts_over_one_data_set_share_its_device_copy():
     prior and K_max; (ii) the copy outlives the parent (destroyed first) for as long as a child uses it; (iii) four
     contexts over a 102-MB X take little more device memory than one with its working buffers; (iv) ChainGroup and
     run_chains_on_device build their chains that way."""
-    import torch
+    import ctypes
     from pybgmm_amd import _lib, chains
     from pybgmm_amd.igmm import CRPMM
     from pybgmm_amd.prior import NIW
@@ -2772,18 +2772,27 @@ def test_contexts_over_one_data_set_share_its_device_copy():
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     us = np.random.RandomState(1).random_sample((2, N))
     z0 = zt.copy(); z0[::97] = (z0[::97] + 1) % K
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    _lib.load()
+    hip = ctypes.CDLL("libamdhip64.so")                  # (the runtime the library itself is linked against)
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return int(f.value)
+    warm = _lib.Context(X[:1000], m_0, k_0, v_0, S_0, 1.0, 4 * K)      # (the runtime's own first allocations out of the way)
+    warm.synchronize()
+    free0 = free_bytes()
     parent = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
     parent.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = free_bytes()
     kids = [_lib.Context(X, m_0, 2.0 * k_0, v_0 + 3, S_0, 0.7, 3 * K, share_with=parent) for _ in range(3)]
     own = _lib.Context(X, m_0, 2.0 * k_0, v_0 + 3, S_0, 0.7, 3 * K)
     for c in kids + [own]:
         c.synchronize()
-    free2 = torch.cuda.mem_get_info()[0]
+    free2 = free_bytes()
+    warm.close()
     x_bytes = X.nbytes
-    per_own = free1 - free0                              # a context with its own copy
+    per_own = free0 - free1                              # a context with its own copy
     assert per_own > x_bytes
     used_by_four = free1 - free2                         # three borrowers + one with its own copy
     assert used_by_four < 4 * per_own - 2.5 * x_bytes, (per_own, used_by_four, x_bytes)
