@@ -62,7 +62,7 @@ int mt_ensure_tables(bgmm_ctx *c, int chains) {
 
 static int mt_depth_for(long long N) {
     if (N < 4096) return 1;                       // (sweep boundaries must lie behind the request's first block)
-    long long m = 4000000 / N;
+    long long m = (long long)bgmm_dev_option("mt_batch_doubles", 4000000) / N;
     if (m < 1) m = 1;
     if (m > kMtMaxMids) m = kMtMaxMids;
     return (int)m;
@@ -132,9 +132,11 @@ int mt_schedule(bgmm_ctx *c, bool hit, const uint32_t *key, int pos) {
         return 0;
     }
     bgmm_ctx::MtBatch *B = c->mt_cur >= 0 ? &c->mt_b[c->mt_cur] : nullptr;
-    if (B && B->launched && B->next >= std::max(1, c->mt_depth - 2) && !c->mt_b[c->mt_cur ^ 1].launched) {
-        // (the state behind this batch is known since its generation finished: the next batch is started two sweeps
-        // before it is needed -- under a running sweep a generation takes about two of them)
+    static const int lead = bgmm_dev_option("mt_lead", 8);
+    if (B && B->launched && B->next >= std::max(1, c->mt_depth - lead) && !c->mt_b[c->mt_cur ^ 1].launched) {
+        // (the state behind this batch is known since its generation finished, the other batch's buffer is free since its
+        // last sweep was: the next batch is started as soon as this one is being served -- `mt_lead` sweeps before it is
+        // needed at the latest; round 5 waited until two were left, and a generation that ran long held the sweep up)
         const int Md = c->mt_depth;
         return mt_launch_batch(c, c->mt_cur ^ 1, B->host + 624 + (size_t)(Md - 1) * 624,
                                (int)B->host[624 + (size_t)Md * 624 + (size_t)(Md - 1)]);

@@ -14,7 +14,7 @@
 // block one after the other -- each is the (k - 227) term of the next, a register -- from the old
 // block in LDS (double buffered); the last word also needs the new word 0, which its lane (169)
 // recomputes from the old block instead of waiting for lane 0.  Tempered words go straight to global
-// memory; a second kernel pairs them into doubles.  A long request is cut into chains of kChainBlocks blocks
+// memory; a second kernel pairs them into doubles.  A long request is cut into chains of chain_blocks() blocks
 // that run side by side from jumped-ahead states (below).
 #include "bgmm_device.h"
 
@@ -53,22 +53,30 @@ __global__ void mt19937_doubles_kernel(const unsigned *__restrict__ words, doubl
 //     x[J + w] = XOR over the set coefficients i of g_J of x[i + w]        (w = 1 .. 623 in full, w = 0: top bit)
 // -- the state J words ahead is a GF(2) convolution of the first 19937 + 623 words of the stream with the
 // coefficient bits of g_J.  One workgroup produces those words (they are the first 33 blocks of the sweep's own
-// uniforms), mt19937_jump_kernel forms the states kChainBlocks, 2 kChainBlocks, ... blocks ahead for all chains at
-// once, and every chain regenerates its kChainBlocks blocks as before.  The low 31 bits of a jumped state's word 0
+// uniforms), mt19937_jump_kernel forms the states cb, 2 cb, ... blocks ahead (cb = chain_blocks()) for all chains at
+// once, and every chain regenerates its cb blocks as before.  The low 31 bits of a jumped state's word 0
 // are not determined -- nor needed: that block is the LAST one of the chain in front, which emits it from the
 // recurrence; the jumped copy only seeds the blocks behind it.  phi comes from Berlekamp-Massey on one output bit
 // (checked: degree 19937), the g_J from shift-and-reduce / multiply-and-reduce on the host, once per process.
 // ------------------------------------------------------------------------------------------
-static constexpr int kChainBlocks = 64;                  // 624-word blocks per chain (>= 33: the first chain emits the convolution's input)
+// 624-word blocks per chain (>= 33: the first chain emits the convolution's input).  The jump costs 19 937 x 624 word
+// operations per chain -- at 64 blocks a chain it was the generator's largest kernel (190 us per four sweeps of C4, on every
+// compute unit); a chain's step is ~0.9 us, so 128 blocks keep a generation (first chain, jump, the other chains) inside the
+// sweeps it runs beside.  Measured at C4 (profiles/r06/mt_chain_blocks.txt): 64: 6 110 sweeps/s, 128: 6 468, 256: 6 483,
+// 512: 4 969 (the generation no longer keeps up).  BGMM_DEV_OPTIONS="mt_chain_blocks=..." (read once per process).
+static int chain_blocks() {
+    static const int v = [] { int b = bgmm_dev_option("mt_chain_blocks", 128); return b < 33 ? 33 : (b > 4096 ? 4096 : b); }();
+    return v;
+}
 static constexpr int kPhiDeg = 19937;
 static constexpr int kPolyWords = 624;                   // 32-bit words of a coefficient vector (19968 bits)
 static constexpr int kRawWords = 33 * 624;               // untempered words the convolution reads: x[0 .. 20591]
 int mt19937_raw_words() { return kRawWords; }
-int mt19937_chain_blocks() { return kChainBlocks; }
+int mt19937_chain_blocks() { return chain_blocks(); }
 static constexpr int kJumpSplits = 16, kJumpTargets = 4; // coefficient range per workgroup / chains per workgroup
 
-// chain `p` of a sweep: seed = block p * kChainBlocks of the stream (key_in for p = 0, a jumped state otherwise);
-// emits the blocks (p kChainBlocks, (p + 1) kChainBlocks] that the request [pos, E) reaches into -- chain 0 also what is
+// chain `p` of a sweep: seed = block p * cb of the stream (key_in for p = 0, a jumped state otherwise);
+// emits the blocks (p cb, (p + 1) cb] that the request [pos, E) reaches into -- chain 0 also what is
 // left of block 0 -- and, if the request ends in its range, the generator state the caller gets back.
 // `mids`: a request that spans several sweeps (the look-ahead, api_inputs.hip) also wants the generator state at every
 // sweep boundary inside it: mids.nb[j] / mids.pos[j] = the block that boundary lies in and the position in it; the chain
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
                                                             unsigned *__restrict__ raw, unsigned *__restrict__ key_out,
                                                             int *__restrict__ pos_out, unsigned *__restrict__ seed_next,
                                                             MtMids mids, unsigned *__restrict__ key_mid, int *__restrict__ pos_mid,
-                                                            int untempered) {
+                                                            int untempered, int cb) {
     __shared__ unsigned blk[2][624];
     const int tid = threadIdx.x;
     const int p = p_first + (int)blockIdx.x;
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(256) void mt19937_chain_kernel(const unsigned *__re
             return;
         }
     }
-    const long long b_lo = (long long)p * kChainBlocks + 1;
-    long long b_hi = b_lo + kChainBlocks - 1;
+    const long long b_lo = (long long)p * cb + 1;
+    long long b_hi = b_lo + cb - 1;
     if (b_hi > nb) b_hi = nb;
     if (b_lo > b_hi) return;
     const int l = tid < 227 ? tid : 0;
@@ -191,7 +199,7 @@ struct MtJumpTables {
     std::mutex mu;
     bool ready = false, failed = false;
     std::vector<int> phi_low;                        // exponents of phi's terms below the leading one
-    std::vector<std::vector<uint64_t>> g;            // g[p] = t^(p * kChainBlocks * 624) mod phi, 312 x 64 bits; g[0] unused
+    std::vector<std::vector<uint64_t>> g;            // g[p] = t^(p * chain_blocks() * 624) mod phi, 312 x 64 bits; g[0] unused
 };
 MtJumpTables g_mtj;
 
@@ -291,7 +299,7 @@ void mulmod_phi(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, 
     out.assign(prod.begin(), prod.begin() + kW64);
 }
 
-// coefficient vectors of t^(p J1) mod phi for p = 1 .. n_chains - 1 (J1 = kChainBlocks * 624 words); grows on demand
+// coefficient vectors of t^(p J1) mod phi for p = 1 .. n_chains - 1 (J1 = chain_blocks() * 624 words); grows on demand
 bool ensure_jump_polys(int n_chains) {
     std::lock_guard<std::mutex> guard(g_mtj.mu);
     if (g_mtj.failed) return false;
@@ -300,7 +308,7 @@ bool ensure_jump_polys(int n_chains) {
         // g_1 = t^J1 mod phi: from t^19936, one multiplication by t (shift, conditional reduction) at a time
         std::vector<uint64_t> v((size_t)kW64 + 1, 0);
         flip_bit(v, kPhiDeg - 1);
-        for (int step = kPhiDeg - 1; step < kChainBlocks * 624; ++step) {
+        for (int step = kPhiDeg - 1; step < chain_blocks() * 624; ++step) {
             for (int k = kW64; k > 0; --k) v[(size_t)k] = (v[(size_t)k] << 1) | (v[(size_t)k - 1] >> 63);
             v[0] <<= 1;
             if (get_bit(v, kPhiDeg)) {
@@ -326,7 +334,7 @@ bool ensure_jump_polys(int n_chains) {
 int mt19937_chains_for(long long pos, long long n) {
     const long long E = pos + 2 * n;
     const long long nb = E > 0 ? (E - 1) / 624 : 0;
-    return (int)((nb + kChainBlocks - 1) / kChainBlocks);          // chains that have a block to emit (>= 1 once nb >= 1)
+    return (int)((nb + chain_blocks() - 1) / chain_blocks());          // chains that have a block to emit (>= 1 once nb >= 1)
 }
 
 // coefficient words of chains 1 .. n_chains - 1 as the device wants them: [n_chains][624] uint32 (row 0 unused).
@@ -368,15 +376,15 @@ void launch_mt19937(const unsigned *key_in, int pos, unsigned *key_out, int *pos
         const int chains = mt19937_chains_for(pos, n);
         for (int p = 0; p < (chains > 1 ? chains : 1); ++p)
             hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, p, pos, E,
-                               words, (unsigned *)nullptr, key_out, pos_out, seeds, mids, key_mid, pos_mid, 0);
+                               words, (unsigned *)nullptr, key_out, pos_out, seeds, mids, key_mid, pos_mid, 0, chain_blocks());
     } else {
         (void)hipMemsetAsync(seeds, 0, sizeof(unsigned) * 624 * (size_t)n_chains, st);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, 0, pos, E, words, raw,
-                           key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0);
+                           key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0, chain_blocks());
         hipLaunchKernelGGL(mt19937_jump_kernel, dim3(kJumpSplits, (unsigned)((n_chains - 1 + kJumpTargets - 1) / kJumpTargets)),
                            dim3(640), 0, st, raw, coef_dev, n_chains, seeds);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3((unsigned)(n_chains - 1)), dim3(256), 0, st, key_in, (const unsigned *)seeds, 1,
-                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0);
+                           pos, E, words, (unsigned *)nullptr, key_out, pos_out, (unsigned *)nullptr, mids, key_mid, pos_mid, 0, chain_blocks());
     }
     hipLaunchKernelGGL(mt19937_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, u, n, n_per, zero_flag);
 }
@@ -390,19 +398,19 @@ void launch_mt19937_raw(const unsigned *key_in, int pos, unsigned *words, long l
     mids.m = 0;
     if (!coef_dev || n_chains < 2) {
         const long long nb = E > 0 ? (E - 1) / 624 : 0;
-        const int chains = (int)((nb + kChainBlocks - 1) / kChainBlocks);
+        const int chains = (int)((nb + chain_blocks() - 1) / chain_blocks());
         for (int p = 0; p < (chains > 1 ? chains : 1); ++p)
             hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, p, pos, E,
-                               words, (unsigned *)nullptr, spare_key, spare_pos, seeds, mids, (unsigned *)nullptr, (int *)nullptr, 1);
+                               words, (unsigned *)nullptr, spare_key, spare_pos, seeds, mids, (unsigned *)nullptr, (int *)nullptr, 1, chain_blocks());
     } else {
         (void)hipMemsetAsync(seeds, 0, sizeof(unsigned) * 624 * (size_t)n_chains, st);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3(1), dim3(256), 0, st, key_in, (const unsigned *)seeds, 0, pos, E, words, raw,
-                           spare_key, spare_pos, (unsigned *)nullptr, mids, (unsigned *)nullptr, (int *)nullptr, 1);
+                           spare_key, spare_pos, (unsigned *)nullptr, mids, (unsigned *)nullptr, (int *)nullptr, 1, chain_blocks());
         hipLaunchKernelGGL(mt19937_jump_kernel, dim3(kJumpSplits, (unsigned)((n_chains - 1 + kJumpTargets - 1) / kJumpTargets)),
                            dim3(640), 0, st, raw, coef_dev, n_chains, seeds);
         hipLaunchKernelGGL(mt19937_chain_kernel, dim3((unsigned)(n_chains - 1)), dim3(256), 0, st, key_in, (const unsigned *)seeds, 1,
                            pos, E, words, (unsigned *)nullptr, spare_key, spare_pos, (unsigned *)nullptr, mids, (unsigned *)nullptr,
-                           (int *)nullptr, 1);
+                           (int *)nullptr, 1, chain_blocks());
     }
 }
 
@@ -410,5 +418,5 @@ void launch_mt19937_raw(const unsigned *key_in, int pos, unsigned *words, long l
 int mt19937_chains_for_words(long long pos, long long n_words) {
     const long long E = pos + n_words;
     const long long nb = E > 0 ? (E - 1) / 624 : 0;
-    return (int)((nb + kChainBlocks - 1) / kChainBlocks);
+    return (int)((nb + chain_blocks() - 1) / chain_blocks());
 }

@@ -3,6 +3,9 @@ stream in between, and the time per call:  python tools/permcheck.py [N] [calls]
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("BGMM_LIB_VARIANT"):          # (tools/build_variant.sh)
+    from pybgmm_amd import _build
+    _build.LIB = os.path.join(os.path.dirname(_build.LIB), "libbgmm_hip_%s.so" % os.environ["BGMM_LIB_VARIANT"])
 from pybgmm_amd import _lib
 from pybgmm_amd.utils import gendata
 
