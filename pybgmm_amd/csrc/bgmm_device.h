@@ -441,7 +441,7 @@ struct PerDeviceLds {
 };
 
 // The ONE gateway to the process environment (api_context.hip): development switches of the tests and tools, read once per
-// process from BGMM_DEV_OPTIONS="name=value,name=value" -- perm_pipe, perm_era, perm_chain_rounds, perm_pipe_fail, perm_rounds,
+// process from BGMM_DEV_OPTIONS="name=value,name=value" -- perm_pipe, perm_era, perm_chain_rounds, perm_pipe_fail, perm_rounds, mt_chain_blocks, mt_batch_doubles, mt_lead,
 // perm_tail_log2, group_split.  Everything a user may want to set has an entry point (include/bgmm.h: bgmm_set_*).
 int bgmm_dev_option(const char *name, int dflt);
 
@@ -494,7 +494,7 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
 bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st);   // cross forms (+ those with the window before) + weights
 void launch_gram_carry(const Dev &d, hipStream_t st);
 bool launch_gram_resolve_only(const Dev &d, int resolve_lds, hipStream_t st);
-// kernels_rng.hip: the caller's MT19937 continued on the device (chains of 64 blocks from jumped-ahead states)
+// kernels_rng.hip: the caller's MT19937 continued on the device (chains of 128 blocks from jumped-ahead states)
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();
 int mt19937_chain_blocks();
