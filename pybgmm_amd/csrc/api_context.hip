@@ -63,6 +63,7 @@ extern "C" void bgmm_destroy(bgmm_ctx *c) {
     }
     if (c->mt_words_ahead) (void)hipFree(c->mt_words_ahead);
     if (c->grp_devs) (void)hipFree(c->grp_devs);
+    if (c->grp_pdevs) (void)hipFree(c->grp_pdevs);
     if (c->grp_ev_in) (void)hipEventDestroy(c->grp_ev_in);
     if (c->grp_ev_out) (void)hipEventDestroy(c->grp_ev_out);
     if (c->pp.fin) { (void)hipStreamSynchronize(c->pp.fin); (void)hipStreamDestroy(c->pp.fin); }

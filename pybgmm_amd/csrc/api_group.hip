@@ -13,12 +13,12 @@
 // trajectories are those of separate sweeps.
 struct GramCombiner {
     enum { UNKNOWN = 0, WAITING = 1, BUSY = 2, DONE = 3 };
-    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int result = 0; hipEvent_t ev = nullptr; };
+    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int pipe_T = 0; long long pos = 0; int result = 0; hipEvent_t ev = nullptr; };
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
     int leader = -1;
-    long long shared_batches = 0, shared_members = 0;
+    long long shared_batches = 0, shared_members = 0, piped_batches = 0;
 
     void elect_locked() {
         if (leader >= 0) return;
@@ -37,11 +37,13 @@ struct GramCombiner {
 };
 
 static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
+static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
 
-// Returns 0: the batch has been queued with the group's (the chain's stream waits for it); 1: queue it yourself; < 0: error.
+// Returns 0: the batch has been queued with the group's (the chain's stream waits for it), 2: ... as PIPELINED windows;
+// 1: queue it yourself; < 0: error.  pipe_T: the pipelined windows this chain could take from visit `pos` on (0: none).
 void combiner_declare_busy(bgmm_ctx *c) { c->combiner->declare(c->combiner_slot, GramCombiner::BUSY); }
 
-int combiner_submit(bgmm_ctx *c, int T) {
+int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
     GramCombiner &G = *c->combiner;
     const int me = c->combiner_slot;
     // (a chain that cannot take part queues its batch itself -- and says so, or the others would wait for its declaration)
@@ -55,7 +57,7 @@ int combiner_submit(bgmm_ctx *c, int T) {
     if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) { G.declare(me, GramCombiner::BUSY); return 1; }
     std::unique_lock<std::mutex> lk(G.mu);
     GramCombiner::Slot &S = G.slots[(size_t)me];
-    S.state = GramCombiner::WAITING; S.T = T; S.result = 1; S.ev = nullptr;
+    S.state = GramCombiner::WAITING; S.T = T; S.pipe_T = pipe_T; S.pos = pos; S.result = 1; S.ev = nullptr;
     G.elect_locked();
     G.cv.wait(lk, [&] { return S.state != GramCombiner::WAITING || G.leader == me; });
     if (S.state == GramCombiner::WAITING) {
@@ -70,23 +72,41 @@ int combiner_submit(bgmm_ctx *c, int T) {
                 if (o.T > Tmax) Tmax = o.T;
             }
         }
-        int rc = 1;
-        std::vector<hipEvent_t> ev_of;                  // per member: the event its stream waits for (its sub-group's)
-        if (members.size() >= 2) {
-            lk.unlock();
-            rc = gram_group_launch(G, members, Tmax, ev_of);
-            lk.lock();
-            if (rc == 0) { G.shared_batches += 1; G.shared_members += (long long)members.size(); }
+        // The members that can take pipelined windows (api_sweep.hip gram_pipe_batch: the next window's cross forms and the
+        // last one's finish on a second stream beside the resolvers) get them in shared launches too -- all of them in ONE
+        // sequence: the pipeline is what keeps the chip busy through the resolvers there --, the others the plain windows.
+        static const bool pipe_on = bgmm_dev_option("group_pipe", 1) != 0;
+        std::vector<int> piped, plain;
+        int Tpipe = 1 << 30;
+        for (int k : members) {
+            const GramCombiner::Slot &o = G.slots[(size_t)k];
+            if (pipe_on && o.pipe_T >= 4) { piped.push_back(k); if (o.pipe_T < Tpipe) Tpipe = o.pipe_T; }
+            else plain.push_back(k);
         }
+        if (piped.size() < 2) { plain = members; piped.clear(); }
+        int rc_plain = 1, rc_piped = 1;
+        std::vector<hipEvent_t> ev_plain, ev_piped;     // per member: the event its stream waits for (its sub-group's)
+        lk.unlock();
+        if (piped.size() >= 2) rc_piped = gram_group_pipe_launch(G, piped, Tpipe, ev_piped);
+        if (plain.size() >= 2) rc_plain = gram_group_launch(G, plain, Tmax, ev_plain);
+        lk.lock();
+        if (rc_piped == 0) { G.shared_batches += 1; G.piped_batches += 1; G.shared_members += (long long)piped.size(); }
+        if (rc_plain == 0) { G.shared_batches += 1; G.shared_members += (long long)plain.size(); }
         // everybody who waited goes on: the members with the shared batch (or, if it could not be queued, on their own),
         // the chains of other shapes on their own
         for (size_t k = 0; k < G.slots.size(); ++k) {
             GramCombiner::Slot &o = G.slots[k];
             if (o.state != GramCombiner::WAITING) continue;
-            const auto it = std::find(members.begin(), members.end(), (int)k);
-            const bool member = it != members.end() && members.size() >= 2;
-            o.result = member ? rc : 1;
-            o.ev = (member && rc == 0) ? ev_of[(size_t)(it - members.begin())] : nullptr;
+            const auto ip = std::find(piped.begin(), piped.end(), (int)k);
+            const auto iq = std::find(plain.begin(), plain.end(), (int)k);
+            o.result = 1; o.ev = nullptr;
+            if (ip != piped.end()) {
+                o.result = rc_piped == 0 ? 2 : rc_piped;
+                if (rc_piped == 0) o.ev = ev_piped[(size_t)(ip - piped.begin())];
+            } else if (iq != plain.end() && plain.size() >= 2) {
+                o.result = rc_plain;
+                if (rc_plain == 0) o.ev = ev_plain[(size_t)(iq - plain.begin())];
+            }
             o.state = GramCombiner::UNKNOWN;
         }
         G.leader = -1;
@@ -95,8 +115,13 @@ int combiner_submit(bgmm_ctx *c, int T) {
     const int result = S.result;
     hipEvent_t ev = S.ev;
     lk.unlock();
-    if (result == 0 && ev && ev != c->grp_ev_out) {       // (a sub-group's leader queued the batch on its own stream)
-        if (hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess) return BGMM_EDEVICE;
+    if ((result == 0 || result == 2) && ev && ev != c->grp_ev_out) {       // (a sub-group's leader queued the batch on its own stream)
+        // Waited for HERE, on the host, not by the chain's stream: a stream parked at a wait is a hardware queue that sits at
+        // a barrier packet for the whole batch, and seven of those beside the two queues the batch runs on cost it a third
+        // of its speed (8 C4 chains, first sweep: 6.9 s -> 5.0 s; round 6) -- the command processor keeps coming back to them.
+        static const bool host_wait = bgmm_dev_option("group_host_wait", 1) != 0;
+        if (host_wait) { if (hipEventSynchronize(ev) != hipSuccess) return BGMM_EDEVICE; }
+        else if (hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess) return BGMM_EDEVICE;
     }
     return result;
 }
@@ -153,6 +178,88 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
         bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
         if (hipEventRecord(sl->grp_ev_out, sl->stream) != hipSuccess) return BGMM_EDEVICE;
     }
+    return 0;
+}
+
+// A batch of T PIPELINED frozen-factor windows for the chains `members` (>= 2, one shape), every kernel of gram_pipe_batch's
+// schedule (api_sweep.hip) ONE launch for all of them -- workgroup (x, chain) --, on the first member's two streams:
+//   main stream   cross(0)  resolve(0)  carry(1) resolve(1)  carry(2) resolve(2) ...
+//   second stream     cross(1)      finish(0) cross(2)   finish(1) cross(3) ...
+// Chain c's window k starts at its own visit pos_c + 64 k and works in its buffer set k & 1 (gram_pgroup_view).  A chain
+// whose pipeline breaks (Ctrl::pipe_break: a component opened or deleted, a window that ended early) stands still for the rest
+// of the batch -- its workgroups return at once -- and the others carry on; each host thread reads its own control block.
+static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of) {
+    bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
+    const int m = (int)members.size();
+    ev_of.assign((size_t)m, nullptr);
+    if (hipSetDevice(lead->device) != hipSuccess) return 1;
+    if (lead->grp_pdevs_cap < 2 * m) {
+        if (lead->grp_pdevs) (void)hipFree(lead->grp_pdevs);
+        lead->grp_pdevs = nullptr; lead->grp_pdevs_cap = 0;
+        if (hipMalloc((void **)&lead->grp_pdevs, sizeof(Dev) * 2 * (size_t)m) != hipSuccess) return 1;
+        lead->grp_pdevs_cap = 2 * m;
+    }
+    while (lead->pipe_ev.size() < (size_t)(2 * T + 2)) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+        lead->pipe_ev.push_back(e);
+    }
+    // The second stream is the SECOND MEMBER's own: idle while its thread waits here, and what that chain queues later comes
+    // behind the batch anyway (a stream of the leader's own, or raised priorities for the chains' main streams, measured the
+    // same: 4.74 - 4.78 s for 8 C4 chains' first sweep).
+    hipStream_t M = lead->stream, S = G.slots[(size_t)members[1]].c->stream;
+    std::vector<Dev> views(2 * (size_t)m);
+    int reach = 0;
+    for (int k = 0; k < m; ++k) {
+        const GramCombiner::Slot &sl = G.slots[(size_t)members[(size_t)k]];
+        bgmm_ctx *o = sl.c;
+        for (int p = 0; p < 2; ++p) {
+            Dev &v = views[(size_t)p * (size_t)m + (size_t)k];
+            v = o->d;
+            gram_point_view(o, v, p);
+            v.pipe = 1;
+            v.pipe_pos = sl.pos;
+        }
+        views[(size_t)k].xp_in = views[(size_t)m + (size_t)k].xp_out;          // (what the window before exported: the other set's)
+        views[(size_t)m + (size_t)k].xp_in = views[(size_t)k].xp_out;
+        const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
+        if (r > reach) reach = r;
+        // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
+        if (o != lead && hipStreamWaitEvent(M, o->grp_ev_in, 0) != hipSuccess) return 1;
+        ev_of[(size_t)k] = lead->grp_ev_out;
+    }
+    // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
+    // have been waited for by every one of its members)
+    if (hipMemcpy(lead->grp_pdevs, views.data(), sizeof(Dev) * 2 * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    const Dev *v0 = lead->grp_pdevs, *v1 = lead->grp_pdevs + m;
+    // (from here on a failure is an error for every member: part of the shared batch may already be in the queue)
+    for (int k = 0; k < m; ++k)
+        if (hipMemsetAsync(&G.slots[(size_t)members[(size_t)k]].c->d.ctrl->pipe_break, 0, sizeof(int), M) != hipSuccess) return BGMM_EDEVICE;
+    auto evG = [&](int k) { return lead->pipe_ev[(size_t)(2 + 2 * k)]; };
+    auto evR = [&](int k) { return lead->pipe_ev[(size_t)(3 + 2 * k)]; };
+    const Dev &L = lead->d;
+    if (!launch_gram_cross_pgroup(L, v0, v1, m, 0, false, M)) return BGMM_EDEVICE;
+    if (hipEventRecord(lead->pipe_ev[0], M) != hipSuccess || hipStreamWaitEvent(S, lead->pipe_ev[0], 0) != hipSuccess) return BGMM_EDEVICE;
+    if (T > 1) {
+        launch_gram_cross_pgroup(L, v0, v1, m, 1, true, S);
+        if (hipEventRecord(evG(1), S) != hipSuccess) return BGMM_EDEVICE;
+    }
+    for (int k = 0; k < T; ++k) {
+        if (k > 0) {
+            if (hipStreamWaitEvent(M, evG(k), 0) != hipSuccess) return BGMM_EDEVICE;
+            launch_gram_carry_pgroup(v0, v1, m, k, M);
+        }
+        launch_gram_resolve_pgroup(L, v0, v1, m, k, reach, lead->gram_lds, M);
+        if (hipEventRecord(evR(k), M) != hipSuccess || hipStreamWaitEvent(S, evR(k), 0) != hipSuccess) return BGMM_EDEVICE;
+        launch_gram_finish_pgroup(L, v0, v1, m, k, S);
+        if (k + 2 < T) {
+            launch_gram_cross_pgroup(L, v0, v1, m, k + 2, true, S);
+            if (hipEventRecord(evG(k + 2), S) != hipSuccess) return BGMM_EDEVICE;
+        }
+    }
+    if (hipEventRecord(lead->pipe_ev[1], S) != hipSuccess || hipStreamWaitEvent(M, lead->pipe_ev[1], 0) != hipSuccess) return BGMM_EDEVICE;
+    if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
+    if (hipEventRecord(lead->grp_ev_out, M) != hipSuccess) return BGMM_EDEVICE;
     return 0;
 }
 

@@ -206,6 +206,8 @@ struct bgmm_ctx {
     int combiner_slot = -1;
     hipEvent_t grp_ev_in = nullptr, grp_ev_out = nullptr;   // this chain's stream has reached the batch / the shared launches are queued
     int grp_devs_cap = 0;
+    Dev *grp_pdevs = nullptr;        // ... and of the views of a pipelined shared batch (two per chain: buffer sets 0 / 1)
+    int grp_pdevs_cap = 0;
     long long short_stood = 0, short_refused = 0;   // short steps over the life of the context (bgmm_get_short_step_stats)
     bool short_ok = false;           // the previous sweep (certified stays off) was ONE pruned window, moved nothing and
                                      // home_kernel decided every visit: the next one tries a short step (Dev::short_step)
@@ -375,5 +377,7 @@ int perm_pipe_drain(bgmm_ctx *c);                                               
 int perm_ensure(bgmm_ctx *c, PermPtrs &P);
 int perm_schedule(bgmm_ctx *c, const PermPtrs &P);
 struct GramCombiner;                                                                // api_group.hip
-int combiner_submit(bgmm_ctx *c, int T);
+// (0: queued with the group's plain windows, 2: with its pipelined windows, 1: queue it yourself, < 0: error)
+int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos);
+void gram_point_view(bgmm_ctx *c, Dev &v, int par);      // api_sweep.hip: the window buffers of set `par` into a view
 void combiner_declare_busy(bgmm_ctx *c);

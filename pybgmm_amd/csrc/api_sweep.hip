@@ -41,7 +41,7 @@ static bool ensure_gram(bgmm_ctx *c, int K) {
 }
 
 // the window buffers of set `par` into a device view (pipelined windows alternate between the two sets; plain ones use set 0)
-static void gram_point_view(bgmm_ctx *c, Dev &v, int par) {
+void gram_point_view(bgmm_ctx *c, Dev &v, int par) {
     void **m = c->gram_mem + 10 * par;
     v.gC = (double *)m[0]; v.gq0 = (double *)m[1]; v.glp0 = (double *)m[2]; v.ge0 = (double *)m[3];
     v.gmoves = (GramMove *)m[4]; v.gtouched = (int *)m[5]; v.gM = (double *)m[6]; v.gcc = (double *)m[7];
@@ -398,13 +398,25 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             first_batch = false;
             // (chains of a group call that are here together share the launches: GramCombiner above)
             int own = 1;
+            bool piped = false;
             if (c->combiner && !c->timing) {
-                own = combiner_submit(c, (int)Tg);
+                // (far inside the mover-dense regime the group's windows are pipelined like a single chain's: every chain says
+                //  how many it could take -- 0: none, e.g. right after a break of its chain)
+                long long Tp = 0;
+                if (c->pipe_mode && c->resolver_mode != 1 && remaining >= 4 * kGramRows && (was_first || hc.job.pos == pos)) {
+                    if (c->pipe_hold > 0) c->pipe_hold -= 1;
+                    else {
+                        Tp = remaining / kGramRows;
+                        if (Tp > Tg) Tp = Tg;
+                        if (Tp < 4) Tp = 0;
+                    }
+                }
+                own = combiner_submit(c, (int)Tg, (int)Tp, pos);
                 if (own < 0) return fail(c, BGMM_EDEVICE, "shared frozen-factor launch failed");
+                if (own == 2) { piped = true; own = 0; c->pipe_batches += 1; }
             }
             // (a chain on its own, far inside the mover-dense regime: the windows pipelined -- gram_finish and the next cross
             //  forms on a second stream beside the resolver; after a break of the chain a couple of plain batches first)
-            bool piped = false;
             if (own && c->pipe_mode && !c->combiner && !c->timing && c->resolver_mode != 1 && remaining >= 4 * kGramRows &&
                 (was_first || hc.job.pos == pos)) {
                 if (c->pipe_hold > 0) c->pipe_hold -= 1;

@@ -243,6 +243,20 @@ __global__ __launch_bounds__(256) void gram_group_kernel(const Dev *__restrict__
     const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
     gram_body<NJ>(d);
 }
+// Window k of a PIPELINED batch of several chains (api_group.hip: gram_group_pipe_launch): v0 / v1 hold every chain's view with
+// the window buffers of set 0 / 1 (xp_in = the other set's xp_out, pipe_pos = the visit the chain's batch starts at); window
+// k works in set k & 1, 64 k visits further on -- what gram_pipe_batch (api_sweep.hip) patches into the view it passes by value.
+__device__ __forceinline__ Dev gram_pgroup_view(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k, int chain) {
+    Dev d = ((k & 1) ? v1 : v0)[chain];
+    d.pipe = k == 0 ? 2 : 1;
+    d.pipe_pos += (long long)kGramRows * k;
+    return d;
+}
+template <int NJ>
+__global__ __launch_bounds__(256) void gram_cross_pgroup_kernel(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k, int with_previous) {
+    const Dev d = gram_pgroup_view(v0, v1, k, (int)blockIdx.y);
+    gram_body<NJ>(d, with_previous != 0);
+}
 
 
 // ------------------------------------------------------------------------------------------
@@ -290,6 +304,10 @@ __global__ __launch_bounds__(256) void gram_weights_kernel(Dev d) { gram_weights
 // (several chains in one launch: workgroup (x, c) works for chain group[c] -- bgmm_group_sweep_staged)
 __global__ __launch_bounds__(256) void gram_weights_group_kernel(const Dev *__restrict__ group) {
     const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
+    gram_weights_body(d);
+}
+__global__ __launch_bounds__(256) void gram_weights_pgroup_kernel(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k) {
+    const Dev d = gram_pgroup_view(v0, v1, k, (int)blockIdx.y);
     gram_weights_body(d);
 }
 
@@ -1136,6 +1154,11 @@ __global__ __launch_bounds__(GRT) void gram_resolve_group_kernel(const Dev *__re
     const Dev d = group[blockIdx.y];               // (a private copy: nothing the body writes can alias it)
     gram_resolve_body<LPL, KC, T>(d);
 }
+template <int LPL, int KC, int T>
+__global__ __launch_bounds__(GRT) void gram_resolve_pgroup_kernel(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k) {
+    const Dev d = gram_pgroup_view(v0, v1, k, (int)blockIdx.y);
+    gram_resolve_body<LPL, KC, T>(d);
+}
 
 
 
@@ -1154,7 +1177,12 @@ __global__ __launch_bounds__(GRT) void gram_resolve_group_kernel(const Dev *__re
 // stream while window w is walked.  A window that ends early, opens or deletes a component or fails breaks the chain
 // (Ctrl::pipe_break): the rest of the batch stands still and the host goes on with plain windows.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) {
+// Terms of ONE column a carry workgroup holds in LDS (16 KB).  Room for all kGramMaxTerms = 128 of a window (64 KB) let two
+// workgroups onto a compute unit -- eight chains' carry launches (up to 1 024 workgroups) went round twice and took 73 us on
+// the chain of every window against 14 for one chain; a column takes one or two terms per window, thirty-two never in the runs
+// measured -- and if it ever does the chain breaks like for any other window the pipeline cannot take.
+static constexpr int kGramCarryTerms = 32;
+__device__ __forceinline__ void gram_carry_body(const Dev &d) {
     extern __shared__ __attribute__((aligned(16))) double wn_raw[];      // [terms of the column][64] w over the NEW rows
     __shared__ int chain[kGramMaxTerms];
     __shared__ double chain_id[kGramMaxTerms];
@@ -1196,7 +1224,11 @@ __global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) {
     const double kN0 = d.k0 + (double)n0, kN1 = d.k0 + (double)n1, ik0 = 1.0 / kN0, ik1 = 1.0 / kN1;
     // ---- the terms' w over the new rows (wave 0, lane = new row: the recursion runs along the column's short chain)
     double q_new = 0.0;
-    if (tid < 64) {
+    if (tid < 64 && m > kGramCarryTerms) {
+        // (more terms on ONE column than the workgroup's LDS holds -- 64 moves of a window would have to pile up on it: the
+        //  chain breaks here, in front of the window's resolver, and the host goes on with plain windows)
+        if (lane == 0) { __hip_atomic_store(&c->pipe_break, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); chain[kGramMaxTerms - 1] = m; }
+    } else if (tid < 64) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double xr[4], idv[4];
         int rov[4];
@@ -1225,6 +1257,7 @@ __global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) {
     }
     __syncthreads();
     m = chain[kGramMaxTerms - 1];
+    if (m > kGramCarryTerms) return;
     // ---- the cross forms of the new window under the true state: every entry of the column's 64 x 64 block (the stored
     // form leaves 1 / k_N out: the resolver adds the NEW count's, so the old one's is swapped for it here)
     const double shift = ik0 - ik1;
@@ -1275,8 +1308,14 @@ __global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) {
     }
 }
 
+__global__ __launch_bounds__(256) void gram_carry_kernel(Dev d) { gram_carry_body(d); }
+__global__ __launch_bounds__(256) void gram_carry_pgroup_kernel(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k) {
+    const Dev d = gram_pgroup_view(v0, v1, k, (int)blockIdx.y);
+    gram_carry_body(d);
+}
+
 void launch_gram_carry(const Dev &d, hipStream_t st) {
-    const int lds = kGramMaxTerms * GR * (int)sizeof(double);
+    const int lds = kGramCarryTerms * GR * (int)sizeof(double);
     static PerDeviceLds attr;
     attr.ensure((const void *)gram_carry_kernel, lds);
     hipLaunchKernelGGL(gram_carry_kernel, dim3(kGramMaxTerms), dim3(256), lds, st, d);
@@ -1308,6 +1347,8 @@ static void configure_resolve_t() {
     (void)hipFuncSetAttribute((const void *)gram_resolve_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GramPlan<KC, T>::bytes);
     (void)hipFuncSetAttribute((const void *)gram_resolve_group_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GramPlan<KC, T>::bytes);
+    (void)hipFuncSetAttribute((const void *)gram_resolve_pgroup_kernel<LPL, KC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GramPlan<KC, T>::bytes);
 }
 
@@ -1414,4 +1455,43 @@ bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach,
     }
     launch_gram_finish_group(lead, group, G, st);
     return true;
+}
+
+// ---- the pipelined windows of several chains in shared launches (api_group.hip: gram_group_pipe_launch) -----------------------
+template <int NJ>
+static void launch_gram_cross_pgroup_t(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, hipStream_t st) {
+    const int lds = 2 * GR * (16 * NJ + 2) * (int)sizeof(double);
+    static PerDeviceLds attr;
+    attr.ensure((const void *)gram_cross_pgroup_kernel<NJ>, lds);
+    hipLaunchKernelGGL((gram_cross_pgroup_kernel<NJ>), dim3(lead.gcols, G), dim3(256), lds, st, v0, v1, k, with_previous ? 1 : 0);
+}
+bool launch_gram_cross_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, hipStream_t st) {
+    switch (lead.Dp / 16) {
+        case 1: launch_gram_cross_pgroup_t<1>(lead, v0, v1, G, k, with_previous, st); break;
+        case 2: launch_gram_cross_pgroup_t<2>(lead, v0, v1, G, k, with_previous, st); break;
+        case 3: launch_gram_cross_pgroup_t<3>(lead, v0, v1, G, k, with_previous, st); break;
+        case 4: launch_gram_cross_pgroup_t<4>(lead, v0, v1, G, k, with_previous, st); break;
+        case 5: launch_gram_cross_pgroup_t<5>(lead, v0, v1, G, k, with_previous, st); break;
+        case 6: launch_gram_cross_pgroup_t<6>(lead, v0, v1, G, k, with_previous, st); break;
+        case 7: launch_gram_cross_pgroup_t<7>(lead, v0, v1, G, k, with_previous, st); break;
+        case 8: launch_gram_cross_pgroup_t<8>(lead, v0, v1, G, k, with_previous, st); break;
+        default: return false;
+    }
+    hipLaunchKernelGGL(gram_weights_pgroup_kernel, dim3(GR, G), dim3(256), 0, st, v0, v1, k);
+    return true;
+}
+void launch_gram_carry_pgroup(const Dev *v0, const Dev *v1, int G, int k, hipStream_t st) {
+    const int lds = kGramCarryTerms * GR * (int)sizeof(double);
+    static PerDeviceLds attr;
+    attr.ensure((const void *)gram_carry_pgroup_kernel, lds);
+    hipLaunchKernelGGL(gram_carry_pgroup_kernel, dim3(kGramMaxTerms, G), dim3(256), lds, st, v0, v1, k);
+}
+void launch_gram_resolve_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, int reach, int resolve_lds, hipStream_t st) {
+    if (lead.gcols == kPlanA_KC) {
+        if (reach <= 128) hipLaunchKernelGGL((gram_resolve_pgroup_kernel<2, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, v0, v1, k);
+        else if (reach <= 256) hipLaunchKernelGGL((gram_resolve_pgroup_kernel<4, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, v0, v1, k);
+        else hipLaunchKernelGGL((gram_resolve_pgroup_kernel<6, kPlanA_KC, kPlanA_T>), dim3(1, G), dim3(GRT), resolve_lds, st, v0, v1, k);
+    } else {
+        hipLaunchKernelGGL((gram_resolve_pgroup_kernel<8, kPlanB_KC, kPlanB_T>), dim3(1, G), dim3(GRT), resolve_lds, st, v0, v1, k);
+    }
 }

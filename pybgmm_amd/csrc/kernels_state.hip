@@ -435,6 +435,26 @@ __global__ __launch_bounds__(TPB, SREGS <= 16 ? 3 : 1) void gram_finish_group_ke
 }
 
 
+// (window k of a pipelined batch of several chains: kernels_gram.hip, gram_pgroup_view)
+template <int SREGS>
+__global__ __launch_bounds__(TPB, SREGS <= 16 ? 3 : 1) void gram_finish_pgroup_kernel(const Dev *__restrict__ v0, const Dev *__restrict__ v1, int k) {
+    Dev d = ((k & 1) ? v1 : v0)[blockIdx.y];
+    d.pipe = k == 0 ? 2 : 1;
+    d.pipe_pos += (long long)kGramRows * k;
+    gram_finish_body<SREGS>(d);
+}
+void launch_gram_finish_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, hipStream_t st) {
+    const int lds = refresh_lds_bytes(lead.D, lead.cov_type);
+    static PerDeviceLds attr16, attr64;
+    if (lead.D <= 64) {
+        ensure_lds((const void *)gram_finish_pgroup_kernel<16>, lds, attr16);
+        hipLaunchKernelGGL(gram_finish_pgroup_kernel<16>, dim3(kGramMaxTerms, G), dim3(TPB), lds, st, v0, v1, k);
+    } else {
+        ensure_lds((const void *)gram_finish_pgroup_kernel<64>, lds, attr64);
+        hipLaunchKernelGGL(gram_finish_pgroup_kernel<64>, dim3(kGramMaxTerms, G), dim3(TPB), lds, st, v0, v1, k);
+    }
+}
+
 void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st) {
     const int lds = refresh_lds_bytes(lead.D, lead.cov_type);
     static PerDeviceLds attr16, attr64;

@@ -619,6 +619,57 @@ def test_pipelined_windows_against_plain_ones(N, D, K_true, K_init):
         assert abs(a[it][2] - b[it][2]) <= 1e-9 * abs(b[it][2])
 
 
+@pytest.mark.parametrize("D,mixed", [(64, False), (16, True)], ids=["D64", "D16-one-chain-plain"])
+def test_chains_side_by_side_share_pipelined_windows(D, mixed):
+    """Round 6: chains of one shape that burn in TOGETHER share their frozen-factor windows' launches (api_group.hip) -- and
+    those windows are pipelined like a single chain's (gram_group_pipe_launch: every kernel of the schedule one launch for all
+    chains, workgroup (x, chain); cross forms of window w + 1 and the finish of window w - 1 on a second stream beside the
+    resolvers).  Four chains from random starts with five times too many components -- windows that delete a component break
+    ONE chain's pipeline on the device while the others carry on -- against the same group with the pipeline switched off for
+    every chain (bgmm_set_window_pipeline(0): shared PLAIN windows), and, `mixed`, with it switched off for one chain only
+    (that one gets plain windows beside the others' pipelined ones): labels, counts, K, log marginal after every sweep."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, K_true, K_init, G = 16000, 10, 50, 4
+    X, _ = gendata.synth_mixture(N, D, K_true, seed=9 + D, mu_scale=3.0)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+
+    def run(pipe_of):
+        chains_ = []
+        for c in range(G):
+            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K_init, share_with=chains_[0][0] if chains_ else None)
+            ctx.set_window_pipeline(pipe_of(c))
+            ctx.set_assignments(np.unique(np.random.RandomState(70 + c).randint(0, K_init, N), return_inverse=True)[1])
+            _, key, _ = random.Random(900 + c).getstate()
+            chains_.append([ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
+        out = []
+        for it in range(3):
+            for ch in chains_:
+                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], None)
+            _lib.group_sweep_staged([ch[0] for ch in chains_], [None] * G)
+            out.append([(ch[0].assignments(), ch[0].counts(), ch[0].K, ch[0].log_marg()) for ch in chains_])
+        stats = [ch[0].window_pipeline_stats() for ch in chains_]
+        for ch in reversed(chains_):
+            ch[0].close()
+        return out, stats
+    piped, sp = run((lambda c: c != 1) if mixed else (lambda c: True))
+    plain, sq = run(lambda c: False)
+    assert all(s_["batches"] == 0 for s_ in sq), sq
+    assert all(s_["batches"] > 0 for c, s_ in enumerate(sp) if not (mixed and c == 1)), sp
+    if mixed:
+        assert sp[1]["batches"] == 0, sp
+    assert sum(s_["breaks"] for s_ in sp) > 0, "components die in these sweeps: some chain's pipeline is meant to break"
+    for it in range(3):
+        for c in range(G):
+            bad = np.nonzero(piped[it][c][0] != plain[it][c][0])[0]
+            assert bad.size == 0, "sweep %d chain %d: %d labels differ, first at i=%d" % (it, c, bad.size, bad[0])
+            npt.assert_array_equal(piped[it][c][1], plain[it][c][1])
+            assert piped[it][c][2] == plain[it][c][2]
+            assert abs(piped[it][c][3] - plain[it][c][3]) <= 1e-9 * abs(plain[it][c][3])
+    assert len({piped[2][c][0].tobytes() for c in range(G)}) == G, "chains with different seeds must differ"
+
+
 def _case_safe_stay(N, D, K, sep, flip):
     from pybgmm_amd.utils import gendata
     X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=sep)
@@ -2490,8 +2541,9 @@ def test_group_sweep_equals_separate_sweeps():
             ch[0].sweep_staged(powers[c])
         for c in range(len(shapes)):
             npt.assert_array_equal(grouped[c][0].assignments(), solo[c][0].assignments(), err_msg="sweep %d chain %d" % (it, c))
-            # (a chain on its own pipelines its frozen-factor windows, the chains of a group share plain ones: the factors
-            #  behind the log determinants are rebuilt by different routes -- the last digit may differ, nothing else)
+            # (pipelined and plain frozen-factor windows -- a lone chain, two chains of a group that share launches, a chain whose
+            #  pipeline broke -- rebuild the factors behind the log determinants by different routes: the last digit may
+            #  differ, nothing else)
             lg, ls = grouped[c][0].log_marg(), solo[c][0].log_marg()
             assert abs(lg - ls) <= 1e-13 * abs(ls)
             sg, ss = grouped[c][0].sweep_stats(), solo[c][0].sweep_stats()
@@ -2546,8 +2598,9 @@ def test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo():
             ch[0].sweep_staged(powers[c])
         for c in range(len(shapes)):
             npt.assert_array_equal(grouped[c][0].assignments(), solo[c][0].assignments(), err_msg="sweep %d chain %d" % (it, c))
-            # (a chain on its own pipelines its frozen-factor windows, the chains of a group share plain ones: the factors
-            #  behind the log determinants are rebuilt by different routes -- the last digit may differ, nothing else)
+            # (pipelined and plain frozen-factor windows -- a lone chain, two chains of a group that share launches, a chain whose
+            #  pipeline broke -- rebuild the factors behind the log determinants by different routes: the last digit may
+            #  differ, nothing else)
             lg, ls = grouped[c][0].log_marg(), solo[c][0].log_marg()
             assert abs(lg - ls) <= 1e-13 * abs(ls)
             sg, ss = grouped[c][0].sweep_stats(), solo[c][0].sweep_stats()

@@ -233,6 +233,8 @@ def chains_burnin(a):
         res[g] = (ts, mv)
         print("%2d chain(s): sweeps %s s, moves %s -> first sweep %.3g moves/s aggregate" % (
             g, " / ".join("%.3f" % t for t in ts), " / ".join(str(m) for m in mv), mv[0] / ts[0]), flush=True)
+        print("   pipelined batches / breaks per chain: %s" % " ".join("%d/%d" % (s_["batches"], s_["breaks"]) for s_ in
+                                                                       (ctx.window_pipeline_stats() for ctx in grp.ctxs)))
         if g == 1:
             solo.append(grp.assignments()[0])
         else:
