@@ -424,9 +424,11 @@ def burnin_chains_leg(args, X, local_rank, single_first):
     one = single_first["moves"] / single_first["seconds"]
     return {"chains": G, "first_sweep_s": round(dt, 3), "moves": int(sum(moves)), "aggregate_moves_per_s": round(agg, 1),
             "single_chain_moves_per_s": round(one, 1), "aggregate_over_single_chain": round(agg / one, 2), "setup_s": round(t_setup, 2),
-            "how": "bgmm_group_sweep_staged: chains that cannot take the one-workgroup sweep run concurrently, one stream and one "
-                   "host thread each; every chain label for label its solo run (tests/test_gpu_parity.py::"
-                   "test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo)"}
+            "how": "bgmm_group_sweep_staged: chains that cannot take the one-workgroup sweep run concurrently, a host thread "
+                   "each; while they burn in together their frozen-factor windows are ONE pipelined sequence of shared launches "
+                   "(workgroup (x, chain); api_group.hip gram_group_pipe_launch); every chain label for label its solo run "
+                   "(tests/test_gpu_parity.py::test_group_sweep_runs_large_chains_concurrently_and_equal_to_solo, "
+                   "::test_chains_side_by_side_share_pipelined_windows)"}
 
 
 def launch_plan(gpus, env, devices_visible):

@@ -307,6 +307,11 @@ BGMM_API int bgmm_get_proof_pass_stats(bgmm_ctx *ctx, int64_t *out2);
  * host reads the control block and runs two plain batches first), the mode, plain batches still to go}. */
 BGMM_API int bgmm_set_window_pipeline(bgmm_ctx *ctx, int32_t enabled);
 BGMM_API int bgmm_get_window_pipeline_stats(bgmm_ctx *ctx, int64_t *out4);
+/* What this chain's batches were queued as inside bgmm_group_sweep_staged calls (chains of one shape that are in the same
+ * regime together share their launches -- one launch per kernel for all of them, workgroup (x, chain)): out4 = {batches of
+ * frozen-factor windows shared, of those pipelined, batches of safe-stay steps shared, batches of either kind this chain
+ * queued on its own although it was in a group (nobody of its shape was there with it)}. */
+BGMM_API int bgmm_get_group_stats(bgmm_ctx *ctx, int64_t *out4);
 /* The dense proof pass of the safe-stay windows takes the exact quadratic forms of its (visit, label) pairs from a
  * LOOK-AHEAD: a second stream scores them a chunk of `chunk_visits` visits at a time (a power of two, default 8192; 0: off
  * -- every stretch scores its own pairs on the chain's stream), every slot, beside the resolver; a stretch re-scores only

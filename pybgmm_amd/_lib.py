@@ -56,6 +56,7 @@ SIGNATURES = {
     "bgmm_set_proof_lookahead": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "bgmm_get_proof_lookahead_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_get_window_pipeline_stats": (ctypes.c_int, [_vp, _vp]),
+    "bgmm_get_group_stats": (ctypes.c_int, [_vp, _vp]),
     "bgmm_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
     "bgmm_group_sweep_staged": (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp]),
     "bgmm_sweep_staged_begin": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double]),
@@ -315,6 +316,12 @@ class Context(object):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.bgmm_get_window_pipeline_stats(self.h, _ptr(out)))
         return {"batches": int(out[0]), "breaks": int(out[1]), "mode": int(out[2]), "hold": int(out[3])}
+
+    def group_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.bgmm_get_group_stats(self.h, _ptr(out)))
+        return {"shared_frozen_factor_batches": int(out[0]), "of_them_pipelined": int(out[1]), "shared_safe_stay_batches": int(out[2]),
+                "batches_on_its_own_in_a_group": int(out[3])}
 
     def permutation_pipe_state(self):
         out = np.zeros(4, dtype=np.int64)

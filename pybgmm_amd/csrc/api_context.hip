@@ -805,6 +805,12 @@ extern "C" int bgmm_get_window_pipeline_stats(bgmm_ctx *c, int64_t *out4) {
     return 0;
 }
 
+extern "C" int bgmm_get_group_stats(bgmm_ctx *c, int64_t *out4) {
+    if (!c || !out4) return BGMM_EINVAL;
+    for (int k = 0; k < 4; ++k) out4[k] = c->grp_stats[k];
+    return 0;
+}
+
 extern "C" int bgmm_set_proof_lookahead(bgmm_ctx *c, int32_t chunk_visits) {
     if (!c || chunk_visits < 0) return BGMM_EINVAL;
     SETTLE(c);

@@ -13,7 +13,7 @@
 // trajectories are those of separate sweeps.
 struct GramCombiner {
     enum { UNKNOWN = 0, WAITING = 1, BUSY = 2, DONE = 3 };
-    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int pipe_T = 0; long long pos = 0; int result = 0; hipEvent_t ev = nullptr; };
+    struct Slot { int state = UNKNOWN; bgmm_ctx *c = nullptr; int T = 0; int pipe_T = 0; long long pos = 0; int kind = 0; int result = 0; hipEvent_t ev = nullptr; };
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
@@ -36,14 +36,14 @@ struct GramCombiner {
     }
 };
 
-static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of, int kind);
 static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of);
 
 // Returns 0: the batch has been queued with the group's (the chain's stream waits for it), 2: ... as PIPELINED windows;
 // 1: queue it yourself; < 0: error.  pipe_T: the pipelined windows this chain could take from visit `pos` on (0: none).
 void combiner_declare_busy(bgmm_ctx *c) { c->combiner->declare(c->combiner_slot, GramCombiner::BUSY); }
 
-int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
+int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos, int kind) {
     GramCombiner &G = *c->combiner;
     const int me = c->combiner_slot;
     // (a chain that cannot take part queues its batch itself -- and says so, or the others would wait for its declaration)
@@ -57,7 +57,7 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
     if (hipEventRecord(c->grp_ev_in, c->stream) != hipSuccess) { G.declare(me, GramCombiner::BUSY); return 1; }
     std::unique_lock<std::mutex> lk(G.mu);
     GramCombiner::Slot &S = G.slots[(size_t)me];
-    S.state = GramCombiner::WAITING; S.T = T; S.pipe_T = pipe_T; S.pos = pos; S.result = 1; S.ev = nullptr;
+    S.state = GramCombiner::WAITING; S.T = T; S.pipe_T = pipe_T; S.pos = pos; S.kind = kind; S.result = 1; S.ev = nullptr;
     G.elect_locked();
     G.cv.wait(lk, [&] { return S.state != GramCombiner::WAITING || G.leader == me; });
     if (S.state == GramCombiner::WAITING) {
@@ -67,7 +67,7 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
         for (size_t k = 0; k < G.slots.size(); ++k) {
             const GramCombiner::Slot &o = G.slots[k];
             if (o.state != GramCombiner::WAITING) continue;
-            if (o.c->device == c->device && o.c->d.D == c->d.D && o.c->d.gcols == c->d.gcols && o.c->gram_lds == c->gram_lds) {
+            if (o.kind == kind && o.c->device == c->device && o.c->d.D == c->d.D && o.c->d.gcols == c->d.gcols && o.c->gram_lds == c->gram_lds) {
                 members.push_back((int)k);
                 if (o.T > Tmax) Tmax = o.T;
             }
@@ -80,7 +80,7 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
         int Tpipe = 1 << 30;
         for (int k : members) {
             const GramCombiner::Slot &o = G.slots[(size_t)k];
-            if (pipe_on && o.pipe_T >= 4) { piped.push_back(k); if (o.pipe_T < Tpipe) Tpipe = o.pipe_T; }
+            if (pipe_on && kind == 0 && o.pipe_T >= 4) { piped.push_back(k); if (o.pipe_T < Tpipe) Tpipe = o.pipe_T; }
             else plain.push_back(k);
         }
         if (piped.size() < 2) { plain = members; piped.clear(); }
@@ -88,7 +88,7 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
         std::vector<hipEvent_t> ev_plain, ev_piped;     // per member: the event its stream waits for (its sub-group's)
         lk.unlock();
         if (piped.size() >= 2) rc_piped = gram_group_pipe_launch(G, piped, Tpipe, ev_piped);
-        if (plain.size() >= 2) rc_plain = gram_group_launch(G, plain, Tmax, ev_plain);
+        if (plain.size() >= 2) rc_plain = gram_group_launch(G, plain, Tmax, ev_plain, kind);
         lk.lock();
         if (rc_piped == 0) { G.shared_batches += 1; G.piped_batches += 1; G.shared_members += (long long)piped.size(); }
         if (rc_plain == 0) { G.shared_batches += 1; G.shared_members += (long long)plain.size(); }
@@ -132,7 +132,7 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos) {
 // C4 chains: 201 + 132 us per window whatever runs beside them).  One stream per chain, the other extreme, keeps only
 // about four kernels in flight and stretches every one of them.  BGMM_DEV_OPTIONS group_split
 // overrides the number of sub-groups (1: one launch sequence for all).
-static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of) {
+static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, int T, std::vector<hipEvent_t> &ev_of, int kind) {
     bgmm_ctx *lead = G.slots[(size_t)members[0]].c;
     const int m = (int)members.size();
     ev_of.assign((size_t)m, nullptr);
@@ -144,10 +144,13 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
         lead->grp_devs_cap = m;
     }
     static const int split_env = bgmm_dev_option("group_split", 0);
-    int n_sub = split_env > 0 ? split_env : (m >= 4 ? 2 : 1);
+    // (safe-stay steps keep a second stream busy themselves -- the look-ahead --: one sequence for all chains measured best,
+    //  8 C4-shaped chains 14.9 sweeps/s against 13.5 with two sub-groups and 11.5 with four)
+    int n_sub = split_env > 0 ? split_env : (kind == 1 ? 1 : (m >= 4 ? 2 : 1));
     if (n_sub > m / 2) n_sub = m / 2 > 0 ? m / 2 : 1;
     std::vector<Dev> views((size_t)m);
-    std::vector<int> reach_of((size_t)n_sub, 0), lo_of((size_t)n_sub + 1, 0);
+    std::vector<int> reach_of((size_t)n_sub, 0), lo_of((size_t)n_sub + 1, 0), nslots_of((size_t)n_sub, 0);
+    std::vector<long long> rows_of((size_t)n_sub, 0);
     for (int g = 0; g <= n_sub; ++g) lo_of[(size_t)g] = (int)((long long)m * g / n_sub);
     for (int g = 0; g < n_sub; ++g) {
         bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
@@ -156,22 +159,68 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
             views[(size_t)k] = o->d;
             const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
             if (r > reach_of[(size_t)g]) reach_of[(size_t)g] = r;
+            if (o->d.nslots > nslots_of[(size_t)g]) nslots_of[(size_t)g] = o->d.nslots;
+            if (o->d.batch_rows > rows_of[(size_t)g]) rows_of[(size_t)g] = o->d.batch_rows;
             // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
             if (o != sl && hipStreamWaitEvent(sl->stream, o->grp_ev_in, 0) != hipSuccess) return 1;
             ev_of[(size_t)k] = sl->grp_ev_out;
         }
     }
+    // (safe-stay steps: a sub-group takes the look-ahead's route iff every chain in it would -- the same chunk for all; its
+    //  second stream and events are its first chain's)
+    std::vector<int> ahead_of((size_t)n_sub, 0);
+    if (kind == 1)
+        for (int g = 0; g < n_sub; ++g) {
+            bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+            long long C = views[(size_t)lo_of[(size_t)g]].ahead_C;
+            for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k)
+                if (views[(size_t)k].ahead_C != C) C = 0;
+            if (C > 0 && !sl->ahead_stream) {
+                if (hipStreamCreateWithFlags(&sl->ahead_stream, hipStreamNonBlocking) != hipSuccess) C = 0;
+                else
+                    for (auto &row : sl->ahead_ev)
+                        for (hipEvent_t &e : row)
+                            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+            }
+            ahead_of[(size_t)g] = C > 0 ? 1 : 0;
+            if (C <= 0)
+                for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k) views[(size_t)k].ahead_C = 0;
+        }
     // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
     // have been waited for by every one of its members)
     if (hipMemcpy(lead->grp_devs, views.data(), sizeof(Dev) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) return 1;
     // (from here on a failure is an error for every member, not a reason to queue their batches separately: part of the shared
     // batch may already be in the queue, and separate launches would run beside it on the same chains)
     // window by window across the sub-groups, so that the host queues them at the same pace
+    if (kind == 1)
+        for (int g = 0; g < n_sub; ++g) {
+            bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
+            launch_safe_open_group(lead->grp_devs + lo_of[(size_t)g], lo_of[(size_t)g + 1] - lo_of[(size_t)g], sl->stream);
+        }
     for (int t = 0; t < T; ++t)
         for (int g = 0; g < n_sub; ++g) {
             bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;
-            if (!launch_gram_group_step(sl->d, lead->grp_devs + lo_of[(size_t)g], lo_of[(size_t)g + 1] - lo_of[(size_t)g],
-                                        reach_of[(size_t)g], sl->gram_lds, sl->stream)) return BGMM_EDEVICE;
+            const Dev *grp = lead->grp_devs + lo_of[(size_t)g];
+            const int cnt = lo_of[(size_t)g + 1] - lo_of[(size_t)g];
+            bool ok;
+            if (kind == 1) {
+                // (a safe-stay step -- the touched labels of every chain's open stretch re-scored, its verdicts and list, then
+                //  the frozen-factor kernels on the listed rows; the look-ahead's ring kept current on the sub-group's second
+                //  stream: launch_safe_step, kernels_safe.hip)
+                const bool ah_on = ahead_of[(size_t)g] != 0;
+                SafeAhead ah{sl->ahead_stream, sl->ahead_ev[0][t & 7], sl->ahead_ev[1][t & 7]};
+                if (ah_on && t > 0 && hipStreamWaitEvent(sl->stream, sl->ahead_ev[1][(t - 1) & 7], 0) != hipSuccess) return BGMM_EDEVICE;
+                ok = launch_safe_group_step(views[(size_t)lo_of[(size_t)g]], grp, cnt, reach_of[(size_t)g], sl->gram_lds, rows_of[(size_t)g],
+                                            nslots_of[(size_t)g], sl->stream, ah_on ? &ah : nullptr);
+            } else {
+                ok = launch_gram_group_step(sl->d, grp, cnt, reach_of[(size_t)g], sl->gram_lds, sl->stream);
+            }
+            if (!ok) return BGMM_EDEVICE;
+        }
+    if (kind == 1)
+        for (int g = 0; g < n_sub; ++g) {
+            bgmm_ctx *sl = G.slots[(size_t)members[(size_t)lo_of[(size_t)g]]].c;       // (the second stream is idle when the batch ends)
+            if (ahead_of[(size_t)g] && hipStreamWaitEvent(sl->stream, sl->ahead_ev[1][(T - 1) & 7], 0) != hipSuccess) return BGMM_EDEVICE;
         }
     if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;
     for (int g = 0; g < n_sub; ++g) {
@@ -199,7 +248,7 @@ static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &membe
         if (hipMalloc((void **)&lead->grp_pdevs, sizeof(Dev) * 2 * (size_t)m) != hipSuccess) return 1;
         lead->grp_pdevs_cap = 2 * m;
     }
-    while (lead->pipe_ev.size() < (size_t)(2 * T + 2)) {
+    while (lead->pipe_ev.size() < (size_t)(3 * T + 5)) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
         lead->pipe_ev.push_back(e);
@@ -209,7 +258,7 @@ static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &membe
     // same: 4.74 - 4.78 s for 8 C4 chains' first sweep).
     hipStream_t M = lead->stream, S = G.slots[(size_t)members[1]].c->stream;
     std::vector<Dev> views(2 * (size_t)m);
-    int reach = 0;
+    int reach = 0, max_K = 0;
     for (int k = 0; k < m; ++k) {
         const GramCombiner::Slot &sl = G.slots[(size_t)members[(size_t)k]];
         bgmm_ctx *o = sl.c;
@@ -224,6 +273,7 @@ static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &membe
         views[(size_t)m + (size_t)k].xp_in = views[(size_t)k].xp_out;
         const int r = o->d.gram_K + o->d.gram_terms / 2 + 2 + 32;
         if (r > reach) reach = r;
+        if (o->d.gram_K > max_K) max_K = o->d.gram_K;
         // (what the member has queued on its own stream -- the sweep's opening, rebuilt factors -- comes first)
         if (o != lead && hipStreamWaitEvent(M, o->grp_ev_in, 0) != hipSuccess) return 1;
         ev_of[(size_t)k] = lead->grp_ev_out;
@@ -235,27 +285,49 @@ static int gram_group_pipe_launch(GramCombiner &G, const std::vector<int> &membe
     // (from here on a failure is an error for every member: part of the shared batch may already be in the queue)
     for (int k = 0; k < m; ++k)
         if (hipMemsetAsync(&G.slots[(size_t)members[(size_t)k]].c->d.ctrl->pipe_break, 0, sizeof(int), M) != hipSuccess) return BGMM_EDEVICE;
-    auto evG = [&](int k) { return lead->pipe_ev[(size_t)(2 + 2 * k)]; };
-    auto evR = [&](int k) { return lead->pipe_ev[(size_t)(3 + 2 * k)]; };
+    auto evG = [&](int k) { return lead->pipe_ev[(size_t)(2 + 3 * k)]; };
+    auto evR = [&](int k) { return lead->pipe_ev[(size_t)(3 + 3 * k)]; };
+    auto evC = [&](int k) { return lead->pipe_ev[(size_t)(4 + 3 * k)]; };
     const Dev &L = lead->d;
-    if (!launch_gram_cross_pgroup(L, v0, v1, m, 0, false, M)) return BGMM_EDEVICE;
+    // (finish(k - 1) is held back until carry(k) is through: the two start at the same moment otherwise -- the end of
+    //  resolve(k - 1) --, and the carry, which is on the chain of every window, took 66 us beside the finish of eight chains
+    //  against 14 alone.  BGMM_DEV_OPTIONS="group_carry_first=0": gram_pipe_batch's order)
+    static const bool carry_first = bgmm_dev_option("group_carry_first", 1) != 0;
+    if (!launch_gram_cross_pgroup(L, v0, v1, m, 0, false, max_K, M)) return BGMM_EDEVICE;
     if (hipEventRecord(lead->pipe_ev[0], M) != hipSuccess || hipStreamWaitEvent(S, lead->pipe_ev[0], 0) != hipSuccess) return BGMM_EDEVICE;
     if (T > 1) {
-        launch_gram_cross_pgroup(L, v0, v1, m, 1, true, S);
+        launch_gram_cross_pgroup(L, v0, v1, m, 1, true, max_K, S);
         if (hipEventRecord(evG(1), S) != hipSuccess) return BGMM_EDEVICE;
     }
     for (int k = 0; k < T; ++k) {
         if (k > 0) {
             if (hipStreamWaitEvent(M, evG(k), 0) != hipSuccess) return BGMM_EDEVICE;
             launch_gram_carry_pgroup(v0, v1, m, k, M);
+            if (carry_first) {
+                // the second stream's share of window k - 1, behind this carry
+                if (hipEventRecord(evC(k), M) != hipSuccess || hipStreamWaitEvent(S, evR(k - 1), 0) != hipSuccess ||
+                    hipStreamWaitEvent(S, evC(k), 0) != hipSuccess) return BGMM_EDEVICE;
+                launch_gram_finish_pgroup(L, v0, v1, m, k - 1, S);
+                if (k + 1 < T) {
+                    launch_gram_cross_pgroup(L, v0, v1, m, k + 1, true, max_K, S);
+                    if (hipEventRecord(evG(k + 1), S) != hipSuccess) return BGMM_EDEVICE;
+                }
+            }
         }
         launch_gram_resolve_pgroup(L, v0, v1, m, k, reach, lead->gram_lds, M);
-        if (hipEventRecord(evR(k), M) != hipSuccess || hipStreamWaitEvent(S, evR(k), 0) != hipSuccess) return BGMM_EDEVICE;
-        launch_gram_finish_pgroup(L, v0, v1, m, k, S);
-        if (k + 2 < T) {
-            launch_gram_cross_pgroup(L, v0, v1, m, k + 2, true, S);
-            if (hipEventRecord(evG(k + 2), S) != hipSuccess) return BGMM_EDEVICE;
+        if (hipEventRecord(evR(k), M) != hipSuccess) return BGMM_EDEVICE;
+        if (!carry_first) {
+            if (hipStreamWaitEvent(S, evR(k), 0) != hipSuccess) return BGMM_EDEVICE;
+            launch_gram_finish_pgroup(L, v0, v1, m, k, S);
+            if (k + 2 < T) {
+                launch_gram_cross_pgroup(L, v0, v1, m, k + 2, true, max_K, S);
+                if (hipEventRecord(evG(k + 2), S) != hipSuccess) return BGMM_EDEVICE;
+            }
         }
+    }
+    if (carry_first) {
+        if (hipStreamWaitEvent(S, evR(T - 1), 0) != hipSuccess) return BGMM_EDEVICE;
+        launch_gram_finish_pgroup(L, v0, v1, m, T - 1, S);
     }
     if (hipEventRecord(lead->pipe_ev[1], S) != hipSuccess || hipStreamWaitEvent(M, lead->pipe_ev[1], 0) != hipSuccess) return BGMM_EDEVICE;
     if (hipGetLastError() != hipSuccess) return BGMM_EDEVICE;

@@ -206,6 +206,7 @@ struct bgmm_ctx {
     int combiner_slot = -1;
     hipEvent_t grp_ev_in = nullptr, grp_ev_out = nullptr;   // this chain's stream has reached the batch / the shared launches are queued
     int grp_devs_cap = 0;
+    long long grp_stats[4] = {0, 0, 0, 0};   // bgmm_get_group_stats
     Dev *grp_pdevs = nullptr;        // ... and of the views of a pipelined shared batch (two per chain: buffer sets 0 / 1)
     int grp_pdevs_cap = 0;
     long long short_stood = 0, short_refused = 0;   // short steps over the life of the context (bgmm_get_short_step_stats)
@@ -378,6 +379,8 @@ int perm_ensure(bgmm_ctx *c, PermPtrs &P);
 int perm_schedule(bgmm_ctx *c, const PermPtrs &P);
 struct GramCombiner;                                                                // api_group.hip
 // (0: queued with the group's plain windows, 2: with its pipelined windows, 1: queue it yourself, < 0: error)
-int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos);
+// kind 0: a batch of frozen-factor windows (pipe_T of them could be pipelined from visit pos on), 1: of safe-stay steps with
+// the dense proof pass and no look-ahead
+int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos, int kind);
 void gram_point_view(bgmm_ctx *c, Dev &v, int par);      // api_sweep.hip: the window buffers of set `par` into a view
 void combiner_declare_busy(bgmm_ctx *c);

@@ -289,7 +289,11 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
         }
         // (beside other chains of a group call: a batch of frozen-factor windows is queued together with theirs -- declared
         // when it is submitted; any other kind of batch is this chain's own business, and nobody waits for it meanwhile)
-        if (c->combiner && !(use_gram && !c->timing)) combiner_declare_busy(c);
+        // (... and so is a batch of safe-stay steps whose proof pass is the dense one: round 6)
+        static const bool group_safe_on = bgmm_dev_option("group_safe", 1) != 0;
+        const bool safe_dense_next = c->safe_dense_pin >= 0 ? c->safe_dense_pin != 0 : c->safe_dense_on;
+        const bool share_safe = use_safe && c->combiner && !c->timing && safe_dense_next && group_safe_on;
+        if (c->combiner && !((use_gram && !c->timing) || share_safe)) combiner_declare_busy(c);
         if (use_safe) {
             const Ctrl &hc = *c->ctrl_host;
             // windows still needed: from the visits a window has covered on average so far in this sweep
@@ -309,6 +313,7 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             d.gram_K = hc.job.K;
             // (a dense proof pass takes its forms from the look-ahead's ring: a second stream scores them a chunk at a time
             //  beside the resolver -- kernels_safe.hip "look-ahead"; not while the launches are being timed one by one)
+            // (chains of a group call that are here together share their steps' launches, look-ahead included: GramCombiner)
             const bool ahead = d.safe_dense && c->ahead_chunk > 0 && !c->timing && d.qstride >= 2ll * c->ahead_chunk &&
                                d.cov_type == COV_FULL && c->kind == KERNEL_MFMA;
             d.ahead_C = ahead ? c->ahead_chunk : 0;
@@ -327,16 +332,26 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
             first_batch = false;
             const long long w0 = hc.safe_windows, mv0 = hc.n_moves, rows0 = hc.safe_rows;
             const auto t_batch0 = std::chrono::steady_clock::now();
-            launch_safe_open(d, st);
-            for (int t = 0; t < (int)Tg; ++t) {
-                SafeAhead ah{c->ahead_stream, c->ahead_ev[0][t & 7], c->ahead_ev[1][t & 7]};
-                // (the request made by the step before has been served before this step's plan books it)
-                if (ahead && t > 0) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][(t - 1) & 7], 0));
-                if (!launch_safe_step(d, c->gram_lds, d.batch_rows, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr,
-                                      ahead ? &ah : nullptr))
-                    return fail(c, BGMM_EDEVICE, "safe-stay window launch failed");
+            int own_safe = 1;
+            if (share_safe) {
+                gram_point(c, 0);
+                d.pipe = 0;
+                own_safe = combiner_submit(c, (int)Tg, 0, pos, 1);
+                if (own_safe < 0) return fail(c, BGMM_EDEVICE, "shared safe-stay launch failed");
+                c->grp_stats[own_safe == 0 ? 2 : 3] += 1;
             }
-            if (ahead) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][((int)Tg - 1) & 7], 0));       // (the second stream is idle when the batch ends)
+            if (own_safe == 1) {
+                launch_safe_open(d, st);
+                for (int t = 0; t < (int)Tg; ++t) {
+                    SafeAhead ah{c->ahead_stream, c->ahead_ev[0][t & 7], c->ahead_ev[1][t & 7]};
+                    // (the request made by the step before has been served before this step's plan books it)
+                    if (ahead && t > 0) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][(t - 1) & 7], 0));
+                    if (!launch_safe_step(d, c->gram_lds, d.batch_rows, st, c->timing ? c->ev0[t] : nullptr, c->timing ? c->ev1[t] : nullptr,
+                                          ahead ? &ah : nullptr))
+                        return fail(c, BGMM_EDEVICE, "safe-stay window launch failed");
+                }
+                if (ahead) CK(c, hipStreamWaitEvent(st, c->ahead_ev[1][((int)Tg - 1) & 7], 0));       // (the second stream is idle when the batch ends)
+            }
             CK(c, hipGetLastError());
             int rc = fetch_ctrl(c);
             if (rc) return rc;
@@ -411,9 +426,10 @@ int sweep_impl(bgmm_ctx *c, int32_t use_power, double power, int phase) {
                         if (Tp < 4) Tp = 0;
                     }
                 }
-                own = combiner_submit(c, (int)Tg, (int)Tp, pos);
+                own = combiner_submit(c, (int)Tg, (int)Tp, pos, 0);
                 if (own < 0) return fail(c, BGMM_EDEVICE, "shared frozen-factor launch failed");
-                if (own == 2) { piped = true; own = 0; c->pipe_batches += 1; }
+                if (own == 2) { piped = true; own = 0; c->pipe_batches += 1; c->grp_stats[1] += 1; }
+                c->grp_stats[own == 0 ? 0 : 3] += 1;
             }
             // (a chain on its own, far inside the mover-dense regime: the windows pipelined -- gram_finish and the next cross
             //  forms on a second stream beside the resolver; after a break of the chain a couple of plain batches first)

@@ -485,11 +485,16 @@ void launch_gram_finish(const Dev &d, hipStream_t st);
 void launch_gram_finish_group(const Dev &lead, const Dev *group, int G, hipStream_t st);
 bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, hipStream_t st);   // G chains, shared launches
 // the pipelined windows of several chains in shared launches (v0 / v1: the chains' views with buffer set 0 / 1, window k)
-bool launch_gram_cross_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, hipStream_t st);
+bool launch_gram_cross_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, int max_K, hipStream_t st);
 void launch_gram_carry_pgroup(const Dev *v0, const Dev *v1, int G, int k, hipStream_t st);
 void launch_gram_resolve_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, int reach, int resolve_lds, hipStream_t st);
 void launch_gram_finish_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, hipStream_t st);
 void launch_safe_open(const Dev &d, hipStream_t st);                     // kernels_safe.hip
+void launch_safe_open_group(const Dev *group, int G, hipStream_t st);
+struct SafeAhead;
+bool launch_safe_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, long long max_rows, int max_nslots,
+                            hipStream_t st, const SafeAhead *ah);
+bool launch_score_proof_group(const Dev &lead, const Dev *group, int G, long long max_rows, int which, hipStream_t st);   // kernels_score.hip
 // (the look-ahead of a dense proof pass: its stream, the events "this step's plan is made" / "its request is served")
 struct SafeAhead { hipStream_t stream; hipEvent_t ev_plan, ev_done; };
 bool launch_safe_step(const Dev &d, int resolve_lds, long long max_rows, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,

@@ -1458,23 +1458,28 @@ bool launch_gram_group_step(const Dev &lead, const Dev *group, int G, int reach,
 }
 
 // ---- the pipelined windows of several chains in shared launches (api_group.hip: gram_group_pipe_launch) -----------------------
+// (cols: columns 0 .. cols - 1 get a workgroup.  A pipelined batch stands still from the window on that opens or deletes a
+//  component, so a chain has the K labels -- and the new table's column K -- it started the batch with: the plan's 448
+//  columns, most of whose workgroups returned at once but waited for 67 KB of LDS first, were seven rounds of eight chains'
+//  launch)
 template <int NJ>
-static void launch_gram_cross_pgroup_t(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, hipStream_t st) {
+static void launch_gram_cross_pgroup_t(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, int cols, hipStream_t st) {
     const int lds = 2 * GR * (16 * NJ + 2) * (int)sizeof(double);
     static PerDeviceLds attr;
     attr.ensure((const void *)gram_cross_pgroup_kernel<NJ>, lds);
-    hipLaunchKernelGGL((gram_cross_pgroup_kernel<NJ>), dim3(lead.gcols, G), dim3(256), lds, st, v0, v1, k, with_previous ? 1 : 0);
+    hipLaunchKernelGGL((gram_cross_pgroup_kernel<NJ>), dim3(cols, G), dim3(256), lds, st, v0, v1, k, with_previous ? 1 : 0);
 }
-bool launch_gram_cross_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, hipStream_t st) {
+bool launch_gram_cross_pgroup(const Dev &lead, const Dev *v0, const Dev *v1, int G, int k, bool with_previous, int max_K, hipStream_t st) {
+    const int cols = max_K + 2 < lead.gcols ? max_K + 2 : lead.gcols;
     switch (lead.Dp / 16) {
-        case 1: launch_gram_cross_pgroup_t<1>(lead, v0, v1, G, k, with_previous, st); break;
-        case 2: launch_gram_cross_pgroup_t<2>(lead, v0, v1, G, k, with_previous, st); break;
-        case 3: launch_gram_cross_pgroup_t<3>(lead, v0, v1, G, k, with_previous, st); break;
-        case 4: launch_gram_cross_pgroup_t<4>(lead, v0, v1, G, k, with_previous, st); break;
-        case 5: launch_gram_cross_pgroup_t<5>(lead, v0, v1, G, k, with_previous, st); break;
-        case 6: launch_gram_cross_pgroup_t<6>(lead, v0, v1, G, k, with_previous, st); break;
-        case 7: launch_gram_cross_pgroup_t<7>(lead, v0, v1, G, k, with_previous, st); break;
-        case 8: launch_gram_cross_pgroup_t<8>(lead, v0, v1, G, k, with_previous, st); break;
+        case 1: launch_gram_cross_pgroup_t<1>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 2: launch_gram_cross_pgroup_t<2>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 3: launch_gram_cross_pgroup_t<3>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 4: launch_gram_cross_pgroup_t<4>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 5: launch_gram_cross_pgroup_t<5>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 6: launch_gram_cross_pgroup_t<6>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 7: launch_gram_cross_pgroup_t<7>(lead, v0, v1, G, k, with_previous, cols, st); break;
+        case 8: launch_gram_cross_pgroup_t<8>(lead, v0, v1, G, k, with_previous, cols, st); break;
         default: return false;
     }
     hipLaunchKernelGGL(gram_weights_pgroup_kernel, dim3(GR, G), dim3(256), 0, st, v0, v1, k);

@@ -41,7 +41,7 @@
 
 // One thread: the open window becomes the stretch of the next proof pass (first step of a batch; later ones are
 // opened by the resolver that closes the window before).
-__global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
+__device__ __forceinline__ void safe_open_body(const Dev &d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode == MODE_DONE) return;
     for (int b = threadIdx.x; b < d.nslots + 2; b += 256) d.bucket_bins[b] = 0;      // (the bucket sort counts from zero)
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void safe_open_kernel(Dev d) {
 //   4 lb0 = Psi_min - logdet0/2 - cap/2    5 hv1_max   6 1: the label keeps >= 2 members whatever the window does
 //   7 dn: how far the resolver lets the label's count drift inside a window (negative: a small label, upwards only)
 // row nslots - 1: 0 e^-cap, 1 e^cap
-__global__ __launch_bounds__(64) void safe_rtab_kernel(Dev d) {
+__device__ __forceinline__ void safe_rtab_body(const Dev &d) {
     const Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     if (c->safe_epoch_built == c->state_epoch && c->safe_cap_built == safe_cap_now(d, c)) return;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void safe_ftab_kernel(Dev d) {
 // visiting order -- at most kSafeList of them: the stretch ends at the next one -- and the start of an epoch: every
 // label's budget account opened (Dev::ep_state), the first window's rows set.  One workgroup: every thread counts a
 // contiguous run, one scan, the threads in front of the cut emit.
-__global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) {
+__device__ __forceinline__ void safe_compact_body(const Dev &d) {
     __shared__ int wsum[16];
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void safe_choice_kernel(Dev d) {
 // against the home's robust lower bound -- the same bounds as above, with nothing excluded and nothing tabulated (sixteen threads per visit).  Where the
 // clusters overlap the per-home tables prove nothing and the pruning kernel keeps every pair: then this is the same arithmetic
 // without the bucket sort, the three table kernels, the home pass and the work lists (3 launches instead of 11 per stretch).
-__global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
+__device__ __forceinline__ void safe_dense_choice_body(const Dev &d) {
     Ctrl *c = d.ctrl;
     if (c->error != 0 || c->job.mode != MODE_FRESH || c->safe_epoch_valid) return;
     const long long base = c->job.win_base, nrows = c->job.win_hi - base;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) {
 //   3. describes the second stream's next work: the same labels over the ring's rows ahead of the stretch (mt_job per half),
 //      and a chunk to score in full (ah_job) -- the one the chain is in, from the end of the stretch at hand, if the ring
 //      does not hold it; else the next one once half of this one is behind the chain.
-__global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
+__device__ __forceinline__ void safe_plan_body(const Dev &d) {
     __shared__ int n_dirty_s, hw_s;
     Ctrl *c = d.ctrl;
     const int tid = threadIdx.x;
@@ -481,6 +481,48 @@ __global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) {
     c->ah_chunk[0] = ch[0]; c->ah_chunk[1] = ch[1]; c->ah_lo[0] = lo[0]; c->ah_lo[1] = lo[1];
     c->ah_seq[0] = ring_seq; c->ah_seq[1] = 1;
     c->ah_req_chunk = want; c->ah_req_seq = c->win_seq; c->ah_req_lo = want_lo;
+}
+
+__global__ __launch_bounds__(256) void safe_plan_kernel(Dev d) { safe_plan_body(d); }
+__global__ __launch_bounds__(256) void safe_plan_group_kernel(const Dev *__restrict__ group) { const Dev d = group[blockIdx.y]; safe_plan_body(d); }
+__global__ __launch_bounds__(256) void safe_open_kernel(Dev d) { safe_open_body(d); }
+__global__ __launch_bounds__(64) void safe_rtab_kernel(Dev d) { safe_rtab_body(d); }
+__global__ __launch_bounds__(1024) void safe_compact_kernel(Dev d) { safe_compact_body(d); }
+__global__ __launch_bounds__(256) void safe_dense_choice_kernel(Dev d) { safe_dense_choice_body(d); }
+// (several chains in one launch: workgroup (x, c) works for chain group[c] -- the shared safe-stay steps of api_group.hip)
+__global__ __launch_bounds__(256) void safe_open_group_kernel(const Dev *__restrict__ group) { const Dev d = group[blockIdx.y]; safe_open_body(d); }
+__global__ __launch_bounds__(64) void safe_rtab_group_kernel(const Dev *__restrict__ group) { const Dev d = group[blockIdx.y]; safe_rtab_body(d); }
+__global__ __launch_bounds__(1024) void safe_compact_group_kernel(const Dev *__restrict__ group) { const Dev d = group[blockIdx.y]; safe_compact_body(d); }
+__global__ __launch_bounds__(256) void safe_dense_choice_group_kernel(const Dev *__restrict__ group) {
+    const Dev d = group[blockIdx.y];
+    safe_dense_choice_body(d);
+}
+
+void launch_safe_open_group(const Dev *group, int G, hipStream_t st) {
+    hipLaunchKernelGGL(safe_open_group_kernel, dim3(1, G), dim3(256), 0, st, group);
+}
+// One safe-stay step of G chains of one shape whose proof pass is the dense one, without the look-ahead (launch_safe_step's
+// second branch), every kernel ONE launch for all of them.  max_rows / max_nslots: the largest stretch grid / slot count.
+// ah (optional; every chain's view then has the same ahead_C > 0): the look-ahead's second stream and events, as in
+// launch_safe_step's first branch -- plan, the second stream's three jobs beside the touched labels' re-scoring.
+bool launch_safe_group_step(const Dev &lead, const Dev *group, int G, int reach, int resolve_lds, long long max_rows, int max_nslots,
+                            hipStream_t st, const SafeAhead *ah) {
+    hipLaunchKernelGGL(safe_rtab_group_kernel, dim3(max_nslots, G), dim3(64), 0, st, group);
+    if (ah && lead.ahead_C > 0) {
+        hipLaunchKernelGGL(safe_plan_group_kernel, dim3(1, G), dim3(256), 0, st, group);
+        if (hipEventRecord(ah->ev_plan, st) != hipSuccess || hipStreamWaitEvent(ah->stream, ah->ev_plan, 0) != hipSuccess) return false;
+        // (a chunk, every slot + the touched labels over this half of the ring + over the other: one launch, grid.z = the job)
+        if (!launch_score_proof_group(lead, group, G, lead.ahead_C, 4, ah->stream)) return false;
+        if (hipEventRecord(ah->ev_done, ah->stream) != hipSuccess) return false;
+        launch_score_proof_group(lead, group, G, max_rows, 3, st);
+        hipLaunchKernelGGL(safe_dense_choice_group_kernel, dim3((unsigned)((max_rows + 15) / 16), G), dim3(256), 0, st, group);
+        hipLaunchKernelGGL(safe_compact_group_kernel, dim3(1, G), dim3(1024), 0, st, group);
+        return launch_gram_group_step(lead, group, G, reach, resolve_lds, st);
+    }
+    if (!launch_score_proof_group(lead, group, G, max_rows, -1, st)) return false;
+    hipLaunchKernelGGL(safe_dense_choice_group_kernel, dim3((unsigned)((max_rows + 15) / 16), G), dim3(256), 0, st, group);
+    hipLaunchKernelGGL(safe_compact_group_kernel, dim3(1, G), dim3(1024), 0, st, group);
+    return launch_gram_group_step(lead, group, G, reach, resolve_lds, st);
 }
 
 void launch_safe_open(const Dev &d, hipStream_t st) {

@@ -80,16 +80,16 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
 // PROOF: the dense proof pass of a safe-stay stretch (skip_pruned_jobs 2) is an instantiation of its own -- with its label split
 // as a run-time variable in the one kernel, the windows' instantiation spilled four A fragments and reloaded them in every
 // slot iteration (mode `full` 52.6 -> 43.8 sweeps/s between rounds 3 and 4).
-template <int NJ, int RB, int MINW, bool PROOF>
-__global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
-                                                            double *__restrict__ q, long long qstride,
-                                                            int col_override, int skip_pruned_jobs) {
+// (bx, by: the workgroup's row block and label chunk, gdy: the chunks the launch provides -- the launch grid's x / y index and y extent)
+template <int NJ, int RB, bool PROOF>
+__device__ __forceinline__ void score_mfma_body(const Dev &d, const Job *__restrict__ jobp, double *__restrict__ q, long long qstride,
+                                                int col_override, int skip_pruned_jobs, int bx, int by, int gdy) {
     const JobView job = load_job(jobp);
     // (PROOF: runs whatever the window's kind, but only in front of a stretch whose proofs are to be made, kernels_safe.hip)
     if (job.mode == MODE_DONE || (!PROOF && skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
         (PROOF && skip_pruned_jobs == 2 && d.ctrl->safe_epoch_valid)) return;      // (3: a job of the look-ahead's -- DONE when idle)
     constexpr int ROWS_W_ = 16 * RB;
-    const int chunk = blockIdx.y;
+    const int chunk = by;
     // (the dense proof pass covers a few thousand rows: its launch brings its own, finer split of the labels -- grid.y --
     // so that every compute unit holds two or three workgroups and a wavefront's factor loads hide behind its neighbours')
     int nchunks = job.chunks;
@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
         // with 400), at most one label chunk per grid row
         const long long rb = (job.win_hi - job.pos + 4 * ROWS_W_ - 1) / (4 * ROWS_W_);
         long long ch = rb > 0 ? (1400 + rb - 1) / rb : 1;
-        nchunks = (int)(ch < 2 ? 2 : (ch > (long long)gridDim.y ? (long long)gridDim.y : ch));
+        nchunks = (int)(ch < 2 ? 2 : (ch > (long long)gdy ? (long long)gdy : ch));
     }
     if (chunk >= nchunks || chunk >= job.nlist) return;
     constexpr int ROWS_W = ROWS_W_;              // rows per wave
     constexpr int NF = 2 * NJ * (NJ + 1);
     constexpr int PF = pick_pf(NF);
-    const long long pb = job.pos + (long long)blockIdx.x * (4 * ROWS_W);
+    const long long pb = job.pos + (long long)bx * (4 * ROWS_W);
     if (pb >= job.win_hi) return;
     const int D = d.D;
     const int lane = threadIdx.x & 63;
@@ -193,6 +193,40 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job 
     }
 }
 
+template <int NJ, int RB, int MINW, bool PROOF>
+__global__ __launch_bounds__(256, MINW) void score_mfma_kernel(Dev d, const Job *__restrict__ jobp,
+                                                            double *__restrict__ q, long long qstride,
+                                                            int col_override, int skip_pruned_jobs) {
+    score_mfma_body<NJ, RB, PROOF>(d, jobp, q, qstride, col_override, skip_pruned_jobs, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+// (the dense proof pass of several chains' stretches in one launch: workgroup (x, y, c) works for chain group[c] on its own
+//  open window, into its own q -- api_group.hip, the shared safe-stay steps)
+// which: -1 the chain's open window, every label (skip mode 2: launch_score(.., 2, ..)); 0 .. 2 the look-ahead's job
+// Dev::ah_job[which], 3 Dev::resc_job (skip mode 3; the list jobs index Dev::resc_list), 4 all three of ah_job (grid.z)
+// The grid is (kProofGroupBlocks, chains): a workgroup takes the (row block, label chunk) pairs of ITS chain's job blockIdx.x,
+// + gridDim.x, ... -- the job's real extent is on the device only, and a grid cut for the largest stretch a batch may reach
+// ((64 row blocks, 64 chunks) per chain, 4 096 workgroups of which a re-scoring of eight touched labels uses 80) made eight
+// chains' launch 32 768 workgroups: 282 us of dispatching against 27 for one chain.
+static constexpr int kProofGroupBlocks = 704, kProofChunks = 64;
+template <int NJ, int RB, int MINW>
+__global__ __launch_bounds__(256, MINW) void score_mfma_proof_group_kernel(const Dev *__restrict__ group, int which) {
+    Dev d = group[blockIdx.y];                     // (a private copy: nothing the body writes can alias it)
+    if (which == 4) which = (int)blockIdx.z;       // (the look-ahead's three jobs in ONE launch: grid.z = 3)
+    const Job *__restrict__ jobp = which < 0 ? &d.ctrl->job : (which == 3 ? d.resc_job : d.ah_job + which);
+    if (which > 0) d.slot_list = d.resc_list;
+    const int skip = which < 0 ? 2 : 3;
+    const JobView job = load_job(jobp);
+    if (job.mode == MODE_DONE) return;
+    const long long rows = job.win_hi - job.pos;
+    if (rows <= 0) return;
+    const int rb_count = (int)((rows + 4 * 16 * RB - 1) / (4 * 16 * RB));
+    const long long items = (long long)rb_count * kProofChunks;       // (chunks beyond the job's own split return at once)
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        // (chunk-major: the first gridDim.x items are the row blocks of the first chunks -- those every job has)
+        score_mfma_body<NJ, RB, true>(d, jobp, d.q, d.qstride, -1, skip, (int)(it % rb_count), (int)(it / rb_count), kProofChunks);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 template <int NJ>
 static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
@@ -213,6 +247,32 @@ static void launch_mfma(const Dev &d, const Job *job, double *q, long long qstri
 
 void launch_score_diag(const Dev &d, const Job *job, double *q, long long qstride, int col_override,
                        long long max_rows, int skip_pruned_jobs, hipStream_t st);
+
+template <int NJ>
+static void launch_mfma_proof_group(const Dev *group, int G, long long max_rows, int which, hipStream_t st) {
+    const unsigned gx = (unsigned)((max_rows + kMfmaRows - 1) / kMfmaRows);
+    constexpr int W = NJ <= 4 ? 3 : (NJ <= 5 ? 2 : 1);
+    constexpr int WP = NJ == 4 ? 2 : W;
+    (void)gx;
+    hipLaunchKernelGGL((score_mfma_proof_group_kernel<NJ, 2, WP>), dim3(kProofGroupBlocks, (unsigned)G, which == 4 ? 3 : 1), dim3(256), 0, st,
+                       group, which);
+}
+// the exact forms of each of G chains (full covariance, D <= 128) in one launch: every pair of its open stretch (which = -1:
+// launch_score(.., 2, ..) for all of them), or a job of its look-ahead (0 .. 2: Dev::ah_job, 3: Dev::resc_job)
+bool launch_score_proof_group(const Dev &lead, const Dev *group, int G, long long max_rows, int which, hipStream_t st) {
+    if (max_rows <= 0 || lead.cov_type != COV_FULL) return false;
+    switch (lead.Dp / 16) {
+        case 1: launch_mfma_proof_group<1>(group, G, max_rows, which, st); return true;
+        case 2: launch_mfma_proof_group<2>(group, G, max_rows, which, st); return true;
+        case 3: launch_mfma_proof_group<3>(group, G, max_rows, which, st); return true;
+        case 4: launch_mfma_proof_group<4>(group, G, max_rows, which, st); return true;
+        case 5: launch_mfma_proof_group<5>(group, G, max_rows, which, st); return true;
+        case 6: launch_mfma_proof_group<6>(group, G, max_rows, which, st); return true;
+        case 7: launch_mfma_proof_group<7>(group, G, max_rows, which, st); return true;
+        case 8: launch_mfma_proof_group<8>(group, G, max_rows, which, st); return true;
+        default: return false;
+    }
+}
 
 void launch_score(const Dev &d, int kind, const Job *job, double *q, long long qstride, int col_override,
                   long long max_rows, int skip_pruned_jobs, hipStream_t st) {

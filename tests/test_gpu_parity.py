@@ -670,6 +670,53 @@ def test_chains_side_by_side_share_pipelined_windows(D, mixed):
     assert len({piped[2][c][0].tobytes() for c in range(G)}) == G, "chains with different seeds must differ"
 
 
+def test_chains_side_by_side_share_safe_stay_steps():
+    """Round 6: chains of one shape whose clusters overlap (the regime a chain lives in: 0.5 % of the visits move at
+    equilibrium) share the launches of their safe-stay steps as well -- the dense proof pass of every chain's stretch, the
+    verdicts, the lists, the frozen-factor kernels on the listed rows: one launch each for all of them (api_group.hip kind 1,
+    kernels_safe.hip launch_safe_group_step).  Four chains with their own generators over one data set, four sweeps from the
+    truth, against the same chains swept one by one (which take the look-ahead's route on two streams of their own): labels,
+    counts, moves and log marginal after every sweep, and the group did share safe-stay batches."""
+    import random
+    from pybgmm_amd import _lib
+    from pybgmm_amd.utils import gendata
+    N, D, K, G = 60000, 64, 40, 4
+    X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=0.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+
+    def build():
+        out = []
+        for c in range(G):
+            ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K, share_with=out[0][0] if out else None)
+            ctx.set_assignments(zt)
+            _, key, _ = random.Random(40 + c).getstate()
+            out.append([ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
+        return out
+    grouped, solo = build(), build()
+    moved = 0
+    for it in range(4):
+        for chains_ in (grouped, solo):
+            for ch in chains_:
+                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], None)
+        _lib.group_sweep_staged([ch[0] for ch in grouped], [None] * G)
+        for ch in solo:
+            ch[0].sweep_staged(None)
+        for c in range(G):
+            bad = np.nonzero(grouped[c][0].assignments() != solo[c][0].assignments())[0]
+            assert bad.size == 0, "sweep %d chain %d: %d labels differ, first at i=%d" % (it, c, bad.size, bad[0])
+            npt.assert_array_equal(grouped[c][0].counts(), solo[c][0].counts())
+            assert grouped[c][0].sweep_stats()["moves"] == solo[c][0].sweep_stats()["moves"]
+            lg, ls = grouped[c][0].log_marg(), solo[c][0].log_marg()
+            assert abs(lg - ls) <= 1e-12 * abs(ls)
+        moved += grouped[0][0].sweep_stats()["moves"]
+    assert moved > 200, "the clusters are meant to overlap"
+    gs = [ch[0].group_stats() for ch in grouped]
+    assert sum(g_["shared_safe_stay_batches"] for g_ in gs) >= 2 * G, gs
+    assert len({ch[0].assignments().tobytes() for ch in grouped}) == G, "chains with different seeds must differ"
+    for ch in reversed(grouped + solo):
+        ch[0].close()
+
+
 def _case_safe_stay(N, D, K, sep, flip):
     from pybgmm_amd.utils import gendata
     X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=sep)
@@ -2826,7 +2873,12 @@ def test_contexts_over_one_data_set_share_its_device_copy():
     us = np.random.RandomState(1).random_sample((2, N))
     z0 = zt.copy(); z0[::97] = (z0[::97] + 1) % K
     _lib.load()
-    hip = ctypes.CDLL("libamdhip64.so")                  # (the runtime the library itself is linked against)
+    # the HIP runtime the library itself is linked against -- by the path it is mapped from: a process that has imported
+    # torch holds torch's own copy of libamdhip64 as well, and that one has no device open ("no device", error 100)
+    with open("/proc/self/maps") as f:
+        paths = [ln.split()[-1] for ln in f if "libamdhip64" in ln]
+    mine = [q for q in paths if "/torch/" not in q]
+    hip = ctypes.CDLL(mine[0] if mine else "libamdhip64.so")
 
     def free_bytes():
         f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)

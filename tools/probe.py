@@ -194,18 +194,25 @@ def chains(a):
     from pybgmm_amd.chains import ChainGroup
     from pybgmm_amd.utils import gendata
     N, D, K, G = a.N, a.D, a.K, a.G
-    X, zt = gendata.synth_mixture(N, D, K, seed=1)
+    X, zt = gendata.synth_mixture(N, D, K, seed=1, mu_scale=a.sep) if a.sep else gendata.synth_mixture(N, D, K, seed=1)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
     for g in (1, G):
         grp = ChainGroup(X, m_0, k_0, v_0, S_0, 1.0, 8 * K, n_chains=g, seed=1)
         grp.set_assignments([zt] * g)
-        grp.sweep(); grp.sweep()
+        if a.ahead >= 0:
+            for ctx in grp.ctxs:
+                ctx.set_proof_lookahead(a.ahead)
+        for _ in range(a.warm):
+            grp.sweep()
         t0 = time.time()
-        n = 5
+        n = a.sweeps
         for _ in range(n):
             grp.sweep()
         dt = (time.time() - t0) / n
-        print("%3d chains: %.2f ms per round of sweeps, %.1f sweeps/s aggregate" % (g, dt * 1e3, g / dt))
+        mv = sum(ctx.sweep_stats()["moves"] for ctx in grp.ctxs)
+        print("%3d chains: %.2f ms per round of sweeps, %.2f sweeps/s aggregate (%d moves in the last round)" % (g, dt * 1e3, g / dt, mv))
+        if g > 1:
+            print("    group stats of chain 0:", grp.ctxs[0].group_stats(), "safe:", grp.ctxs[0].path_stats())
         grp.close()
 
 
@@ -350,6 +357,10 @@ def parser():
     g.add_argument("G", type=int)
     g.add_argument("N", type=int, nargs="?", default=100000)
     g.add_argument("K", type=int, nargs="?", default=20)
+    g.add_argument("--sep", type=float, default=0.0, help="mu_scale of the data (0.55: the steady_moving regime of bench.py)")
+    g.add_argument("--sweeps", type=int, default=5)
+    g.add_argument("--warm", type=int, default=2)
+    g.add_argument("--ahead", type=int, default=-1, help="chunk of the proof pass's look-ahead for every chain (0: off; default: the library's)")
     gb = sub.add_parser("chains-burnin")
     for n in ("N", "D", "K", "G"):
         gb.add_argument(n, type=int)
