@@ -171,7 +171,35 @@ def steady_moving_leg(args, local_rank):
     timed = sweeps[3:]
     t = sum(x["seconds"] for x in timed)
     mv = sum(x["moves"] for x in timed)
+    side = None
+    if args.burnin_chains > 1 and model != "PCRPMM" and args.cov == "full":
+        # the same regime with G chains side by side on this GPU (their own generators over one copy of the data): chains of
+        # one shape share the launches of their safe-stay steps (api_group.hip)
+        from pybgmm_amd.chains import ChainGroup
+        G = args.burnin_chains
+        m_0, k_0, v_0, S_0 = prior_for(args.cov, D)
+        grp = ChainGroup(X2, m_0, k_0, v_0, S_0, 1.0, max(4 * K, 64), n_chains=G, seed=4100 + args.seed, device=local_rank, cov_type=args.cov)
+        grp.set_assignments([zt] * G)
+        for _ in range(3):
+            grp.sweep()
+        for c_ in grp.ctxs:
+            c_.synchronize()
+        t0 = time.time()
+        n_rounds = 3
+        for _ in range(n_rounds):
+            grp.sweep()
+        dtg = (time.time() - t0) / n_rounds
+        gs = grp.ctxs[0].group_stats()
+        mvg = sum(c_.sweep_stats()["moves"] for c_ in grp.ctxs)
+        grp.close()
+        one = len(timed) / t
+        side = {"chains": G, "ms_per_round_of_sweeps": round(1e3 * dtg, 2), "aggregate_sweeps_per_s": round(G / dtg, 2),
+                "aggregate_over_single_chain": round(G / dtg / one, 2), "moves_in_the_last_round": int(mvg),
+                "shared_safe_stay_batches_of_chain_0": gs["shared_safe_stay_batches"],
+                "how": "bgmm_group_sweep_staged: the chains' safe-stay steps are one launch per kernel for all of them (workgroup (x, chain)); "
+                       "every chain label for label its solo run (tests/test_gpu_parity.py::test_chains_side_by_side_share_safe_stay_steps)"}
     return {"workload": "%s shape, centres at mu_scale = %.2f (at-rest data: 4.0): clusters overlap" % (args.workload, args.moving_sep),
+            "chains_side_by_side": side,
             "sweeps_per_s": round(len(timed) / t, 3), "ms_per_sweep": round(1e3 * t / len(timed), 2),
             "moves_per_sweep": round(mv / len(timed), 1), "movers_fraction": round(mv / len(timed) / N, 5),
             "us_per_move": round(1e6 * t / max(mv, 1), 2),

@@ -215,7 +215,7 @@ static int create_impl(bgmm_ctx *c, int device, int64_t N, int32_t D, int32_t K_
     DALLOC(c, d.resc_list, ns);
     DALLOC(c, d.touch_seq, ns);
     CK(c, hipMemsetAsync(d.touch_seq, 0, sizeof(long long) * ns, c->stream));
-    d.ahead_C = 0; d.slot_list = nullptr;
+    d.ahead_C = 0; d.slot_list = nullptr; d.ahead_lazy = 0;
     DALLOC(c, d.glist, (size_t)kSafeList + 1);
     DALLOC(c, d.ep_state, ns);
     DALLOC(c, d.rtab, ns * 8);

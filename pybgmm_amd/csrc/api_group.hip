@@ -183,8 +183,11 @@ static int gram_group_launch(GramCombiner &G, const std::vector<int> &members, i
                             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
             }
             ahead_of[(size_t)g] = C > 0 ? 1 : 0;
-            if (C <= 0)
-                for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k) views[(size_t)k].ahead_C = 0;
+            static const bool lazy = bgmm_dev_option("group_lazy", 0) != 0;
+            for (int k = lo_of[(size_t)g]; k < lo_of[(size_t)g + 1]; ++k) {
+                if (C <= 0) views[(size_t)k].ahead_C = 0;
+                views[(size_t)k].ahead_lazy = (C > 0 && lazy) ? 1 : 0;
+            }
         }
     // (a blocking copy: the views are host memory of this call; the array's last readers -- the shared batch before this one --
     // have been waited for by every one of its members)

@@ -191,6 +191,7 @@ struct Ctrl {
                                        // it is dirty; [1] 1: a plan has been handed to the second stream in this batch
     long long ah_lo[2];                // ... first visit of the chunk that was scored
     long long ah_req_chunk, ah_req_seq, ah_req_lo;   // the request the second stream is serving (-1: none)
+    long long ah_hseq[2];              // (Dev::ahead_lazy) per half of the ring: the windows closed when its chunk was scored
     long long ah_served, ah_self, ah_dirty, ah_chunks;   // this sweep: stretches re-scored from the ring / scored in full,
                                                          // labels re-scored over the former, chunks requested
 };
@@ -378,6 +379,7 @@ struct Dev {
                                  // either half of the ring) / what the stretch at hand re-scores
     int *resc_list;              // [nslots] the dirty slots of resc_job
     const int *slot_list;        // MODE_LIST: the list this launch's job indexes
+    int ahead_lazy;              // 1: the ring's chunks are never re-scored -- a stretch re-scores every label touched since ITS chunk was made
     long long *touch_seq;        // [nslots] per slot: win_seq of the last window that changed it
     double *rtab;                // [nslots][8] per label of the frozen state: robust constants (kernels_safe.hip)
     double *ftabR;               // [nslots][64] per home label: robust upper bound of every other label's score

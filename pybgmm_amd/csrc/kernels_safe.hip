@@ -52,6 +52,7 @@ __device__ __forceinline__ void safe_open_body(const Dev &d) {
         c->ah_chunk[0] = c->ah_chunk[1] = -1;
         c->ah_req_chunk = -1;
         c->ah_seq[0] = c->win_seq; c->ah_seq[1] = 0;      // ([1]: no plan has been handed to the second stream yet)
+        c->ah_hseq[0] = c->ah_hseq[1] = c->win_seq;
     }
 }
 
@@ -430,7 +431,14 @@ __device__ __forceinline__ void safe_plan_body(const Dev &d) {
     long long ring_seq = c->ah_seq[0];
     const bool served = c->ah_seq[1] != 0;                          // (a plan was handed to the second stream last step)
     if (served) ring_seq = c->ah_req_seq;
-    if (c->ah_req_chunk >= 0) { ch[c->ah_req_chunk & 1] = c->ah_req_chunk; lo[c->ah_req_chunk & 1] = c->ah_req_lo; }
+    // (lazy: nobody keeps the ring current -- a half is as good as the state its chunk was scored under, and a stretch re-scores
+    //  every label touched since.  Several chains side by side: re-scoring the touched labels over ALL the ring's rows ahead
+    //  after every window is free beside one chain's resolver, and three quarters of the device's time beside eight)
+    long long hs[2] = {c->ah_hseq[0], c->ah_hseq[1]};
+    if (c->ah_req_chunk >= 0) {
+        ch[c->ah_req_chunk & 1] = c->ah_req_chunk; lo[c->ah_req_chunk & 1] = c->ah_req_lo;
+        hs[c->ah_req_chunk & 1] = c->ah_req_seq;
+    }
     const Job &j = c->job;
     const int K = j.K;
     const long long a = j.win_base, b = j.win_hi;
@@ -444,7 +452,7 @@ __device__ __forceinline__ void safe_plan_body(const Dev &d) {
     for (int t = tid; t < K; t += 256) {
         const int s = d.perm[t];
         hw = s + 1 > hw ? s + 1 : hw;
-        if (d.touch_seq[s] > ring_seq) d.resc_list[atomicAdd(&n_dirty_s, 1)] = s;
+        if (d.touch_seq[s] > (d.ahead_lazy ? hs[hc] : ring_seq)) d.resc_list[atomicAdd(&n_dirty_s, 1)] = s;
     }
     atomicMax(&hw_s, hw);
     __syncthreads();
@@ -467,9 +475,9 @@ __device__ __forceinline__ void safe_plan_body(const Dev &d) {
     const long long end_n = (cur + 2) * C < c->n_visits ? (cur + 2) * C : c->n_visits;
     {
         const long long p0 = from > lo[hc] ? from : lo[hc];
-        d.ah_job[1] = (ch[hc] == cur) ? job_of(MODE_LIST, p0, end_c, nd) : job_of(MODE_DONE, 0, 0, 0);
-        d.ah_job[2] = (ch[hn] == cur + 1) ? job_of(MODE_LIST, lo[hn] > (cur + 1) * C ? lo[hn] : (cur + 1) * C, end_n, nd)
-                                          : job_of(MODE_DONE, 0, 0, 0);
+        d.ah_job[1] = (ch[hc] == cur && !d.ahead_lazy) ? job_of(MODE_LIST, p0, end_c, nd) : job_of(MODE_DONE, 0, 0, 0);
+        d.ah_job[2] = (ch[hn] == cur + 1 && !d.ahead_lazy) ? job_of(MODE_LIST, lo[hn] > (cur + 1) * C ? lo[hn] : (cur + 1) * C, end_n, nd)
+                                                            : job_of(MODE_DONE, 0, 0, 0);
     }
     // ... and a chunk in full
     long long want = -1, want_lo = 0, want_hi = 0;
@@ -480,6 +488,7 @@ __device__ __forceinline__ void safe_plan_body(const Dev &d) {
     else c->ah_chunks += 1;
     c->ah_chunk[0] = ch[0]; c->ah_chunk[1] = ch[1]; c->ah_lo[0] = lo[0]; c->ah_lo[1] = lo[1];
     c->ah_seq[0] = ring_seq; c->ah_seq[1] = 1;
+    c->ah_hseq[0] = hs[0]; c->ah_hseq[1] = hs[1];
     c->ah_req_chunk = want; c->ah_req_seq = c->win_seq; c->ah_req_lo = want_lo;
 }
 
@@ -511,8 +520,9 @@ bool launch_safe_group_step(const Dev &lead, const Dev *group, int G, int reach,
     if (ah && lead.ahead_C > 0) {
         hipLaunchKernelGGL(safe_plan_group_kernel, dim3(1, G), dim3(256), 0, st, group);
         if (hipEventRecord(ah->ev_plan, st) != hipSuccess || hipStreamWaitEvent(ah->stream, ah->ev_plan, 0) != hipSuccess) return false;
-        // (a chunk, every slot + the touched labels over this half of the ring + over the other: one launch, grid.z = the job)
-        if (!launch_score_proof_group(lead, group, G, lead.ahead_C, 4, ah->stream)) return false;
+        // (a chunk, every slot + the touched labels over this half of the ring + over the other: one launch, grid.z = the job;
+        //  lazy: only the chunk)
+        if (!launch_score_proof_group(lead, group, G, lead.ahead_C, lead.ahead_lazy ? 0 : 4, ah->stream)) return false;
         if (hipEventRecord(ah->ev_done, ah->stream) != hipSuccess) return false;
         launch_score_proof_group(lead, group, G, max_rows, 3, st);
         hipLaunchKernelGGL(safe_dense_choice_group_kernel, dim3((unsigned)((max_rows + 15) / 16), G), dim3(256), 0, st, group);
