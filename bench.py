@@ -444,7 +444,15 @@ def burnin_chains_leg(args, X, local_rank, single_first):
     rs = np.random.RandomState(7100 + args.seed)
     orders = [rs.permutation(N).astype(np.int64) for _ in range(G)] if model == "PCRPMM" else None
     t0 = time.time()
-    grp.sweep(orders, None)
+    try:
+        grp.sweep(orders, None)
+    except Exception:
+        for c_, ctx in enumerate(grp.ctxs):          # (what every chain was doing: a failure here is a finding)
+            try:
+                print("chain %d: %s %s %s K=%d" % (c_, ctx.sweep_stats(), ctx.window_pipeline_stats(), ctx.group_stats(), ctx.K), file=sys.stderr)
+            except Exception as e2:                  # noqa: BLE001
+                print("chain %d: %s" % (c_, e2), file=sys.stderr)
+        raise
     dt = time.time() - t0
     moves = [ctx.sweep_stats()["moves"] for ctx in grp.ctxs]
     grp.close()

@@ -1006,9 +1006,13 @@ __device__ __forceinline__ void gram_resolve_body(const Dev &d) {
         if (cl == cprior || colLast[cl] < 0 || colSlot[cl] < 0) continue;
         const int s = colSlot[cl], n = colN[cl];
         // (pipelined windows: gram_finish_kernel writes the count -- it runs beside the NEXT resolver, whose close would
-        //  otherwise overwrite the count this window's finish still has to read)
-        if (!d.pipe || n <= 0) d.n[s] = n;
-        if (n > 0) {
+        //  otherwise overwrite the count this window's finish still has to read.  EVERY count, a deleted component's zero too:
+        //  until round 6 the resolver wrote that one itself, and the finish kernel of the window BEFORE -- eight chains' at
+        //  D = 128 is three rounds of workgroups, 437 us against this kernel's 208 -- could get to the slot after this close
+        //  and write its old count back: a dead slot with a member, one failed C5 chain in ten at the end of a first sweep,
+        //  where the random start's components die)
+        if (!d.pipe) d.n[s] = n;
+        if (n > 0 || d.pipe) {
             const int at = atomicAdd(&d.gfin[0], 1);
             d.gtouched[at] = s;
             d.gfin[16 + at] = n;

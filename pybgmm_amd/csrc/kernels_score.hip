@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void score_valu_kernel(Dev d, const Job *__res
 // (bx, by: the workgroup's row block and label chunk, gdy: the chunks the launch provides -- the launch grid's x / y index and y extent)
 template <int NJ, int RB, bool PROOF>
 __device__ __forceinline__ void score_mfma_body(const Dev &d, const Job *__restrict__ jobp, double *__restrict__ q, long long qstride,
-                                                int col_override, int skip_pruned_jobs, int bx, int by, int gdy) {
+                                                int col_override, int skip_pruned_jobs, int bx, int by, int gdy, int wg_target = 1400) {
     const JobView job = load_job(jobp);
     // (PROOF: runs whatever the window's kind, but only in front of a stretch whose proofs are to be made, kernels_safe.hip)
     if (job.mode == MODE_DONE || (!PROOF && skip_pruned_jobs == 1 && job_is_pruned(d, job.mode, job.prune)) ||
@@ -97,7 +97,7 @@ __device__ __forceinline__ void score_mfma_body(const Dev &d, const Job *__restr
         // ~1 400 workgroups whatever the stretch's length (measured: 197 ms per sweep at 0.5 % movers against 207 with 700, 240
         // with 400), at most one label chunk per grid row
         const long long rb = (job.win_hi - job.pos + 4 * ROWS_W_ - 1) / (4 * ROWS_W_);
-        long long ch = rb > 0 ? (1400 + rb - 1) / rb : 1;
+        long long ch = rb > 0 ? (wg_target + rb - 1) / rb : 1;
         nchunks = (int)(ch < 2 ? 2 : (ch > (long long)gdy ? (long long)gdy : ch));
     }
     if (chunk >= nchunks || chunk >= job.nlist) return;
@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_proof_group_kernel(const
     const Job *__restrict__ jobp = which < 0 ? &d.ctrl->job : (which == 3 ? d.resc_job : d.ah_job + which);
     if (which > 0) d.slot_list = d.resc_list;
     const int skip = which < 0 ? 2 : 3;
+    // (the ~1 400 workgroups a proof launch is cut into are for ONE chain's job to fill the chip: with gridDim.y chains -- and
+    //  gridDim.z jobs -- in the launch each job is cut into its share, and a workgroup keeps its rows for several labels)
+    const int wg_target = max(1400 / (int)(gridDim.y * gridDim.z), 64);
     const JobView job = load_job(jobp);
     if (job.mode == MODE_DONE) return;
     const long long rows = job.win_hi - job.pos;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, MINW) void score_mfma_proof_group_kernel(const
     const long long items = (long long)rb_count * kProofChunks;       // (chunks beyond the job's own split return at once)
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         // (chunk-major: the first gridDim.x items are the row blocks of the first chunks -- those every job has)
-        score_mfma_body<NJ, RB, true>(d, jobp, d.q, d.qstride, -1, skip, (int)(it % rb_count), (int)(it / rb_count), kProofChunks);
+        score_mfma_body<NJ, RB, true>(d, jobp, d.q, d.qstride, -1, skip, (int)(it % rb_count), (int)(it / rb_count), kProofChunks, wg_target);
     }
 }
 

@@ -246,7 +246,9 @@ __device__ __forceinline__ void gram_finish_body(const Dev &d) {
     // (the look-ahead of the dense proof pass re-scores a label iff a window closed after its chunk's request changed it)
     if (threadIdx.x == 0 && d.touch_seq) d.touch_seq[s] = d.ctrl->win_seq;
     if (d.pipe) {              // (the slot's count behind this window: the resolver left it on the list, see there)
-        if (threadIdx.x == 0) d.n[s] = d.gfin[16 + blockIdx.x];
+        const int n_now = d.gfin[16 + blockIdx.x];
+        if (threadIdx.x == 0) d.n[s] = n_now;
+        if (n_now <= 0) return;                    // (the window deleted this component: its count is all there is to write)
         __syncthreads();
     }
     const int D = d.D, nm = d.gfin[1], tid = threadIdx.x;
