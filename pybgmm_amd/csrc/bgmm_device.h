@@ -444,6 +444,7 @@ struct PerDeviceLds {
 
 // The ONE gateway to the process environment (api_context.hip): development switches of the tests and tools, read once per
 // process from BGMM_DEV_OPTIONS="name=value,name=value" -- perm_pipe, perm_era, perm_chain_rounds, perm_pipe_fail, perm_rounds, mt_chain_blocks, mt_batch_doubles, mt_lead,
+// group_pipe, group_safe, group_host_wait, group_carry_first, group_lazy,
 // perm_tail_log2, group_split.  Everything a user may want to set has an entry point (include/bgmm.h: bgmm_set_*).
 int bgmm_dev_option(const char *name, int dflt);
 
