@@ -1,6 +1,6 @@
 """What runs on more than one host thread, under ThreadSanitizer:   tools/build_tsan.sh, then this script with
 the sanitizer's runtime preloaded -- see the header of tools/build_tsan.sh.  Three exercises, each checked for its result as
-the GPU suite checks it:
+the GPU suite checks it (four since the second half of round 6: chains with few movers share their safe-stay steps):
   1. permutations in flight: the context's worker thread queues generations while the caller's thread takes them, with
      foreign draws in between (drains) and eras that run out (restarts);
   2. chains side by side from a random start: a host thread per chain, the rendezvous that shares their frozen-factor
@@ -83,8 +83,36 @@ def lookahead():
     assert np.array_equal(out[0], out[1])
 
 
+def chains_with_few_movers():
+    """Round 6: chains whose clusters overlap share the launches of their safe-stay steps (the rendezvous' kind 1, the
+    look-ahead's second stream driven by the leader)."""
+    N, D, K, G = 60000, 64, 40, 4
+    X, zt = gendata.synth_mixture(N, D, K, seed=141, mu_scale=0.5)
+    m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
+
+    def build(c):
+        ctx = _lib.Context(X, m_0, k_0, v_0, S_0, 1.0, 4 * K)
+        ctx.set_assignments(zt)
+        _, key, _ = random.Random(40 + c).getstate()
+        return [ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])]
+    solo, grp = [build(c) for c in range(G)], [build(c) for c in range(G)]
+    for it in range(3):
+        for s in solo:
+            s[1], s[2] = s[0].stage_mt19937(s[1], s[2], None)
+            s[0].sweep_staged(None)
+        for g in grp:
+            g[1], g[2] = g[0].stage_mt19937(g[1], g[2], None)
+        _lib.group_sweep_staged([g[0] for g in grp], None)
+        for c in range(G):
+            assert np.array_equal(solo[c][0].assignments(), grp[c][0].assignments()), (it, c)
+    print("chains with few movers side by side: %d chains equal their solo runs, %s" % (G, grp[0][0].group_stats()), flush=True)
+    for s in solo + grp:
+        s[0].close()
+
+
 if __name__ == "__main__":
     permutations()
     chains()
+    chains_with_few_movers()
     lookahead()
     print("TSAN RUN DONE", flush=True)
