@@ -83,7 +83,10 @@ int combiner_submit(bgmm_ctx *c, int T, int pipe_T, long long pos, int kind) {
             if (pipe_on && kind == 0 && o.pipe_T >= 4) { piped.push_back(k); if (o.pipe_T < Tpipe) Tpipe = o.pipe_T; }
             else plain.push_back(k);
         }
-        if (piped.size() < 2) { plain = members; piped.clear(); }
+        // (the pipeline keeps the chip busy through the resolvers of up to a dozen chains; beyond, the wide kernels of one
+        //  launch sequence ARE the window, and two sequences of plain windows whose phases interleave do better -- first sweep
+        //  of 12 / 16 / 32 C4-shaped chains from "rand": 7.8 / 8.4 / 9.7 x one chain pipelined, 6.4 / 9.3 / 11.7 x plain)
+        if (piped.size() < 2 || members.size() > 12) { plain = members; piped.clear(); }
         int rc_plain = 1, rc_piped = 1;
         std::vector<hipEvent_t> ev_plain, ev_piped;     // per member: the event its stream waits for (its sub-group's)
         lk.unlock();
