@@ -670,7 +670,9 @@ def test_chains_side_by_side_share_pipelined_windows(D, mixed):
     assert len({piped[2][c][0].tobytes() for c in range(G)}) == G, "chains with different seeds must differ"
 
 
-def test_chains_side_by_side_share_safe_stay_steps():
+@pytest.mark.parametrize("N,D,K,sep,pcrp", [(60000, 64, 40, 0.5, False), (40000, 128, 20, 0.28, False), (100000, 16, 100, 1.0, True)],
+                         ids=["D64", "D128", "D16-pcrp"])
+def test_chains_side_by_side_share_safe_stay_steps(N, D, K, sep, pcrp):
     """Round 6: chains of one shape whose clusters overlap (the regime a chain lives in: 0.5 % of the visits move at
     equilibrium) share the launches of their safe-stay steps as well -- the dense proof pass of every chain's stretch, the
     verdicts, the lists, the frozen-factor kernels on the listed rows: one launch each for all of them (api_group.hip kind 1,
@@ -680,8 +682,8 @@ def test_chains_side_by_side_share_safe_stay_steps():
     import random
     from pybgmm_amd import _lib
     from pybgmm_amd.utils import gendata
-    N, D, K, G = 60000, 64, 40, 4
-    X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=0.5)
+    G = 4
+    X, zt = gendata.synth_mixture(N, D, K, seed=77 + D, mu_scale=sep)
     m_0, k_0, v_0, S_0 = gendata.demo_prior_params(D)
 
     def build():
@@ -693,14 +695,18 @@ def test_chains_side_by_side_share_safe_stay_steps():
             out.append([ctx, np.asarray(key[:-1], dtype=np.uint32), int(key[-1])])
         return out
     grouped, solo = build(), build()
+    rs = np.random.RandomState(D)
     moved = 0
     for it in range(4):
+        # (pcrp: a fresh visiting order per chain and sweep and the seating power of pcrpmm.py:100-104)
+        orders = [rs.permutation(N).astype(np.int64) if pcrp else None for _ in range(G)]
+        powers = [1.0 + 0.01 * it if pcrp else None for _ in range(G)]
         for chains_ in (grouped, solo):
-            for ch in chains_:
-                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], None)
-        _lib.group_sweep_staged([ch[0] for ch in grouped], [None] * G)
-        for ch in solo:
-            ch[0].sweep_staged(None)
+            for c, ch in enumerate(chains_):
+                ch[1], ch[2] = ch[0].stage_mt19937(ch[1], ch[2], orders[c])
+        _lib.group_sweep_staged([ch[0] for ch in grouped], powers)
+        for c, ch in enumerate(solo):
+            ch[0].sweep_staged(powers[c])
         for c in range(G):
             bad = np.nonzero(grouped[c][0].assignments() != solo[c][0].assignments())[0]
             assert bad.size == 0, "sweep %d chain %d: %d labels differ, first at i=%d" % (it, c, bad.size, bad[0])
@@ -709,9 +715,9 @@ def test_chains_side_by_side_share_safe_stay_steps():
             lg, ls = grouped[c][0].log_marg(), solo[c][0].log_marg()
             assert abs(lg - ls) <= 1e-12 * abs(ls)
         moved += grouped[0][0].sweep_stats()["moves"]
-    assert moved > 200, "the clusters are meant to overlap"
+    assert moved > 100, "the clusters are meant to overlap"
     gs = [ch[0].group_stats() for ch in grouped]
-    assert sum(g_["shared_safe_stay_batches"] for g_ in gs) >= 2 * G, gs
+    assert sum(g_["shared_safe_stay_batches"] for g_ in gs) >= G, gs
     assert len({ch[0].assignments().tobytes() for ch in grouped}) == G, "chains with different seeds must differ"
     for ch in reversed(grouped + solo):
         ch[0].close()
