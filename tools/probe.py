@@ -212,7 +212,11 @@ def chains(a):
         mv = sum(ctx.sweep_stats()["moves"] for ctx in grp.ctxs)
         print("%3d chains: %.2f ms per round of sweeps, %.2f sweeps/s aggregate (%d moves in the last round)" % (g, dt * 1e3, g / dt, mv))
         if g > 1:
-            print("    group stats of chain 0:", grp.ctxs[0].group_stats(), "safe:", grp.ctxs[0].path_stats())
+            gs = [ctx.group_stats() for ctx in grp.ctxs]
+            print("    batches of all chains: shared frozen-factor %d (pipelined %d), shared safe-stay %d, on their own %d; proof passes %s" % (
+                sum(x["shared_frozen_factor_batches"] for x in gs), sum(x["of_them_pipelined"] for x in gs),
+                sum(x["shared_safe_stay_batches"] for x in gs), sum(x["batches_on_its_own_in_a_group"] for x in gs),
+                [tuple(ctx.proof_pass_stats().values()) if hasattr(ctx, "proof_pass_stats") else None for ctx in grp.ctxs][:3]))
         grp.close()
 
 
