@@ -142,7 +142,7 @@ BGMM_API int bgmm_group_sweep_staged(bgmm_ctx *const *ctxs, int32_t n, const int
  */
 BGMM_API int bgmm_stage_mt19937(bgmm_ctx *ctx, const int64_t *order, uint32_t *key624, int32_t *pos);
 /* The N uniforms currently staged for the next sweep (whichever way they got there). */
-/* bgmm_stage_mt19937 cuts a long request into chains of 128 blocks (79 872 words) that run side by side from
+/* bgmm_stage_mt19937 cuts a long request into chains of 256 blocks (159 744 words) that run side by side from
  * jumped-ahead generator states (the state J words ahead is a GF(2) convolution of the next 20 560 words with the
  * coefficients of t^J modulo the generator's characteristic polynomial; the polynomials are built on the host once
  * per process).  0 = run the chains one after the other instead -- same doubles, same final state. */
@@ -155,11 +155,11 @@ BGMM_API int bgmm_set_mt_jump(bgmm_ctx *ctx, int32_t enabled);
  * nothing from its generator since the previous call (the sampler loops of crpmm.py:57-88 / pcrpmm.py:93-131 never do);
  * otherwise the batch is thrown away and the request is generated on the spot as if there had been no look-ahead.  Same
  * doubles, same states handed back either way; costs two buffers of sweeps x N doubles.  sweeps: -1 = on, depth chosen
- * from N (about 4e6 doubles per batch, at most 8 sweeps; the default), 0 = off, 1 .. 8 = that many sweeps per batch.
+ * from N (about 8e6 doubles per batch, at most 8 sweeps; the default), 0 = off, 1 .. 8 = that many sweeps per batch.
  * out2 = {requests served by the look-ahead, requests generated on the spot}. */
 BGMM_API int bgmm_set_mt_lookahead(bgmm_ctx *ctx, int32_t sweeps);
 BGMM_API int bgmm_get_mt_lookahead_stats(bgmm_ctx *ctx, int64_t *out2);
-/* The coefficient bits (19 937 of them, bit i = word i / 32, bit i % 32) of t^(chain * 79 872) modulo the characteristic
+/* The coefficient bits (19 937 of them, bit i = word i / 32, bit i % 32) of t^(chain * 159 744) modulo the characteristic
  * polynomial of MT19937: host arithmetic only, no device needed (what the CPU tests check against numpy's generator). */
 BGMM_API int bgmm_mt19937_jump_poly(int32_t chain, uint32_t *coef624);
 /* 624-word blocks per chain (the J of the polynomials above is this many blocks). */

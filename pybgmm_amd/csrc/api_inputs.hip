@@ -62,7 +62,7 @@ int mt_ensure_tables(bgmm_ctx *c, int chains) {
 
 static int mt_depth_for(long long N) {
     if (N < 4096) return 1;                       // (sweep boundaries must lie behind the request's first block)
-    long long m = (long long)bgmm_dev_option("mt_batch_doubles", 4000000) / N;
+    long long m = (long long)bgmm_dev_option("mt_batch_doubles", 8000000) / N;
     if (m < 1) m = 1;
     if (m > kMtMaxMids) m = kMtMaxMids;
     return (int)m;

@@ -507,7 +507,7 @@ bool launch_gram_core(const Dev &d, int resolve_lds, hipStream_t st, hipEvent_t 
 bool launch_gram_cross(const Dev &d, bool with_previous, hipStream_t st);   // cross forms (+ those with the window before) + weights
 void launch_gram_carry(const Dev &d, hipStream_t st);
 bool launch_gram_resolve_only(const Dev &d, int resolve_lds, hipStream_t st);
-// kernels_rng.hip: the caller's MT19937 continued on the device (chains of 128 blocks from jumped-ahead states)
+// kernels_rng.hip: the caller's MT19937 continued on the device (chains of 256 blocks from jumped-ahead states)
 int mt19937_chains_for(long long pos, long long n);
 int mt19937_raw_words();
 int mt19937_chain_blocks();

@@ -61,11 +61,13 @@ __global__ void mt19937_doubles_kernel(const unsigned *__restrict__ words, doubl
 // ------------------------------------------------------------------------------------------
 // 624-word blocks per chain (>= 33: the first chain emits the convolution's input).  The jump costs 19 937 x 624 word
 // operations per chain -- at 64 blocks a chain it was the generator's largest kernel (190 us per four sweeps of C4, on every
-// compute unit); a chain's step is ~0.9 us, so 128 blocks keep a generation (first chain, jump, the other chains) inside the
-// sweeps it runs beside.  Measured at C4 (profiles/r06/mt_chain_blocks.txt): 64: 6 110 sweeps/s, 128: 6 468, 256: 6 483,
-// 512: 4 969 (the generation no longer keeps up).  BGMM_DEV_OPTIONS="mt_chain_blocks=..." (read once per process).
+// compute unit); a chain's step is ~0.9 us, so the chains must still finish inside the sweeps they run beside.  Measured at C4
+// on one box (profiles/r06/perm_rounds_experiments.txt, last paragraph), sweeps/s and home_kernel's time beside the generator:
+// 64 blocks, batches of 4e6 doubles: 5 973 - 5 999, 0.128 ms;  128 / 4e6: 6 326 - 6 397, 0.133 - 0.134;  128 / 8e6: 6 296 -
+// 6 352, 0.126 - 0.128;  256 / 8e6: 6 463 - 6 557, 0.130 - 0.131;  512: the generation no longer keeps up.
+// BGMM_DEV_OPTIONS="mt_chain_blocks=..." (read once per process).
 static int chain_blocks() {
-    static const int v = [] { int b = bgmm_dev_option("mt_chain_blocks", 128); return b < 33 ? 33 : (b > 4096 ? 4096 : b); }();
+    static const int v = [] { int b = bgmm_dev_option("mt_chain_blocks", 256); return b < 33 ? 33 : (b > 4096 ? 4096 : b); }();
     return v;
 }
 static constexpr int kPhiDeg = 19937;

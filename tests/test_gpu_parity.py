@@ -1609,8 +1609,8 @@ def test_device_mt19937_continues_the_callers_stream(seed, burn):
 
 @pytest.mark.parametrize("N,burn", [(70000, 0), (200000, 311), (1000003, 1247), (2600001, 5)])
 def test_device_mt19937_jump_ahead_across_chains(N, burn):
-    """Requests longer than one chain of bgmm_mt19937_chain_blocks() = 128 blocks (79 872 words) run as chains side by side
-    from jumped-ahead states (kernels_rng.hip): 2, 6, 26 and 66 chains here, from an even and an odd position, against
+    """Requests longer than one chain of bgmm_mt19937_chain_blocks() = 256 blocks (159 744 words) run as chains side by side
+    from jumped-ahead states (kernels_rng.hip): 1, 3, 13 and 33 chains here, from an even and an odd position, against
     random.random() -- and against the same chains run one after the other (bgmm_set_mt_jump(0))."""
     import random
     from pybgmm_amd import _lib
